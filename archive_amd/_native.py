@@ -1,0 +1,62 @@
+"""ctypes binding of libarchive_hip.so (include/archive_hip.h).
+
+There is deliberately no fallback: if the shared library is missing or no GPU is usable,
+calls raise -- nothing in this package decodes on the CPU.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libarchive_hip.so")
+
+AHIP_OK, AHIP_FALSE, AHIP_RANGE, AHIP_HANG = 0, 1, 2, 3
+AHIP_E_CAP, AHIP_E_DEVICE, AHIP_E_UNSUPPORTED, AHIP_E_ARG = -1, -2, -3, -4
+
+# every symbol include/archive_hip.h declares
+EXPORTS = [
+    "ahip_init", "ahip_shutdown", "ahip_last_error", "ahip_abi_version",
+    "ahip_inflate_raw", "ahip_gzip_decode", "ahip_zlib_decode",
+    "ahip_gzip_decode_device", "ahip_gzip_plan_create", "ahip_gzip_plan_info", "ahip_gzip_plan_run",
+    "ahip_gzip_plan_status", "ahip_gzip_plan_destroy",
+    "ahip_crc32", "ahip_adler32",
+]
+
+_lib = None
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryMissing(
+            "%s not built -- run `python -m archive_amd.build` (needs hipcc); there is no CPU fallback" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, sz, i32, u32, u64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int32, ctypes.c_uint32, ctypes.c_uint64
+    szp = ctypes.POINTER(sz)
+    L.ahip_init.argtypes = [i32]; L.ahip_init.restype = i32
+    L.ahip_shutdown.argtypes = []; L.ahip_shutdown.restype = None
+    L.ahip_last_error.argtypes = []; L.ahip_last_error.restype = ctypes.c_char_p
+    L.ahip_abi_version.argtypes = []; L.ahip_abi_version.restype = u32
+    L.ahip_inflate_raw.argtypes = [vp, sz, vp, sz, szp, szp]; L.ahip_inflate_raw.restype = i32
+    L.ahip_gzip_decode.argtypes = [vp, sz, i32, i32, vp, sz, szp]; L.ahip_gzip_decode.restype = i32
+    L.ahip_zlib_decode.argtypes = [vp, sz, i32, i32, vp, sz, szp]; L.ahip_zlib_decode.restype = i32
+    L.ahip_gzip_decode_device.argtypes = [vp, sz, vp, sz, szp, vp]; L.ahip_gzip_decode_device.restype = i32
+    L.ahip_gzip_plan_create.argtypes = [vp, sz, vp, ctypes.POINTER(vp)]; L.ahip_gzip_plan_create.restype = i32
+    L.ahip_gzip_plan_info.argtypes = [vp, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u64)]
+    L.ahip_gzip_plan_info.restype = i32
+    L.ahip_gzip_plan_run.argtypes = [vp, vp, sz, vp]; L.ahip_gzip_plan_run.restype = i32
+    L.ahip_gzip_plan_status.argtypes = [vp, szp]; L.ahip_gzip_plan_status.restype = i32
+    L.ahip_gzip_plan_destroy.argtypes = [vp]; L.ahip_gzip_plan_destroy.restype = None
+    L.ahip_crc32.argtypes = [vp, sz, u32]; L.ahip_crc32.restype = u32
+    L.ahip_adler32.argtypes = [vp, sz, u32]; L.ahip_adler32.restype = u32
+    _lib = L
+    return L
+
+
+def last_error():
+    return lib().ahip_last_error().decode("utf-8", "replace")

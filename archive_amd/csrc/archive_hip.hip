@@ -1,0 +1,551 @@
+// archive_hip.hip -- kernels + C-ABI of libarchive_hip.so (see include/archive_hip.h).
+// gfx950 only.  No CPU decode path exists in this library: without a GPU every entry point
+// that would decode returns AHIP_E_DEVICE.
+#include "../../include/archive_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+#include "gzip_index.hpp"
+#include "inflate_wave.hpp"
+
+using namespace ahip;
+
+// ------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------
+constexpr int WAVES_PER_BLOCK = 4;
+
+template <bool WRITE>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void inflate_members_kernel(const u8 *__restrict__ in, u64 in_len,
+                                                                             const MemberDesc *__restrict__ members,
+                                                                             u32 n_members, u8 *out,
+                                                                             MemberResult *__restrict__ results) {
+  __shared__ WaveLds lds[WAVES_PER_BLOCK];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const u32 m = blockIdx.x * WAVES_PER_BLOCK + wave;
+  if (m >= n_members) return;
+  MemberDesc d = members[m];
+  d.in_off = uniform64(d.in_off);
+  d.out_off = uniform64(d.out_off);
+  d.out_limit = uniform64(d.out_limit);
+  inflate_member<WRITE>(lds[wave], in, in_len, d, out, results[m], lane);
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+namespace {
+
+thread_local std::string g_err;
+std::mutex g_mu;
+bool g_inited = false;
+
+int32_t fail(int32_t code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess)                                                                              \
+      return fail(AHIP_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));                   \
+  } while (0)
+
+// grow-only device scratch
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    size_t want = n + (n >> 2) + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <class T> T *as() const { return (T *)p; }
+};
+
+inline u32 cdiv(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
+
+int32_t ensure_init() {
+  if (g_inited) return AHIP_OK;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(AHIP_E_DEVICE, std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "count=0"));
+  g_inited = true;
+  return AHIP_OK;
+}
+
+}  // namespace
+
+// A plan = the member index of one gzip stream, resident in device memory.
+struct ahip_gzip_plan {
+  const u8 *d_in = nullptr;
+  u64 in_len = 0;
+  bool sized = false;  // sizes come from a sizing run (exact) rather than BC/ISIZE (trusted, verified)
+  u32 K = 0;           // candidates
+  ChainSummary sum{};
+  DevBuf tile_counts, tile_offsets, cand_pos, hdr, scratch_u32, members, expect_status, results, sizing_descs,
+      sizing_results, dsum, drun;
+  bool ran = false;
+  ~ahip_gzip_plan() {
+    for (DevBuf *b : {&tile_counts, &tile_offsets, &cand_pos, &hdr, &scratch_u32, &members, &expect_status, &results,
+                      &sizing_descs, &sizing_results, &dsum, &drun})
+      b->release();
+  }
+};
+
+namespace {
+
+// Build (or rebuild with force_sizing) the member index for d_in[start..n).
+int32_t plan_build(ahip_gzip_plan *pl, bool force_sizing, hipStream_t st) {
+  const u8 *in = pl->d_in;
+  const u64 n = pl->in_len, start = 0;
+  pl->sized = false;
+  pl->sum = ChainSummary{};
+  pl->K = 0;
+  HIP_TRY(pl->dsum.reserve(sizeof(ChainSummary)));
+  HIP_TRY(hipMemsetAsync(pl->dsum.p, 0, sizeof(ChainSummary), st));
+  if (n < 3) {
+    pl->sum.tail_pos = start;
+    return AHIP_OK;
+  }
+  const u32 tiles = cdiv(n - start, TILE_BYTES);
+  HIP_TRY(pl->tile_counts.reserve((size_t)tiles * 4 + 4));
+  HIP_TRY(pl->tile_offsets.reserve((size_t)tiles * 4 + 4));
+  u32 *d_total = pl->tile_offsets.as<u32>() + tiles;
+  hipLaunchKernelGGL(gz_count_candidates, dim3(tiles), dim3(256), 0, st, in, start, n, pl->tile_counts.as<u32>());
+  hipLaunchKernelGGL(scan_exclusive_u32, dim3(1), dim3(1024), 0, st, pl->tile_counts.as<u32>(),
+                     pl->tile_offsets.as<u32>(), (u64)tiles, d_total);
+  u32 K = 0;
+  HIP_TRY(hipMemcpyAsync(&K, d_total, 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  pl->K = K;
+  if (K == 0) {
+    pl->sum.tail_pos = start;
+    return AHIP_OK;
+  }
+  HIP_TRY(pl->cand_pos.reserve((size_t)K * 8));
+  HIP_TRY(pl->hdr.reserve((size_t)K * sizeof(GzHeader)));
+  hipLaunchKernelGGL(gz_write_candidates, dim3(tiles), dim3(256), 0, st, in, start, n, pl->tile_counts.as<u32>(),
+                     pl->tile_offsets.as<u32>(), pl->cand_pos.as<u64>());
+  hipLaunchKernelGGL(gz_parse_headers, dim3(cdiv(K, 256)), dim3(256), 0, st, in, n, pl->cand_pos.as<u64>(), K,
+                     pl->hdr.as<GzHeader>(), pl->dsum.as<ChainSummary>());
+  u32 unknown = 0;
+  if (!force_sizing) {
+    HIP_TRY(hipMemcpyAsync(&unknown, &pl->dsum.as<ChainSummary>()->unknown, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  if (force_sizing || unknown > 0) {
+    // sizing run over every candidate: exact end position, size and verdict, no stores
+    HIP_TRY(pl->sizing_descs.reserve((size_t)K * sizeof(MemberDesc)));
+    HIP_TRY(pl->sizing_results.reserve((size_t)K * sizeof(MemberResult)));
+    hipLaunchKernelGGL(gz_make_sizing_descs, dim3(cdiv(K, 256)), dim3(256), 0, st, pl->hdr.as<GzHeader>(), K,
+                       pl->sizing_descs.as<MemberDesc>());
+    hipLaunchKernelGGL(inflate_members_kernel<false>, dim3(cdiv(K, WAVES_PER_BLOCK)), dim3(64 * WAVES_PER_BLOCK), 0, st,
+                       in, n, pl->sizing_descs.as<MemberDesc>(), K, (u8 *)nullptr, pl->sizing_results.as<MemberResult>());
+    hipLaunchKernelGGL(gz_apply_sizing, dim3(cdiv(K, 256)), dim3(256), 0, st, pl->hdr.as<GzHeader>(), K,
+                       pl->sizing_results.as<MemberResult>(), n);
+    pl->sized = true;
+  }
+  HIP_TRY(pl->scratch_u32.reserve((size_t)(K + 1) * 4 * 4));
+  HIP_TRY(pl->members.reserve((size_t)K * sizeof(MemberDesc)));
+  HIP_TRY(pl->expect_status.reserve((size_t)K * 4));
+  u32 *s = pl->scratch_u32.as<u32>();
+  hipLaunchKernelGGL(gz_chain, dim3(1), dim3(1024), 0, st, pl->cand_pos.as<u64>(), pl->hdr.as<GzHeader>(), K, start, n,
+                     s, s + (K + 1), s + 2 * (size_t)(K + 1), s + 3 * (size_t)(K + 1), pl->members.as<MemberDesc>(),
+                     pl->expect_status.as<u32>(), pl->dsum.as<ChainSummary>());
+  HIP_TRY(hipMemcpyAsync(&pl->sum, pl->dsum.p, sizeof(ChainSummary), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipGetLastError());
+  if (!pl->sum.first_is_gzip) { pl->sum.members = 0; pl->sum.total_out = 0; pl->sum.tail_pos = start; }
+  return AHIP_OK;
+}
+
+int32_t plan_run(ahip_gzip_plan *pl, u8 *d_out, size_t out_cap, hipStream_t st) {
+  const u32 M = (u32)pl->sum.members;
+  if (pl->sum.total_out > out_cap) return fail(AHIP_E_CAP, "output buffer too small");
+  HIP_TRY(pl->drun.reserve(sizeof(RunSummary)));
+  RunSummary init{};
+  init.first_bad = 0xffffffffu;
+  HIP_TRY(hipMemcpyAsync(pl->drun.p, &init, sizeof init, hipMemcpyHostToDevice, st));
+  pl->ran = true;
+  if (M == 0) return AHIP_OK;
+  HIP_TRY(pl->results.reserve((size_t)M * sizeof(MemberResult)));
+  hipLaunchKernelGGL(inflate_members_kernel<true>, dim3(cdiv(M, WAVES_PER_BLOCK)), dim3(64 * WAVES_PER_BLOCK), 0, st,
+                     pl->d_in, pl->in_len, pl->members.as<MemberDesc>(), M, d_out, pl->results.as<MemberResult>());
+  hipLaunchKernelGGL(gz_verify, dim3(cdiv(M, 256)), dim3(256), 0, st, pl->members.as<MemberDesc>(),
+                     pl->expect_status.as<u32>(), pl->results.as<MemberResult>(), M, pl->drun.as<RunSummary>());
+  HIP_TRY(hipGetLastError());
+  return AHIP_OK;
+}
+
+// verdict of the member chain alone (the tail, if any, is the caller's business)
+//  returns AHIP_* ; *needs_sizing set when the trusted index was wrong
+int32_t plan_verdict(ahip_gzip_plan *pl, hipStream_t st, bool *needs_sizing) {
+  *needs_sizing = false;
+  RunSummary rs{};
+  HIP_TRY(hipMemcpyAsync(&rs, pl->drun.p, sizeof rs, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (rs.mismatches) {
+    if (!pl->sized) { *needs_sizing = true; return AHIP_OK; }
+    return fail(AHIP_E_DEVICE, "internal: decode disagrees with its own sizing run");
+  }
+  if (rs.any_farref & 2u) return AHIP_RANGE;  // first member: source before the start of the stream
+  if (rs.any_range) return AHIP_RANGE;
+  if (rs.any_hang) return AHIP_HANG;
+  if (rs.any_farref) return fail(AHIP_E_UNSUPPORTED, "back-reference reaches into a previous gzip member");
+  if (rs.any_oversub) return fail(AHIP_E_UNSUPPORTED, "over-subscribed Huffman code");
+  return AHIP_OK;
+}
+
+// Inflate one raw stream that starts at d_in[off]; output appended at d_out (device), window [0, cap).
+// Runs a sizing pass first when `cap` may be too small.  Single wave: the serial path of the
+// reference has no member parallelism to offer.
+struct OneResult { MemberResult r; };
+int32_t inflate_one(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool write, MemberResult *res,
+                    hipStream_t st) {
+  static DevBuf dd, dr;
+  HIP_TRY(dd.reserve(sizeof(MemberDesc)));
+  HIP_TRY(dr.reserve(sizeof(MemberResult)));
+  MemberDesc d{off, 0, out_cap, POS_UNKNOWN};
+  HIP_TRY(hipMemcpyAsync(dd.p, &d, sizeof d, hipMemcpyHostToDevice, st));
+  if (write)
+    hipLaunchKernelGGL(inflate_members_kernel<true>, dim3(1), dim3(64 * WAVES_PER_BLOCK), 0, st, d_in, n,
+                       dd.as<MemberDesc>(), 1u, d_out, dr.as<MemberResult>());
+  else
+    hipLaunchKernelGGL(inflate_members_kernel<false>, dim3(1), dim3(64 * WAVES_PER_BLOCK), 0, st, d_in, n,
+                       dd.as<MemberDesc>(), 1u, (u8 *)nullptr, dr.as<MemberResult>());
+  HIP_TRY(hipMemcpyAsync(res, dr.p, sizeof *res, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipGetLastError());
+  return AHIP_OK;
+}
+
+int32_t member_status_to_abi(u32 ms) {
+  switch (ms) {
+    case MS_OK: case MS_EOS: return AHIP_OK;
+    case MS_FALSE: return AHIP_FALSE;
+    case MS_RANGE: case MS_FARREF: return AHIP_RANGE;  // single stream: source before index 0
+    case MS_HANG: return AHIP_HANG;
+    case MS_OVERSUB: g_err = "over-subscribed Huffman code"; return AHIP_E_UNSUPPORTED;
+    default: g_err = "internal: unexpected member status"; return AHIP_E_DEVICE;
+  }
+}
+
+// _ZLibDecoder.decodeStream on device memory (serial member loop, deferred flush, quirk q7).
+//  d_out: device output, `committed` bytes already hold earlier output.  The member being
+//  inflated is written right behind the committed bytes and only counted once the NEXT header
+//  passed its checks (or the input ended).
+//  host_in: host copy of the input (headers/trailers are read there).
+int32_t zlib_stream_device(const u8 *host_in, const u8 *d_in, u64 n, u64 pos, bool big_endian, int verify, int raw,
+                           DevBuf &outbuf, u64 *committed_io, hipStream_t st) {
+  u64 committed = *committed_io;
+  bool have = false;
+  u64 buf_len = 0;
+  std::vector<u8> tmp;
+  while (pos < n) {
+    if (!raw) {
+      if (pos + 2 > n) return AHIP_RANGE;
+      u32 cmf = host_in[pos], flg = host_in[pos + 1];
+      pos += 2;
+      if ((cmf & 8) != 8) { *committed_io = committed; return AHIP_FALSE; }
+      if (((cmf * 256) + flg) % 31 != 0) { *committed_io = committed; return AHIP_FALSE; }
+      if ((flg & 32) >> 5) {
+        *committed_io = committed;
+        return (pos + 4 > n) ? AHIP_RANGE : AHIP_FALSE;
+      }
+    }
+    if (have) committed += buf_len;
+    // sizing pass, then the real one into a window of exactly that size
+    MemberResult r{};
+    int32_t rc = inflate_one(d_in, n, pos, nullptr, ~0ull, false, &r, st);
+    if (rc != AHIP_OK) return rc;
+    if (r.status == MS_RANGE || r.status == MS_FARREF) return AHIP_RANGE;
+    if (r.status == MS_HANG) return AHIP_HANG;
+    if (r.status == MS_OVERSUB) return fail(AHIP_E_UNSUPPORTED, "over-subscribed Huffman code");
+    if (r.out_len) {
+      // grow keeping the committed prefix
+      if (committed + r.out_len > outbuf.cap) {
+        DevBuf nb;
+        HIP_TRY(nb.reserve((committed + r.out_len) * 2));
+        if (committed) HIP_TRY(hipMemcpyAsync(nb.p, outbuf.p, committed, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        outbuf.release();
+        outbuf = nb;
+      }
+      MemberResult r2{};
+      rc = inflate_one(d_in, n, pos, outbuf.as<u8>() + committed, r.out_len, true, &r2, st);
+      if (rc != AHIP_OK) return rc;
+      if (r2.out_len != r.out_len || r2.end_pos != r.end_pos)
+        return fail(AHIP_E_DEVICE, "internal: decode disagrees with its own sizing run");
+    }
+    have = true;
+    buf_len = r.out_len;
+    pos = r.end_pos;
+    if (!raw) {
+      if (pos + 4 > n) return AHIP_RANGE;
+      u32 a = host_in[pos], b = host_in[pos + 1], c = host_in[pos + 2], d = host_in[pos + 3];
+      u32 want = big_endian ? ((a << 24) | (b << 16) | (c << 8) | d) : ((d << 24) | (c << 16) | (b << 8) | a);
+      pos += 4;
+      if (verify) {
+        tmp.resize(buf_len);
+        if (buf_len) HIP_TRY(hipMemcpy(tmp.data(), outbuf.as<u8>() + committed, buf_len, hipMemcpyDeviceToHost));
+        if (ahip_adler32(tmp.data(), buf_len, 1) != want) { *committed_io = committed; return AHIP_FALSE; }
+      }
+    }
+  }
+  if (have) committed += buf_len;
+  *committed_io = committed;
+  return AHIP_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// C-ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+uint32_t ahip_abi_version(void) { return (1u << 16) | 0u; }
+
+const char *ahip_last_error(void) { return g_err.c_str(); }
+
+int32_t ahip_init(int32_t device) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  int32_t rc = ensure_init();
+  if (rc != AHIP_OK) return rc;
+  if (device >= 0) HIP_TRY(hipSetDevice(device));
+  return AHIP_OK;
+}
+
+void ahip_shutdown(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_inited = false;
+}
+
+uint32_t ahip_crc32(const uint8_t *data, size_t len, uint32_t crc) {
+  static uint32_t table[256];
+  static bool ready = false;
+  if (!ready) {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
+      table[i] = c;
+    }
+    ready = true;
+  }
+  crc ^= 0xffffffffu;
+  for (size_t i = 0; i < len; ++i) crc = table[(crc ^ data[i]) & 0xff] ^ (crc >> 8);
+  return crc ^ 0xffffffffu;
+}
+
+uint32_t ahip_adler32(const uint8_t *data, size_t len, uint32_t adler) {
+  uint64_t s1 = adler & 0xffff, s2 = adler >> 16;
+  size_t i = 0;
+  while (len > 0) {
+    size_t k = len < 3800 ? len : 3800;
+    len -= k;
+    while (k--) { s1 += data[i++]; s2 += s1; }
+    s1 %= 65521; s2 %= 65521;
+  }
+  return (uint32_t)((s2 << 16) | s1);
+}
+
+int32_t ahip_gzip_plan_create(const void *d_in, size_t in_len, void *stream, ahip_gzip_plan **plan) {
+  if (!plan) return fail(AHIP_E_ARG, "plan == NULL");
+  *plan = nullptr;
+  std::lock_guard<std::mutex> lk(g_mu);
+  int32_t rc = ensure_init();
+  if (rc != AHIP_OK) return rc;
+  ahip_gzip_plan *pl = new ahip_gzip_plan();
+  pl->d_in = (const u8 *)d_in;
+  pl->in_len = in_len;
+  rc = plan_build(pl, false, (hipStream_t)stream);
+  if (rc != AHIP_OK) { delete pl; return rc; }
+  *plan = pl;
+  return AHIP_OK;
+}
+
+int32_t ahip_gzip_plan_info(const ahip_gzip_plan *plan, uint64_t *members, uint64_t *out_bytes,
+                            uint64_t *payload_bytes) {
+  if (!plan) return fail(AHIP_E_ARG, "plan == NULL");
+  if (members) *members = plan->sum.members;
+  if (out_bytes) *out_bytes = plan->sum.total_out;
+  if (payload_bytes) *payload_bytes = plan->sum.payload_bytes;
+  return AHIP_OK;
+}
+
+int32_t ahip_gzip_plan_run(ahip_gzip_plan *plan, void *d_out, size_t out_cap, void *stream) {
+  if (!plan) return fail(AHIP_E_ARG, "plan == NULL");
+  std::lock_guard<std::mutex> lk(g_mu);
+  return plan_run(plan, (u8 *)d_out, out_cap, (hipStream_t)stream);
+}
+
+int32_t ahip_gzip_plan_status(ahip_gzip_plan *plan, size_t *out_len) {
+  if (!plan) return fail(AHIP_E_ARG, "plan == NULL");
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (out_len) *out_len = plan->sum.total_out;
+  if (!plan->ran) return fail(AHIP_E_ARG, "plan has not been run");
+  bool needs = false;
+  int32_t rc = plan_verdict(plan, nullptr, &needs);
+  if (rc != AHIP_OK) return rc;
+  if (needs) return fail(AHIP_E_UNSUPPORTED, "member index (BC/ISIZE) disagrees with the data; use ahip_gzip_decode_device");
+  if (plan->sum.range_error) return AHIP_RANGE;
+  if (plan->sum.tail_pos != plan->in_len) return AHIP_FALSE;
+  return AHIP_OK;
+}
+
+void ahip_gzip_plan_destroy(ahip_gzip_plan *plan) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  delete plan;
+}
+
+// Shared body of the gzip entry points.  host_in may be NULL (device API): then a tail that is
+// not a gzip member is inspected through a small D2H copy.
+static int32_t gzip_decode_impl(const u8 *host_in, const u8 *d_in, size_t in_len, int verify, int raw, u8 *d_out,
+                                size_t out_cap, bool out_is_growable, DevBuf *grow, size_t *out_len, hipStream_t st) {
+  ahip_gzip_plan pl;
+  pl.d_in = d_in;
+  pl.in_len = in_len;
+  int32_t rc = plan_build(&pl, false, st);
+  if (rc != AHIP_OK) return rc;
+  for (int attempt = 0;; ++attempt) {
+    if (out_is_growable) {
+      HIP_TRY(grow->reserve(pl.sum.total_out + 16));
+      d_out = grow->as<u8>();
+      out_cap = grow->cap;
+    }
+    if (out_len) *out_len = pl.sum.total_out;
+    if (pl.sum.total_out > out_cap) return fail(AHIP_E_CAP, "output buffer too small");
+    rc = plan_run(&pl, d_out, out_cap, st);
+    if (rc != AHIP_OK) return rc;
+    bool needs = false;
+    rc = plan_verdict(&pl, st, &needs);
+    if (rc != AHIP_OK) return rc;
+    if (!needs) break;
+    if (attempt) return fail(AHIP_E_DEVICE, "internal: sizing run did not settle the member index");
+    rc = plan_build(&pl, true, st);  // BC/ISIZE lied: take sizes from the data
+    if (rc != AHIP_OK) return rc;
+  }
+  if (pl.sum.range_error) return AHIP_RANGE;
+  u64 committed = pl.sum.total_out;
+  if (out_len) *out_len = committed;
+  if (pl.sum.tail_pos >= in_len) return AHIP_OK;
+  // The bytes at tail_pos are not a gzip header: the reference hands the rest of the stream to
+  // the zlib decoder (little-endian stream, so its Adler-32 is read byte-swapped).
+  std::vector<u8> tail_host;
+  const u8 *h = host_in;
+  if (!h) {
+    tail_host.resize(in_len - pl.sum.tail_pos);
+    HIP_TRY(hipMemcpy(tail_host.data(), d_in + pl.sum.tail_pos, tail_host.size(), hipMemcpyDeviceToHost));
+    h = tail_host.data() - pl.sum.tail_pos;
+  }
+  // cheap pre-check of the first header so the common "trailing garbage" case needs no kernels
+  if (!raw) {
+    u64 p = pl.sum.tail_pos;
+    if (p + 2 > in_len) return AHIP_RANGE;
+    u32 cmf = h[p], flg = h[p + 1];
+    if ((cmf & 8) != 8 || ((cmf * 256) + flg) % 31 != 0) return AHIP_FALSE;
+  }
+  if (!out_is_growable) {
+    // fixed caller buffer: decode the tail into scratch, then append what fits
+    DevBuf scratch;
+    u64 tail_committed = 0;
+    rc = zlib_stream_device(h, d_in, in_len, pl.sum.tail_pos, false, verify, raw, scratch, &tail_committed, st);
+    if (rc == AHIP_OK || rc == AHIP_FALSE) {
+      if (out_len) *out_len = committed + tail_committed;
+      if (committed + tail_committed > out_cap) { scratch.release(); return fail(AHIP_E_CAP, "output buffer too small"); }
+      if (tail_committed) HIP_TRY(hipMemcpy(d_out + committed, scratch.p, tail_committed, hipMemcpyDeviceToDevice));
+    }
+    scratch.release();
+    return rc;
+  }
+  rc = zlib_stream_device(h, d_in, in_len, pl.sum.tail_pos, false, verify, raw, *grow, &committed, st);
+  if (out_len) *out_len = committed;
+  return rc;
+}
+
+int32_t ahip_gzip_decode_device(const void *d_in, size_t in_len, void *d_out, size_t out_cap, size_t *out_len,
+                                void *stream) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  int32_t rc = ensure_init();
+  if (rc != AHIP_OK) return rc;
+  return gzip_decode_impl(nullptr, (const u8 *)d_in, in_len, 0, 0, (u8 *)d_out, out_cap, false, nullptr, out_len,
+                          (hipStream_t)stream);
+}
+
+int32_t ahip_gzip_decode(const uint8_t *in, size_t in_len, int32_t verify, int32_t raw, uint8_t *out, size_t out_cap,
+                         size_t *out_len) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  int32_t rc = ensure_init();
+  if (rc != AHIP_OK) return rc;
+  static DevBuf din, dout;
+  HIP_TRY(din.reserve(in_len + 16));
+  if (in_len) HIP_TRY(hipMemcpy(din.p, in, in_len, hipMemcpyHostToDevice));
+  size_t produced = 0;
+  rc = gzip_decode_impl(in, din.as<u8>(), in_len, verify, raw, nullptr, 0, true, &dout, &produced, nullptr);
+  if (out_len) *out_len = produced;
+  if (rc == AHIP_OK || rc == AHIP_FALSE) {
+    if (produced > out_cap) return fail(AHIP_E_CAP, "output buffer too small");
+    if (produced) HIP_TRY(hipMemcpy(out, dout.p, produced, hipMemcpyDeviceToHost));
+  }
+  return rc;
+}
+
+int32_t ahip_zlib_decode(const uint8_t *in, size_t in_len, int32_t verify, int32_t raw, uint8_t *out, size_t out_cap,
+                         size_t *out_len) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  int32_t rc = ensure_init();
+  if (rc != AHIP_OK) return rc;
+  static DevBuf din, dout;
+  HIP_TRY(din.reserve(in_len + 16));
+  if (in_len) HIP_TRY(hipMemcpy(din.p, in, in_len, hipMemcpyHostToDevice));
+  u64 committed = 0;
+  rc = zlib_stream_device(in, din.as<u8>(), in_len, 0, true, verify, raw, dout, &committed, nullptr);
+  if (out_len) *out_len = committed;
+  if (rc == AHIP_OK || rc == AHIP_FALSE) {
+    if (committed > out_cap) return fail(AHIP_E_CAP, "output buffer too small");
+    if (committed) HIP_TRY(hipMemcpy(out, dout.p, committed, hipMemcpyDeviceToHost));
+  }
+  return rc;
+}
+
+int32_t ahip_inflate_raw(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap, size_t *out_len,
+                         size_t *consumed) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  int32_t rc = ensure_init();
+  if (rc != AHIP_OK) return rc;
+  static DevBuf din, dout;
+  HIP_TRY(din.reserve(in_len + 16));
+  if (in_len) HIP_TRY(hipMemcpy(din.p, in, in_len, hipMemcpyHostToDevice));
+  MemberResult r{};
+  rc = inflate_one(din.as<u8>(), in_len, 0, nullptr, ~0ull, false, &r, nullptr);
+  if (rc != AHIP_OK) return rc;
+  if (out_len) *out_len = r.out_len;
+  if (consumed) *consumed = r.end_pos;
+  int32_t st = member_status_to_abi(r.status);
+  if (st < 0 || st == AHIP_RANGE || st == AHIP_HANG) return st;
+  if (r.out_len > out_cap) return fail(AHIP_E_CAP, "output buffer too small");
+  if (r.out_len) {
+    HIP_TRY(dout.reserve(r.out_len));
+    MemberResult r2{};
+    rc = inflate_one(din.as<u8>(), in_len, 0, dout.as<u8>(), r.out_len, true, &r2, nullptr);
+    if (rc != AHIP_OK) return rc;
+    if (r2.out_len != r.out_len) return fail(AHIP_E_DEVICE, "internal: decode disagrees with its own sizing run");
+    HIP_TRY(hipMemcpy(out, dout.p, r.out_len, hipMemcpyDeviceToHost));
+  }
+  return st;
+}
+
+}  // extern "C"

@@ -1,0 +1,325 @@
+// gzip_index.hpp -- device-side member index for multi-member gzip.
+//
+// The reference discovers member boundaries serially, by inflating each member
+// (codecs/zlib/_gzip_decoder_web.dart:27-58).  To shard members over wavefronts (and GPUs)
+// the boundaries have to be known up front, so this builds them on the GPU:
+//
+//   1. gz_count_candidates / gz_write_candidates : every byte position holding `1f 8b 08`
+//      (ID1 ID2 CM, _gzip_decoder_web.dart:99-109) becomes a candidate, in position order.
+//   2. gz_parse_headers : the reference's _readHeader (:60-138) per candidate.  A BGZF-style
+//      `BC` FEXTRA subfield (skipped by the reference, :119-122) yields the member size, so
+//      next member = pos + BSIZE + 1 and ISIZE = u32 at next-4.
+//   3. candidates without `BC`: a sizing run of the inflate kernel (no stores) yields the
+//      true end position and size of every candidate.
+//   4. gz_chain : the member chain is the orbit of position 0 under `next`; false candidates
+//      (the magic inside compressed data) are not on it.  Pointer doubling + scans give the
+//      ordered member list and each member's output offset.
+#pragma once
+#include "common.hpp"
+
+namespace ahip {
+
+constexpr u32 TILE_BYTES = 4096;  // 256 threads x 16 bytes
+constexpr u64 POS_UNKNOWN = ~0ull;
+
+constexpr u32 HF_BC = 1;     // size known from the BC subfield
+constexpr u32 HF_RANGE = 2;  // header runs past the end of the input: RangeError in the reference
+constexpr u32 HF_SIZED = 4;  // next_pos/size come from a sizing run
+
+struct GzHeader {
+  u64 payload_off;  // first DEFLATE byte
+  u64 next_pos;     // position after the 8-byte trailer (POS_UNKNOWN until sized)
+  u64 size;         // decoded size (ISIZE when HF_BC, else from the sizing run)
+  u32 flags;
+  u32 status;       // expected MS_* of the member (MS_OK for BC members)
+};
+
+struct ChainSummary {
+  u64 members;       // members on the chain
+  u64 total_out;     // sum of their sizes
+  u64 payload_bytes; // sum of (next_pos - pos) over the chain = compressed bytes incl. framing
+  u64 tail_pos;      // stream position where the chain stopped (== in_len when it consumed everything)
+  u32 first_is_gzip; // candidate 0 sits at the start position
+  u32 range_error;   // a header or trailer on the chain runs past the end
+  u32 unknown;       // candidates whose size is not known yet (valid after gz_parse_headers)
+  u32 pad;
+};
+
+// 16-bit mask of candidate positions base+0 .. base+15
+AHIP_DEVINL u32 candidate_mask16(const u8 *in, u64 n, u64 base) {
+  if (base >= n) return 0;
+  u64 w0, w1;
+  u32 w2;
+  if (base + 20 <= n) {
+    w0 = load_u64_unaligned(in + base);
+    w1 = load_u64_unaligned(in + base + 8);
+    w2 = load_u32_unaligned(in + base + 16);
+  } else {
+    u8 t[20];
+    for (int k = 0; k < 20; ++k) t[k] = (base + k < n) ? in[base + k] : 0;
+    w0 = w1 = 0; w2 = 0;
+    for (int k = 0; k < 8; ++k) { w0 |= (u64)t[k] << (8 * k); w1 |= (u64)t[8 + k] << (8 * k); }
+    for (int k = 0; k < 4; ++k) w2 |= (u32)t[16 + k] << (8 * k);
+  }
+  u32 mask = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    u32 v;
+    if (k < 6) v = (u32)(w0 >> (8 * k));
+    else if (k < 8) v = (u32)((w0 >> (8 * k)) | (w1 << (64 - 8 * k)));
+    else if (k < 14) v = (u32)(w1 >> (8 * (k - 8)));
+    else v = (u32)((w1 >> (8 * (k - 8))) | ((u64)w2 << (64 - 8 * (k - 8))));
+    if ((v & 0xffffff) == 0x088b1f && base + k + 3 <= n) mask |= 1u << k;
+  }
+  return mask;
+}
+
+AHIP_DEVINL u32 block_reduce_add_256(u32 v, u32 *sm) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) sm[w] = v;
+  __syncthreads();
+  u32 t = sm[0] + sm[1] + sm[2] + sm[3];
+  __syncthreads();
+  return t;
+}
+
+__global__ __launch_bounds__(256) void gz_count_candidates(const u8 *in, u64 start, u64 n, u32 *tile_counts) {
+  __shared__ u32 sm[4];
+  u64 base = start + (u64)blockIdx.x * TILE_BYTES + threadIdx.x * 16;
+  u32 c = __popc(candidate_mask16(in, n, base));
+  u32 t = block_reduce_add_256(c, sm);
+  if (threadIdx.x == 0) tile_counts[blockIdx.x] = t;
+}
+
+// Exclusive scan of `num` u32 values by ONE workgroup of 1024 threads; total to *total.
+__global__ __launch_bounds__(1024) void scan_exclusive_u32(const u32 *in, u32 *out, u64 num, u32 *total) {
+  __shared__ u32 wsum[16];
+  __shared__ u32 carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (u64 base = 0; base < num; base += 1024) {
+    u64 i = base + threadIdx.x;
+    u32 v = (i < num) ? in[i] : 0;
+    u32 x = v;
+    for (int o = 1; o < 64; o <<= 1) { u32 y = __shfl_up(x, o); if (lane >= o) x += y; }
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    u32 woff = 0;
+    for (int k = 0; k < w; ++k) woff += wsum[k];
+    u32 carry = carry_s;
+    if (i < num) out[i] = carry + woff + x - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = carry + woff + x;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = carry_s;
+}
+
+__global__ __launch_bounds__(256) void gz_write_candidates(const u8 *in, u64 start, u64 n, const u32 *tile_counts,
+                                                           const u32 *tile_offsets, u64 *cand_pos) {
+  if (tile_counts[blockIdx.x] == 0) return;  // uniform per block
+  __shared__ u32 wsum[4];
+  u64 base = start + (u64)blockIdx.x * TILE_BYTES + threadIdx.x * 16;
+  u32 mask = candidate_mask16(in, n, base);
+  u32 c = __popc(mask), x = c;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int o = 1; o < 64; o <<= 1) { u32 y = __shfl_up(x, o); if (lane >= o) x += y; }
+  if (lane == 63) wsum[w] = x;
+  __syncthreads();
+  u32 off = tile_offsets[blockIdx.x] + x - c;
+  for (int k = 0; k < w; ++k) off += wsum[k];
+  while (mask) {
+    int k = __ffs(mask) - 1;
+    mask &= mask - 1;
+    cand_pos[off++] = base + k;
+  }
+}
+
+// _GZipDecoder._readHeader for one candidate (signature and CM already matched)
+__global__ __launch_bounds__(256) void gz_parse_headers(const u8 *in, u64 n, const u64 *cand_pos, u32 K,
+                                                        GzHeader *hdr, ChainSummary *sum) {
+  u32 i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= K) return;
+  u64 p = cand_pos[i];
+  GzHeader h;
+  h.payload_off = 0; h.next_pos = POS_UNKNOWN; h.size = 0; h.flags = 0; h.status = MS_OK;
+  bool range = false;
+  u64 q = p + 3;
+  u32 flags = 0;
+  if (q < n) flags = in[q]; else range = true;
+  q = p + 10;  // flags, mtime(4), xfl, os
+  if (q > n) range = true;
+  u64 bc_next = POS_UNKNOWN;
+  if (!range && (flags & 0x04)) {
+    if (q + 2 > n) range = true;
+    else {
+      u32 xlen = in[q] | ((u32)in[q + 1] << 8);
+      q += 2;
+      u64 xend = q + xlen;
+      if (xend > n) xend = n;  // readBytes clamps
+      // look for SI1='B' SI2='C' SLEN=2 (BGZF); the reference skips the whole field
+      u64 s = q;
+      while (s + 4 <= xend) {
+        u32 slen = in[s + 2] | ((u32)in[s + 3] << 8);
+        if (in[s] == 66 && in[s + 1] == 67 && slen == 2 && s + 6 <= xend) {
+          u32 bsize = in[s + 4] | ((u32)in[s + 5] << 8);
+          bc_next = p + bsize + 1;
+          break;
+        }
+        s += 4 + slen;
+      }
+      q = xend;
+    }
+  }
+  if (!range && (flags & 0x08)) { while (q < n) { if (in[q++] == 0) break; } }
+  if (!range && (flags & 0x10)) { while (q < n) { if (in[q++] == 0) break; } }
+  if (!range && (flags & 0x02)) { if (q + 2 > n) range = true; else q += 2; }
+  h.payload_off = q;
+  if (range) {
+    h.flags |= HF_RANGE;
+    h.next_pos = n;
+  } else if (bc_next != POS_UNKNOWN && bc_next <= n && bc_next >= q + 8) {
+    h.flags |= HF_BC;
+    h.next_pos = bc_next;
+    h.size = load_u32_unaligned(in + bc_next - 4);  // ISIZE
+  } else {
+    atomicAdd(&sum->unknown, 1u);
+  }
+  hdr[i] = h;
+}
+
+// Sizing run plumbing: one MemberDesc per candidate, then fold the results back.
+__global__ __launch_bounds__(256) void gz_make_sizing_descs(const GzHeader *hdr, u32 K, MemberDesc *descs) {
+  u32 i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= K) return;
+  MemberDesc d;
+  d.in_off = hdr[i].payload_off;
+  d.out_off = 0;
+  d.out_limit = ~0ull;
+  d.expect_end = POS_UNKNOWN;
+  descs[i] = d;
+}
+__global__ __launch_bounds__(256) void gz_apply_sizing(GzHeader *hdr, u32 K, const MemberResult *res, u64 n) {
+  u32 i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= K) return;
+  GzHeader h = hdr[i];
+  if (h.flags & HF_RANGE) return;
+  MemberResult r = res[i];
+  h.flags = (h.flags & ~HF_BC) | HF_SIZED;
+  h.size = r.out_len;
+  h.status = r.status;
+  h.next_pos = r.end_pos + 8;  // CRC32 + ISIZE are read unconditionally (:40-41)
+  if (h.next_pos > n) { h.flags |= HF_RANGE; h.next_pos = n; }
+  hdr[i] = h;
+}
+
+// Member chain from `start`, ONE workgroup of 1024 threads.
+//   nxt/jmp/jmp2/reach: scratch arrays of K+1 u32.
+__global__ __launch_bounds__(1024) void gz_chain(const u64 *cand_pos, const GzHeader *hdr, u32 K, u64 start, u64 n,
+                                                 u32 *nxt, u32 *jmp, u32 *jmp2, u32 *reach, MemberDesc *members,
+                                                 u32 *expect_status, ChainSummary *sum) {
+  const u32 tid = threadIdx.x;
+  __shared__ u64 wsum_a[16], wsum_b[16], wsum_c[16];
+  __shared__ u64 carry_a, carry_b, carry_c;
+  const bool first_ok = K > 0 && cand_pos[0] == start;
+  // A: successor index of every candidate
+  for (u32 i = tid; i < K; i += 1024) {
+    u64 np = hdr[i].next_pos;
+    u32 j = K;
+    if (!(hdr[i].flags & HF_RANGE) && np < n) {
+      u32 lo = i + 1, hi = K;  // candidates are sorted; next_pos > pos
+      while (lo < hi) { u32 mid = (lo + hi) >> 1; if (cand_pos[mid] < np) lo = mid + 1; else hi = mid; }
+      if (lo < K && cand_pos[lo] == np) j = lo;
+    }
+    nxt[i] = j;
+    jmp[i] = j;
+    reach[i] = (i == 0 && first_ok) ? 1u : 0u;
+  }
+  if (tid == 0) { nxt[K] = K; jmp[K] = K; jmp2[K] = K; reach[K] = 0; }
+  __syncthreads();
+  // B: reachability by pointer doubling
+  u32 *ja = jmp, *jb = jmp2;
+  for (u64 span = 1; span < (u64)K; span <<= 1) {
+    for (u32 i = tid; i < K; i += 1024) {
+      u32 j = ja[i];
+      if (reach[i] && j < K) reach[j] = 1;
+      jb[i] = (j < K) ? ja[j] : K;
+    }
+    __syncthreads();
+    u32 *t = ja; ja = jb; jb = t;
+  }
+  // C: ordered member list + output offsets (exclusive scans over the reach flags)
+  if (tid == 0) { carry_a = 0; carry_b = 0; carry_c = 0; }
+  __syncthreads();
+  const int lane = tid & 63, w = tid >> 6;
+  u64 tail = start;
+  u32 range_err = 0;
+  for (u32 base = 0; base < K; base += 1024) {
+    u32 i = base + tid;
+    bool on = i < K && reach[i];
+    GzHeader h;
+    if (on) h = hdr[i];
+    u64 a = on ? 1 : 0, b = on ? h.size : 0, c = on ? (h.next_pos - cand_pos[i]) : 0;
+    u64 xa = a, xb = b, xc = c;
+    for (int o = 1; o < 64; o <<= 1) {
+      u64 ya = __shfl_up(xa, o), yb = __shfl_up(xb, o), yc = __shfl_up(xc, o);
+      if (lane >= o) { xa += ya; xb += yb; xc += yc; }
+    }
+    if (lane == 63) { wsum_a[w] = xa; wsum_b[w] = xb; wsum_c[w] = xc; }
+    __syncthreads();
+    u64 oa = carry_a, ob = carry_b, oc = carry_c;
+    for (int k = 0; k < w; ++k) { oa += wsum_a[k]; ob += wsum_b[k]; oc += wsum_c[k]; }
+    if (on) {
+      u64 m = oa + xa - a;
+      MemberDesc d;
+      d.in_off = h.payload_off;
+      d.out_off = ob + xb - b;
+      d.out_limit = h.size;
+      d.expect_end = (h.flags & HF_RANGE) ? POS_UNKNOWN : h.next_pos - 8;
+      members[m] = d;
+      expect_status[m] = h.status;
+      if (nxt[i] == K) {  // last member of the chain
+        sum->tail_pos = h.next_pos;
+      }
+      if (h.flags & HF_RANGE) atomicOr(&sum->range_error, 1u);
+    }
+    __syncthreads();
+    if (tid == 1023) { carry_a = oa + xa; carry_b = ob + xb; carry_c = oc + xc; }
+    __syncthreads();
+  }
+  (void)tail; (void)range_err;
+  if (tid == 0) {
+    sum->members = carry_a;
+    sum->total_out = carry_b;
+    sum->payload_bytes = carry_c;
+    sum->first_is_gzip = first_ok ? 1u : 0u;
+    if (!first_ok) sum->tail_pos = start;
+  }
+}
+
+// Post-decode check of the trusted (BC/ISIZE) index and of per-member verdicts.
+struct RunSummary {
+  u32 mismatches;   // members whose size / end position / status differ from the index
+  u32 worst_status; // max MS_* over members (MS_OK.. order is by severity for 0..3)
+  u32 first_bad;    // index of the first mismatching member
+  u32 any_range, any_hang, any_farref, any_oversub, any_false;
+};
+__global__ __launch_bounds__(256) void gz_verify(const MemberDesc *members, const u32 *expect_status,
+                                                 const MemberResult *res, u32 M, RunSummary *rs) {
+  u32 i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= M) return;
+  MemberResult r = res[i];
+  MemberDesc d = members[i];
+  bool bad = r.out_len != d.out_limit || r.status != expect_status[i] ||
+             (d.expect_end != POS_UNKNOWN && r.end_pos != d.expect_end);
+  if (bad) { atomicAdd(&rs->mismatches, 1u); atomicMin(&rs->first_bad, i); }
+  if (r.status == MS_RANGE) atomicOr(&rs->any_range, 1u);
+  if (r.status == MS_HANG) atomicOr(&rs->any_hang, 1u);
+  if (r.status == MS_FARREF) atomicOr(&rs->any_farref, i == 0 ? 2u : 1u);
+  if (r.status == MS_OVERSUB) atomicOr(&rs->any_oversub, 1u);
+  if (r.status == MS_FALSE || r.status == MS_EOS) atomicOr(&rs->any_false, 1u);
+}
+
+}  // namespace ahip

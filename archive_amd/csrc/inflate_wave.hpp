@@ -1,0 +1,446 @@
+// inflate_wave.hpp -- one wave64 inflates one DEFLATE stream ("member").
+//
+// Reproduces, bit for bit on valid streams and on the documented malformed cases, the
+// reference's pure-Dart decoder (all paths relative to /root/reference/lib/src):
+//   codecs/zlib/inflate.dart:104-156   _inflate/_parseBlock          -> inflate_member()
+//   codecs/zlib/inflate.dart:159-211   _readBits/_readCodeByTable    -> BitCursor + table lookup
+//   codecs/zlib/inflate.dart:213-234   _parseUncompressedBlock       -> stored_block()
+//   codecs/zlib/inflate.dart:239-298   _parseDynamicHuffmanBlock     -> dynamic_header()
+//   codecs/zlib/inflate.dart:300-343   _decodeHuffman                -> huffman_block()
+//   codecs/zlib/inflate.dart:345-401   _decode                       -> dynamic_header()
+//   codecs/zlib/_huffman_table.dart:9-46  HuffmanTable               -> build_decode_table()
+//   util/output_memory_stream.dart:79-98  writeBackReference         -> lz_copy()
+//
+// The reference keeps one 2^maxCodeLength-entry table per code (up to 128 KiB); here each code
+// is a root-bits primary table in LDS plus a canonical (first-code / count / sorted-symbol)
+// search for the rare longer codes.  Both give the same (symbol, length) for every bit pattern
+// of a non-over-subscribed code, including the "unfilled entry = symbol 0, length 0" behaviour
+// of incomplete codes.
+//
+// Stream position model: the reference's byte-at-a-time accumulator is replaced by an absolute
+// bit cursor.  _readBits(n) fails iff cursor+n > 8*len; _readCodeByTable fails iff
+// cursor+maxCodeLength > 8*len (quirk q2); at block ends the reference un-reads whole bytes, so
+// its InputStream position is ceil(cursor/8).
+#pragma once
+#include "common.hpp"
+
+namespace ahip {
+
+// ---- decode-table entry ----
+//  bits 0-3  code length, bits 4-7 extra-bit count, bits 8-12 flags, bits 16-31 value
+constexpr u32 E_LIT = 0x100;   // value = literal byte
+constexpr u32 E_EOB = 0x200;   // end of block (symbol 256)
+constexpr u32 E_BAD = 0x400;   // litlen 286/287, distance 30/31: reference returns -1
+constexpr u32 E_LONG = 0x800;  // code longer than the primary table: canonical search
+constexpr u32 E_HOLE = 0x1000; // unfilled litlen entry (symbol 0, length 0): literal-0 forever
+
+constexpr int LL_ROOT = 10;
+constexpr int D_ROOT = 8;
+
+AHIP_DEVINL u32 litlen_entry(u32 sym, u32 len) {
+  if (sym < 256) return (sym << 16) | E_LIT | len;
+  if (sym == 256) return E_EOB | len;
+  if (sym > 285) return E_BAD | len;
+  u32 i = sym - 257;
+  u32 xb = (i < 8 || i == 28) ? 0u : ((i - 4) >> 2);
+  u32 base = (i < 8) ? (3 + i) : (i == 28 ? 258u : (3 + ((4 + (i & 3)) << xb)));
+  return (base << 16) | (xb << 4) | len;
+}
+AHIP_DEVINL u32 dist_entry(u32 sym, u32 len) {
+  if (sym > 29) return E_BAD | len;
+  u32 xb = (sym < 4) ? 0u : ((sym - 2) >> 1);
+  u32 base = (sym < 4) ? (sym + 1) : (1 + ((2 + (sym & 1)) << xb));
+  return (base << 16) | (xb << 4) | len;
+}
+
+// Canonical description of one Huffman code, kept in LDS next to its primary table.
+struct CodeDesc {
+  u16 count[16];   // symbols per code length
+  u16 first[16];   // first canonical code of each length
+  u16 offset[16];  // index of the first symbol of each length in sorted[]
+  u32 maxlen;      // reference HuffmanTable.maxCodeLength
+  u32 pad;
+};
+
+struct WaveLds {
+  u32 ll[1 << LL_ROOT];
+  u32 dt[1 << D_ROOT];
+  u32 cl[128];        // code-length code: single level, built exactly like the reference
+  CodeDesc lld, dd;
+  u16 ll_sorted[288];
+  u16 d_sorted[32];
+  u8 lens[320 + 8];
+};
+
+struct BitCursor {
+  const u8 *in;
+  u64 in_len;
+  u64 total_bits;
+  u64 pos;  // absolute bit index
+};
+
+// >= 57 valid bits starting at the cursor; bytes past the end read as zero.
+AHIP_DEVINL u64 peek_bits(const BitCursor &b) {
+  u64 byte = b.pos >> 3;
+  u32 sh = (u32)b.pos & 7;
+  u64 w;
+  if (byte + 8 <= b.in_len) {
+    w = load_u64_unaligned(b.in + byte);
+  } else {
+    w = 0;
+    for (int k = 0; k < 8; ++k)
+      if (byte + k < b.in_len) w |= (u64)b.in[byte + k] << (8 * k);
+  }
+  return w >> sh;
+}
+// _readBits: -1 when fewer than n bits are left, 0 for n == 0
+AHIP_DEVINL int read_bits(BitCursor &b, u32 n) {
+  if (n == 0) return 0;
+  if (b.pos + n > b.total_bits) return -1;
+  u32 v = (u32)peek_bits(b) & ((1u << n) - 1);
+  b.pos += n;
+  return (int)v;
+}
+
+// Resolve a bit pattern against the canonical description (codes longer than `root`).
+template <bool IS_DIST>
+AHIP_DEVINL u32 long_lookup(const CodeDesc &cd, const u16 *sorted, u32 bits, int root) {
+  u32 rev = __brev(bits);
+  u32 maxlen = cd.maxlen;
+  for (u32 L = root + 1; L <= maxlen; ++L) {
+    u32 code = rev >> (32 - L);
+    u32 idx = code - cd.first[L];
+    if (idx < cd.count[L]) {
+      u32 sym = sorted[cd.offset[L] + idx];
+      return IS_DIST ? dist_entry(sym, L) : litlen_entry(sym, L);
+    }
+  }
+  return IS_DIST ? dist_entry(0, 0) : E_HOLE;  // unfilled entry: symbol 0, length 0
+}
+
+// Build primary table + canonical description from `n` code lengths in LDS (wave-cooperative).
+// Returns false for an over-subscribed set (not reproduced).
+template <bool IS_DIST>
+AHIP_DEVINL bool build_decode_table(const u8 *lens, int n, u32 *primary, int root, CodeDesc &cd, u16 *sorted,
+                                    int lane) {
+  constexpr int CHUNKS = IS_DIST ? 1 : 5;
+  u32 mylen[CHUNKS], myrank[CHUNKS];
+  u32 cnt[16];
+#pragma unroll
+  for (int L = 0; L < 16; ++L) cnt[L] = 0;
+  const u64 lt_mask = (1ull << lane) - 1;
+#pragma unroll
+  for (int c = 0; c < CHUNKS; ++c) {
+    int s = c * 64 + lane;
+    u32 l = (s < n) ? lens[s] : 0u;
+    mylen[c] = l;
+    u32 r = 0;
+#pragma unroll
+    for (int L = 1; L < 16; ++L) {
+      u64 m = __ballot(l == (u32)L);
+      if (l == (u32)L) r = cnt[L] + __popcll(m & lt_mask);
+      cnt[L] += __popcll(m);
+    }
+    myrank[c] = r;
+  }
+  // canonical first codes / offsets (uniform)
+  u32 code = 0, off = 0, maxlen = 0;
+  bool over = false;
+  u32 first[16], offs[16];
+  first[0] = 0; offs[0] = 0;
+#pragma unroll
+  for (int L = 1; L < 16; ++L) {
+    first[L] = code;
+    offs[L] = off;
+    if (cnt[L]) maxlen = L;
+    if (code + cnt[L] > (1u << L)) over = true;
+    code = (code + cnt[L]) << 1;
+    off += cnt[L];
+  }
+  if (lane < 16) {
+    u32 c = 0, f = 0, o = 0;
+#pragma unroll
+    for (int L = 0; L < 16; ++L)
+      if (lane == L) { c = cnt[L]; f = first[L]; o = offs[L]; }
+    cd.count[lane] = (u16)c;
+    cd.first[lane] = (u16)f;
+    cd.offset[lane] = (u16)o;
+  }
+  if (lane == 0) cd.maxlen = maxlen;
+  // default fill
+  const u32 hole = ((int)maxlen > root) ? E_LONG : (IS_DIST ? dist_entry(0, 0) : E_HOLE);
+  for (int i = lane; i < (1 << root); i += 64) primary[i] = hole;
+  wave_sync();
+  // symbols -> sorted[] and primary entries
+#pragma unroll
+  for (int c = 0; c < CHUNKS; ++c) {
+    u32 l = mylen[c];
+    if (l) {
+      u32 s = c * 64 + lane;
+      u32 cde = cd.first[l] + myrank[c];
+      sorted[cd.offset[l] + myrank[c]] = (u16)s;
+      if ((int)l <= root) {
+        u32 rev = __brev(cde) >> (32 - l);
+        u32 e = IS_DIST ? dist_entry(s, l) : litlen_entry(s, l);
+        for (u32 j = rev; j < (1u << root); j += (1u << l)) primary[j] = e;
+      }
+    }
+  }
+  wave_sync();
+  return !over;
+}
+
+// Fixed-Huffman code lengths (inflate.dart:408-735): 144x8, 112x9, 24x7, 8x8; 30 distance codes of 5.
+AHIP_DEVINL void fixed_lengths(u8 *lens, int lane) {
+  for (int s = lane; s < 288; s += 64) lens[s] = (s < 144) ? 8 : (s < 256) ? 9 : (s < 280) ? 7 : 8;
+  if (lane < 30) lens[288 + lane] = 5;
+  wave_sync();
+}
+
+struct OutCursor {
+  u8 *base;   // member's output window
+  u64 pos;    // bytes produced
+  u64 limit;  // window size
+};
+
+// writeBackReference(distance, count): every lane copies bytes lane, lane+64, ...
+// All sources lie in [pos-dist, pos), i.e. bytes that existed before this call.
+template <bool WRITE>
+AHIP_DEVINL void lz_copy(OutCursor &o, u32 dist, u32 len, int lane) {
+  if (WRITE) {
+    u8 *dst = o.base + o.pos;
+    const u8 *src = dst - dist;
+    if (dist >= len) {
+      for (u32 i = lane; i < len; i += 64) dst[i] = src[i];
+    } else {
+      for (u32 i = lane; i < len; i += 64) dst[i] = src[i % dist];
+    }
+  }
+  o.pos += len;
+}
+
+// One literal/length(+distance) token.  Returns 0 = continue, 1 = end of block, else MS_* + 100.
+template <bool WRITE, bool CAREFUL>
+AHIP_DEVINL u32 huffman_token(WaveLds &L, BitCursor &b, OutCursor &o, u32 ll_max, u32 d_max, int lane) {
+  if (CAREFUL && b.pos + ll_max > b.total_bits) return 100 + MS_FALSE_EOS;
+  u64 w = peek_bits(b);
+  u32 e = uniform(L.ll[(u32)w & ((1u << LL_ROOT) - 1)]);
+  if (e & E_LONG) e = uniform(long_lookup<false>(L.lld, L.ll_sorted, (u32)w, LL_ROOT));
+  u32 cl = e & 15;
+  if (e & (E_LIT | E_EOB | E_BAD | E_HOLE)) {
+    if (e & E_LIT) {
+      if (o.pos >= o.limit) return 100 + MS_CAP;
+      if (WRITE && lane == 0) o.base[o.pos] = (u8)(e >> 16);
+      o.pos += 1;
+      b.pos += cl;
+      return 0;
+    }
+    if (e & E_EOB) { b.pos += cl; return 1; }
+    if (e & E_BAD) return 100 + MS_FALSE;
+    return 100 + MS_HANG;
+  }
+  // length symbol
+  u32 used = cl;
+  w >>= cl;
+  u32 xb = (e >> 4) & 15;
+  i32 len = (i32)(e >> 16);
+  if (CAREFUL && xb && b.pos + used + xb > b.total_bits) {
+    len -= 1;  // _readBits returned -1 and the reference adds it (inflate.dart:322)
+  } else {
+    len += (i32)((u32)w & ((1u << xb) - 1));
+    w >>= xb;
+    used += xb;
+  }
+  if (CAREFUL && b.pos + used + d_max > b.total_bits) return 100 + MS_FALSE_EOS;
+  u32 d = uniform(L.dt[(u32)w & ((1u << D_ROOT) - 1)]);
+  if (d & E_LONG) d = uniform(long_lookup<true>(L.dd, L.d_sorted, (u32)w, D_ROOT));
+  if (d & E_BAD) return 100 + MS_FALSE;
+  u32 dl = d & 15;
+  w >>= dl;
+  used += dl;
+  u32 dxb = (d >> 4) & 15;
+  i32 dist = (i32)(d >> 16);
+  if (CAREFUL && dxb && b.pos + used + dxb > b.total_bits) {
+    dist -= 1;
+  } else {
+    dist += (i32)((u32)w & ((1u << dxb) - 1));
+    used += dxb;
+  }
+  b.pos += used;
+  if ((u64)dist > o.pos) return 100 + MS_FARREF;
+  if (o.pos + (u64)len > o.limit) return 100 + MS_CAP;
+  lz_copy<WRITE>(o, (u32)dist, (u32)len, lane);
+  return 0;
+}
+
+template <bool WRITE>
+AHIP_DEVINL u32 huffman_block(WaveLds &L, BitCursor &b, OutCursor &o, int lane) {
+  const u32 ll_max = L.lld.maxlen, d_max = L.dd.maxlen;
+  for (;;) {
+    u32 r;
+    // 16 readable bytes ahead: every EOS test of the careful path is trivially false
+    if ((b.pos >> 3) + 16 <= b.in_len) r = huffman_token<WRITE, false>(L, b, o, ll_max, d_max, lane);
+    else r = huffman_token<WRITE, true>(L, b, o, ll_max, d_max, lane);
+    if (r == 0) continue;
+    if (r == 1) return MS_OK;
+    return r - 100;
+  }
+}
+
+// _parseUncompressedBlock
+template <bool WRITE>
+AHIP_DEVINL u32 stored_block(BitCursor &b, OutCursor &o, int lane) {
+  b.pos = (b.pos + 7) & ~7ull;  // the accumulator is dropped; it never holds a whole byte here
+  int len = read_bits(b, 16);
+  int nlen_raw = read_bits(b, 16);
+  int nlen = nlen_raw ^ 0xffff;
+  if (len != 0 && len != nlen) return (len < 0 || nlen_raw < 0) ? MS_FALSE_EOS : MS_FALSE;
+  u64 byte = b.pos >> 3;
+  if ((u64)len > b.in_len - byte) return MS_FALSE;
+  if (o.pos + (u64)len > o.limit) return MS_CAP;
+  if (WRITE) {
+    const u8 *src = b.in + byte;
+    u8 *dst = o.base + o.pos;
+    for (int i = lane; i < len; i += 64) dst[i] = src[i];
+  }
+  o.pos += (u64)len;
+  b.pos += 8ull * (u64)len;
+  return MS_OK;
+}
+
+// _parseDynamicHuffmanBlock header + _decode; leaves litlen/dist lengths in L.lens
+AHIP_DEVINL u32 dynamic_header(WaveLds &L, BitCursor &b, int lane, int &hlit_out, int &hdist_out) {
+  int hlit = read_bits(b, 5);
+  if (hlit < 0) return MS_FALSE_EOS;
+  hlit += 257;
+  if (hlit > 288) return MS_FALSE;
+  int hdist = read_bits(b, 5);
+  if (hdist < 0) return MS_FALSE_EOS;
+  hdist += 1;
+  if (hdist > 32) return MS_FALSE;
+  int hclen = read_bits(b, 4);
+  if (hclen < 0) return MS_FALSE_EOS;
+  hclen += 4;
+  if (hclen > 19) return MS_FALSE;
+  // code-length code lengths, in the permuted order 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
+  // (inflate.dart:738-758)
+  u32 cl_len[19];
+#pragma unroll
+  for (int i = 0; i < 19; ++i) cl_len[i] = 0;
+  const u8 order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+#pragma unroll
+  for (int i = 0; i < 19; ++i) {
+    if (i < hclen) {
+      int v = read_bits(b, 3);
+      if (v < 0) return MS_FALSE_EOS;
+      cl_len[order[i]] = (u32)v;
+    }
+  }
+  // HuffmanTable(codeLengths): single level, same fill order as the reference (serial, lane 0)
+  u32 cl_max = 0;
+#pragma unroll
+  for (int i = 0; i < 19; ++i) cl_max = cl_len[i] > cl_max ? cl_len[i] : cl_max;
+  const u32 cl_size = 1u << cl_max;
+  for (u32 i = lane; i < 128; i += 64) L.cl[i] = 0;
+  wave_sync();
+  if (lane == 0) {
+    u32 code = 0, skip = 2;
+    for (u32 bl = 1; bl <= cl_max; ++bl) {
+#pragma unroll
+      for (int i = 0; i < 19; ++i) {
+        if (cl_len[i] == bl) {
+          u32 rev = __brev(code) >> (32 - bl);
+          for (u32 j = rev; j < cl_size; j += skip) L.cl[j] = (bl << 16) | (u32)i;
+          ++code;
+        }
+      }
+      code <<= 1;
+      skip <<= 1;
+    }
+  }
+  wave_sync();
+  // _decode: run-length coded lengths
+  const int num = hlit + hdist;
+  int i = 0;
+  u32 prev = 0;
+  while (i < num) {
+    if (b.pos + cl_max > b.total_bits) return MS_FALSE_EOS;
+    u32 e = uniform(L.cl[(u32)peek_bits(b) & (cl_size - 1)]);
+    b.pos += e >> 16;
+    u32 code = e & 0xffff;
+    int repeat;
+    u32 fill;
+    if (code < 16) {
+      repeat = 1; fill = code; prev = code;
+    } else if (code == 16) {
+      repeat = read_bits(b, 2);
+      if (repeat < 0) return MS_FALSE_EOS;
+      repeat += 3; fill = prev;
+    } else if (code == 17) {
+      repeat = read_bits(b, 3);
+      if (repeat < 0) return MS_FALSE_EOS;
+      repeat += 3; fill = 0; prev = 0;
+    } else {
+      repeat = read_bits(b, 7);
+      if (repeat < 0) return MS_FALSE_EOS;
+      repeat += 11; fill = 0; prev = 0;
+    }
+    if (i + repeat > num) return MS_RANGE;  // Dart: index past the end of the Uint8List
+    if (lane < repeat) L.lens[i + lane] = (u8)fill;
+    if (lane + 64 < repeat) L.lens[i + lane + 64] = (u8)fill;
+    if (lane + 128 < repeat) L.lens[i + lane + 128] = (u8)fill;
+    i += repeat;
+  }
+  wave_sync();
+  hlit_out = hlit;
+  hdist_out = hdist;
+  return MS_OK;
+}
+
+// Inflate one stream.  Mirrors Inflate._inflate(): loop blocks until BFINAL, an error, or EOS.
+template <bool WRITE>
+AHIP_DEVINL void inflate_member(WaveLds &L, const u8 *in, u64 in_len, const MemberDesc &m, u8 *out,
+                                MemberResult &res, int lane) {
+  BitCursor b{in, in_len, in_len * 8, m.in_off * 8};
+  OutCursor o{out + m.out_off, 0, m.out_limit};
+  u32 status = MS_EOS, blocks = 0;
+  for (;;) {
+    if (((b.pos + 7) >> 3) >= in_len) { status = MS_EOS; break; }
+    int hdr = read_bits(b, 3);
+    ++blocks;
+    const bool final_block = hdr & 1;
+    const int btype = hdr >> 1;
+    u32 r;
+    if (btype == 0) {
+      r = stored_block<WRITE>(b, o, lane);
+    } else if (btype == 3) {
+      r = MS_FALSE;
+    } else {
+      int hlit = 288, hdist = 30;
+      r = MS_OK;
+      if (btype == 1) fixed_lengths(L.lens, lane);
+      else r = dynamic_header(L, b, lane, hlit, hdist);
+      if (r == MS_OK) {
+        bool ok = build_decode_table<false>(L.lens, hlit, L.ll, LL_ROOT, L.lld, L.ll_sorted, lane);
+        ok &= build_decode_table<true>(L.lens + hlit, hdist, L.dt, D_ROOT, L.dd, L.d_sorted, lane);
+        r = ok ? huffman_block<WRITE>(L, b, o, lane) : (u32)MS_OVERSUB;
+      }
+    }
+    if (r != MS_OK) { status = r; break; }
+    if (final_block) { status = MS_OK; break; }
+  }
+  if (lane == 0) {
+    // Position the reference's InputStream is left at.  Exact after a complete block
+    // (whole bytes are un-read) and after an end-of-input failure; after a bad-symbol failure
+    // in the middle of the input the reference has over-read by up to two bytes -- see
+    // DESIGN.md "deviations".
+    u64 end = (b.pos + 7) >> 3;
+    if (status == MS_FALSE_EOS) { end = in_len; status = MS_FALSE; }  // every byte was pulled into the accumulator
+    res.end_pos = end > in_len ? in_len : end;
+    res.out_len = o.pos;
+    res.status = status;
+    res.blocks = blocks;
+  }
+}
+
+}  // namespace ahip

@@ -1,0 +1,98 @@
+/*
+ * archive_hip.h -- C-ABI of libarchive_hip.so: the MI355X (gfx950) implementation of the
+ * Inflate/Deflate hot path of the Dart `archive` package (brendan-duncan/archive 4.2.0).
+ *
+ * This is the drop-in boundary: these are the entry points a dart:ffi binding (see
+ * INTEGRATION.md, dart/) or the Python host mirror (archive_amd/) binds.  Plain pointers and
+ * sizes only; no C++ exceptions cross it; the library never frees caller memory.
+ * All `ref:` citations are relative to /root/reference/lib/src/.
+ *
+ * Status codes (shared by every entry point that returns int32_t):
+ *    0  AHIP_OK      the reference's decodeStream returned true / Inflate reached a final block
+ *    1  AHIP_FALSE   the reference stopped early (its silent `return false` / `-1`); the bytes
+ *                    produced so far are in `out` exactly as the reference would have kept them
+ *    2  AHIP_RANGE   the reference would throw RangeError (read past the end of the buffer,
+ *                    back-reference before the start of the stream); no output is defined
+ *    3  AHIP_HANG    the reference would not terminate (zero-length litlen table entry)
+ *   -1  AHIP_E_CAP   `out` is too small; *out_len holds the required size
+ *   -2  AHIP_E_DEVICE no usable GPU / HIP runtime error (ahip_last_error() has the text)
+ *   -3  AHIP_E_UNSUPPORTED input uses a malformed construct this build does not reproduce
+ *                    (over-subscribed Huffman code, cross-member back-reference)
+ *   -4  AHIP_E_ARG   bad argument
+ */
+#ifndef ARCHIVE_HIP_H
+#define ARCHIVE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AHIP_OK 0
+#define AHIP_FALSE 1
+#define AHIP_RANGE 2
+#define AHIP_HANG 3
+#define AHIP_E_CAP (-1)
+#define AHIP_E_DEVICE (-2)
+#define AHIP_E_UNSUPPORTED (-3)
+#define AHIP_E_ARG (-4)
+
+/* ---- library lifetime ---- */
+/* Selects the HIP device for this process (one process per GPU).  device < 0 keeps the
+ * current device.  Returns AHIP_OK or AHIP_E_DEVICE.  Idempotent. */
+int32_t ahip_init(int32_t device);
+void ahip_shutdown(void);
+/* Text of the last AHIP_E_* error on this thread ("" if none).  Never NULL. */
+const char *ahip_last_error(void);
+/* ABI version of this header (major << 16 | minor). */
+uint32_t ahip_abi_version(void);
+
+/* ---- Inflate: host-pointer entry points (what dart:ffi binds) ---- */
+
+/* ref: codecs/zlib/inflate.dart:23-39,104-116  `Inflate(bytes).getBytes()`.
+ * Raw DEFLATE stream -> bytes.  *consumed = the reference InputStream position afterwards. */
+int32_t ahip_inflate_raw(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap,
+                         size_t *out_len, size_t *consumed);
+
+/* ref: codecs/zlib/_gzip_decoder_web.dart:19-58  `GZipDecoderWeb().decodeBytes(data, verify, raw)`.
+ * Multi-member gzip; CRC32/ISIZE are not verified (the reference ignores them); a non-gzip
+ * header falls through to the zlib decoder exactly as the reference does. */
+int32_t ahip_gzip_decode(const uint8_t *in, size_t in_len, int32_t verify, int32_t raw,
+                         uint8_t *out, size_t out_cap, size_t *out_len);
+
+/* ref: codecs/zlib/_zlib_decoder_web.dart:21-107  `ZLibDecoderWeb().decodeBytes(data, verify, raw)`.
+ * Multi-member zlib with the reference's deferred-flush behaviour; Adler-32 big-endian. */
+int32_t ahip_zlib_decode(const uint8_t *in, size_t in_len, int32_t verify, int32_t raw,
+                         uint8_t *out, size_t out_cap, size_t *out_len);
+
+/* ---- Inflate: device-resident entry points (bench, multi-GPU sharding, zero-copy callers) ----
+ * d_in / d_out are device pointers on the current HIP device; `stream` is a hipStream_t
+ * (NULL = the default stream).  The call enqueues all work on `stream` and synchronises it
+ * before returning (sizes come back to the host).  d_in must be readable for in_len bytes;
+ * d_out writable for out_cap bytes. */
+int32_t ahip_gzip_decode_device(const void *d_in, size_t in_len, void *d_out, size_t out_cap,
+                                size_t *out_len, void *stream);
+
+/* Plan/run split of the same path: the plan holds the member index (payload offsets, output
+ * offsets) in device memory, so repeated runs time only the decode (bench.py times run). */
+typedef struct ahip_gzip_plan ahip_gzip_plan;
+int32_t ahip_gzip_plan_create(const void *d_in, size_t in_len, void *stream, ahip_gzip_plan **plan);
+/* number of gzip members, total decoded size, total compressed payload bytes */
+int32_t ahip_gzip_plan_info(const ahip_gzip_plan *plan, uint64_t *members, uint64_t *out_bytes,
+                            uint64_t *payload_bytes);
+/* Decode every member of the plan into d_out (asynchronous on `stream`; no host sync). */
+int32_t ahip_gzip_plan_run(ahip_gzip_plan *plan, void *d_out, size_t out_cap, void *stream);
+/* After the stream is synchronised: per-run verdict (AHIP_OK / AHIP_FALSE / ...). */
+int32_t ahip_gzip_plan_status(ahip_gzip_plan *plan, size_t *out_len);
+void ahip_gzip_plan_destroy(ahip_gzip_plan *plan);
+
+/* ---- checksums (ref: util/crc32.dart:6-27, util/adler32.dart:29-52), chainable ---- */
+uint32_t ahip_crc32(const uint8_t *data, size_t len, uint32_t crc /* 0 to start */);
+uint32_t ahip_adler32(const uint8_t *data, size_t len, uint32_t adler /* 1 to start */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARCHIVE_HIP_H */

@@ -1,0 +1,94 @@
+"""ctypes loader for the CPU oracle (oracle/*_oracle.c) -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+The product package (archive_amd) never does.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_build", "liboracle.so")
+
+ORC_OK, ORC_FALSE, ORC_RANGE, ORC_HANG, ORC_CAP = 0, 1, 2, 3, -1
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith("_oracle.c")]
+    if (not force and os.path.exists(_LIB)
+            and all(os.path.getmtime(_LIB) >= os.path.getmtime(s) for s in srcs)):
+        return _LIB
+    subprocess.check_call(["make", "-s", "-C", _HERE, "-B"])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_LIB)
+        u8p, szp = ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)
+        L.orc_inflate_raw.argtypes = [u8p, ctypes.c_size_t, u8p, ctypes.c_size_t, szp, szp]
+        L.orc_gzip_decode.argtypes = [u8p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, u8p, ctypes.c_size_t, szp]
+        L.orc_zlib_decode.argtypes = [u8p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, u8p, ctypes.c_size_t, szp]
+        L.orc_crc32.argtypes = [u8p, ctypes.c_size_t, ctypes.c_uint32]
+        L.orc_crc32.restype = ctypes.c_uint32
+        L.orc_adler32.argtypes = [u8p, ctypes.c_size_t, ctypes.c_uint32]
+        L.orc_adler32.restype = ctypes.c_uint32
+        _lib = L
+    return _lib
+
+
+def _inbuf(data):
+    data = bytes(data)
+    return (ctypes.c_char * max(1, len(data))).from_buffer_copy(data or b"\0"), len(data)
+
+
+def _run(fn, data, pre, cap):
+    buf, n = _inbuf(data)
+    cap = cap if cap is not None else max(1 << 16, 8 * n)
+    while True:
+        out = ctypes.create_string_buffer(cap)
+        olen = ctypes.c_size_t(0)
+        st, extra = fn(buf, n, out, cap, olen, *pre)
+        if st != ORC_CAP:
+            return st, out.raw[:olen.value], extra
+        cap *= 4
+
+
+def inflate_raw(data, cap=None):
+    """Inflate(bytes).getBytes() -> (status, output, input_position)"""
+    def fn(buf, n, out, cap, olen):
+        pos = ctypes.c_size_t(0)
+        st = lib().orc_inflate_raw(ctypes.addressof(buf), n, ctypes.addressof(out), cap, ctypes.byref(olen), ctypes.byref(pos))
+        return st, pos.value
+    return _run(fn, data, (), cap)
+
+
+def gzip_decode(data, verify=False, raw=False, cap=None):
+    """GZipDecoderWeb().decodeBytes -> (status, output)"""
+    def fn(buf, n, out, cap, olen):
+        return lib().orc_gzip_decode(ctypes.addressof(buf), n, int(verify), int(raw), ctypes.addressof(out), cap, ctypes.byref(olen)), None
+    st, o, _ = _run(fn, data, (), cap)
+    return st, o
+
+
+def zlib_decode(data, verify=False, raw=False, cap=None):
+    """ZLibDecoderWeb().decodeBytes -> (status, output)"""
+    def fn(buf, n, out, cap, olen):
+        return lib().orc_zlib_decode(ctypes.addressof(buf), n, int(verify), int(raw), ctypes.addressof(out), cap, ctypes.byref(olen)), None
+    st, o, _ = _run(fn, data, (), cap)
+    return st, o
+
+
+def crc32(data, crc=0):
+    buf, n = _inbuf(data)
+    return lib().orc_crc32(ctypes.addressof(buf), n, crc)
+
+
+def adler32(data, adler=1):
+    buf, n = _inbuf(data)
+    return lib().orc_adler32(ctypes.addressof(buf), n, adler)

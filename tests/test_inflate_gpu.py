@@ -1,0 +1,188 @@
+"""GPU parity tests: the HIP path, called through the C-ABI, against the CPU oracle, the
+committed golden vectors and size-independent properties."""
+import ctypes
+import gzip
+import hashlib
+import zlib
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from tests import streams  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def amd(native_built):
+    import archive_amd
+    from archive_amd import _native as N
+    assert N.lib().ahip_init(0) == 0, N.last_error()
+    return archive_amd
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import pyoracle
+    return pyoracle
+
+
+def _raw(amd, data):
+    from archive_amd import errors
+    try:
+        z = amd.Inflate(data)
+        return z.status, z.get_bytes(), z.input_position
+    except errors.RangeError:
+        return 2, None, None
+    except errors.ReferenceWouldHang:
+        return 3, None, None
+
+
+def _gz(amd, data, **kw):
+    from archive_amd import errors
+    d = amd.GZipDecoder()
+    try:
+        out = d.decode_bytes(data, **kw)
+        return d.last_status, out
+    except errors.RangeError:
+        return 2, None
+
+
+def _zl(amd, data, **kw):
+    from archive_amd import errors
+    d = amd.ZLibDecoder()
+    try:
+        out = d.decode_bytes(data, **kw)
+        return d.last_status, out
+    except errors.RangeError:
+        return 2, None
+
+
+def test_golden_vectors(amd, golden):
+    for v in golden["vectors"]:
+        kind, data, exp = v["kind"], v["input"], v["expected"]
+        if kind == "raw":
+            st, out, _ = _raw(amd, data)
+        elif kind == "gzip":
+            st, out = _gz(amd, data)
+        else:
+            st, out = _zl(amd, data, verify=True)
+        assert st == 0, v["name"]
+        assert out == exp, v["name"]
+        assert hashlib.sha256(out).hexdigest() == v["sha256"]
+
+
+@pytest.mark.parametrize("name,raw", streams.valid_raw_streams())
+def test_valid_raw_streams_match_oracle(amd, orc, name, raw):
+    st, out, pos = _raw(amd, raw)
+    ost, oout, opos = orc.inflate_raw(raw)
+    assert (st, pos) == (ost, opos)
+    assert out == oout
+    st, out, pos = _raw(amd, raw + bytes(4))
+    assert (st, out, pos) == orc.inflate_raw(raw + bytes(4))
+
+
+def test_malformed_raw_streams_match_oracle(amd, orc):
+    for name, raw in streams.malformed_raw_streams():
+        st, out, pos = _raw(amd, raw)
+        ost, oout, opos = orc.inflate_raw(raw)
+        assert st == ost, name
+        if ost in (0, 1):
+            assert out == oout, name
+            if not name.startswith("fixed_bad"):  # position after a bad symbol: DESIGN.md deviations
+                assert pos == opos, name
+
+
+def test_gzip_framing_matches_oracle(amd, orc):
+    a, b = streams.text(1000, 1), streams.text(70000, 2)
+    g = streams.gz_member(a, name=b"a.txt", comment=b"hi", hcrc=True) + streams.gz_member(b, extra=b"XY\x02\x00zz") \
+        + streams.bgzf_member(a)
+    cases = [g, g + bytes(5), g[:-3], zlib.compress(a), b"", streams.bgzf_member(a) * 3,
+             streams.bgzf_member(a) + g, g + zlib.compress(b), b"\x1f\x8b\x08", b"junk" + g]
+    for i, c in enumerate(cases):
+        assert _gz(amd, c) == _noneify(orc.gzip_decode(c)), i
+    assert _gz(amd, zlib.compress(a), verify=True) == _noneify(orc.gzip_decode(zlib.compress(a), verify=True))
+
+
+def _noneify(t):
+    st, out = t
+    return (st, None) if st == 2 else (st, out)
+
+
+def test_zlib_framing_matches_oracle(amd, orc):
+    a, b = streams.text(3000, 3), streams.text(4000, 4)
+    za, zb = zlib.compress(a), zlib.compress(b)
+    bad = bytearray(za + zb)
+    bad[-1] ^= 1
+    for data, kw in [(za + zb, dict(verify=True)), (za + b"\x00\x00", dict(verify=True)), (za + zb + b"\x01\x02", {}),
+                     (bytes(bad), dict(verify=True)), (bytes(bad), {}), (streams.raw_deflate(a), dict(raw=True)),
+                     (za[:-2], {}), (b"", {})]:
+        assert _zl(amd, data, **kw) == _noneify(orc.zlib_decode(data, **kw)), (len(data), kw)
+
+
+def test_bsize_or_isize_lies_are_caught(amd, orc):
+    """A wrong BC/ISIZE must not change the result (the reference ignores both)."""
+    a, b = streams.text(5000, 5), streams.text(6000, 6)
+    m1, m2 = bytearray(streams.bgzf_member(a)), streams.bgzf_member(b)
+    wrong_isize = bytes(m1[:-4]) + (len(a) + 7).to_bytes(4, "little") + m2
+    assert _gz(amd, wrong_isize) == orc.gzip_decode(wrong_isize) == (0, a + b)
+    m1[16] ^= 0x10  # BSIZE points into the middle of nowhere
+    wrong_bsize = bytes(m1) + m2
+    assert _gz(amd, wrong_bsize) == orc.gzip_decode(wrong_bsize) == (0, a + b)
+
+
+def test_multimember_log_text_matches_oracle_and_zlib(amd, orc):
+    from tools import corpus
+    for bc in (True, False):
+        comp, plain = corpus.make_gzip(n_members=257, bc=bc, want_plain=True)
+        st, out = _gz(amd, bytes(comp))
+        assert st == 0
+        assert out == bytes(plain)
+        assert orc.gzip_decode(bytes(comp), cap=len(plain) + 8) == (0, bytes(plain))
+
+
+def test_wiki_text_dynamic_blocks(amd):
+    from tools import corpus
+    comp, plain = corpus.make_gzip(kind=corpus.WIKI, seed=8, n_members=64, want_plain=True)
+    st, out = _gz(amd, bytes(comp))
+    assert st == 0 and out == bytes(plain)
+
+
+def test_ragged_members(amd):
+    """empty, 1-byte, stored, incompressible and >64 KiB members in one stream"""
+    import random
+    rnd = random.Random(3)
+    parts = [b"", b"x", streams.text(100, 1), bytes(rnd.getrandbits(8) for _ in range(70000)), streams.text(300000, 2),
+             bytes(200000), b"", streams.text(65536, 3)]
+    g = b"".join(streams.gz_member(p, level=(0 if i == 2 else 6)) for i, p in enumerate(parts))
+    assert _gz(amd, g) == (0, b"".join(parts))
+    assert gzip.decompress(g) == b"".join(parts)
+
+
+def test_device_resident_plan_api(amd):
+    import torch
+    from archive_amd import _native as N
+    from tools import corpus
+    comp, plain = corpus.make_gzip(n_members=512, want_plain=True)
+    d_in = torch.from_numpy(comp).cuda()
+    plan = ctypes.c_void_p()
+    assert N.lib().ahip_gzip_plan_create(d_in.data_ptr(), d_in.numel(), None, ctypes.byref(plan)) == 0, N.last_error()
+    members, out_bytes, payload = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+    N.lib().ahip_gzip_plan_info(plan, ctypes.byref(members), ctypes.byref(out_bytes), ctypes.byref(payload))
+    assert (members.value, out_bytes.value, payload.value) == (512, len(plain), len(comp))
+    d_out = torch.zeros(len(plain), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    assert N.lib().ahip_gzip_plan_run(plan, d_out.data_ptr(), d_out.numel(), stream) == 0, N.last_error()
+    torch.cuda.synchronize()
+    olen = ctypes.c_size_t()
+    assert N.lib().ahip_gzip_plan_status(plan, ctypes.byref(olen)) == 0
+    assert olen.value == len(plain)
+    assert bytes(d_out.cpu().numpy()) == bytes(plain)
+    N.lib().ahip_gzip_plan_destroy(plan)
+    # one-call device API, too-small buffer first
+    small = torch.zeros(10, dtype=torch.uint8, device="cuda")
+    assert N.lib().ahip_gzip_decode_device(d_in.data_ptr(), d_in.numel(), small.data_ptr(), 10, ctypes.byref(olen), None) == -1
+    assert olen.value == len(plain)
+    d_out.zero_()
+    assert N.lib().ahip_gzip_decode_device(d_in.data_ptr(), d_in.numel(), d_out.data_ptr(), d_out.numel(),
+                                           ctypes.byref(olen), None) == 0
+    assert hashlib.sha256(d_out.cpu().numpy().tobytes()).digest() == hashlib.sha256(bytes(plain)).digest()
