@@ -35,6 +35,14 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise NativeLibraryMissing(
             "%s not built -- run `python -m archive_amd.build` (needs hipcc); there is no CPU fallback" % LIB_PATH)
+    # One HIP runtime per process: when PyTorch-ROCm is installed its bundled libamdhip64 must be
+    # the one this library binds to (same SONAME), otherwise device pointers and streams could not
+    # be shared with torch and the second runtime to start finds no GPU.  Dart/FFI processes have
+    # no torch and simply use the system ROCm runtime.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for the C-ABI
+        pass
     L = ctypes.CDLL(LIB_PATH)
     vp, sz, i32, u32, u64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int32, ctypes.c_uint32, ctypes.c_uint64
     szp = ctypes.POINTER(sz)

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void inflate_members_kernel(c
 namespace {
 
 thread_local std::string g_err;
-std::mutex g_mu;
+std::recursive_mutex g_mu;
 bool g_inited = false;
 
 int32_t fail(int32_t code, const std::string &msg) {
@@ -57,20 +57,35 @@ int32_t fail(int32_t code, const std::string &msg) {
       return fail(AHIP_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));                   \
   } while (0)
 
-// grow-only device scratch
+// Device scratch with a process-wide free list: hipMalloc/hipFree cost far more than the index
+// kernels they would serve, so released blocks are kept and handed to the next plan.
+struct DevBlock { void *p; size_t cap; };
+std::vector<DevBlock> g_pool;  // guarded by g_mu (every entry point holds it)
+
 struct DevBuf {
   void *p = nullptr;
   size_t cap = 0;
   hipError_t reserve(size_t n) {
     if (n <= cap) return hipSuccess;
-    if (p) (void)hipFree(p);
-    p = nullptr; cap = 0;
+    release();
+    int best = -1;
+    for (int i = 0; i < (int)g_pool.size(); ++i)
+      if (g_pool[i].cap >= n && (best < 0 || g_pool[i].cap < g_pool[best].cap)) best = i;
+    if (best >= 0 && g_pool[best].cap <= 4 * n + 4096) {
+      p = g_pool[best].p; cap = g_pool[best].cap;
+      g_pool.erase(g_pool.begin() + best);
+      return hipSuccess;
+    }
     size_t want = n + (n >> 2) + 256;
     hipError_t e = hipMalloc(&p, want);
-    if (e == hipSuccess) cap = want;
+    if (e == hipSuccess) cap = want; else p = nullptr;
     return e;
   }
-  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  void release() {
+    if (!p) return;
+    if (g_pool.size() < 64) g_pool.push_back({p, cap}); else (void)hipFree(p);
+    p = nullptr; cap = 0;
+  }
   template <class T> T *as() const { return (T *)p; }
 };
 
@@ -322,7 +337,7 @@ uint32_t ahip_abi_version(void) { return (1u << 16) | 0u; }
 const char *ahip_last_error(void) { return g_err.c_str(); }
 
 int32_t ahip_init(int32_t device) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
   int32_t rc = ensure_init();
   if (rc != AHIP_OK) return rc;
   if (device >= 0) HIP_TRY(hipSetDevice(device));
@@ -330,7 +345,9 @@ int32_t ahip_init(int32_t device) {
 }
 
 void ahip_shutdown(void) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  for (auto &b : g_pool) (void)hipFree(b.p);
+  g_pool.clear();
   g_inited = false;
 }
 
@@ -365,7 +382,7 @@ uint32_t ahip_adler32(const uint8_t *data, size_t len, uint32_t adler) {
 int32_t ahip_gzip_plan_create(const void *d_in, size_t in_len, void *stream, ahip_gzip_plan **plan) {
   if (!plan) return fail(AHIP_E_ARG, "plan == NULL");
   *plan = nullptr;
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
   int32_t rc = ensure_init();
   if (rc != AHIP_OK) return rc;
   ahip_gzip_plan *pl = new ahip_gzip_plan();
@@ -388,13 +405,13 @@ int32_t ahip_gzip_plan_info(const ahip_gzip_plan *plan, uint64_t *members, uint6
 
 int32_t ahip_gzip_plan_run(ahip_gzip_plan *plan, void *d_out, size_t out_cap, void *stream) {
   if (!plan) return fail(AHIP_E_ARG, "plan == NULL");
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
   return plan_run(plan, (u8 *)d_out, out_cap, (hipStream_t)stream);
 }
 
 int32_t ahip_gzip_plan_status(ahip_gzip_plan *plan, size_t *out_len) {
   if (!plan) return fail(AHIP_E_ARG, "plan == NULL");
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
   if (out_len) *out_len = plan->sum.total_out;
   if (!plan->ran) return fail(AHIP_E_ARG, "plan has not been run");
   bool needs = false;
@@ -407,7 +424,7 @@ int32_t ahip_gzip_plan_status(ahip_gzip_plan *plan, size_t *out_len) {
 }
 
 void ahip_gzip_plan_destroy(ahip_gzip_plan *plan) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
   delete plan;
 }
 
@@ -421,6 +438,9 @@ static int32_t gzip_decode_impl(const u8 *host_in, const u8 *d_in, size_t in_len
   int32_t rc = plan_build(&pl, false, st);
   if (rc != AHIP_OK) return rc;
   for (int attempt = 0;; ++attempt) {
+    // a header or trailer on the member chain runs past the end of the input: the reference
+    // throws RangeError out of decodeBytes, whatever was decoded before is lost
+    if (pl.sum.range_error) return AHIP_RANGE;
     if (out_is_growable) {
       HIP_TRY(grow->reserve(pl.sum.total_out + 16));
       d_out = grow->as<u8>();
@@ -478,7 +498,7 @@ static int32_t gzip_decode_impl(const u8 *host_in, const u8 *d_in, size_t in_len
 
 int32_t ahip_gzip_decode_device(const void *d_in, size_t in_len, void *d_out, size_t out_cap, size_t *out_len,
                                 void *stream) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
   int32_t rc = ensure_init();
   if (rc != AHIP_OK) return rc;
   return gzip_decode_impl(nullptr, (const u8 *)d_in, in_len, 0, 0, (u8 *)d_out, out_cap, false, nullptr, out_len,
@@ -487,7 +507,7 @@ int32_t ahip_gzip_decode_device(const void *d_in, size_t in_len, void *d_out, si
 
 int32_t ahip_gzip_decode(const uint8_t *in, size_t in_len, int32_t verify, int32_t raw, uint8_t *out, size_t out_cap,
                          size_t *out_len) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
   int32_t rc = ensure_init();
   if (rc != AHIP_OK) return rc;
   static DevBuf din, dout;
@@ -505,7 +525,7 @@ int32_t ahip_gzip_decode(const uint8_t *in, size_t in_len, int32_t verify, int32
 
 int32_t ahip_zlib_decode(const uint8_t *in, size_t in_len, int32_t verify, int32_t raw, uint8_t *out, size_t out_cap,
                          size_t *out_len) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
   int32_t rc = ensure_init();
   if (rc != AHIP_OK) return rc;
   static DevBuf din, dout;
@@ -523,7 +543,7 @@ int32_t ahip_zlib_decode(const uint8_t *in, size_t in_len, int32_t verify, int32
 
 int32_t ahip_inflate_raw(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap, size_t *out_len,
                          size_t *consumed) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
   int32_t rc = ensure_init();
   if (rc != AHIP_OK) return rc;
   static DevBuf din, dout;
