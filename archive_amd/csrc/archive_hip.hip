@@ -156,12 +156,7 @@ int32_t plan_build(ahip_gzip_plan *pl, bool force_sizing, hipStream_t st) {
                      pl->tile_offsets.as<u32>(), pl->cand_pos.as<u64>());
   hipLaunchKernelGGL(gz_parse_headers, dim3(cdiv(K, 256)), dim3(256), 0, st, in, n, pl->cand_pos.as<u64>(), K,
                      pl->hdr.as<GzHeader>(), pl->dsum.as<ChainSummary>());
-  u32 unknown = 0;
-  if (!force_sizing) {
-    HIP_TRY(hipMemcpyAsync(&unknown, &pl->dsum.as<ChainSummary>()->unknown, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-  }
-  if (force_sizing || unknown > 0) {
+  if (force_sizing) {
     // sizing run over every candidate: exact end position, size and verdict, no stores
     HIP_TRY(pl->sizing_descs.reserve((size_t)K * sizeof(MemberDesc)));
     HIP_TRY(pl->sizing_results.reserve((size_t)K * sizeof(MemberResult)));
@@ -184,6 +179,9 @@ int32_t plan_build(ahip_gzip_plan *pl, bool force_sizing, hipStream_t st) {
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipGetLastError());
   if (!pl->sum.first_is_gzip) { pl->sum.members = 0; pl->sum.total_out = 0; pl->sum.tail_pos = start; }
+  // Candidates without a BC subfield only matter when the member chain actually walks into one
+  // (false candidates inside compressed data never do): then sizes have to come from the data.
+  if (!force_sizing && pl->sum.first_is_gzip && pl->sum.stopped_unknown) return plan_build(pl, true, st);
   return AHIP_OK;
 }
 

@@ -42,7 +42,7 @@ struct ChainSummary {
   u32 first_is_gzip; // candidate 0 sits at the start position
   u32 range_error;   // a header or trailer on the chain runs past the end
   u32 unknown;       // candidates whose size is not known yet (valid after gz_parse_headers)
-  u32 pad;
+  u32 stopped_unknown; // the chain reached a member of unknown size: a sizing run is needed
 };
 
 // 16-bit mask of candidate positions base+0 .. base+15
@@ -282,6 +282,7 @@ __global__ __launch_bounds__(1024) void gz_chain(const u64 *cand_pos, const GzHe
       expect_status[m] = h.status;
       if (nxt[i] == K) {  // last member of the chain
         sum->tail_pos = h.next_pos;
+        if (!(h.flags & (HF_BC | HF_SIZED | HF_RANGE))) sum->stopped_unknown = 1;
       }
       if (h.flags & HF_RANGE) atomicOr(&sum->range_error, 1u);
     }
