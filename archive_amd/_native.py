@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libarchive_hip.so")
+LIB_PATH = os.environ.get("AHIP_LIB") or os.path.join(_HERE, "lib", "libarchive_hip.so")
 
 AHIP_OK, AHIP_FALSE, AHIP_RANGE, AHIP_HANG = 0, 1, 2, 3
 AHIP_E_CAP, AHIP_E_DEVICE, AHIP_E_UNSUPPORTED, AHIP_E_ARG = -1, -2, -3, -4
@@ -17,7 +17,7 @@ EXPORTS = [
     "ahip_init", "ahip_shutdown", "ahip_last_error", "ahip_abi_version",
     "ahip_inflate_raw", "ahip_gzip_decode", "ahip_zlib_decode",
     "ahip_gzip_decode_device", "ahip_gzip_plan_create", "ahip_gzip_plan_info", "ahip_gzip_plan_run",
-    "ahip_gzip_plan_status", "ahip_gzip_plan_destroy",
+    "ahip_gzip_plan_status", "ahip_gzip_plan_destroy", "ahip_debug_plan_results",
     "ahip_crc32", "ahip_adler32",
 ]
 
@@ -60,6 +60,7 @@ def lib():
     L.ahip_gzip_plan_run.argtypes = [vp, vp, sz, vp]; L.ahip_gzip_plan_run.restype = i32
     L.ahip_gzip_plan_status.argtypes = [vp, szp]; L.ahip_gzip_plan_status.restype = i32
     L.ahip_gzip_plan_destroy.argtypes = [vp]; L.ahip_gzip_plan_destroy.restype = None
+    L.ahip_debug_plan_results.argtypes = [vp, vp, sz, szp]; L.ahip_debug_plan_results.restype = i32
     L.ahip_crc32.argtypes = [vp, sz, u32]; L.ahip_crc32.restype = u32
     L.ahip_adler32.argtypes = [vp, sz, u32]; L.ahip_adler32.restype = u32
     _lib = L

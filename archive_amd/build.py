@@ -18,18 +18,27 @@ def _newest_source():
     return t
 
 
-def build(force=False, verbose=False):
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_source():
-        return LIB
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+PROF_LIB = os.path.join(_HERE, "lib", "libarchive_hip_prof.so")
+
+
+def build(force=False, verbose=False, profile=False, defines=()):
+    """profile=True builds the instrumented variant (per-phase cycle counters) next to the
+    production library; it is only ever loaded by tools/kstats.py via AHIP_LIB."""
+    lib = PROF_LIB if profile else LIB
+    if not force and os.path.exists(lib) and os.path.getmtime(lib) >= _newest_source():
+        return lib
+    os.makedirs(os.path.dirname(lib), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", lib]
+    if profile:
+        cmd.append("-DAHIP_PROFILE=1")
+    cmd += ["-D" + d for d in defines]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv, profile="--profile" in sys.argv))

@@ -5,35 +5,60 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <mutex>
 #include <string>
 #include <vector>
 
 #include "common.hpp"
 #include "gzip_index.hpp"
-#include "inflate_wave.hpp"
+#include "inflate_par.hpp"
 
 using namespace ahip;
 
 // ------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------
-constexpr int WAVES_PER_BLOCK = 4;
+// One wave64 per member, one wave per workgroup: no workgroup barrier is ever needed and the
+// LDS footprint (tables + window + token queue + output window) is allocated per wave.
+constexpr int WAVES_PER_BLOCK = 1;
+
+struct KernelLds {
+  WaveLds w;
+  ParLds p;
+};
 
 template <bool WRITE>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void inflate_members_kernel(const u8 *__restrict__ in, u64 in_len,
-                                                                             const MemberDesc *__restrict__ members,
-                                                                             u32 n_members, u8 *out,
-                                                                             MemberResult *__restrict__ results) {
-  __shared__ WaveLds lds[WAVES_PER_BLOCK];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const u32 m = blockIdx.x * WAVES_PER_BLOCK + wave;
+__global__ __launch_bounds__(64) void inflate_members_kernel(const u8 *__restrict__ in, u64 in_len,
+                                                            const MemberDesc *__restrict__ members, u32 n_members,
+                                                            u8 *out, MemberResult *__restrict__ results) {
+  __shared__ KernelLds lds;
+  const int lane = threadIdx.x;
+  const u32 m = blockIdx.x;
   if (m >= n_members) return;
   MemberDesc d = members[m];
   d.in_off = uniform64(d.in_off);
   d.out_off = uniform64(d.out_off);
   d.out_limit = uniform64(d.out_limit);
-  inflate_member<WRITE>(lds[wave], in, in_len, d, out, results[m], lane);
+  inflate_member<WRITE, true>(lds.w, &lds.p, in, in_len, d, out, results[m], lane);
+}
+
+// The serial decoder alone (one lane-uniform symbol at a time): kept as the checked fallback of
+// the parallel kernel and as an A/B baseline (AHIP_SERIAL=1).
+template <bool WRITE>
+__global__ __launch_bounds__(64) void inflate_members_serial_kernel(const u8 *__restrict__ in, u64 in_len,
+                                                                   const MemberDesc *__restrict__ members,
+                                                                   u32 n_members, u8 *out,
+                                                                   MemberResult *__restrict__ results) {
+  __shared__ WaveLds lds;
+  const int lane = threadIdx.x;
+  const u32 m = blockIdx.x;
+  if (m >= n_members) return;
+  MemberDesc d = members[m];
+  d.in_off = uniform64(d.in_off);
+  d.out_off = uniform64(d.out_off);
+  d.out_limit = uniform64(d.out_limit);
+  inflate_member<WRITE, false>(lds, nullptr, in, in_len, d, out, results[m], lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -90,6 +115,21 @@ struct DevBuf {
 };
 
 inline u32 cdiv(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
+
+bool use_serial_kernel() {
+  static int v = -1;
+  if (v < 0) { const char *e = getenv("AHIP_SERIAL"); v = (e && e[0] == '1') ? 1 : 0; }
+  return v == 1;
+}
+
+template <bool WRITE>
+void launch_inflate(const u8 *in, u64 n, const MemberDesc *members, u32 M, u8 *out, MemberResult *res, hipStream_t st) {
+  if (M == 0) return;
+  if (use_serial_kernel())
+    hipLaunchKernelGGL(inflate_members_serial_kernel<WRITE>, dim3(M), dim3(64), 0, st, in, n, members, M, out, res);
+  else
+    hipLaunchKernelGGL(inflate_members_kernel<WRITE>, dim3(M), dim3(64), 0, st, in, n, members, M, out, res);
+}
 
 int32_t ensure_init() {
   if (g_inited) return AHIP_OK;
@@ -162,8 +202,8 @@ int32_t plan_build(ahip_gzip_plan *pl, bool force_sizing, hipStream_t st) {
     HIP_TRY(pl->sizing_results.reserve((size_t)K * sizeof(MemberResult)));
     hipLaunchKernelGGL(gz_make_sizing_descs, dim3(cdiv(K, 256)), dim3(256), 0, st, pl->hdr.as<GzHeader>(), K,
                        pl->sizing_descs.as<MemberDesc>());
-    hipLaunchKernelGGL(inflate_members_kernel<false>, dim3(cdiv(K, WAVES_PER_BLOCK)), dim3(64 * WAVES_PER_BLOCK), 0, st,
-                       in, n, pl->sizing_descs.as<MemberDesc>(), K, (u8 *)nullptr, pl->sizing_results.as<MemberResult>());
+    launch_inflate<false>(in, n, pl->sizing_descs.as<MemberDesc>(), K, (u8 *)nullptr,
+                          pl->sizing_results.as<MemberResult>(), st);
     hipLaunchKernelGGL(gz_apply_sizing, dim3(cdiv(K, 256)), dim3(256), 0, st, pl->hdr.as<GzHeader>(), K,
                        pl->sizing_results.as<MemberResult>(), n);
     pl->sized = true;
@@ -195,8 +235,7 @@ int32_t plan_run(ahip_gzip_plan *pl, u8 *d_out, size_t out_cap, hipStream_t st) 
   pl->ran = true;
   if (M == 0) return AHIP_OK;
   HIP_TRY(pl->results.reserve((size_t)M * sizeof(MemberResult)));
-  hipLaunchKernelGGL(inflate_members_kernel<true>, dim3(cdiv(M, WAVES_PER_BLOCK)), dim3(64 * WAVES_PER_BLOCK), 0, st,
-                     pl->d_in, pl->in_len, pl->members.as<MemberDesc>(), M, d_out, pl->results.as<MemberResult>());
+  launch_inflate<true>(pl->d_in, pl->in_len, pl->members.as<MemberDesc>(), M, d_out, pl->results.as<MemberResult>(), st);
   hipLaunchKernelGGL(gz_verify, dim3(cdiv(M, 256)), dim3(256), 0, st, pl->members.as<MemberDesc>(),
                      pl->expect_status.as<u32>(), pl->results.as<MemberResult>(), M, pl->drun.as<RunSummary>());
   HIP_TRY(hipGetLastError());
@@ -233,12 +272,8 @@ int32_t inflate_one(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool
   HIP_TRY(dr.reserve(sizeof(MemberResult)));
   MemberDesc d{off, 0, out_cap, POS_UNKNOWN};
   HIP_TRY(hipMemcpyAsync(dd.p, &d, sizeof d, hipMemcpyHostToDevice, st));
-  if (write)
-    hipLaunchKernelGGL(inflate_members_kernel<true>, dim3(1), dim3(64 * WAVES_PER_BLOCK), 0, st, d_in, n,
-                       dd.as<MemberDesc>(), 1u, d_out, dr.as<MemberResult>());
-  else
-    hipLaunchKernelGGL(inflate_members_kernel<false>, dim3(1), dim3(64 * WAVES_PER_BLOCK), 0, st, d_in, n,
-                       dd.as<MemberDesc>(), 1u, (u8 *)nullptr, dr.as<MemberResult>());
+  if (write) launch_inflate<true>(d_in, n, dd.as<MemberDesc>(), 1u, d_out, dr.as<MemberResult>(), st);
+  else launch_inflate<false>(d_in, n, dd.as<MemberDesc>(), 1u, (u8 *)nullptr, dr.as<MemberResult>(), st);
   HIP_TRY(hipMemcpyAsync(res, dr.p, sizeof *res, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipGetLastError());
@@ -418,6 +453,18 @@ int32_t ahip_gzip_plan_status(ahip_gzip_plan *plan, size_t *out_len) {
   if (needs) return fail(AHIP_E_UNSUPPORTED, "member index (BC/ISIZE) disagrees with the data; use ahip_gzip_decode_device");
   if (plan->sum.range_error) return AHIP_RANGE;
   if (plan->sum.tail_pos != plan->in_len) return AHIP_FALSE;
+  return AHIP_OK;
+}
+
+// Diagnostics (not part of the drop-in surface): per-member results of the last run, as
+// 18 u32 words each {end_pos lo/hi, out_len lo/hi, status, blocks, windows, rounds, fallbacks, partial, cyc[8]}.
+int32_t ahip_debug_plan_results(ahip_gzip_plan *plan, uint32_t *host_words, size_t max_members, size_t *n_members) {
+  if (!plan || !plan->ran) return fail(AHIP_E_ARG, "plan has not been run");
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  size_t M = plan->sum.members < max_members ? plan->sum.members : max_members;
+  if (n_members) *n_members = M;
+  static_assert(sizeof(MemberResult) == 72, "MemberResult layout");
+  if (M) HIP_TRY(hipMemcpy(host_words, plan->results.p, M * sizeof(MemberResult), hipMemcpyDeviceToHost));
   return AHIP_OK;
 }
 

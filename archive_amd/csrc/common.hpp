@@ -39,9 +39,23 @@ struct MemberResult {
   u64 out_len;  // bytes produced
   u32 status;   // MS_*
   u32 blocks;   // DEFLATE blocks parsed
+  u32 windows;  // parallel-decode windows committed        (diagnostics)
+  u32 rounds;   // pass-B rounds over all windows           (diagnostics)
+  u32 fallbacks;// windows handed to the serial decoder     (diagnostics)
+  u32 partial;  // windows cut short by the token/byte caps (diagnostics)
+  u32 cyc[8];   // -DAHIP_PROFILE builds: shader-clock cycles / 16 per phase
+                //  0 header+tables 1 stage 2 pass A 3 pass B 4 emit 5 resolve 6 flush 7 serial decode
 };
 
 #define AHIP_DEVINL __device__ __forceinline__
+
+#ifdef AHIP_PROFILE
+#define AHIP_TICK(var) const u64 var = __builtin_amdgcn_s_memtime()
+#define AHIP_ACC(slot, t0, t1) (slot) += (u32)(((t1) - (t0)) >> 4)
+#else
+#define AHIP_TICK(var) do { } while (0)
+#define AHIP_ACC(slot, t0, t1) do { } while (0)
+#endif
 
 // Compiler-level ordering point for cross-lane traffic through LDS/global inside ONE wave.
 // The hardware already executes a wave's DS (and vector-memory) instructions in issue order;
@@ -55,6 +69,59 @@ AHIP_DEVINL u32 uniform(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int
 AHIP_DEVINL u64 uniform64(u64 v) {
   u32 lo = uniform((u32)v), hi = uniform((u32)(v >> 32));
   return ((u64)hi << 32) | lo;
+}
+
+// ---- cross-lane primitives on the DPP / readlane paths (no LDS crossbar round trip) ----
+// gfx9-family DPP controls: row_shr:n = 0x110+n, wave_shr:1 = 0x138, row_bcast:15 = 0x142,
+// row_bcast:31 = 0x143.
+template <int CTRL, int ROW_MASK>
+AHIP_DEVINL u32 dpp_zero(u32 v) {  // lanes without a source (or masked rows) read 0
+  return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+AHIP_DEVINL u32 lane_bcast(u32 v, int src_lane /* wave-uniform */) {
+  return (u32)__builtin_amdgcn_readlane((int)v, src_lane);
+}
+// value of lane-1 (0 for lane 0)
+AHIP_DEVINL u32 lane_prev(u32 v) { return dpp_zero<0x138, 0xf>(v); }
+// inclusive prefix sum over the wave
+AHIP_DEVINL u32 wave_incl_sum(u32 v) {
+  v += dpp_zero<0x111, 0xf>(v);
+  v += dpp_zero<0x112, 0xf>(v);
+  v += dpp_zero<0x114, 0xf>(v);
+  v += dpp_zero<0x118, 0xf>(v);
+  v += dpp_zero<0x142, 0xa>(v);
+  v += dpp_zero<0x143, 0xc>(v);
+  return v;
+}
+// exclusive prefix sum; total = wave sum (uniform)
+AHIP_DEVINL u32 wave_excl_sum(u32 v, u32 &total) {
+  u32 inc = wave_incl_sum(v);
+  total = lane_bcast(inc, 63);
+  return inc - v;
+}
+// inclusive prefix maximum over the wave (0 is the identity)
+AHIP_DEVINL u32 wave_incl_umax(u32 v) {
+  u32 t;
+  t = dpp_zero<0x111, 0xf>(v); v = t > v ? t : v;
+  t = dpp_zero<0x112, 0xf>(v); v = t > v ? t : v;
+  t = dpp_zero<0x114, 0xf>(v); v = t > v ? t : v;
+  t = dpp_zero<0x118, 0xf>(v); v = t > v ? t : v;
+  t = dpp_zero<0x142, 0xa>(v); v = t > v ? t : v;
+  t = dpp_zero<0x143, 0xc>(v); v = t > v ? t : v;
+  return v;
+}
+// value held by lane `src` (per-lane index): LDS crossbar
+AHIP_DEVINL u32 lane_gather(u32 v, u32 src) { return (u32)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)v); }
+// wave maximum (uniform result)
+AHIP_DEVINL u32 wave_umax(u32 v) {
+  u32 t;
+  t = dpp_zero<0x111, 0xf>(v); v = t > v ? t : v;
+  t = dpp_zero<0x112, 0xf>(v); v = t > v ? t : v;
+  t = dpp_zero<0x114, 0xf>(v); v = t > v ? t : v;
+  t = dpp_zero<0x118, 0xf>(v); v = t > v ? t : v;
+  t = dpp_zero<0x142, 0xa>(v); v = t > v ? t : v;
+  t = dpp_zero<0x143, 0xc>(v); v = t > v ? t : v;
+  return lane_bcast(v, 63);
 }
 
 struct __attribute__((packed, aligned(1))) unaligned_u64 { u64 v; };

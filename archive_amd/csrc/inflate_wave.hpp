@@ -397,50 +397,4 @@ AHIP_DEVINL u32 dynamic_header(WaveLds &L, BitCursor &b, int lane, int &hlit_out
   return MS_OK;
 }
 
-// Inflate one stream.  Mirrors Inflate._inflate(): loop blocks until BFINAL, an error, or EOS.
-template <bool WRITE>
-AHIP_DEVINL void inflate_member(WaveLds &L, const u8 *in, u64 in_len, const MemberDesc &m, u8 *out,
-                                MemberResult &res, int lane) {
-  BitCursor b{in, in_len, in_len * 8, m.in_off * 8};
-  OutCursor o{out + m.out_off, 0, m.out_limit};
-  u32 status = MS_EOS, blocks = 0;
-  for (;;) {
-    if (((b.pos + 7) >> 3) >= in_len) { status = MS_EOS; break; }
-    int hdr = read_bits(b, 3);
-    ++blocks;
-    const bool final_block = hdr & 1;
-    const int btype = hdr >> 1;
-    u32 r;
-    if (btype == 0) {
-      r = stored_block<WRITE>(b, o, lane);
-    } else if (btype == 3) {
-      r = MS_FALSE;
-    } else {
-      int hlit = 288, hdist = 30;
-      r = MS_OK;
-      if (btype == 1) fixed_lengths(L.lens, lane);
-      else r = dynamic_header(L, b, lane, hlit, hdist);
-      if (r == MS_OK) {
-        bool ok = build_decode_table<false>(L.lens, hlit, L.ll, LL_ROOT, L.lld, L.ll_sorted, lane);
-        ok &= build_decode_table<true>(L.lens + hlit, hdist, L.dt, D_ROOT, L.dd, L.d_sorted, lane);
-        r = ok ? huffman_block<WRITE>(L, b, o, lane) : (u32)MS_OVERSUB;
-      }
-    }
-    if (r != MS_OK) { status = r; break; }
-    if (final_block) { status = MS_OK; break; }
-  }
-  if (lane == 0) {
-    // Position the reference's InputStream is left at.  Exact after a complete block
-    // (whole bytes are un-read) and after an end-of-input failure; after a bad-symbol failure
-    // in the middle of the input the reference has over-read by up to two bytes -- see
-    // DESIGN.md "deviations".
-    u64 end = (b.pos + 7) >> 3;
-    if (status == MS_FALSE_EOS) { end = in_len; status = MS_FALSE; }  // every byte was pulled into the accumulator
-    res.end_pos = end > in_len ? in_len : end;
-    res.out_len = o.pos;
-    res.status = status;
-    res.blocks = blocks;
-  }
-}
-
 }  // namespace ahip
