@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <string>
@@ -28,19 +29,27 @@ struct KernelLds {
   ParLds p;
 };
 
+// Persistent workgroups: the grid is sized to what is resident at once and strides over the
+// members, so the token slab (scratch, SLAB_WORDS u32 per workgroup)
+// is a few hundred KiB-per-CU working set that lives in L2 instead of one slab per member.
 template <bool WRITE>
 __global__ __launch_bounds__(64) void inflate_members_kernel(const u8 *__restrict__ in, u64 in_len,
                                                             const MemberDesc *__restrict__ members, u32 n_members,
-                                                            u8 *out, MemberResult *__restrict__ results) {
+                                                            u8 *out, MemberResult *__restrict__ results,
+                                                            u32 *__restrict__ next_member, u32 *__restrict__ scratch) {
   __shared__ KernelLds lds;
   const int lane = threadIdx.x;
-  const u32 m = blockIdx.x;
-  if (m >= n_members) return;
-  MemberDesc d = members[m];
-  d.in_off = uniform64(d.in_off);
-  d.out_off = uniform64(d.out_off);
-  d.out_limit = uniform64(d.out_limit);
-  inflate_member<WRITE, true>(lds.w, &lds.p, in, in_len, d, out, results[m], lane);
+  u32 *slab = scratch + (size_t)blockIdx.x * SLAB_WORDS;
+  (void)next_member;
+  // grid-stride over members (a device work counter would balance ragged members better; the
+  // wave-aggregated atomic hipcc generates for it hung on gfx950, so the static schedule stays)
+  for (u32 m = blockIdx.x; m < n_members; m += gridDim.x) {
+    MemberDesc d = members[m];
+    d.in_off = uniform64(d.in_off);
+    d.out_off = uniform64(d.out_off);
+    d.out_limit = uniform64(d.out_limit);
+    inflate_member<WRITE, true>(lds.w, &lds.p, slab, in, in_len, d, out, results[m], lane);
+  }
 }
 
 // The serial decoder alone (one lane-uniform symbol at a time): kept as the checked fallback of
@@ -58,7 +67,7 @@ __global__ __launch_bounds__(64) void inflate_members_serial_kernel(const u8 *__
   d.in_off = uniform64(d.in_off);
   d.out_off = uniform64(d.out_off);
   d.out_limit = uniform64(d.out_limit);
-  inflate_member<WRITE, false>(lds, nullptr, in, in_len, d, out, results[m], lane);
+  inflate_member<WRITE, false>(lds, nullptr, nullptr, in, in_len, d, out, results[m], lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -114,6 +123,13 @@ struct DevBuf {
   template <class T> T *as() const { return (T *)p; }
 };
 
+DevBuf g_scratch;
+hipError_t scratch_reserve(size_t bytes, void **p) {
+  hipError_t e = g_scratch.reserve(bytes);
+  *p = g_scratch.p;
+  return e;
+}
+
 inline u32 cdiv(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
 
 bool use_serial_kernel() {
@@ -122,13 +138,47 @@ bool use_serial_kernel() {
   return v == 1;
 }
 
+// device scratch of the persistent kernel: member counter + token slabs
+struct DevBuf;
+hipError_t scratch_reserve(size_t bytes, void **p);
+
 template <bool WRITE>
-void launch_inflate(const u8 *in, u64 n, const MemberDesc *members, u32 M, u8 *out, MemberResult *res, hipStream_t st) {
-  if (M == 0) return;
-  if (use_serial_kernel())
+hipError_t launch_inflate(const u8 *in, u64 n, const MemberDesc *members, u32 M, u8 *out, MemberResult *res,
+                          hipStream_t st) {
+  if (M == 0) return hipSuccess;
+  if (use_serial_kernel()) {
     hipLaunchKernelGGL(inflate_members_serial_kernel<WRITE>, dim3(M), dim3(64), 0, st, in, n, members, M, out, res);
-  else
-    hipLaunchKernelGGL(inflate_members_kernel<WRITE>, dim3(M), dim3(64), 0, st, in, n, members, M, out, res);
+    return hipGetLastError();
+  }
+  static int wgs_resident = 0;
+  if (!wgs_resident) {
+    int dev = 0, cus = 0, per_cu = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return e;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, inflate_members_kernel<true>, 64, 0);
+    if (e != hipSuccess) return e;
+    wgs_resident = cus * (per_cu > 0 ? per_cu : 1);
+  }
+  const u32 grid = M < (u32)wgs_resident ? M : (u32)wgs_resident;
+  if (getenv("AHIP_DEBUG")) fprintf(stderr, "[ahip] launch_inflate M=%u grid=%u resident=%d write=%d\n", M, grid, wgs_resident, (int)WRITE);
+  void *sp = nullptr;
+  hipError_t e = scratch_reserve(256 + (size_t)grid * SLAB_WORDS * 4, &sp);
+  if (e != hipSuccess) return e;
+  u32 *counter = (u32 *)sp;
+  u32 *slabs = (u32 *)((u8 *)sp + 256);
+  e = hipMemsetAsync(counter, 0, 4, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(inflate_members_kernel<WRITE>, dim3(grid), dim3(64), 0, st, in, n, members, M, out, res, counter,
+                     slabs);
+  if (getenv("AHIP_DEBUG")) {
+    hipError_t se = hipStreamSynchronize(st);
+    u32 c = 0;
+    (void)hipMemcpy(&c, counter, 4, hipMemcpyDeviceToHost);
+    fprintf(stderr, "[ahip] kernel done: %s, counter=%u\n", hipGetErrorString(se), c);
+  }
+  return hipGetLastError();
 }
 
 int32_t ensure_init() {
@@ -202,8 +252,8 @@ int32_t plan_build(ahip_gzip_plan *pl, bool force_sizing, hipStream_t st) {
     HIP_TRY(pl->sizing_results.reserve((size_t)K * sizeof(MemberResult)));
     hipLaunchKernelGGL(gz_make_sizing_descs, dim3(cdiv(K, 256)), dim3(256), 0, st, pl->hdr.as<GzHeader>(), K,
                        pl->sizing_descs.as<MemberDesc>());
-    launch_inflate<false>(in, n, pl->sizing_descs.as<MemberDesc>(), K, (u8 *)nullptr,
-                          pl->sizing_results.as<MemberResult>(), st);
+    HIP_TRY(launch_inflate<false>(in, n, pl->sizing_descs.as<MemberDesc>(), K, (u8 *)nullptr,
+                                  pl->sizing_results.as<MemberResult>(), st));
     hipLaunchKernelGGL(gz_apply_sizing, dim3(cdiv(K, 256)), dim3(256), 0, st, pl->hdr.as<GzHeader>(), K,
                        pl->sizing_results.as<MemberResult>(), n);
     pl->sized = true;
@@ -235,7 +285,8 @@ int32_t plan_run(ahip_gzip_plan *pl, u8 *d_out, size_t out_cap, hipStream_t st) 
   pl->ran = true;
   if (M == 0) return AHIP_OK;
   HIP_TRY(pl->results.reserve((size_t)M * sizeof(MemberResult)));
-  launch_inflate<true>(pl->d_in, pl->in_len, pl->members.as<MemberDesc>(), M, d_out, pl->results.as<MemberResult>(), st);
+  HIP_TRY(launch_inflate<true>(pl->d_in, pl->in_len, pl->members.as<MemberDesc>(), M, d_out,
+                               pl->results.as<MemberResult>(), st));
   hipLaunchKernelGGL(gz_verify, dim3(cdiv(M, 256)), dim3(256), 0, st, pl->members.as<MemberDesc>(),
                      pl->expect_status.as<u32>(), pl->results.as<MemberResult>(), M, pl->drun.as<RunSummary>());
   HIP_TRY(hipGetLastError());
@@ -272,8 +323,8 @@ int32_t inflate_one(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool
   HIP_TRY(dr.reserve(sizeof(MemberResult)));
   MemberDesc d{off, 0, out_cap, POS_UNKNOWN};
   HIP_TRY(hipMemcpyAsync(dd.p, &d, sizeof d, hipMemcpyHostToDevice, st));
-  if (write) launch_inflate<true>(d_in, n, dd.as<MemberDesc>(), 1u, d_out, dr.as<MemberResult>(), st);
-  else launch_inflate<false>(d_in, n, dd.as<MemberDesc>(), 1u, (u8 *)nullptr, dr.as<MemberResult>(), st);
+  if (write) HIP_TRY(launch_inflate<true>(d_in, n, dd.as<MemberDesc>(), 1u, d_out, dr.as<MemberResult>(), st));
+  else HIP_TRY(launch_inflate<false>(d_in, n, dd.as<MemberDesc>(), 1u, (u8 *)nullptr, dr.as<MemberResult>(), st));
   HIP_TRY(hipMemcpyAsync(res, dr.p, sizeof *res, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipGetLastError());

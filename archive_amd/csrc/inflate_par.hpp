@@ -33,19 +33,24 @@
 namespace ahip {
 
 #ifndef AHIP_SUB_BITS
-#define AHIP_SUB_BITS 256
+#define AHIP_SUB_BITS 512
 #endif
 #ifndef AHIP_TOK_CAP
-#define AHIP_TOK_CAP (5 * AHIP_SUB_BITS)
+#define AHIP_TOK_CAP 1280
 #endif
 #ifndef AHIP_OB_CAP
-#define AHIP_OB_CAP (24 * AHIP_SUB_BITS)
+#define AHIP_OB_CAP 6144
+#endif
+#ifndef AHIP_SLAB_ROWS
+#define AHIP_SLAB_ROWS 192
 #endif
 constexpr int SUB_BITS = AHIP_SUB_BITS;          // bits per lane subsequence
 constexpr int WIN_BITS = 64 * SUB_BITS;          // compressed bits per window (2 KiB at 256)
-constexpr int IN_DWORDS = WIN_BITS / 32 + 8;     // + slack: a token may run 48 bits past the window
-constexpr int TOK_CAP = AHIP_TOK_CAP;            // token queue entries per window
-constexpr int OB_CAP = AHIP_OB_CAP;              // output bytes assembled in LDS per window
+constexpr int IN_DWORDS = WIN_BITS / 32 + 8;     // + slack: a token may run 48 bits past the window (multiple of 4)
+constexpr int TOK_CAP = AHIP_TOK_CAP;            // token queue entries per resolve batch
+constexpr int OB_CAP = AHIP_OB_CAP;              // output bytes assembled in LDS per resolve batch
+constexpr int SLAB_ROWS = AHIP_SLAB_ROWS;        // tokens one lane may record per window
+constexpr int SLAB_WORDS = SLAB_ROWS * 64;       // per-workgroup token slab in device scratch (L2-resident)
 
 constexpr u32 TK_LIT = 0x80000000u;  // | byte
 constexpr u32 TK_EOB = 0x40000000u;
@@ -53,13 +58,13 @@ constexpr u32 TK_ERR = 0x20000000u;
 // match: len << 16 | dist   (len <= 258, dist <= 32768)
 
 struct ParLds {
-  u32 inbuf[IN_DWORDS];
+  u32 inbuf[IN_DWORDS] __attribute__((aligned(16)));
   u32 tok[TOK_CAP];
   u8 obuf[OB_CAP + 32] __attribute__((aligned(16)));
   u32 slot[64];
 };
 
-struct ParStats { u32 windows, rounds, fallbacks, partial; u32 cyc[8]; };
+struct ParStats { u32 windows, rounds, fallbacks, partial; u32 cyc[8]; u32 dbg; };
 
 // Per-lane LSB-first bit reader over the LDS window.  The stream continues at bit `sh` of the
 // 64-bit pair (hi:lo); `nextw` is the dword after `hi`, always already requested from LDS, so a
@@ -161,45 +166,35 @@ AHIP_DEVINL u32 decode_token(LaneBits &d, const WaveLds &L, const BlockMeta &M, 
   return tok;
 }
 
-constexpr u32 LR_EOB = 1, LR_ERR = 2, LR_CAP = 4, LR_FAR = 8;
+constexpr u32 LR_EOB = 1, LR_ERR = 2, LR_OVF = 4;
 struct LaneRun { u32 end, flags, ntok, nbytes; };
 
 // Decode from `start` until the cursor reaches `boundary` (or EOB / error).
-//  EMIT: also write tokens to tok[tok_base + j] while they fit (token and byte caps) and check
-//        every distance against the bytes that exist before the token (hist0 = bytes of this
-//        member before the window, byte_base = bytes of the window before this lane).
-template <bool EMIT, bool STORE>
-AHIP_DEVINL LaneRun run_lane(bool active, u32 start, u32 boundary, const WaveLds &L, const BlockMeta &M, ParLds &P,
-                             u32 tok_base, u32 byte_base, u32 byte_cap, u64 hist0) {
+//  RECORD: token j of this lane goes to slab[j * 64 + lane] -- every active lane is at the same
+//          j, so each step is one coalesced 256-byte row store into the L2-resident slab.
+template <bool RECORD>
+AHIP_DEVINL LaneRun run_lane(bool active, u32 start, u32 boundary, const WaveLds &L, const BlockMeta &M, const u32 *inbuf,
+                             u32 *slab, int lane) {
   LaneRun r{start, 0, 0, 0};
   LaneBits d{0, 0, 0, 0, 2};
-  if (active) lb_init(d, P.inbuf, start);
+  if (active) lb_init(d, inbuf, start);
+  u32 lguard = 0;
   for (;;) {
     bool go = active && r.end < boundary && r.flags == 0;
     if (!__any(go)) break;
+    if (++lguard > 2048) { r.flags = LR_ERR; break; }
     if (go) {
-      u32 t = decode_token(d, L, M, P.inbuf);
+      u32 t = decode_token(d, L, M, inbuf);
       if (t & (TK_EOB | TK_ERR)) {
         r.flags = (t & TK_EOB) ? LR_EOB : LR_ERR;
         r.end = lb_pos(d);
+      } else if (RECORD && r.ntok >= (u32)SLAB_ROWS) {
+        r.flags = LR_OVF;
       } else {
-        u32 len = (t >> 31) ? 1u : (t >> 16);
-        if (EMIT) {
-          if (!(t >> 31) && (u64)(t & 0xffff) > hist0 + byte_base + r.nbytes) {
-            r.flags = LR_FAR;
-          } else if (STORE && (tok_base + r.ntok >= (u32)TOK_CAP || byte_base + r.nbytes + len > byte_cap)) {
-            r.flags = LR_CAP;  // r.end stays at this token's start: the next window begins here
-          } else {
-            if (STORE) P.tok[tok_base + r.ntok] = t;
-            r.ntok += 1;
-            r.nbytes += len;
-            r.end = lb_pos(d);
-          }
-        } else {
-          r.ntok += 1;
-          r.nbytes += len;
-          r.end = lb_pos(d);
-        }
+        if (RECORD) slab[r.ntok * 64 + lane] = t;
+        r.ntok += 1;
+        r.nbytes += (t >> 31) ? 1u : (t >> 16);
+        r.end = lb_pos(d);
       }
     }
   }
@@ -259,6 +254,7 @@ AHIP_DEVINL void resolve_back(ParLds &P, const GroupFront &f, u32 g0, u8 *ob, in
   if (__any(dep)) {
     u32 srcl = dep ? (u32)(f.si - (i32)g0) : (u32)lane;
     bool res = !dep;
+    int guard = 0;  // a chain of lower-lane pointers halves every step: 6 steps always suffice
     do {
       const u32 sv = lane_gather(val, srcl);
       const u32 sr = lane_gather(res ? 1u : 0u, srcl);
@@ -267,7 +263,7 @@ AHIP_DEVINL void resolve_back(ParLds &P, const GroupFront &f, u32 g0, u8 *ob, in
         if (sr) { val = sv; res = true; }
         else srcl = ss;
       }
-    } while (__any(!res));
+    } while (__any(!res) && ++guard < 8);
   }
   if (f.act) ob[g0 + lane] = (u8)val;
 }
@@ -291,6 +287,7 @@ AHIP_DEVINL void resolve_window(ParLds &P, u32 ntok, u32 nbytes, const u8 *hist,
   u8 *ob = P.obuf + A;
   u32 tcur = 0, carry = 0;
   GroupFront cur = resolve_front(P, ntok, nbytes, hist, 0, tcur, carry, lane);
+  if (nbytes > (u32)OB_CAP || ntok > (u32)TOK_CAP) return;  // cannot happen; never spin on corrupt bookkeeping
   for (u32 g0 = 0; g0 < nbytes; g0 += 64) {
     GroupFront nxt = cur;
     if (g0 + 64 < nbytes) nxt = resolve_front(P, ntok, nbytes, hist, g0 + 64, tcur, carry, lane);
@@ -314,21 +311,56 @@ AHIP_DEVINL void flush_window(const ParLds &P, u8 *g, u32 A, u32 nbytes, int lan
   if (tail0 + lane < nbytes) g[tail0 + lane] = P.obuf[A + tail0 + lane];
 }
 
+// Move the tokens of lanes [la, lb) from the slab into the LDS queue in stream order, checking
+// every distance against the bytes that exist before the token.  Returns false when a
+// back-reference reaches before the member start (the serial decoder then decides).
+//  T/B: exclusive prefix sums of tokens / bytes over the window's lanes; Ta/Ba: their values at la.
+AHIP_DEVINL bool gather_batch(ParLds &P, const u32 *slab, int la, int lb, u32 n, u32 T, u32 B, u32 Ta, u32 Ba,
+                              u64 hist0, int lane) {
+  const bool mine = lane >= la && lane < lb;
+  const u32 cnt = mine ? n : 0u;
+  const u32 steps = wave_umax(cnt);
+  u32 *q = P.tok + (T - Ta);
+  u64 avail = hist0 + (B - Ba);  // bytes of this member that precede the lane's first token
+  bool far = false;
+  for (u32 k = 0; k < steps; k += 4) {
+    u32 t[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) t[u] = (k + u < cnt) ? slab[(k + u) * 64 + lane] : 0u;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (k + u < cnt) {
+        const bool lit = t[u] >> 31;
+        if (!lit && (u64)(t[u] & 0xffff) > avail) far = true;
+        avail += lit ? 1u : (t[u] >> 16);
+        q[k + u] = t[u];
+      }
+    }
+  }
+  return !__any(far);
+}
+
 // Decode one Huffman block (tables already built in L) starting at b.pos.
 // Returns MS_* exactly like huffman_block().
 template <bool WRITE>
-AHIP_DEVINL u32 huffman_block_parallel(WaveLds &L, ParLds &P, BitCursor &b, OutCursor &o, int lane, ParStats &st) {
+AHIP_DEVINL u32 huffman_block_parallel(WaveLds &L, ParLds &P, u32 *slab, BitCursor &b, OutCursor &o, int lane,
+                                       ParStats &st) {
   BlockMeta M;
   load_long_meta(M.ll, L.lld, LL_ROOT);
   load_long_meta(M.d, L.dd, D_ROOT);
+  u32 wguard = 0;
   for (;;) {
+    if (++wguard > 4096) { st.dbg |= 1; break; }
     const u64 gbyte = (b.pos >> 3) & ~3ull;
     if (gbyte + (u64)IN_DWORDS * 4 > b.in_len) break;  // too close to the end: checked serial path
     // ---- stage the window ----
     AHIP_TICK(t_a);
     {
       const u8 *g = b.in + gbyte;
-      for (int k = lane; k < IN_DWORDS; k += 64) P.inbuf[k] = load_u32_unaligned(g + 4 * k);
+      for (int k = lane * 4; k < IN_DWORDS; k += 256) {
+        const uint4 v = load_u128_unaligned(g + 4 * k);  // IN_DWORDS is a multiple of 4
+        *(uint4 *)(P.inbuf + k) = v;
+      }
     }
     wave_sync();
     AHIP_TICK(t_b);
@@ -336,13 +368,15 @@ AHIP_DEVINL u32 huffman_block_parallel(WaveLds &L, ParLds &P, BitCursor &b, OutC
     st.windows++;
     const u32 s0 = (u32)(b.pos - gbyte * 8);
     const u32 boundary = (u32)(lane + 1) * SUB_BITS;
-    // ---- pass A: lane 0 true start, others blind ----
-    LaneRun R = run_lane<false, false>(true, lane == 0 ? s0 : (u32)lane * SUB_BITS, boundary, L, M, P, 0, 0, 0, 0);
+    // ---- pass A: lane 0 from the true boundary (recording), the others blind ----
+    LaneRun R = run_lane<true>(true, lane == 0 ? s0 : (u32)lane * SUB_BITS, boundary, L, M, P.inbuf, slab, lane);
     AHIP_TICK(t_c);
     AHIP_ACC(st.cyc[2], t_b, t_c);
     // ---- pass B rounds: restart from the predecessor's end until the chain is consistent ----
     int final_upto = 0;
+    u32 rguard = 0;
     for (;;) {
+      if (++rguard > 80) { st.dbg |= 2; break; }
       u64 flagged = __ballot(R.flags != 0);
       u64 final_mask = (final_upto >= 63) ? ~0ull : ((2ull << final_upto) - 1);
       if (flagged & final_mask) break;  // a final lane ended the block (or hit an error)
@@ -350,7 +384,7 @@ AHIP_DEVINL u32 huffman_block_parallel(WaveLds &L, ParLds &P, BitCursor &b, OutC
       u32 prev_end = lane_prev(R.end);
       u32 prev_flags = lane_prev(R.flags);
       bool act = lane > final_upto && prev_flags == 0;
-      LaneRun R2 = run_lane<false, false>(act, prev_end, boundary, L, M, P, 0, 0, 0, 0);
+      LaneRun R2 = run_lane<true>(act, prev_end, boundary, L, M, P.inbuf, slab, lane);
       bool mism = act && (R2.end != R.end || R2.flags != R.flags);
       if (act) R = R2;
       u64 mm = __ballot(mism);
@@ -365,52 +399,62 @@ AHIP_DEVINL u32 huffman_block_parallel(WaveLds &L, ParLds &P, BitCursor &b, OutC
     u64 flagged = __ballot(R.flags != 0) & final_mask;
     int kstop = flagged ? (__ffsll((long long)flagged) - 1) : 64;
     u32 stop_flags = flagged ? lane_bcast(R.flags, kstop) : 0u;
-    if (stop_flags & LR_ERR) { st.fallbacks++; break; }  // bad symbol on the true path: serial path decides
-    const bool valid = lane <= kstop;                     // kstop's tokens before its EOB count too
+    if (stop_flags & (LR_ERR | LR_OVF)) { st.fallbacks++; break; }  // the serial decoder decides
+    const int nlanes = kstop < 64 ? kstop + 1 : 64;  // kstop's tokens before its EOB count too
+    const bool valid = lane < nlanes;
     u32 tot_tok, tot_bytes;
     const u32 T = wave_excl_sum(valid ? R.ntok : 0u, tot_tok);
     const u32 B = wave_excl_sum(valid ? R.nbytes : 0u, tot_bytes);
     if ((u64)tot_bytes > o.limit - o.pos) { st.fallbacks++; break; }  // output window exhausted: serial path reports it
-    // ---- emit: tokens into the queue (and the far-reference check) ----
-    u32 prev_end = lane_prev(R.end);
-    LaneRun E = run_lane<true, WRITE>(valid, lane == 0 ? s0 : prev_end, boundary, L, M, P, T, B, (u32)OB_CAP, o.pos);
-    AHIP_TICK(t_e);
-    AHIP_ACC(st.cyc[4], t_d, t_e);
-    if (__any(valid && (E.flags & LR_FAR))) { st.fallbacks++; break; }
-    u64 capped = __ballot(valid && (E.flags & LR_CAP));
-    u32 commit_tok = tot_tok, commit_bytes = tot_bytes, next_pos;
-    bool block_done;
-    if (capped) {
-      int kc = __ffsll((long long)capped) - 1;
-      commit_tok = lane_bcast(T + E.ntok, kc);
-      commit_bytes = lane_bcast(B + E.nbytes, kc);
-      next_pos = lane_bcast(E.end, kc);
-      block_done = false;
-      st.partial++;
-    } else if (kstop < 64) {
-      next_pos = lane_bcast(R.end, kstop);  // just past the end-of-block code
-      block_done = true;
-    } else {
-      next_pos = lane_bcast(R.end, 63);
-      block_done = false;
-    }
-    if (WRITE && commit_bytes) {
-      u8 *g = o.base + o.pos;
-      const u32 A = (u32)((uintptr_t)g & 15);
+    const u32 next_pos = lane_bcast(R.end, kstop < 64 ? kstop : 63);  // past the EOB code, or lane 63's end
+    const u32 lane_start = lane == 0 ? s0 : lane_prev(R.end);
+    // ---- resolve in batches of whole lanes that fit the LDS token queue / output window ----
+    bool bail = false;
+    int la = 0;
+    u32 bguard = 0;
+    while (la < nlanes) {
+      if (++bguard > 80) { st.dbg |= 4; bail = true; break; }
+      const u32 Ta = lane_bcast(T, la), Ba = lane_bcast(B, la);
+      const bool fits = valid && lane >= la && (T + R.ntok - Ta <= (u32)TOK_CAP) && (B + R.nbytes - Ba <= (u32)OB_CAP);
+      const u64 fm = __ballot(fits) >> la;            // lanes la, la+1, ... as bits 0, 1, ...
+      const int take = fm == ~0ull ? 64 : (__ffsll((long long)~fm) - 1);  // leading run of fitting lanes
+      if (take == 0) {  // one lane alone exceeds the queue (very dense or very long tokens)
+        b.pos = gbyte * 8 + lane_bcast(lane_start, la);
+        bail = true;
+        break;
+      }
+      const int lb = la + take;
+      const u32 Tb = lb < 64 ? lane_bcast(T, lb < 64 ? lb : 63) : tot_tok;
+      const u32 Bb = lb < 64 ? lane_bcast(B, lb < 64 ? lb : 63) : tot_bytes;
+      const u32 ntok = (lb < nlanes ? Tb : tot_tok) - Ta, nbytes = (lb < nlanes ? Bb : tot_bytes) - Ba;
+      AHIP_TICK(t_e0);
+      if (!gather_batch(P, slab, la, lb, R.ntok, T, B, Ta, Ba, o.pos, lane)) {
+        b.pos = gbyte * 8 + lane_bcast(lane_start, la);
+        bail = true;
+        break;
+      }
       wave_sync();
       AHIP_TICK(t_f);
-      resolve_window(P, commit_tok, commit_bytes, g, A, lane);
-      wave_sync();
-      AHIP_TICK(t_g);
-      AHIP_ACC(st.cyc[5], t_f, t_g);
-      flush_window(P, g, A, commit_bytes, lane);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // later windows read this output back
-      AHIP_TICK(t_h);
-      AHIP_ACC(st.cyc[6], t_g, t_h);
+      AHIP_ACC(st.cyc[4], t_e0, t_f);
+      if (WRITE && nbytes) {
+        u8 *g = o.base + o.pos;
+        const u32 A = (u32)((uintptr_t)g & 15);
+        resolve_window(P, ntok, nbytes, g, A, lane);
+        wave_sync();
+        AHIP_TICK(t_g);
+        AHIP_ACC(st.cyc[5], t_f, t_g);
+        flush_window(P, g, A, nbytes, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // later batches read this output back
+        AHIP_TICK(t_h);
+        AHIP_ACC(st.cyc[6], t_g, t_h);
+      }
+      o.pos += nbytes;
+      la = lb;
+      if (la < nlanes) st.partial++;
     }
-    o.pos += commit_bytes;
+    if (bail) { st.fallbacks++; break; }
     b.pos = gbyte * 8 + next_pos;
-    if (block_done) return MS_OK;
+    if (kstop < 64) return MS_OK;
   }
   AHIP_TICK(t_s0);
   u32 rs = huffman_block<WRITE>(L, b, o, lane);
@@ -422,8 +466,8 @@ AHIP_DEVINL u32 huffman_block_parallel(WaveLds &L, ParLds &P, BitCursor &b, OutC
 // Inflate one stream.  Mirrors Inflate._inflate(): loop blocks until BFINAL, an error, or EOS.
 //  PAR: Huffman blocks go through huffman_block_parallel (P must be valid), else the serial decoder.
 template <bool WRITE, bool PAR>
-AHIP_DEVINL void inflate_member(WaveLds &L, ParLds *P, const u8 *in, u64 in_len, const MemberDesc &m, u8 *out,
-                                MemberResult &res, int lane) {
+AHIP_DEVINL void inflate_member(WaveLds &L, ParLds *P, u32 *slab, const u8 *in, u64 in_len, const MemberDesc &m,
+                                u8 *out, MemberResult &res, int lane) {
   ParStats st{};
   BitCursor b{in, in_len, in_len * 8, m.in_off * 8};
   OutCursor o{out + m.out_off, 0, m.out_limit};
@@ -451,7 +495,7 @@ AHIP_DEVINL void inflate_member(WaveLds &L, ParLds *P, const u8 *in, u64 in_len,
         AHIP_TICK(t_h1);
         AHIP_ACC(st.cyc[0], t_h0, t_h1);
         if (!ok) r = MS_OVERSUB;
-        else if (PAR) r = huffman_block_parallel<WRITE>(L, *P, b, o, lane, st);
+        else if (PAR) r = huffman_block_parallel<WRITE>(L, *P, slab, b, o, lane, st);
         else r = huffman_block<WRITE>(L, b, o, lane);
       }
     }
@@ -474,6 +518,7 @@ AHIP_DEVINL void inflate_member(WaveLds &L, ParLds *P, const u8 *in, u64 in_len,
     res.fallbacks = st.fallbacks;
     res.partial = st.partial;
     for (int k = 0; k < 8; ++k) res.cyc[k] = st.cyc[k];
+    if (st.dbg) res.cyc[7] = 0xdead0000u | st.dbg;
   }
 }
 

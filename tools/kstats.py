@@ -28,6 +28,7 @@ print("kernel %.3f ms  %.1f GB/s out  ok=%s" % (ms, len(plain) / ms / 1e6, bool(
 print("per member: blocks %.2f windows %.2f rounds %.2f (%.3f per window) fallbacks %.3f partial %.2f" % (
     r[:, 5].mean(), r[:, 6].mean(), r[:, 7].mean(), r[:, 7].sum() / max(1, r[:, 6].sum()), r[:, 8].mean(), r[:, 9].mean()))
 print("status histogram", np.bincount(r[:, 4]))
+print("debug codes", sorted(set(hex(v) for v in r[:, 17] if (v >> 16) == 0xdead)))
 cyc = r[:, 10:18].astype(np.float64).mean(axis=0) * 16
 if cyc.sum() > 0:
     names = ["header+tables", "stage", "passA", "passB", "emit", "resolve", "flush", "serial"]
