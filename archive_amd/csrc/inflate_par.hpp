@@ -9,17 +9,19 @@
 //   pass A      lane 0 starts at the known token boundary; every other lane starts blind at the
 //               first bit of its subsequence and decodes until it crosses into the next one.
 //               Huffman streams self-synchronise, so most blind lanes end on a true boundary.
-//   pass B..    lane i restarts from the end position lane i-1 reported and counts tokens and
-//               output bytes.  Lanes up to the first one whose end position changed are final
-//               (their start was true); the rest repeat.  Usually one round.
-//   emit        wave prefix sums of the per-lane counts give every lane its slot in the token
-//               queue; lanes decode once more and write packed tokens in stream order.
-//   resolve     64 tokens at a time: a wave scan of lengths gives each token its output offset
-//               (the literal/match boundary scan); literals and matches whose source is already
-//               complete are executed by all lanes at once, the few that depend on bytes of the
-//               same 64-token group go in further rounds.  Output is assembled in an LDS window
-//               and flushed to HBM with coalesced stores; matches that reach further back than
-//               the window read the already-flushed output (L2-resident).
+//   pass B..    lane i restarts from the end position lane i-1 reported, counts tokens and
+//               output bytes and records its tokens (one coalesced row store per step into a
+//               per-workgroup slab in device scratch).  Lanes up to the first one whose end
+//               position changed are final (their start was true); the rest repeat.
+//   gather      wave prefix sums of the per-lane counts give every lane its slot in the LDS token
+//               queue; whole lanes are taken in batches that fit the queue / output window.
+//   resolve     pass 1: wave scans of token lengths give each token its output offset (the
+//               literal/match boundary scan).  pass 2: 64 output BYTES at a time, one per lane:
+//               a start-slot scatter + wave prefix-max finds the token covering each byte; the
+//               byte is a literal, an earlier byte of the LDS window, a byte of already flushed
+//               output (L2-resident), or -- runs and very short distances -- the byte of a lower
+//               lane, resolved by pointer doubling.  The window is flushed to HBM with coalesced
+//               16-byte stores.
 //
 // Any anomaly (bad symbol on the true path, back-reference before the member start, output
 // window exhausted, input too close to its end for unchecked reads) drops to the serial
@@ -36,10 +38,10 @@ namespace ahip {
 #define AHIP_SUB_BITS 512
 #endif
 #ifndef AHIP_TOK_CAP
-#define AHIP_TOK_CAP 1280
+#define AHIP_TOK_CAP 1024
 #endif
 #ifndef AHIP_OB_CAP
-#define AHIP_OB_CAP 6144
+#define AHIP_OB_CAP 4608
 #endif
 #ifndef AHIP_SLAB_ROWS
 #define AHIP_SLAB_ROWS 192
@@ -61,7 +63,7 @@ struct ParLds {
   u32 inbuf[IN_DWORDS] __attribute__((aligned(16)));
   u32 tok[TOK_CAP];
   u8 obuf[OB_CAP + 32] __attribute__((aligned(16)));
-  u32 slot[64];
+  u32 slot[3 * 64];  // two alternating 64-entry start-slot rows + one dump row
 };
 
 struct ParStats { u32 windows, rounds, fallbacks, partial; u32 cyc[8]; u32 dbg; };
@@ -173,8 +175,8 @@ struct LaneRun { u32 end, flags, ntok, nbytes; };
 //  RECORD: token j of this lane goes to slab[j * 64 + lane] -- every active lane is at the same
 //          j, so each step is one coalesced 256-byte row store into the L2-resident slab.
 template <bool RECORD>
-AHIP_DEVINL LaneRun run_lane(bool active, u32 start, u32 boundary, const WaveLds &L, const BlockMeta &M, const u32 *inbuf,
-                             u32 *slab, int lane) {
+AHIP_DEVINL LaneRun run_lane(bool active, bool rec, u32 start, u32 boundary, const WaveLds &L, const BlockMeta &M,
+                             const u32 *inbuf, u32 *slab, int lane) {
   LaneRun r{start, 0, 0, 0};
   LaneBits d{0, 0, 0, 0, 2};
   if (active) lb_init(d, inbuf, start);
@@ -191,7 +193,7 @@ AHIP_DEVINL LaneRun run_lane(bool active, u32 start, u32 boundary, const WaveLds
       } else if (RECORD && r.ntok >= (u32)SLAB_ROWS) {
         r.flags = LR_OVF;
       } else {
-        if (RECORD) slab[r.ntok * 64 + lane] = t;
+        if (RECORD && rec) slab[r.ntok * 64 + lane] = t;
         r.ntok += 1;
         r.nbytes += (t >> 31) ? 1u : (t >> 16);
         r.end = lb_pos(d);
@@ -222,19 +224,21 @@ struct GroupFront {
 };
 AHIP_DEVINL GroupFront resolve_front(ParLds &P, u32 ntok, u32 nbytes, const u8 *hist, u32 g0, u32 &tcur, u32 &carry,
                                      int lane) {
+  u32 *slot = P.slot + ((g0 >> 6) & 1) * 64;  // two slot arrays alternate: no write-after-read stall
   wave_sync();
-  P.slot[lane] = 0;
+  slot[lane] = 0;
   const u32 kidx = tcur + lane;
   const u32 k = kidx < ntok ? P.tok[kidx] : 0u;
   const u32 offk = (k >> 17) & 0x1fff;
   const bool ing = k != 0 && offk < g0 + 64;  // tokens are sorted by offset, so these form lanes 0..cnt-1
-  if (ing) P.slot[offk - g0] = k;
+  (ing ? slot + (offk - g0) : P.slot + 128 + lane)[0] = k;  // lanes without a start write to the dump row (branch-free)
   const u32 cnt = (u32)__popcll(__ballot(ing));
   wave_sync();  // other lanes wrote slot[]: without this hipcc forwards this lane's own 0
-  u32 key = P.slot[lane];
+  u32 key = slot[lane];
   key = wave_incl_umax(key);
   key = key > carry ? key : carry;  // the token that covers the start of the group
-  if (cnt) carry = lane_bcast(k, (int)cnt - 1);
+  const u32 last = lane_bcast(k, (int)((cnt - 1) & 63));
+  carry = cnt ? last : carry;
   tcur += cnt;
   GroupFront f;
   const u32 x = g0 + lane;
@@ -242,7 +246,9 @@ AHIP_DEVINL GroupFront resolve_front(ParLds &P, u32 ntok, u32 nbytes, const u8 *
   f.lit = (key >> 16) & 1;
   f.val = key & 0xff;
   f.si = (i32)x - (i32)((key & 0x7fff) + 1);
+#ifndef AHIP_ABLATE_FAR
   if (f.act && !f.lit && f.si < 0) f.val = hist[f.si];
+#endif
   return f;
 }
 AHIP_DEVINL void resolve_back(ParLds &P, const GroupFront &f, u32 g0, u8 *ob, int lane) {
@@ -286,14 +292,15 @@ AHIP_DEVINL void resolve_window(ParLds &P, u32 ntok, u32 nbytes, const u8 *hist,
   // pass 2: bytes
   u8 *ob = P.obuf + A;
   u32 tcur = 0, carry = 0;
+  if (nbytes == 0 || nbytes > (u32)OB_CAP || ntok > (u32)TOK_CAP) return;  // never spin on corrupt bookkeeping
   GroupFront cur = resolve_front(P, ntok, nbytes, hist, 0, tcur, carry, lane);
-  if (nbytes > (u32)OB_CAP || ntok > (u32)TOK_CAP) return;  // cannot happen; never spin on corrupt bookkeeping
-  for (u32 g0 = 0; g0 < nbytes; g0 += 64) {
-    GroupFront nxt = cur;
-    if (g0 + 64 < nbytes) nxt = resolve_front(P, ntok, nbytes, hist, g0 + 64, tcur, carry, lane);
+  u32 g0 = 0;
+  for (; g0 + 64 < nbytes; g0 += 64) {  // front of the next group and back of this one: one straight-line body
+    GroupFront nxt = resolve_front(P, ntok, nbytes, hist, g0 + 64, tcur, carry, lane);
     resolve_back(P, cur, g0, ob, lane);
     cur = nxt;
   }
+  resolve_back(P, cur, g0, ob, lane);
 }
 
 // Flush the assembled window to HBM: byte head up to 16-byte alignment, 16-byte body, byte tail.
@@ -323,12 +330,12 @@ AHIP_DEVINL bool gather_batch(ParLds &P, const u32 *slab, int la, int lb, u32 n,
   u32 *q = P.tok + (T - Ta);
   u64 avail = hist0 + (B - Ba);  // bytes of this member that precede the lane's first token
   bool far = false;
-  for (u32 k = 0; k < steps; k += 4) {
-    u32 t[4];
+  for (u32 k = 0; k < steps; k += 8) {
+    u32 t[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) t[u] = (k + u < cnt) ? slab[(k + u) * 64 + lane] : 0u;
+    for (int u = 0; u < 8; ++u) t[u] = (k + u < cnt) ? slab[(k + u) * 64 + lane] : 0u;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
       if (k + u < cnt) {
         const bool lit = t[u] >> 31;
         if (!lit && (u64)(t[u] & 0xffff) > avail) far = true;
@@ -369,7 +376,7 @@ AHIP_DEVINL u32 huffman_block_parallel(WaveLds &L, ParLds &P, u32 *slab, BitCurs
     const u32 s0 = (u32)(b.pos - gbyte * 8);
     const u32 boundary = (u32)(lane + 1) * SUB_BITS;
     // ---- pass A: lane 0 from the true boundary (recording), the others blind ----
-    LaneRun R = run_lane<true>(true, lane == 0 ? s0 : (u32)lane * SUB_BITS, boundary, L, M, P.inbuf, slab, lane);
+    LaneRun R = run_lane<true>(true, lane == 0, lane == 0 ? s0 : (u32)lane * SUB_BITS, boundary, L, M, P.inbuf, slab, lane);
     AHIP_TICK(t_c);
     AHIP_ACC(st.cyc[2], t_b, t_c);
     // ---- pass B rounds: restart from the predecessor's end until the chain is consistent ----
@@ -384,7 +391,7 @@ AHIP_DEVINL u32 huffman_block_parallel(WaveLds &L, ParLds &P, u32 *slab, BitCurs
       u32 prev_end = lane_prev(R.end);
       u32 prev_flags = lane_prev(R.flags);
       bool act = lane > final_upto && prev_flags == 0;
-      LaneRun R2 = run_lane<true>(act, prev_end, boundary, L, M, P.inbuf, slab, lane);
+      LaneRun R2 = run_lane<true>(act, true, prev_end, boundary, L, M, P.inbuf, slab, lane);
       bool mism = act && (R2.end != R.end || R2.flags != R.flags);
       if (act) R = R2;
       u64 mm = __ballot(mism);
@@ -469,7 +476,7 @@ template <bool WRITE, bool PAR>
 AHIP_DEVINL void inflate_member(WaveLds &L, ParLds *P, u32 *slab, const u8 *in, u64 in_len, const MemberDesc &m,
                                 u8 *out, MemberResult &res, int lane) {
   ParStats st{};
-  BitCursor b{in, in_len, in_len * 8, m.in_off * 8};
+  BitCursor b{in, in_len, in_len * 8, m.in_off * 8, nullptr, 0, 0};
   OutCursor o{out + m.out_off, 0, m.out_limit};
   u32 status = MS_EOS, blocks = 0;
   for (;;) {
@@ -488,7 +495,20 @@ AHIP_DEVINL void inflate_member(WaveLds &L, ParLds *P, u32 *slab, const u8 *in, 
       r = MS_OK;
       AHIP_TICK(t_h0);
       if (btype == 1) fixed_lengths(L.lens, lane);
-      else r = dynamic_header(L, b, lane, hlit, hdist);
+      else {
+        if (PAR) {  // stage the (at most 569-byte) dynamic header into the idle window buffer
+          const u64 sb = (b.pos >> 3) & ~3ull;
+          constexpr u32 HDR_STAGE = 640;
+          if (sb + HDR_STAGE <= in_len) {
+            for (u32 k = lane * 4; k < HDR_STAGE / 4; k += 256)
+              *(uint4 *)(P->inbuf + k) = load_u128_unaligned(in + sb + 4 * k);
+            wave_sync();
+            b.stage = P->inbuf; b.stage_byte = sb; b.stage_len = HDR_STAGE;
+          }
+        }
+        r = dynamic_header(L, b, lane, hlit, hdist);
+        b.stage = nullptr;
+      }
       if (r == MS_OK) {
         bool ok = build_decode_table<false>(L.lens, hlit, L.ll, LL_ROOT, L.lld, L.ll_sorted, lane);
         ok &= build_decode_table<true>(L.lens + hlit, hdist, L.dt, D_ROOT, L.dd, L.d_sorted, lane);

@@ -77,6 +77,11 @@ struct BitCursor {
   u64 in_len;
   u64 total_bits;
   u64 pos;  // absolute bit index
+  // optional LDS copy of in[stage_byte .. stage_byte + stage_len): block headers are decoded
+  // symbol by symbol, and every global read would cost an HBM/L2 round trip
+  const u32 *stage;
+  u64 stage_byte;
+  u32 stage_len;
 };
 
 // >= 57 valid bits starting at the cursor; bytes past the end read as zero.
@@ -84,6 +89,14 @@ AHIP_DEVINL u64 peek_bits(const BitCursor &b) {
   u64 byte = b.pos >> 3;
   u32 sh = (u32)b.pos & 7;
   u64 w;
+  if (b.stage && byte >= b.stage_byte && byte + 12 <= b.stage_byte + b.stage_len) {
+    const u32 rel = (u32)(byte - b.stage_byte);  // stage_byte is 4-aligned relative to `in`
+    const u32 *p = b.stage + (rel >> 2);
+    const u32 w0 = p[0], w1 = p[1], w2 = p[2];
+    const u32 bsh = (rel & 3) * 8;
+    const u32 lo = __builtin_amdgcn_alignbit(w1, w0, bsh), hi = __builtin_amdgcn_alignbit(w2, w1, bsh);
+    return (((u64)hi << 32) | lo) >> sh;
+  }
   if (byte + 8 <= b.in_len) {
     w = load_u64_unaligned(b.in + byte);
   } else {

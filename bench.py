@@ -149,6 +149,18 @@ def main():
                          "kernel": "inflate_members_kernel<true>", "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes": int(algo_bytes)},
         }
+        # HBM-side traffic of the dominant kernel: PMC counters cannot be read from inside this
+        # process; the figure measured by rocprofv3 (separate --pmc passes, profiles/) is attached
+        # when this run uses the profiled workload.
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                pmc = json.load(f)
+            w = pmc["workload"]
+            if (w["members"], w["member_bytes"], w["kind"], w["bc"]) == (args.members, args.member_bytes, args.kind, not args.no_bc):
+                line["roofline"]["traffic"] = round(pmc["traffic_bytes_per_launch"] / 1e9, 2)
+                line["roofline"]["traffic_unit"] = "GB per launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, raw, profiles/r01_pmc_traffic.md)"
+        except Exception:
+            pass
         if args.cpu_seconds > 0 and world >= 1:
             line["cpu_baseline"] = cpu_baseline(comp, args, out_bytes)
         print(json.dumps(line), flush=True)
