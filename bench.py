@@ -73,8 +73,6 @@ def main():
     out_bytes = args.members * args.member_bytes
     d_in = torch.from_numpy(comp).to(dev)
     d_out = torch.empty(out_bytes + 64, dtype=torch.uint8, device=dev)
-    sizes = torch.zeros(world, dtype=torch.int64, device=dev)
-    mine = torch.zeros(1, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream()
     sh = ctypes.c_void_p(stream.cuda_stream)
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -97,10 +95,9 @@ def main():
         L.ahip_gzip_plan_destroy(plan)
         if rc != 0 or olen.value != out_bytes:
             raise SystemExit("decode verdict %d, %d bytes (expected %d): %s" % (rc, olen.value, out_bytes, N.last_error()))
-        if world > 1:  # the path's one exchange: output-size all-gather -> shard offsets
-            mine.fill_(olen.value)
-            dist.all_gather_into_tensor(sizes, mine)
-            _ = torch.cumsum(sizes, 0) - sizes
+        if world > 1:  # the path's one exchange: output-size all-gather -> shard offsets (RCCL)
+            from archive_amd.sharding import exchange_output_offsets
+            exchange_output_offsets(olen.value, device=dev)
         return olen.value
 
     for _ in range(args.warmup):
