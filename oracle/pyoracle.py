@@ -38,6 +38,10 @@ def lib():
         L.orc_crc32.restype = ctypes.c_uint32
         L.orc_adler32.argtypes = [u8p, ctypes.c_size_t, ctypes.c_uint32]
         L.orc_adler32.restype = ctypes.c_uint32
+        L.orc_deflate_raw.argtypes = [u8p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, u8p, ctypes.c_size_t, szp,
+                                      ctypes.POINTER(ctypes.c_uint32)]
+        L.orc_gzip_encode.argtypes = [u8p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint32, u8p, ctypes.c_size_t, szp]
+        L.orc_zlib_encode.argtypes = [u8p, ctypes.c_size_t, ctypes.c_int, u8p, ctypes.c_size_t, szp]
         _lib = L
     return _lib
 
@@ -92,3 +96,35 @@ def crc32(data, crc=0):
 def adler32(data, adler=1):
     buf, n = _inbuf(data)
     return lib().orc_adler32(ctypes.addressof(buf), n, adler)
+
+
+def deflate_raw(data, level=6, truncate_heuristic=True):
+    """Deflate(bytes, level: L).getBytes() -> (compressed bytes, crc32).  truncate_heuristic=False
+    switches off the reference's block-truncation heuristic (= stock zlib behaviour)."""
+    buf, n = _inbuf(data)
+    cap = n + n // 8 + 1024
+    out = ctypes.create_string_buffer(cap)
+    olen = ctypes.c_size_t(0)
+    crc = ctypes.c_uint32(0)
+    rc = lib().orc_deflate_raw(ctypes.addressof(buf), n, level, int(truncate_heuristic), ctypes.addressof(out), cap,
+                               ctypes.byref(olen), ctypes.byref(crc))
+    assert rc == 0
+    return out.raw[:olen.value], crc.value
+
+
+def gzip_encode(data, level=6, mtime=0):
+    buf, n = _inbuf(data)
+    cap = n + n // 8 + 1024
+    out = ctypes.create_string_buffer(cap)
+    olen = ctypes.c_size_t(0)
+    assert lib().orc_gzip_encode(ctypes.addressof(buf), n, level, mtime, ctypes.addressof(out), cap, ctypes.byref(olen)) == 0
+    return out.raw[:olen.value]
+
+
+def zlib_encode(data, level=6):
+    buf, n = _inbuf(data)
+    cap = n + n // 8 + 1024
+    out = ctypes.create_string_buffer(cap)
+    olen = ctypes.c_size_t(0)
+    assert lib().orc_zlib_encode(ctypes.addressof(buf), n, level, ctypes.addressof(out), cap, ctypes.byref(olen)) == 0
+    return out.raw[:olen.value]
