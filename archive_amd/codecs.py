@@ -116,6 +116,90 @@ class GZipDecoder:
     decodeStream = decode_stream
 
 
+class DeflateLevel:
+    """deflate.dart:10-18"""
+    none = 0
+    bestSpeed = 1
+    defaultCompression = 6
+    bestCompression = 9
+
+
+class Deflate:
+    """`Deflate(bytes, level: 6).getBytes()` -- raw DEFLATE encode (deflate.dart:25-99).
+
+    Output is valid DEFLATE whose size is within the tolerance stated in DESIGN.md of the
+    reference's; an invalid level yields empty output, like the reference's silent `_init`."""
+
+    def __init__(self, data, level=DeflateLevel.defaultCompression, window_bits=15, output=None):
+        buf, n = _as_buffer(data)
+        self.level = level
+        crc = ctypes.c_uint32(0)
+        bound = N.lib().ahip_deflate_bound(n)
+        out = ctypes.create_string_buffer(max(1, bound))
+        olen = ctypes.c_size_t(0)
+        rc = N.lib().ahip_deflate_raw(buf, n, level, window_bits, out, bound, ctypes.byref(olen), ctypes.byref(crc))
+        if rc != N.AHIP_OK:
+            _check(rc)
+        self._bytes = out.raw[:olen.value]
+        self.crc32 = crc.value
+        self.total = n
+        if output is not None:
+            output.extend(self._bytes)
+
+    def get_bytes(self):
+        return self._bytes
+
+    def take_bytes(self):
+        b, self._bytes = self._bytes, b""
+        return b
+
+    def finish(self):
+        pass
+
+    getBytes = get_bytes
+    takeBytes = take_bytes
+
+
+def _encode(fn, data, extra):
+    buf, n = _as_buffer(data)
+    bound = N.lib().ahip_deflate_bound(n) + 32
+    out = ctypes.create_string_buffer(bound)
+    olen = ctypes.c_size_t(0)
+    rc = fn(buf, n, *extra, out, bound, ctypes.byref(olen))
+    if rc != N.AHIP_OK:
+        _check(rc)
+    return out.raw[:olen.value]
+
+
+class ZLibEncoder:
+    """`ZLibEncoder().encodeBytes(data, level: 6, raw: false)` (zlib_encoder.dart:14-38)"""
+
+    def encode_bytes(self, data, level=None, window_bits=None, raw=False):
+        level = 6 if level is None else level
+        if raw:
+            return Deflate(data, level=level, window_bits=15 if window_bits is None else window_bits).get_bytes()
+        return _encode(N.lib().ahip_zlib_encode, data, (level,))
+
+    encodeBytes = encode_bytes
+
+
+class GZipEncoder:
+    """`GZipEncoder().encodeBytes(data, level: 6)` (gzip_encoder.dart:14-30).  The reference
+    stamps the current time into the header; pass `mtime` to make the bytes reproducible."""
+
+    def encode_bytes(self, data, level=None, window_bits=None, raw=False, mtime=None):
+        import time
+        level = 6 if level is None else level
+        if raw:
+            return Deflate(data, level=level, window_bits=15 if window_bits is None else window_bits).get_bytes()
+        return _encode(N.lib().ahip_gzip_encode, data, (level, int(time.time()) if mtime is None else mtime))
+
+    encodeBytes = encode_bytes
+
+
+ZLibEncoderWeb = ZLibEncoder
+GZipEncoderWeb = GZipEncoder
+
 # The reference's *Web classes force the pure-Dart path; here both names are the HIP path.
 ZLibDecoderWeb = ZLibDecoder
 GZipDecoderWeb = GZipDecoder

@@ -7,12 +7,14 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <string>
 #include <vector>
 
 #include "common.hpp"
 #include "gzip_index.hpp"
+#include "deflate_kernels.hpp"
 #include "inflate_par.hpp"
 
 using namespace ahip;
@@ -461,6 +463,125 @@ uint32_t ahip_adler32(const uint8_t *data, size_t len, uint32_t adler) {
     s1 %= 65521; s2 %= 65521;
   }
   return (uint32_t)((s2 << 16) | s1);
+}
+
+size_t ahip_deflate_bound(size_t in_len) {
+  const size_t chunks = (in_len + DF_CHUNK - 1) / DF_CHUNK;
+  return in_len + chunks * 16 + 64;
+}
+
+// Deflate on device memory.  Returns the compressed size through *out_len.
+static int32_t deflate_device_impl(const u8 *d_in, size_t n, int level, u8 *d_out, size_t cap, size_t *out_len,
+                                   hipStream_t st) {
+  static DevBuf b_mlen, b_mdist, b_tok, b_ntok, b_slabs, b_csize, b_coff;
+  if (out_len) *out_len = 0;
+  if (level < 0 || level > 9) return AHIP_OK;  // the reference's _init fails silently: no output
+  if (n == 0) {  // reference: one fixed-Huffman block holding only the end-of-block code (level >= 1), or an empty stored block
+    const u8 fixed_empty[2] = {0x03, 0x00}, stored_empty[5] = {0x01, 0x00, 0x00, 0xff, 0xff};
+    const u8 *src = level == 0 ? stored_empty : fixed_empty;
+    const size_t len = level == 0 ? 5 : 2;
+    if (cap < len) { if (out_len) *out_len = len; return fail(AHIP_E_CAP, "output buffer too small"); }
+    HIP_TRY(hipMemcpyAsync(d_out, src, len, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (out_len) *out_len = len;
+    return AHIP_OK;
+  }
+  DeflateParams P;
+  P.n = n;
+  P.chunks = (u32)((n + DF_CHUNK - 1) / DF_CHUNK);
+  P.lazy = level >= 4 ? 1u : 0u;
+  P.store = level == 0 ? 1u : 0u;
+  P.max_cmp = 258;
+  HIP_TRY(b_mlen.reserve(n * 2 + 64));
+  HIP_TRY(b_mdist.reserve(n * 2 + 64));
+  HIP_TRY(b_tok.reserve(n * 4 + 64));
+  HIP_TRY(b_ntok.reserve((size_t)P.chunks * 4));
+  HIP_TRY(b_slabs.reserve((size_t)P.chunks * DF_SLAB));
+  HIP_TRY(b_csize.reserve((size_t)P.chunks * 4));
+  HIP_TRY(b_coff.reserve((size_t)P.chunks * 8));
+  if (!P.store)
+    hipLaunchKernelGGL(deflate_match_kernel, dim3(P.chunks), dim3(256), 0, st, d_in, P, b_mlen.as<u16>(), b_mdist.as<u16>());
+  hipLaunchKernelGGL(deflate_parse_kernel, dim3(cdiv(P.chunks, 64)), dim3(64), 0, st, d_in, P, b_mlen.as<u16>(),
+                     b_mdist.as<u16>(), b_tok.as<u32>(), b_ntok.as<u32>());
+  hipLaunchKernelGGL(deflate_encode_kernel, dim3(P.chunks), dim3(256), 0, st, d_in, P, b_tok.as<u32>(), b_ntok.as<u32>(),
+                     b_slabs.as<u8>(), b_csize.as<u32>());
+  std::vector<u32> csize(P.chunks);
+  HIP_TRY(hipMemcpyAsync(csize.data(), b_csize.p, (size_t)P.chunks * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipGetLastError());
+  std::vector<u64> coff(P.chunks);
+  u64 total = 0;
+  for (u32 i = 0; i < P.chunks; ++i) { coff[i] = total; total += csize[i]; }
+  if (out_len) *out_len = total;
+  if (total > cap) return fail(AHIP_E_CAP, "output buffer too small");
+  HIP_TRY(hipMemcpyAsync(b_coff.p, coff.data(), (size_t)P.chunks * 8, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(deflate_concat_kernel, dim3(P.chunks), dim3(256), 0, st, b_slabs.as<u8>(), b_csize.as<u32>(),
+                     b_coff.as<u64>(), d_out);
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipGetLastError());
+  return AHIP_OK;
+}
+
+int32_t ahip_deflate_raw_device(const void *d_in, size_t in_len, int32_t level, void *d_out, size_t out_cap,
+                                size_t *out_len, void *stream) {
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  int32_t rc = ensure_init();
+  if (rc != AHIP_OK) return rc;
+  return deflate_device_impl((const u8 *)d_in, in_len, level, (u8 *)d_out, out_cap, out_len, (hipStream_t)stream);
+}
+
+int32_t ahip_deflate_raw(const uint8_t *in, size_t in_len, int32_t level, int32_t window_bits, uint8_t *out,
+                         size_t out_cap, size_t *out_len, uint32_t *crc32) {
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  if (out_len) *out_len = 0;
+  if (crc32) *crc32 = 0;
+  if (window_bits < 9 || window_bits > 15 || level < 0 || level > 9) return AHIP_OK;  // reference: silent no-op
+  if (window_bits != 15) return fail(AHIP_E_UNSUPPORTED, "only windowBits 15 is implemented");
+  int32_t rc = ensure_init();
+  if (rc != AHIP_OK) return rc;
+  static DevBuf din, dout;
+  HIP_TRY(din.reserve(in_len + 16));
+  const size_t bound = ahip_deflate_bound(in_len);
+  HIP_TRY(dout.reserve(bound));
+  if (in_len) HIP_TRY(hipMemcpy(din.p, in, in_len, hipMemcpyHostToDevice));
+  size_t produced = 0;
+  rc = deflate_device_impl(din.as<u8>(), in_len, level, dout.as<u8>(), bound, &produced, nullptr);
+  if (rc != AHIP_OK) return rc;
+  if (out_len) *out_len = produced;
+  if (crc32) *crc32 = ahip_crc32(in, in_len, 0);
+  if (produced > out_cap) return fail(AHIP_E_CAP, "output buffer too small");
+  if (produced) HIP_TRY(hipMemcpy(out, dout.p, produced, hipMemcpyDeviceToHost));
+  return AHIP_OK;
+}
+
+int32_t ahip_gzip_encode(const uint8_t *in, size_t in_len, int32_t level, uint32_t mtime, uint8_t *out, size_t out_cap,
+                         size_t *out_len) {
+  if (out_len) *out_len = 0;
+  if (out_cap < 18) { if (out_len) *out_len = ahip_deflate_bound(in_len) + 18; return fail(AHIP_E_CAP, "output buffer too small"); }
+  size_t clen = 0;
+  uint32_t crc = 0;
+  int32_t rc = ahip_deflate_raw(in, in_len, level, 15, out + 10, out_cap - 18, &clen, &crc);
+  if (out_len) *out_len = clen + 18;
+  if (rc != AHIP_OK) return rc;
+  const uint8_t h[10] = {0x1f, 0x8b, 8, 0, (uint8_t)mtime, (uint8_t)(mtime >> 8), (uint8_t)(mtime >> 16), (uint8_t)(mtime >> 24), 0, 0xff};
+  memcpy(out, h, 10);
+  uint8_t *t = out + 10 + clen;
+  for (int k = 0; k < 4; k++) { t[k] = (uint8_t)(crc >> (8 * k)); t[4 + k] = (uint8_t)(((uint32_t)in_len) >> (8 * k)); }
+  return AHIP_OK;
+}
+
+int32_t ahip_zlib_encode(const uint8_t *in, size_t in_len, int32_t level, uint8_t *out, size_t out_cap, size_t *out_len) {
+  if (out_len) *out_len = 0;
+  if (out_cap < 6) { if (out_len) *out_len = ahip_deflate_bound(in_len) + 6; return fail(AHIP_E_CAP, "output buffer too small"); }
+  size_t clen = 0;
+  int32_t rc = ahip_deflate_raw(in, in_len, level, 15, out + 2, out_cap - 6, &clen, nullptr);
+  if (out_len) *out_len = clen + 6;
+  if (rc != AHIP_OK) return rc;
+  out[0] = 0x78; out[1] = 0x01;
+  const uint32_t a = ahip_adler32(in, in_len, 1);
+  uint8_t *t = out + 2 + clen;
+  t[0] = (uint8_t)(a >> 24); t[1] = (uint8_t)(a >> 16); t[2] = (uint8_t)(a >> 8); t[3] = (uint8_t)a;
+  return AHIP_OK;
 }
 
 int32_t ahip_gzip_plan_create(const void *d_in, size_t in_len, void *stream, ahip_gzip_plan **plan) {

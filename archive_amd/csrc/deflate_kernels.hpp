@@ -1,0 +1,516 @@
+// deflate_kernels.hpp -- DEFLATE encoder on gfx950 (first correct version).
+//
+// The reference encoder (/root/reference/lib/src/codecs/zlib/deflate.dart) is one sequential
+// pass: hash-chain LZ77 with lazy matching (_deflateSlow :997-1118, _longestMatch :1120-1206),
+// a symbol buffer (_trTally :531-568) and per-block Huffman coding (_trFlushBlock :747-807,
+// _buildTree :2656, _compressBlock :571-614, _sendBits :487-499).  Its output bytes are not pinned
+// by any reference test; what must hold is (a) the stream inflates to the input through the
+// reference's Inflate and (b) the size stays within a stated tolerance of the reference's.
+//
+// Here the input is cut into independent 32 KiB chunks (each may still reference the 32 KiB of
+// raw input before it) and every chunk becomes one DEFLATE block, closed -- except the last --
+// by an empty stored block so that it ends on a byte boundary (the Z_SYNC_FLUSH marker the
+// reference itself emits through _trStoredBlock(0, 0, false), deflate.dart:219):
+//
+//   D1 deflate_match_kernel   one workgroup per chunk.  4-way bucketed hash of 4-byte strings in
+//                             LDS; positions are processed 256 at a time (probe, then insert), so
+//                             every probe sees exactly the strings before its own sub-block.
+//                             Candidates are verified with 4-byte compares; best (len, dist) per
+//                             position goes to scratch.
+//   D2 deflate_parse_kernel   one lane per chunk walks the match arrays with the reference's
+//                             one-step lazy rule and writes the token list.
+//   D3 deflate_encode_kernel  one workgroup per chunk: symbol histogram (LDS atomics), zlib's
+//                             heap Huffman construction with the 15/7-bit limit (restated from
+//                             deflate.dart:2567-2784, run by one lane), dynamic header, then the
+//                             tokens 256 at a time: workgroup prefix sum of code lengths -> bit
+//                             offsets -> atomicOr into the LDS output image.  A chunk that does
+//                             not shrink is emitted as a stored block.
+//   D4 deflate_concat_kernel  exclusive scan of chunk sizes (host) -> byte-granular gather.
+#pragma once
+#include "common.hpp"
+
+namespace ahip {
+
+constexpr u32 DF_CHUNK = 32768;          // bytes per chunk = one DEFLATE block
+constexpr u32 DF_SLAB = DF_CHUNK + 512;  // per-chunk output slab (a stored block needs CHUNK + 5 + flush)
+#ifndef AHIP_DF_HASH_BITS
+#define AHIP_DF_HASH_BITS 12
+#endif
+#ifndef AHIP_DF_WAYS
+#define AHIP_DF_WAYS 4
+#endif
+constexpr u32 DF_HASH_BITS = AHIP_DF_HASH_BITS, DF_WAYS = AHIP_DF_WAYS;
+constexpr u32 DF_SUB = 256;              // positions probed, then inserted, per step (one workgroup)
+constexpr u32 DF_MINLEN = 4;             // 4-byte hash: 3-byte matches are not searched
+constexpr u32 DF_EMPTY = 0xffff;
+
+struct DeflateParams {
+  u64 n;        // input bytes
+  u32 chunks;
+  u32 lazy;     // 1 = one-step lazy evaluation (levels 4..9), 0 = greedy (levels 1..3)
+  u32 store;    // 1 = level 0: stored blocks only
+  u32 max_cmp;  // longest match searched (258)
+};
+
+AHIP_DEVINL u32 df_hash4(u32 w) { return (w * 2654435761u) >> (32 - DF_HASH_BITS); }
+
+// ------------------------------------------------------------------------------------------
+// D1: per-position best match
+// ------------------------------------------------------------------------------------------
+// longest common prefix of the strings at window offsets c < p, both known to share 4 bytes
+AHIP_DEVINL u32 df_match_len(const u8 *win, u32 c, u32 p, u32 maxl) {
+  u32 l = 4;
+  while (l + 4 <= maxl) {
+    const u32 x = load_u32_unaligned(win + c + l) ^ load_u32_unaligned(win + p + l);
+    if (x) return l + ((u32)__builtin_ctz(x) >> 3);
+    l += 4;
+  }
+  while (l < maxl && win[c + l] == win[p + l]) ++l;
+  return l;
+}
+
+__global__ __launch_bounds__(256) void deflate_match_kernel(const u8 *__restrict__ in, DeflateParams P,
+                                                            u16 *__restrict__ mlen, u16 *__restrict__ mdist) {
+  __shared__ u16 tbl[(1u << DF_HASH_BITS) * DF_WAYS];
+  const u32 chunk = blockIdx.x, tid = threadIdx.x;
+  const u64 cstart = (u64)chunk * DF_CHUNK;
+  const u32 clen = (u32)((P.n - cstart) < DF_CHUNK ? (P.n - cstart) : DF_CHUNK);
+  const u32 dict = cstart >= DF_CHUNK ? DF_CHUNK : (u32)cstart;  // raw bytes before the chunk that may be referenced
+  const u8 *win = in + cstart - dict;                            // window base; positions are relative to it
+  const u32 wlen = dict + clen;
+  for (u32 i = tid; i < (1u << DF_HASH_BITS) * DF_WAYS; i += 256) tbl[i] = (u16)DF_EMPTY;
+  __syncthreads();
+  if (P.store) return;
+  // 256 positions per step: probe everything inserted by earlier steps, insert (slot = step number
+  // mod ways, so a bucket keeps its most recent strings), then probe the slot just written for a
+  // lower position of the SAME step (distances below 256: runs and short periods).
+  for (u32 base = 0; base < wlen; base += DF_SUB) {
+    const u32 p = base + tid;
+    const bool has4 = p + 4 <= wlen;
+    const bool search = has4 && p >= dict;
+    u32 w = 0, h = 0, best_len = 0, best_dist = 0;
+    const u32 maxl = (wlen - p) < P.max_cmp ? (wlen - p) : P.max_cmp;
+    if (has4) { w = load_u32_unaligned(win + p); h = df_hash4(w); }
+    if (search) {
+#pragma unroll
+      for (u32 way = 0; way < DF_WAYS; ++way) {
+        const u32 c = tbl[h * DF_WAYS + way];
+        if (c == DF_EMPTY) continue;
+        const u32 dist = p - c;  // c < p: inserted by an earlier step
+        if (dist > 32768) continue;
+        if (load_u32_unaligned(win + c) != w) continue;
+        const u32 l = df_match_len(win, c, p, maxl);
+        if (l > best_len || (l == best_len && dist < best_dist)) { best_len = l; best_dist = dist; }
+      }
+    }
+    const u32 slot = h * DF_WAYS + ((base / DF_SUB) & (DF_WAYS - 1));
+    __syncthreads();
+    if (has4) tbl[slot] = (u16)p;  // same-hash writers of one step race: any winner is valid
+    __syncthreads();
+    if (search) {
+      const u32 c = tbl[slot];
+      if (c < p && c >= base && load_u32_unaligned(win + c) == w) {
+        const u32 l = df_match_len(win, c, p, maxl);
+        if (l > best_len) { best_len = l; best_dist = p - c; }
+      }
+    }
+    if (p >= dict && p < wlen) {
+      const bool ok = best_len >= DF_MINLEN;
+      mlen[cstart + (p - dict)] = ok ? (u16)best_len : (u16)0;
+      if (ok) mdist[cstart + (p - dict)] = (u16)best_dist;  // 32768 fits
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// D2: parse (one lane per chunk)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void deflate_parse_kernel(const u8 *__restrict__ in, DeflateParams P,
+                                                           const u16 *__restrict__ mlen, const u16 *__restrict__ mdist,
+                                                           u32 *__restrict__ tok, u32 *__restrict__ ntok) {
+  const u32 chunk = blockIdx.x * 64 + threadIdx.x;
+  if (chunk >= P.chunks) return;
+  const u64 cstart = (u64)chunk * DF_CHUNK;
+  const u32 clen = (u32)((P.n - cstart) < DF_CHUNK ? (P.n - cstart) : DF_CHUNK);
+  u32 *t = tok + cstart;  // at most one token per byte
+  u32 k = 0, i = 0;
+  if (!P.store) {
+    while (i < clen) {
+      u32 l = mlen[cstart + i];
+      if (l > clen - i) l = clen - i;
+      if (l >= DF_MINLEN) {
+        if (P.lazy && i + 1 < clen && mlen[cstart + i + 1] > l) {  // a longer match starts at the next byte
+          t[k++] = 0x80000000u | in[cstart + i];
+          i += 1;
+          continue;
+        }
+        t[k++] = (l << 16) | mdist[cstart + i];
+        i += l;
+      } else {
+        t[k++] = 0x80000000u | in[cstart + i];
+        i += 1;
+      }
+    }
+  }
+  ntok[chunk] = k;
+}
+
+// ------------------------------------------------------------------------------------------
+// D3: Huffman coding of one chunk
+// ------------------------------------------------------------------------------------------
+constexpr int DF_LCODES = 286, DF_DCODES = 30, DF_BLCODES = 19, DF_HEAP = 573;
+
+struct EncLds {
+  u32 fl[288], fd[32];
+  u16 ltree[DF_HEAP * 2], dtree[(2 * DF_DCODES + 1) * 2], bltree[(2 * DF_BLCODES + 1) * 2];
+  u16 heap[DF_HEAP];
+  u8 depth[DF_HEAP];
+  u16 bl_count[16];
+  int heap_len, heap_max;
+  u32 opt_len;
+  u32 wsum[4];
+  u32 run_bits;
+  u32 obuf[DF_SLAB / 4];
+};
+
+__device__ const u8 k_extra_lbits[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__device__ const u8 k_extra_dbits[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__device__ const u8 k_extra_blbits[19] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2, 3, 7};
+__device__ const u8 k_bl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+// length (3..258) -> (code 0..28, extra bit count, extra value); distance (1..32768) likewise
+AHIP_DEVINL void df_len_code(u32 len, u32 &code, u32 &xb, u32 &xv) {
+  const u32 lc = len - 3;
+  if (lc < 8) { code = lc; xb = 0; xv = 0; return; }
+  if (lc == 255) { code = 28; xb = 0; xv = 0; return; }
+  const u32 k = 31 - (u32)__builtin_clz(lc);
+  code = (k - 1) * 4 + ((lc >> (k - 2)) & 3);
+  xb = k - 2;
+  xv = lc & ((1u << xb) - 1);
+}
+AHIP_DEVINL void df_dist_code(u32 dist, u32 &code, u32 &xb, u32 &xv) {
+  const u32 d = dist - 1;
+  if (d < 4) { code = d; xb = 0; xv = 0; return; }
+  const u32 k = 31 - (u32)__builtin_clz(d);
+  code = 2 * k + ((d >> (k - 1)) & 1);
+  xb = k - 1;
+  xv = d & ((1u << xb) - 1);
+}
+
+struct DfTreeDesc { u16 *tree; int elems, max_length, max_code; const u8 *extra; int extra_base; };
+
+AHIP_DEVINL bool df_smaller(const u16 *tree, int n, int m, const u8 *depth) {
+  return tree[n * 2] < tree[m * 2] || (tree[n * 2] == tree[m * 2] && depth[n] <= depth[m]);
+}
+__device__ inline void df_pqdownheap(EncLds &E, const u16 *tree, int k) {
+  const int v = E.heap[k];
+  int j = k << 1;
+  while (j <= E.heap_len) {
+    if (j < E.heap_len && df_smaller(tree, E.heap[j + 1], E.heap[j], E.depth)) j++;
+    if (df_smaller(tree, v, E.heap[j], E.depth)) break;
+    E.heap[k] = E.heap[j];
+    k = j;
+    j <<= 1;
+  }
+  E.heap[k] = (u16)v;
+}
+AHIP_DEVINL u32 df_bi_reverse(u32 code, int len) { return __brev(code) >> (32 - len); }
+
+// zlib's build_tree / gen_bitlen / gen_codes (deflate.dart:2567-2784), run by ONE lane on LDS arrays.
+__device__ inline void df_build_tree(EncLds &E, DfTreeDesc &d) {
+  u16 *tree = d.tree;
+  int n, m, max_code = -1, node;
+  E.heap_len = 0;
+  E.heap_max = DF_HEAP;
+  for (n = 0; n < d.elems; n++) {
+    if (tree[n * 2] != 0) { E.heap[++E.heap_len] = (u16)(max_code = n); E.depth[n] = 0; }
+    else tree[n * 2 + 1] = 0;
+  }
+  while (E.heap_len < 2) {
+    node = E.heap[++E.heap_len] = (u16)(max_code < 2 ? ++max_code : 0);
+    tree[node * 2] = 1;
+    E.depth[node] = 0;
+  }
+  d.max_code = max_code;
+  for (n = E.heap_len / 2; n >= 1; n--) df_pqdownheap(E, tree, n);
+  node = d.elems;
+  do {
+    n = E.heap[1];
+    E.heap[1] = E.heap[E.heap_len--];
+    df_pqdownheap(E, tree, 1);
+    m = E.heap[1];
+    E.heap[--E.heap_max] = (u16)n;
+    E.heap[--E.heap_max] = (u16)m;
+    tree[node * 2] = (u16)(tree[n * 2] + tree[m * 2]);
+    E.depth[node] = (u8)((E.depth[n] > E.depth[m] ? E.depth[n] : E.depth[m]) + 1);
+    tree[n * 2 + 1] = tree[m * 2 + 1] = (u16)node;
+    E.heap[1] = (u16)node++;
+    df_pqdownheap(E, tree, 1);
+  } while (E.heap_len >= 2);
+  E.heap[--E.heap_max] = E.heap[1];
+  // gen_bitlen
+  int h, bits, overflow = 0;
+  for (bits = 0; bits <= 15; bits++) E.bl_count[bits] = 0;
+  tree[E.heap[E.heap_max] * 2 + 1] = 0;
+  for (h = E.heap_max + 1; h < DF_HEAP; h++) {
+    n = E.heap[h];
+    bits = tree[tree[n * 2 + 1] * 2 + 1] + 1;
+    if (bits > d.max_length) { bits = d.max_length; overflow++; }
+    tree[n * 2 + 1] = (u16)bits;
+    if (n > max_code) continue;
+    E.bl_count[bits]++;
+    int xbits = n >= d.extra_base ? d.extra[n - d.extra_base] : 0;
+    E.opt_len += (u32)tree[n * 2] * (u32)(bits + xbits);
+  }
+  if (overflow > 0) {
+    do {
+      bits = d.max_length - 1;
+      while (E.bl_count[bits] == 0) bits--;
+      E.bl_count[bits]--;
+      E.bl_count[bits + 1] = (u16)(E.bl_count[bits + 1] + 2);
+      E.bl_count[d.max_length]--;
+      overflow -= 2;
+    } while (overflow > 0);
+    for (bits = d.max_length; bits != 0; bits--) {
+      n = E.bl_count[bits];
+      while (n != 0) {
+        m = E.heap[--h];
+        if (m > max_code) continue;
+        if (tree[m * 2 + 1] != bits) {
+          E.opt_len += (u32)((bits - (int)tree[m * 2 + 1]) * (int)tree[m * 2]);
+          tree[m * 2 + 1] = (u16)bits;
+        }
+        n--;
+      }
+    }
+  }
+  // gen_codes
+  u16 next_code[16];
+  u32 code = 0;
+  next_code[0] = 0;
+  for (bits = 1; bits <= 15; bits++) { code = (code + E.bl_count[bits - 1]) << 1; next_code[bits] = (u16)code; }
+  for (n = 0; n <= max_code; n++) {
+    const int len = tree[n * 2 + 1];
+    if (len == 0) continue;
+    tree[n * 2] = (u16)df_bi_reverse(next_code[len]++, len);
+  }
+}
+
+// serial LSB-first bit writer into the LDS output image (one lane, before the parallel phase)
+struct DfBits { u32 *buf; u32 pos; };
+AHIP_DEVINL void df_put(DfBits &b, u32 v, u32 n) {
+  if (!n) return;
+  const u32 w = b.pos >> 5, s = b.pos & 31;
+  b.buf[w] |= v << s;
+  if (s + n > 32) b.buf[w + 1] |= v >> (32 - s);
+  b.pos += n;
+}
+AHIP_DEVINL void df_put_code(DfBits &b, const u16 *tree, int c) { df_put(b, tree[c * 2], tree[c * 2 + 1]); }
+
+__device__ inline void df_scan_tree(EncLds &E, u16 *tree, int max_code) {
+  int prevlen = -1, curlen, nextlen = tree[1], count = 0, max_count = 7, min_count = 4;
+  if (nextlen == 0) { max_count = 138; min_count = 3; }
+  tree[(max_code + 1) * 2 + 1] = 0xffff;
+  for (int n = 0; n <= max_code; n++) {
+    curlen = nextlen;
+    nextlen = tree[(n + 1) * 2 + 1];
+    if (++count < max_count && curlen == nextlen) continue;
+    else if (count < min_count) E.bltree[curlen * 2] = (u16)(E.bltree[curlen * 2] + count);
+    else if (curlen != 0) { if (curlen != prevlen) E.bltree[curlen * 2]++; E.bltree[16 * 2]++; }
+    else if (count <= 10) E.bltree[17 * 2]++;
+    else E.bltree[18 * 2]++;
+    count = 0; prevlen = curlen;
+    if (nextlen == 0) { max_count = 138; min_count = 3; }
+    else if (curlen == nextlen) { max_count = 6; min_count = 3; }
+    else { max_count = 7; min_count = 4; }
+  }
+}
+__device__ inline void df_send_tree(EncLds &E, DfBits &b, const u16 *tree, int max_code) {
+  int prevlen = -1, curlen, nextlen = tree[1], count = 0, max_count = 7, min_count = 4;
+  if (nextlen == 0) { max_count = 138; min_count = 3; }
+  for (int n = 0; n <= max_code; n++) {
+    curlen = nextlen;
+    nextlen = tree[(n + 1) * 2 + 1];
+    if (++count < max_count && curlen == nextlen) continue;
+    else if (count < min_count) { do { df_put_code(b, E.bltree, curlen); } while (--count != 0); }
+    else if (curlen != 0) {
+      if (curlen != prevlen) { df_put_code(b, E.bltree, curlen); count--; }
+      df_put_code(b, E.bltree, 16); df_put(b, (u32)(count - 3), 2);
+    } else if (count <= 10) { df_put_code(b, E.bltree, 17); df_put(b, (u32)(count - 3), 3); }
+    else { df_put_code(b, E.bltree, 18); df_put(b, (u32)(count - 11), 7); }
+    count = 0; prevlen = curlen;
+    if (nextlen == 0) { max_count = 138; min_count = 3; }
+    else if (curlen == nextlen) { max_count = 6; min_count = 3; }
+    else { max_count = 7; min_count = 4; }
+  }
+}
+
+__global__ __launch_bounds__(256) void deflate_encode_kernel(const u8 *__restrict__ in, DeflateParams P,
+                                                             const u32 *__restrict__ tok, const u32 *__restrict__ ntok,
+                                                             u8 *__restrict__ slabs, u32 *__restrict__ csize) {
+  __shared__ EncLds E;
+  const u32 chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const u64 cstart = (u64)chunk * DF_CHUNK;
+  const u32 clen = (u32)((P.n - cstart) < DF_CHUNK ? (P.n - cstart) : DF_CHUNK);
+  const bool last = chunk + 1 == P.chunks;
+  const u32 nt = ntok[chunk];
+  const u32 *t = tok + cstart;
+  u8 *slab = slabs + (u64)chunk * DF_SLAB;
+  for (u32 i = tid; i < DF_SLAB / 4; i += 256) E.obuf[i] = 0;
+  for (u32 i = tid; i < 288; i += 256) E.fl[i] = 0;
+  if (tid < 32) E.fd[tid] = 0;
+  __syncthreads();
+  bool stored = P.store != 0;
+  u32 total_bits = 0;
+  if (!stored) {
+    // ---- histogram ----
+    for (u32 i = tid; i < nt; i += 256) {
+      const u32 v = t[i];
+      if (v >> 31) atomicAdd(&E.fl[v & 0xff], 1u);
+      else {
+        u32 c, xb, xv;
+        df_len_code(v >> 16, c, xb, xv);
+        atomicAdd(&E.fl[257 + c], 1u);
+        df_dist_code(v & 0xffff, c, xb, xv);
+        atomicAdd(&E.fd[c], 1u);
+      }
+    }
+    __syncthreads();
+    for (u32 i = tid; i < DF_HEAP * 2; i += 256) E.ltree[i] = 0;
+    for (u32 i = tid; i < (2 * DF_DCODES + 1) * 2; i += 256) E.dtree[i] = 0;
+    for (u32 i = tid; i < (2 * DF_BLCODES + 1) * 2; i += 256) E.bltree[i] = 0;
+    __syncthreads();
+    for (u32 i = tid; i < 286; i += 256) E.ltree[i * 2] = (u16)E.fl[i];
+    if (tid < 30) E.dtree[tid * 2] = (u16)E.fd[tid];
+    __syncthreads();
+    // ---- trees + header (one lane) ----
+    if (tid == 0) {
+      E.ltree[256 * 2] = 1;  // end of block
+      E.opt_len = 0;
+      DfTreeDesc ld{E.ltree, DF_LCODES, 15, 0, k_extra_lbits, 257};
+      DfTreeDesc dd{E.dtree, DF_DCODES, 15, 0, k_extra_dbits, 0};
+      DfTreeDesc bd{E.bltree, DF_BLCODES, 7, 0, k_extra_blbits, 0};
+      df_build_tree(E, ld);
+      df_build_tree(E, dd);
+      df_scan_tree(E, E.ltree, ld.max_code);
+      df_scan_tree(E, E.dtree, dd.max_code);
+      df_build_tree(E, bd);
+      int max_blindex;
+      for (max_blindex = DF_BLCODES - 1; max_blindex >= 3; max_blindex--)
+        if (E.bltree[k_bl_order[max_blindex] * 2 + 1] != 0) break;
+      DfBits b{E.obuf, 0};
+      df_put(b, (2u << 1) | (last ? 1u : 0u), 3);  // dynamic block, BFINAL on the last chunk
+      df_put(b, (u32)(ld.max_code + 1 - 257), 5);
+      df_put(b, (u32)(dd.max_code + 1 - 1), 5);
+      df_put(b, (u32)(max_blindex + 1 - 4), 4);
+      for (int r = 0; r <= max_blindex; r++) df_put(b, E.bltree[k_bl_order[r] * 2 + 1], 3);
+      df_send_tree(E, b, E.ltree, ld.max_code);
+      df_send_tree(E, b, E.dtree, dd.max_code);
+      E.run_bits = b.pos;
+    }
+    __syncthreads();
+    // ---- exact size first: a chunk that does not shrink (or would not fit the LDS image) is stored ----
+    {
+      u32 mybits = 0;
+      for (u32 i = tid; i < nt; i += 256) {
+        const u32 v = t[i];
+        if (v >> 31) mybits += E.ltree[(v & 0xff) * 2 + 1];
+        else {
+          u32 c, xb, xv;
+          df_len_code(v >> 16, c, xb, xv);
+          mybits += E.ltree[(257 + c) * 2 + 1] + xb;
+          df_dist_code(v & 0xffff, c, xb, xv);
+          mybits += E.dtree[c * 2 + 1] + xb;
+        }
+      }
+      if (tid == 0) E.opt_len = 0;
+      __syncthreads();
+      atomicAdd(&E.opt_len, mybits);
+      __syncthreads();
+      const u32 need = (E.run_bits + E.opt_len + E.ltree[256 * 2 + 1] + 3 + 7 + 32 + 7) / 8;
+      if (need > clen + 5 || need > DF_SLAB - 16) stored = true;
+    }
+    if (!stored) {
+    // ---- tokens, 256 per round ----
+    for (u32 base = 0; base < nt; base += 256) {
+      const u32 i = base + tid;
+      u64 bits = 0;
+      u32 nb = 0;
+      if (i < nt) {
+        const u32 v = t[i];
+        if (v >> 31) {
+          const u32 s = v & 0xff;
+          bits = E.ltree[s * 2];
+          nb = E.ltree[s * 2 + 1];
+        } else {
+          u32 c, xb, xv;
+          df_len_code(v >> 16, c, xb, xv);
+          bits = E.ltree[(257 + c) * 2];
+          nb = E.ltree[(257 + c) * 2 + 1];
+          bits |= (u64)xv << nb; nb += xb;
+          df_dist_code(v & 0xffff, c, xb, xv);
+          bits |= (u64)E.dtree[c * 2] << nb; nb += E.dtree[c * 2 + 1];
+          bits |= (u64)xv << nb; nb += xb;
+        }
+      }
+      const u32 inc = wave_incl_sum(nb);
+      if (lane == 63) E.wsum[wave] = inc;
+      __syncthreads();
+      u32 off = E.run_bits + inc - nb;
+      for (u32 w = 0; w < wave; ++w) off += E.wsum[w];
+      if (nb) {
+        const u32 wi = off >> 5, s = off & 31;
+        const u64 lo = bits << s;
+        atomicOr(&E.obuf[wi], (u32)lo);
+        if ((u32)(lo >> 32)) atomicOr(&E.obuf[wi + 1], (u32)(lo >> 32));
+        if (s && (bits >> (64 - s))) atomicOr(&E.obuf[wi + 2], (u32)(bits >> (64 - s)));
+      }
+      __syncthreads();
+      if (tid == 0) E.run_bits += E.wsum[0] + E.wsum[1] + E.wsum[2] + E.wsum[3];
+      __syncthreads();
+    }
+    // ---- end of block, then the byte-aligning empty stored block (not after the last chunk) ----
+    if (tid == 0) {
+      DfBits b{E.obuf, E.run_bits};
+      df_put_code(b, E.ltree, 256);
+      if (!last) {
+        df_put(b, 0, 3);                    // BFINAL=0, BTYPE=00
+        b.pos = (b.pos + 7) & ~7u;          // _biWindup
+        df_put(b, 0x0000, 16);
+        df_put(b, 0xffff, 16);
+      } else {
+        b.pos = (b.pos + 7) & ~7u;
+      }
+      E.run_bits = b.pos;
+    }
+    __syncthreads();
+    total_bits = E.run_bits;
+    }
+  }
+  if (stored) {
+    // one stored block: header byte, LEN, NLEN, raw bytes (clen <= 32768 < 65536); byte aligned by itself
+    if (tid == 0) {
+      slab[0] = last ? 1 : 0;
+      slab[1] = (u8)clen; slab[2] = (u8)(clen >> 8);
+      slab[3] = (u8)~clen; slab[4] = (u8)(~clen >> 8);
+      csize[chunk] = clen + 5;
+    }
+    for (u32 i = tid; i < clen; i += 256) slab[5 + i] = in[cstart + i];
+    return;
+  }
+  const u32 nbytes = total_bits / 8;
+  for (u32 i = tid; i < (nbytes + 3) / 4; i += 256) ((u32 *)slab)[i] = E.obuf[i];
+  if (tid == 0) csize[chunk] = nbytes;
+}
+
+// D4: gather the chunk slabs into the contiguous output
+__global__ __launch_bounds__(256) void deflate_concat_kernel(const u8 *__restrict__ slabs, const u32 *__restrict__ csize,
+                                                             const u64 *__restrict__ coff, u8 *__restrict__ out) {
+  const u32 chunk = blockIdx.x;
+  const u8 *src = slabs + (u64)chunk * DF_SLAB;
+  u8 *dst = out + coff[chunk];
+  const u32 n = csize[chunk];
+  for (u32 i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+}
+
+}  // namespace ahip

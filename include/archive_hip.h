@@ -92,6 +92,27 @@ void ahip_gzip_plan_destroy(ahip_gzip_plan *plan);
  * (cyc: per-phase shader-clock cycles / 16, filled by -DAHIP_PROFILE builds only). */
 int32_t ahip_debug_plan_results(ahip_gzip_plan *plan, uint32_t *host_words, size_t max_members, size_t *n_members);
 
+/* ---- Deflate ----
+ * ref: codecs/zlib/deflate.dart:39-48 `Deflate(bytes, level: L).getBytes()`; level 0..9 as in
+ * DeflateLevel (deflate.dart:10-18), window_bits must be 15.  The stream is valid DEFLATE for any
+ * inflater (and round-trips through ahip_inflate_raw); its SIZE is within the tolerance DESIGN.md
+ * states of the reference's, its bytes are not the reference's (no reference test pins them).
+ * An invalid level or window writes nothing and returns AHIP_OK, like the reference's silent _init.
+ * *crc32 receives the CRC-32 of the input (the reference's Deflate.crc32). */
+int32_t ahip_deflate_raw(const uint8_t *in, size_t in_len, int32_t level, int32_t window_bits, uint8_t *out,
+                         size_t out_cap, size_t *out_len, uint32_t *crc32);
+/* ref: codecs/zlib/_gzip_encoder_web.dart:27-100 (mtime supplied by the caller; the reference stamps "now") */
+int32_t ahip_gzip_encode(const uint8_t *in, size_t in_len, int32_t level, uint32_t mtime, uint8_t *out,
+                         size_t out_cap, size_t *out_len);
+/* ref: codecs/zlib/_zlib_encoder_web.dart:27-73 (`78 01`, Adler-32 big-endian) */
+int32_t ahip_zlib_encode(const uint8_t *in, size_t in_len, int32_t level, uint8_t *out, size_t out_cap,
+                         size_t *out_len);
+/* device-resident form: d_in/d_out on the current device; synchronises `stream` before returning */
+int32_t ahip_deflate_raw_device(const void *d_in, size_t in_len, int32_t level, void *d_out, size_t out_cap,
+                                size_t *out_len, void *stream);
+/* upper bound of the compressed size for in_len input bytes */
+size_t ahip_deflate_bound(size_t in_len);
+
 /* ---- checksums (ref: util/crc32.dart:6-27, util/adler32.dart:29-52), chainable ---- */
 uint32_t ahip_crc32(const uint8_t *data, size_t len, uint32_t crc /* 0 to start */);
 uint32_t ahip_adler32(const uint8_t *data, size_t len, uint32_t adler /* 1 to start */);
