@@ -116,6 +116,26 @@ class GZipDecoder:
     decodeStream = decode_stream
 
 
+class BZip2Decoder:
+    """`BZip2Decoder().decodeBytes(data, verify: false)` (bzip2_decoder.dart:12-88); blocks are
+    decoded in parallel, one wavefront each."""
+
+    def decode_bytes(self, data, verify=False):
+        buf, n = _as_buffer(data)
+        st, out = _call_growing(lambda o, cap, olen: N.lib().ahip_bzip2_decode(buf, n, int(verify), o, cap, olen), n,
+                                hint=8 * n + 1024)
+        self.last_status = st
+        return out
+
+    def decode_stream(self, input_bytes, output, verify=False):
+        out = self.decode_bytes(input_bytes, verify=verify)
+        output.extend(out)
+        return self.last_status == N.AHIP_OK
+
+    decodeBytes = decode_bytes
+    decodeStream = decode_stream
+
+
 class DeflateLevel:
     """deflate.dart:10-18"""
     none = 0

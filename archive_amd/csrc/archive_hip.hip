@@ -7,6 +7,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -14,6 +15,7 @@
 
 #include "common.hpp"
 #include "gzip_index.hpp"
+#include "bzip2_kernels.hpp"
 #include "deflate_kernels.hpp"
 #include "inflate_par.hpp"
 
@@ -463,6 +465,135 @@ uint32_t ahip_adler32(const uint8_t *data, size_t len, uint32_t adler) {
     s1 %= 65521; s2 %= 65521;
   }
   return (uint32_t)((s2 << 16) | s1);
+}
+
+int32_t ahip_bzip2_decode(const uint8_t *in, size_t in_len, int32_t verify, uint8_t *out, size_t out_cap,
+                          size_t *out_len) {
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  if (out_len) *out_len = 0;
+  // BZh + level, read through the bit reader: fewer than 4 bytes is a RangeError in the reference
+  if (in_len < 4) {
+    for (size_t i = 0; i < in_len && i < 3; ++i) if (in[i] != "BZh"[i]) return AHIP_FALSE;
+    return AHIP_RANGE;
+  }
+  if (in[0] != 'B' || in[1] != 'Z' || in[2] != 'h') return AHIP_FALSE;
+  const int level = (int)in[3] - 0x30;
+  if (level < 0 || level > 9) return AHIP_FALSE;
+  if (in_len == 4) return AHIP_OK;  // while (!input.isEOS) never runs
+  int32_t rc = ensure_init();
+  if (rc != AHIP_OK) return rc;
+  if (level == 0) return AHIP_FALSE;  // zero-sized tt: the first symbol already fails nblock >= nblockMAX
+  static DevBuf din, dcand, dcount, dtt, dsel, dslabs, dres, dcrc, dord, doff, dlen, dout;
+  hipStream_t st = nullptr;
+  HIP_TRY(din.reserve(in_len + 16));
+  HIP_TRY(hipMemcpy(din.p, in, in_len, hipMemcpyHostToDevice));
+  // B0: block / end-of-stream magics at any bit offset
+  const u32 cap_c = (u32)(in_len / 32 + 64);
+  HIP_TRY(dcand.reserve((size_t)cap_c * sizeof(BzCand)));
+  HIP_TRY(dcount.reserve(16));
+  HIP_TRY(hipMemsetAsync(dcount.p, 0, 4, st));
+  hipLaunchKernelGGL(bz_scan_magic, dim3(cdiv(in_len, 256)), dim3(256), 0, st, din.as<u8>(), (u64)in_len,
+                     dcand.as<BzCand>(), dcount.as<u32>(), cap_c);
+  u32 ncand = 0;
+  HIP_TRY(hipMemcpy(&ncand, dcount.p, 4, hipMemcpyDeviceToHost));
+  if (ncand > cap_c) return fail(AHIP_E_UNSUPPORTED, "too many bzip2 block-magic candidates");
+  std::vector<BzCand> cands(ncand);
+  if (ncand) HIP_TRY(hipMemcpy(cands.data(), dcand.p, (size_t)ncand * sizeof(BzCand), hipMemcpyDeviceToHost));
+  std::sort(cands.begin(), cands.end(), [](const BzCand &a, const BzCand &b) { return a.bit < b.bit; });
+  // the first block type is read at bit 32; anything else there is "Invalid Block Signature"
+  if (ncand == 0 || cands[0].bit != 32) {
+    return in_len * 8 < 32 + 48 ? AHIP_RANGE : AHIP_FALSE;
+  }
+  HIP_TRY(hipMemcpy(dcand.p, cands.data(), (size_t)ncand * sizeof(BzCand), hipMemcpyHostToDevice));
+  const u64 nblock_max = 100000ull * (u64)level;
+  const u64 slab_cap = nblock_max + nblock_max / 4 + 4096;
+  HIP_TRY(dtt.reserve((size_t)ncand * nblock_max * 4));
+  HIP_TRY(dsel.reserve((size_t)ncand * BZ_MAX_SELECTORS));
+  HIP_TRY(dslabs.reserve((size_t)ncand * slab_cap));
+  HIP_TRY(dres.reserve((size_t)ncand * sizeof(BzResult)));
+  {
+    u32 table[256];
+    for (u32 i = 0; i < 256; ++i) {
+      u32 c = i << 24;
+      for (int k = 0; k < 8; ++k) c = (c & 0x80000000u) ? ((c << 1) ^ 0x04c11db7u) : (c << 1);
+      table[i] = c;
+    }
+    HIP_TRY(dcrc.reserve(1024));
+    HIP_TRY(hipMemcpy(dcrc.p, table, 1024, hipMemcpyHostToDevice));
+  }
+  hipLaunchKernelGGL(bz_decode_block, dim3(ncand), dim3(64), 0, st, din.as<u8>(), (u64)in_len, dcand.as<BzCand>(), ncand,
+                     (u32)level, dtt.as<u32>(), dsel.as<u8>(), dslabs.as<u8>(), slab_cap, dres.as<BzResult>());
+  hipLaunchKernelGGL(bz_tinv_scatter, dim3(ncand), dim3(64), 0, st, dtt.as<u32>(), (u32)level, dcand.as<BzCand>(),
+                     dres.as<BzResult>());
+  hipLaunchKernelGGL(bz_unbwt, dim3(cdiv(ncand, 64)), dim3(64), 0, st, dtt.as<u32>(), (u32)level, ncand,
+                     dcand.as<BzCand>(), dslabs.as<u8>(), slab_cap, dres.as<BzResult>(), dcrc.as<u32>(),
+                     (const u64 *)nullptr, (u8 *)nullptr);
+  std::vector<BzResult> res(ncand);
+  HIP_TRY(hipMemcpy(res.data(), dres.p, (size_t)ncand * sizeof(BzResult), hipMemcpyDeviceToHost));
+  HIP_TRY(hipGetLastError());
+  // follow the chain of blocks exactly like decodeStream: a block ends where the next magic starts
+  std::vector<u32> order;
+  std::vector<u64> off, len;
+  u64 total = 0;
+  u32 combined = 0;
+  int32_t verdict = AHIP_OK;
+  size_t i = 0;
+  u64 byte_pos_after = 0;  // reference InputStream position (bytes pulled into the bit reader)
+  for (;;) {
+    const BzResult &r = res[i];
+    if (cands[i].kind == 2) {  // end of stream: combined CRC, then decodeStream returns true
+      if (r.status == BZ_ST_RANGE) { verdict = AHIP_RANGE; break; }
+      if (verify && r.stored_crc != combined) verdict = AHIP_FALSE;
+      break;
+    }
+    if (r.status == BZ_ST_RANGE) { verdict = AHIP_RANGE; break; }
+    if (r.status == BZ_ST_UNSUPPORTED) return fail(AHIP_E_UNSUPPORTED, "randomised bzip2 block");
+    if (r.status != BZ_ST_OK && r.status != BZ_ST_OVERFLOW) { verdict = AHIP_FALSE; break; }
+    order.push_back((u32)i); off.push_back(total); len.push_back(r.out_len);
+    total += r.out_len;
+    if (verify && r.crc != r.stored_crc) { verdict = AHIP_FALSE; break; }  // the block's bytes were already written
+    combined = ((combined << 1) | (combined >> 31)) ^ r.crc;
+    // next block type is read at r.end_bit
+    byte_pos_after = (r.end_bit + 7) / 8;
+    if (byte_pos_after >= in_len) break;  // while (!input.isEOS): clean end without an end-of-stream block
+    size_t j = i + 1;
+    while (j < ncand && cands[j].bit < r.end_bit) ++j;
+    if (j >= ncand || cands[j].bit != r.end_bit) {
+      // not a block magic there: _readBlockType returns -1 (or runs off the end)
+      verdict = (r.end_bit + 48 > (u64)in_len * 8) ? AHIP_RANGE : AHIP_FALSE;
+      break;
+    }
+    i = j;
+  }
+  if (out_len) *out_len = total;
+  if (verdict == AHIP_RANGE) return AHIP_RANGE;
+  if (total > out_cap) return fail(AHIP_E_CAP, "output buffer too small");
+  if (!order.empty() && total) {
+    const u32 nb = (u32)order.size();
+    HIP_TRY(dord.reserve(nb * 4)); HIP_TRY(doff.reserve(nb * 8)); HIP_TRY(dlen.reserve(nb * 8)); HIP_TRY(dout.reserve(total));
+    HIP_TRY(hipMemcpy(dord.p, order.data(), nb * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(doff.p, off.data(), nb * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dlen.p, len.data(), nb * 8, hipMemcpyHostToDevice));
+    // blocks that outgrew their slab (long runs) are un-BWT'ed a second time straight into place
+    std::vector<u64> direct(ncand, ~0ull);
+    bool any_direct = false;
+    for (u32 k = 0; k < nb; ++k)
+      if (res[order[k]].status == BZ_ST_OVERFLOW) { direct[order[k]] = off[k]; len[k] = 0; any_direct = true; }
+    HIP_TRY(hipMemcpy(dlen.p, len.data(), nb * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(bz_gather, dim3(64, nb), dim3(256), 0, st, dslabs.as<u8>(), slab_cap, dord.as<u32>(), doff.as<u64>(),
+                       dlen.as<u64>(), dout.as<u8>());
+    if (any_direct) {
+      static DevBuf ddir;
+      HIP_TRY(ddir.reserve((size_t)ncand * 8));
+      HIP_TRY(hipMemcpy(ddir.p, direct.data(), (size_t)ncand * 8, hipMemcpyHostToDevice));
+      hipLaunchKernelGGL(bz_unbwt, dim3(cdiv(ncand, 64)), dim3(64), 0, st, dtt.as<u32>(), (u32)level, ncand,
+                         dcand.as<BzCand>(), dslabs.as<u8>(), slab_cap, dres.as<BzResult>(), dcrc.as<u32>(),
+                         ddir.as<u64>(), dout.as<u8>());
+    }
+    HIP_TRY(hipMemcpy(out, dout.p, total, hipMemcpyDeviceToHost));
+    HIP_TRY(hipGetLastError());
+  }
+  return verdict;
 }
 
 size_t ahip_deflate_bound(size_t in_len) {

@@ -113,6 +113,13 @@ int32_t ahip_deflate_raw_device(const void *d_in, size_t in_len, int32_t level, 
 /* upper bound of the compressed size for in_len input bytes */
 size_t ahip_deflate_bound(size_t in_len);
 
+/* ---- BZip2 ----
+ * ref: codecs/bzip2_decoder.dart:13-88 `BZip2Decoder().decodeBytes(data, verify: false)`: ONE bzip2
+ * stream (the reference returns at the first end-of-stream block); blocks are decoded in parallel.
+ * The obsolete randomised-block mode returns AHIP_E_UNSUPPORTED. */
+int32_t ahip_bzip2_decode(const uint8_t *in, size_t in_len, int32_t verify, uint8_t *out, size_t out_cap,
+                          size_t *out_len);
+
 /* ---- checksums (ref: util/crc32.dart:6-27, util/adler32.dart:29-52), chainable ---- */
 uint32_t ahip_crc32(const uint8_t *data, size_t len, uint32_t crc /* 0 to start */);
 uint32_t ahip_adler32(const uint8_t *data, size_t len, uint32_t adler /* 1 to start */);

@@ -38,6 +38,7 @@ def lib():
         L.orc_crc32.restype = ctypes.c_uint32
         L.orc_adler32.argtypes = [u8p, ctypes.c_size_t, ctypes.c_uint32]
         L.orc_adler32.restype = ctypes.c_uint32
+        L.orc_bzip2_decode.argtypes = [u8p, ctypes.c_size_t, ctypes.c_int, u8p, ctypes.c_size_t, szp]
         L.orc_deflate_raw.argtypes = [u8p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, u8p, ctypes.c_size_t, szp,
                                       ctypes.POINTER(ctypes.c_uint32)]
         L.orc_gzip_encode.argtypes = [u8p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint32, u8p, ctypes.c_size_t, szp]
@@ -128,3 +129,11 @@ def zlib_encode(data, level=6):
     olen = ctypes.c_size_t(0)
     assert lib().orc_zlib_encode(ctypes.addressof(buf), n, level, ctypes.addressof(out), cap, ctypes.byref(olen)) == 0
     return out.raw[:olen.value]
+
+
+def bzip2_decode(data, verify=False, cap=None):
+    """BZip2Decoder().decodeBytes -> (status, output)"""
+    def fn(buf, n, out, cap, olen):
+        return lib().orc_bzip2_decode(ctypes.addressof(buf), n, int(verify), ctypes.addressof(out), cap, ctypes.byref(olen)), None
+    st, o, _ = _run(fn, data, (), cap if cap is not None else max(1 << 16, 64 * len(bytes(data))))
+    return st, o

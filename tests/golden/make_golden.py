@@ -91,6 +91,15 @@ def main():
                     "test/zip_test.dart:11-28 (test/_data/zip/test.zip)")
                 break
 
+    # bzip2: test/bzip2_test.dart:8-15 (test.bz2 only asserted to decode) and test2.tar.bz2 -> test2.tar
+    # (test/io_test.dart:364,636)
+    import bz2
+    d = rd("test/_data/bzip2/test.bz2")
+    add("bzip2_test_bz2", "bzip2", d, bz2.decompress(d), "test/bzip2_test.dart:8-15")
+    d = rd("test/_data/test2.tar.bz2")
+    assert bz2.decompress(d) == rd("test/_data/test2.tar")
+    add("test2_tar_bz2", "bzip2", d, rd("test/_data/test2.tar"), "test/io_test.dart:364")
+
     # checksum known-answer tests: test/crc32_test.dart:5-25, test/adler32_test.dart:5-25
     kat = {
         "crc32": [["01", "A505DF1B"], ["01020304050607080900", "C5F5BE65"], ["01020304050607080900*10000", "3AC67C2B"]],

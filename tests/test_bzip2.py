@@ -1,0 +1,77 @@
+"""bzip2 decoder: CPU tests pin the oracle (oracle/bzip2_oracle.c) against CPython's libbzip2 and the
+reference's fixtures; GPU tests check the HIP block-parallel decoder against the oracle."""
+import bz2
+import random
+
+import pytest
+
+from tests import streams
+
+
+def _corpora():
+    from tools import corpus
+    rnd = random.Random(1)
+    return {
+        "wiki": bytes(corpus.text(corpus.WIKI, 8, 0, 1500000)),
+        "log": bytes(corpus.text(corpus.LOG, 1234, 0, 700000)),
+        "zeros": bytes(1200000),
+        "random": bytes(rnd.getrandbits(8) for _ in range(250000)),
+        "runs": b"".join(bytes([rnd.randrange(4)]) * rnd.randrange(1, 600) for _ in range(3000)),
+        "empty": b"", "one": b"x", "text": streams.text(99999, 4),
+    }
+
+
+def _malformed():
+    c = bz2.compress(b"hello world" * 1000)
+    bad_block = bytearray(bz2.compress(streams.text(50000, 1), 1))
+    bad_block[len(bad_block) // 2] ^= 0x10
+    return {"truncated_tail": c[:-3], "truncated_mid": c[:50], "no_magic": b"BZh9" + bytes(20), "not_bz": b"hello",
+            "short": b"BZ", "header_only": b"BZh9", "bad_level": b"BZhx" + c[4:], "two_streams": c + c,
+            "corrupt_block": bytes(bad_block)}
+
+
+def test_oracle_matches_libbzip2():
+    from oracle import pyoracle as orc
+    for name, d in _corpora().items():
+        for level in (1, 9):
+            c = bz2.compress(d, level)
+            assert orc.bzip2_decode(c, verify=True, cap=len(d) + 64) == (0, d), (name, level)
+
+
+def test_oracle_malformed():
+    from oracle import pyoracle as orc
+    m = _malformed()
+    assert orc.bzip2_decode(m["truncated_tail"])[0] == 2
+    assert orc.bzip2_decode(m["truncated_mid"])[0] == 2
+    assert orc.bzip2_decode(m["no_magic"]) == (1, b"")
+    assert orc.bzip2_decode(m["not_bz"]) == (1, b"")
+    assert orc.bzip2_decode(m["header_only"]) == (0, b"")
+    assert orc.bzip2_decode(m["short"])[0] == 2  # the third readByte() throws before the compare
+    assert orc.bzip2_decode(m["bad_level"]) == (1, b"")
+    assert orc.bzip2_decode(m["two_streams"]) == (0, b"hello world" * 1000)  # ONE stream only (bzip2_decoder.dart:70-85)
+
+
+@pytest.mark.gpu
+def test_gpu_matches_oracle(native_built):
+    import archive_amd
+    from archive_amd import _native as N
+    from archive_amd import errors
+    from oracle import pyoracle as orc
+    assert N.lib().ahip_init(0) == 0
+
+    def run(data, verify):
+        d = archive_amd.BZip2Decoder()
+        try:
+            out = d.decode_bytes(data, verify=verify)
+            return d.last_status, out
+        except errors.RangeError:
+            return 2, None
+    for name, d in _corpora().items():
+        for level in (1, 9):
+            c = bz2.compress(d, level)
+            assert run(c, True) == (0, d), (name, level)
+    for name, c in _malformed().items():
+        for verify in (False, True):
+            st, out = orc.bzip2_decode(c, verify=verify)
+            got = run(c, verify)
+            assert got == ((2, None) if st == 2 else (st, out)), (name, verify, got[0], st)

@@ -64,6 +64,10 @@ def test_golden_vectors(amd, golden):
             st, out, _ = _raw(amd, data)
         elif kind == "gzip":
             st, out = _gz(amd, data)
+        elif kind == "bzip2":
+            d = amd.BZip2Decoder()
+            out = d.decode_bytes(data, verify=True)
+            st = d.last_status
         else:
             st, out = _zl(amd, data, verify=True)
         assert st == 0, v["name"]

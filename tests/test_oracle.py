@@ -20,6 +20,8 @@ def test_golden_vectors(golden):
             st, out = orc.zlib_decode(data, verify=True)
         elif kind == "zlib_verify":
             st, out = orc.zlib_decode(data, verify=True)
+        elif kind == "bzip2":
+            st, out = orc.bzip2_decode(data, verify=True)
         else:
             raise AssertionError(kind)
         assert st == orc.ORC_OK, v["name"]
