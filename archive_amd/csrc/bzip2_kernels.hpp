@@ -52,21 +52,43 @@ __global__ __launch_bounds__(256) void bz_scan_magic(const u8 *__restrict__ in, 
 }
 
 // ---- MSB-first bit reader over global memory (Bz2BitReader) ----
+// 64-bit left-aligned buffer refilled 32 bits at a time: one global load per ~4 symbols instead of
+// one (or more) per field.  `bit` is always the position of the next unread bit.
 struct BzBits {
   const u8 *in; u64 n;
   u64 bit;     // next bit to read
   bool fault;  // read past the end: RangeError in the reference
+  u64 buf;     // unread bits, MSB first
+  u32 cnt;     // valid bits in buf
+  u64 fetch;   // byte offset of the next refill
 };
+AHIP_DEVINL void bz_seek(BzBits &b, u64 bit) {
+  b.bit = bit; b.buf = 0; b.cnt = 0; b.fetch = bit >> 3; b.fault = false;
+  // prime with the partial first byte
+  const u32 sh = (u32)bit & 7;
+  if (sh) {
+    const u64 v = b.fetch < b.n ? b.in[b.fetch] : 0;
+    b.buf = (v << (56 + sh));
+    b.cnt = 8 - sh;
+    b.fetch += 1;
+  }
+}
 AHIP_DEVINL u32 bz_bits(BzBits &b, u32 nb) {  // nb <= 24
   if (nb == 0) return 0;
   if (b.bit + nb > b.n * 8) { b.fault = true; b.bit += nb; return 0; }
-  const u64 byte = b.bit >> 3;
-  u32 w = 0;
-  if (byte + 4 <= b.n) w = __builtin_bswap32(load_u32_unaligned(b.in + byte));
-  else for (int k = 0; k < 4; ++k) w = (w << 8) | (byte + k < b.n ? b.in[byte + k] : 0);
-  const u32 sh = (u32)b.bit & 7;
+  if (b.cnt < nb) {
+    u32 w = 0;
+    if (b.fetch + 4 <= b.n) w = __builtin_bswap32(load_u32_unaligned(b.in + b.fetch));
+    else for (int k = 0; k < 4; ++k) w = (w << 8) | (b.fetch + k < b.n ? b.in[b.fetch + k] : 0);
+    b.buf |= (u64)w << (32 - b.cnt);
+    b.cnt += 32;
+    b.fetch += 4;
+  }
+  const u32 v = (u32)(b.buf >> (64 - nb));
+  b.buf <<= nb;
+  b.cnt -= nb;
   b.bit += nb;
-  return (w << sh) >> (32 - nb);
+  return v;
 }
 
 struct BzLds {
@@ -91,7 +113,8 @@ __global__ __launch_bounds__(64) void bz_decode_block(const u8 *__restrict__ in,
   u8 *sel = sel_all + (u64)blk * BZ_MAX_SELECTORS;
   u8 *slab = slabs + (u64)blk * slab_cap;
   BzResult R{0, 0, BZ_ST_OK, 0, 0, 0, 0, 0};
-  BzBits b{in, n, cands[blk].bit + 48, false};
+  BzBits b{in, n, 0, false, 0, 0, 0};
+  bz_seek(b, cands[blk].bit + 48);
   u32 status = BZ_ST_OK;
   u32 nblock = 0, orig_ptr = 0;
   if (cands[blk].kind != 0) {  // end-of-stream marker: just the combined CRC
