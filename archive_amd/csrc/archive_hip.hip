@@ -24,35 +24,56 @@ using namespace ahip;
 // ------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------
-// One wave64 per member, one wave per workgroup: no workgroup barrier is ever needed and the
-// LDS footprint (tables + window + token queue + output window) is allocated per wave.
+// One wave64 per member, one wave per workgroup: no workgroup barrier is ever needed.  The decode
+// is split into two kernels so that each keeps a small LDS footprint (more resident waves hide
+// the LDS/L2 latency this work is bound by):
+//   inflate_tokenize_kernel  Huffman side: tables + bitstream window in LDS (10.7 KiB/wave) -> the
+//                            member's token stream in device scratch
+//   inflate_resolve_kernel   LZ77 side: token queue + output window in LDS (9.6 KiB/wave) -> bytes
 constexpr int WAVES_PER_BLOCK = 1;
 
-struct KernelLds {
+struct TokKernelLds {
   WaveLds w;
-  ParLds p;
+  TokLds p;
 };
 
 // Persistent workgroups: the grid is sized to what is resident at once and strides over the
-// members, so the token slab (scratch, SLAB_WORDS u32 per workgroup)
-// is a few hundred KiB-per-CU working set that lives in L2 instead of one slab per member.
-template <bool WRITE>
-__global__ __launch_bounds__(64) void inflate_members_kernel(const u8 *__restrict__ in, u64 in_len,
-                                                            const MemberDesc *__restrict__ members, u32 n_members,
-                                                            u8 *out, MemberResult *__restrict__ results,
-                                                            u32 *__restrict__ next_member, u32 *__restrict__ scratch) {
-  __shared__ KernelLds lds;
+// members, so the per-workgroup slab (scratch, SLAB_WORDS u32) stays L2-resident.
+//  tokens == nullptr: sizing run (end position, size and verdict only).
+__global__ __launch_bounds__(64) void inflate_tokenize_kernel(const u8 *__restrict__ in, u64 in_len,
+                                                             const MemberDesc *__restrict__ members, u32 first_member,
+                                                             u32 n_members, u32 *__restrict__ tokens, u64 group_out0,
+                                                             MemberResult *__restrict__ results,
+                                                             u32 *__restrict__ scratch) {
+  __shared__ TokKernelLds lds;
   const int lane = threadIdx.x;
   u32 *slab = scratch + (size_t)blockIdx.x * SLAB_WORDS;
-  (void)next_member;
-  // grid-stride over members (a device work counter would balance ragged members better; the
-  // wave-aggregated atomic hipcc generates for it hung on gfx950, so the static schedule stays)
-  for (u32 m = blockIdx.x; m < n_members; m += gridDim.x) {
+  for (u32 k = blockIdx.x; k < n_members; k += gridDim.x) {
+    const u32 m = first_member + k;
     MemberDesc d = members[m];
     d.in_off = uniform64(d.in_off);
     d.out_off = uniform64(d.out_off);
     d.out_limit = uniform64(d.out_limit);
-    inflate_member<WRITE, true>(lds.w, &lds.p, slab, in, in_len, d, out, results[m], lane);
+    u32 *tk = tokens ? tokens + (d.out_off - group_out0) : nullptr;
+    inflate_member<false, true>(lds.w, &lds.p, slab, in, in_len, d, (u8 *)nullptr, tk, results[m], lane);
+  }
+}
+
+__global__ __launch_bounds__(64) void inflate_resolve_kernel(const u8 *__restrict__ in,
+                                                            const MemberDesc *__restrict__ members, u32 first_member,
+                                                            u32 n_members, u8 *out, const u32 *__restrict__ tokens,
+                                                            u64 group_out0, MemberResult *__restrict__ results) {
+  __shared__ ParLds lds;
+  const int lane = threadIdx.x;
+  for (u32 k = blockIdx.x; k < n_members; k += gridDim.x) {
+    const u32 m = first_member + k;
+    const u64 out_off = uniform64(members[m].out_off);
+    const u64 nwords = uniform64(results[m].tok_words);
+    u32 cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    resolve_member(lds, in, tokens + (out_off - group_out0), nwords, out + out_off, cyc, lane);
+#ifdef AHIP_PROFILE
+    if (lane == 0) { results[m].cyc[4] += cyc[4]; results[m].cyc[5] += cyc[5]; results[m].cyc[6] += cyc[6]; }
+#endif
   }
 }
 
@@ -71,7 +92,7 @@ __global__ __launch_bounds__(64) void inflate_members_serial_kernel(const u8 *__
   d.in_off = uniform64(d.in_off);
   d.out_off = uniform64(d.out_off);
   d.out_limit = uniform64(d.out_limit);
-  inflate_member<WRITE, false>(lds, nullptr, nullptr, in, in_len, d, out, results[m], lane);
+  inflate_member<WRITE, false>(lds, nullptr, nullptr, in, in_len, d, out, nullptr, results[m], lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -127,10 +148,15 @@ struct DevBuf {
   template <class T> T *as() const { return (T *)p; }
 };
 
-DevBuf g_scratch;
+DevBuf g_scratch, g_tokens;
 hipError_t scratch_reserve(size_t bytes, void **p) {
   hipError_t e = g_scratch.reserve(bytes);
   *p = g_scratch.p;
+  return e;
+}
+hipError_t tokens_reserve(size_t bytes, void **p) {
+  hipError_t e = g_tokens.reserve(bytes);
+  *p = g_tokens.p;
   return e;
 }
 
@@ -142,47 +168,75 @@ bool use_serial_kernel() {
   return v == 1;
 }
 
-// device scratch of the persistent kernel: member counter + token slabs
+// device scratch: per-workgroup token slabs of the tokenizer, and the token streams handed to the resolver
 struct DevBuf;
 hipError_t scratch_reserve(size_t bytes, void **p);
+hipError_t tokens_reserve(size_t bytes, void **p);
 
+// Largest output (bytes) decoded per tokenize/resolve launch pair: its token streams take 4x that.
+constexpr u64 GROUP_OUT_MAX = 6ull << 30;
+
+// members[first .. first+count) with output offsets [out0, out1): tokenize (+ resolve when WRITE)
+template <bool WRITE>
+hipError_t launch_inflate_group(const u8 *in, u64 n, const MemberDesc *members, u32 first, u32 count, u64 out0, u64 out1,
+                                u8 *out, MemberResult *res, hipStream_t st) {
+  static int tok_resident = 0, res_resident = 0;
+  if (!tok_resident) {
+    int dev = 0, cus = 0, a = 0, b = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return e;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, inflate_tokenize_kernel, 64, 0);
+    if (e != hipSuccess) return e;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, inflate_resolve_kernel, 64, 0);
+    if (e != hipSuccess) return e;
+    tok_resident = cus * (a > 0 ? a : 1);
+    res_resident = cus * (b > 0 ? b : 1);
+  }
+  const u32 grid1 = count < (u32)tok_resident ? count : (u32)tok_resident;
+  void *sp = nullptr, *tp = nullptr;
+  hipError_t e = scratch_reserve((size_t)grid1 * SLAB_WORDS * 4, &sp);
+  if (e != hipSuccess) return e;
+  if (WRITE) {
+    e = tokens_reserve((size_t)(out1 - out0) * 4 + 64, &tp);
+    if (e != hipSuccess) return e;
+  }
+  if (getenv("AHIP_DEBUG")) fprintf(stderr, "[ahip] inflate group first=%u count=%u grid=%u/%d out=%llu write=%d\n", first, count, grid1, res_resident, (unsigned long long)(out1 - out0), (int)WRITE);
+  hipLaunchKernelGGL(inflate_tokenize_kernel, dim3(grid1), dim3(64), 0, st, in, n, members, first, count, (u32 *)tp, out0,
+                     res, (u32 *)sp);
+  if (WRITE) {
+    const u32 grid2 = count < (u32)res_resident ? count : (u32)res_resident;
+    hipLaunchKernelGGL(inflate_resolve_kernel, dim3(grid2), dim3(64), 0, st, in, members, first, count, out,
+                       (const u32 *)tp, out0, res);
+  }
+  return hipGetLastError();
+}
+
+// host_out_off: output offset of every member plus one trailing total (M + 1 entries), or nullptr when
+// the whole range is known to be small / a sizing run.
 template <bool WRITE>
 hipError_t launch_inflate(const u8 *in, u64 n, const MemberDesc *members, u32 M, u8 *out, MemberResult *res,
-                          hipStream_t st) {
+                          hipStream_t st, const u64 *host_out_off = nullptr) {
   if (M == 0) return hipSuccess;
   if (use_serial_kernel()) {
     hipLaunchKernelGGL(inflate_members_serial_kernel<WRITE>, dim3(M), dim3(64), 0, st, in, n, members, M, out, res);
     return hipGetLastError();
   }
-  static int wgs_resident = 0;
-  if (!wgs_resident) {
-    int dev = 0, cus = 0, per_cu = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (e != hipSuccess) return e;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, inflate_members_kernel<true>, 64, 0);
-    if (e != hipSuccess) return e;
-    wgs_resident = cus * (per_cu > 0 ? per_cu : 1);
+  if (!WRITE || !host_out_off) {
+    const u64 total = host_out_off ? host_out_off[M] : 0;
+    return launch_inflate_group<WRITE>(in, n, members, 0, M, 0, total, out, res, st);
   }
-  const u32 grid = M < (u32)wgs_resident ? M : (u32)wgs_resident;
-  if (getenv("AHIP_DEBUG")) fprintf(stderr, "[ahip] launch_inflate M=%u grid=%u resident=%d write=%d\n", M, grid, wgs_resident, (int)WRITE);
-  void *sp = nullptr;
-  hipError_t e = scratch_reserve(256 + (size_t)grid * SLAB_WORDS * 4, &sp);
-  if (e != hipSuccess) return e;
-  u32 *counter = (u32 *)sp;
-  u32 *slabs = (u32 *)((u8 *)sp + 256);
-  e = hipMemsetAsync(counter, 0, 4, st);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(inflate_members_kernel<WRITE>, dim3(grid), dim3(64), 0, st, in, n, members, M, out, res, counter,
-                     slabs);
-  if (getenv("AHIP_DEBUG")) {
-    hipError_t se = hipStreamSynchronize(st);
-    u32 c = 0;
-    (void)hipMemcpy(&c, counter, 4, hipMemcpyDeviceToHost);
-    fprintf(stderr, "[ahip] kernel done: %s, counter=%u\n", hipGetErrorString(se), c);
+  u32 first = 0;
+  while (first < M) {
+    u32 last = first + 1;
+    while (last < M && host_out_off[last + 1] - host_out_off[first] <= GROUP_OUT_MAX) ++last;
+    hipError_t e = launch_inflate_group<WRITE>(in, n, members, first, last - first, host_out_off[first], host_out_off[last],
+                                               out, res, st);
+    if (e != hipSuccess) return e;
+    first = last;
   }
-  return hipGetLastError();
+  return hipSuccess;
 }
 
 int32_t ensure_init() {
@@ -207,6 +261,7 @@ struct ahip_gzip_plan {
   DevBuf tile_counts, tile_offsets, cand_pos, hdr, scratch_u32, members, expect_status, results, sizing_descs,
       sizing_results, dsum, drun;
   bool ran = false;
+  std::vector<u64> host_out_off;  // M + 1 entries: output offset of every member, then the total
   ~ahip_gzip_plan() {
     for (DevBuf *b : {&tile_counts, &tile_offsets, &cand_pos, &hdr, &scratch_u32, &members, &expect_status, &results,
                       &sizing_descs, &sizing_results, &dsum, &drun})
@@ -273,6 +328,15 @@ int32_t plan_build(ahip_gzip_plan *pl, bool force_sizing, hipStream_t st) {
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipGetLastError());
   if (!pl->sum.first_is_gzip) { pl->sum.members = 0; pl->sum.total_out = 0; pl->sum.tail_pos = start; }
+  // output offsets on the host: the decode is launched in groups whose token streams fit the scratch
+  pl->host_out_off.clear();
+  if (pl->sum.members) {
+    std::vector<MemberDesc> md(pl->sum.members);
+    HIP_TRY(hipMemcpy(md.data(), pl->members.p, md.size() * sizeof(MemberDesc), hipMemcpyDeviceToHost));
+    pl->host_out_off.resize(md.size() + 1);
+    for (size_t i = 0; i < md.size(); ++i) pl->host_out_off[i] = md[i].out_off;
+    pl->host_out_off[md.size()] = pl->sum.total_out;
+  }
   // Candidates without a BC subfield only matter when the member chain actually walks into one
   // (false candidates inside compressed data never do): then sizes have to come from the data.
   if (!force_sizing && pl->sum.first_is_gzip && pl->sum.stopped_unknown) return plan_build(pl, true, st);
@@ -290,7 +354,7 @@ int32_t plan_run(ahip_gzip_plan *pl, u8 *d_out, size_t out_cap, hipStream_t st) 
   if (M == 0) return AHIP_OK;
   HIP_TRY(pl->results.reserve((size_t)M * sizeof(MemberResult)));
   HIP_TRY(launch_inflate<true>(pl->d_in, pl->in_len, pl->members.as<MemberDesc>(), M, d_out,
-                               pl->results.as<MemberResult>(), st));
+                               pl->results.as<MemberResult>(), st, pl->host_out_off.data()));
   hipLaunchKernelGGL(gz_verify, dim3(cdiv(M, 256)), dim3(256), 0, st, pl->members.as<MemberDesc>(),
                      pl->expect_status.as<u32>(), pl->results.as<MemberResult>(), M, pl->drun.as<RunSummary>());
   HIP_TRY(hipGetLastError());
@@ -327,7 +391,8 @@ int32_t inflate_one(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool
   HIP_TRY(dr.reserve(sizeof(MemberResult)));
   MemberDesc d{off, 0, out_cap, POS_UNKNOWN};
   HIP_TRY(hipMemcpyAsync(dd.p, &d, sizeof d, hipMemcpyHostToDevice, st));
-  if (write) HIP_TRY(launch_inflate<true>(d_in, n, dd.as<MemberDesc>(), 1u, d_out, dr.as<MemberResult>(), st));
+  const u64 one_off[2] = {0, out_cap};
+  if (write) HIP_TRY(launch_inflate<true>(d_in, n, dd.as<MemberDesc>(), 1u, d_out, dr.as<MemberResult>(), st, one_off));
   else HIP_TRY(launch_inflate<false>(d_in, n, dd.as<MemberDesc>(), 1u, (u8 *)nullptr, dr.as<MemberResult>(), st));
   HIP_TRY(hipMemcpyAsync(res, dr.p, sizeof *res, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
@@ -760,13 +825,13 @@ int32_t ahip_gzip_plan_status(ahip_gzip_plan *plan, size_t *out_len) {
 }
 
 // Diagnostics (not part of the drop-in surface): per-member results of the last run, as
-// 18 u32 words each {end_pos lo/hi, out_len lo/hi, status, blocks, windows, rounds, fallbacks, partial, cyc[8]}.
+// 20 u32 words each {end_pos lo/hi, out_len lo/hi, status, blocks, windows, rounds, fallbacks, partial, cyc[8], tok_words lo/hi}.
 int32_t ahip_debug_plan_results(ahip_gzip_plan *plan, uint32_t *host_words, size_t max_members, size_t *n_members) {
   if (!plan || !plan->ran) return fail(AHIP_E_ARG, "plan has not been run");
   std::lock_guard<std::recursive_mutex> lk(g_mu);
   size_t M = plan->sum.members < max_members ? plan->sum.members : max_members;
   if (n_members) *n_members = M;
-  static_assert(sizeof(MemberResult) == 72, "MemberResult layout");
+  static_assert(sizeof(MemberResult) == 80, "MemberResult layout");
   if (M) HIP_TRY(hipMemcpy(host_words, plan->results.p, M * sizeof(MemberResult), hipMemcpyDeviceToHost));
   return AHIP_OK;
 }

@@ -45,6 +45,7 @@ struct MemberResult {
   u32 partial;  // windows cut short by the token/byte caps (diagnostics)
   u32 cyc[8];   // -DAHIP_PROFILE builds: shader-clock cycles / 16 per phase
                 //  0 header+tables 1 stage 2 pass A 3 pass B 4 emit 5 resolve 6 flush 7 serial decode
+  u64 tok_words; // words the tokenizer wrote for this member
 };
 
 #define AHIP_DEVINL __device__ __forceinline__

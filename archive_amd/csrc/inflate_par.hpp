@@ -59,11 +59,26 @@ constexpr u32 TK_EOB = 0x40000000u;
 constexpr u32 TK_ERR = 0x20000000u;
 // match: len << 16 | dist   (len <= 258, dist <= 32768)
 
-struct ParLds {
+// LDS of the tokenizer (next to WaveLds): the staged bitstream window
+struct TokLds {
   u32 inbuf[IN_DWORDS] __attribute__((aligned(16)));
+};
+// LDS of the resolver: token queue, output window, start-slot rows
+struct ParLds {
   u32 tok[TOK_CAP];
   u8 obuf[OB_CAP + 32] __attribute__((aligned(16)));
   u32 slot[3 * 64];  // two alternating 64-entry start-slot rows + one dump row
+  u32 misc[4];       // [0] index of the first stored-run record in the current batch
+};
+
+constexpr u32 TK_STORED = 0x60000000u;  // | len (3..65535), followed by two words: absolute input byte offset lo, hi
+
+// Append-only token stream of one member in device memory (tokenizer -> resolver hand-off).
+// A member never needs more words than it has output bytes: every literal/match token covers
+// >= 1 byte and a stored run of >= 3 bytes takes 3 words (shorter runs are emitted as literals).
+struct TokSink {
+  u32 *base;  // nullptr: sizing run, nothing is stored
+  u64 w;      // words written
 };
 
 struct ParStats { u32 windows, rounds, fallbacks, partial; u32 cyc[8]; u32 dbg; };
@@ -169,7 +184,7 @@ AHIP_DEVINL u32 decode_token(LaneBits &d, const WaveLds &L, const BlockMeta &M, 
 }
 
 constexpr u32 LR_EOB = 1, LR_ERR = 2, LR_OVF = 4;
-struct LaneRun { u32 end, flags, ntok, nbytes; };
+struct LaneRun { u32 end, flags, ntok, nbytes; i32 need; };  // need = max over matches of (dist - bytes before it in this lane)
 
 // Decode from `start` until the cursor reaches `boundary` (or EOB / error).
 //  RECORD: token j of this lane goes to slab[j * 64 + lane] -- every active lane is at the same
@@ -177,7 +192,7 @@ struct LaneRun { u32 end, flags, ntok, nbytes; };
 template <bool RECORD>
 AHIP_DEVINL LaneRun run_lane(bool active, bool rec, u32 start, u32 boundary, const WaveLds &L, const BlockMeta &M,
                              const u32 *inbuf, u32 *slab, int lane) {
-  LaneRun r{start, 0, 0, 0};
+  LaneRun r{start, 0, 0, 0, 0};
   LaneBits d{0, 0, 0, 0, 2};
   if (active) lb_init(d, inbuf, start);
   u32 lguard = 0;
@@ -194,8 +209,11 @@ AHIP_DEVINL LaneRun run_lane(bool active, bool rec, u32 start, u32 boundary, con
         r.flags = LR_OVF;
       } else {
         if (RECORD && rec) slab[r.ntok * 64 + lane] = t;
+        const bool lit = t >> 31;
+        const i32 req = lit ? 0 : (i32)(t & 0xffff) - (i32)r.nbytes;
+        r.need = req > r.need ? req : r.need;
         r.ntok += 1;
-        r.nbytes += (t >> 31) ? 1u : (t >> 16);
+        r.nbytes += lit ? 1u : (t >> 16);
         r.end = lb_pos(d);
       }
     }
@@ -221,6 +239,7 @@ struct GroupFront {
   u32 val;    // literal byte, or history byte (once the load lands)
   i32 si;     // source offset inside the window (negative: flushed history)
   bool act, lit;
+  bool pre;   // byte of a far match already deposited into the window by pass 1
 };
 AHIP_DEVINL GroupFront resolve_front(ParLds &P, u32 ntok, u32 nbytes, const u8 *hist, u32 g0, u32 &tcur, u32 &carry,
                                      int lane) {
@@ -244,10 +263,11 @@ AHIP_DEVINL GroupFront resolve_front(ParLds &P, u32 ntok, u32 nbytes, const u8 *
   const u32 x = g0 + lane;
   f.act = x < nbytes;
   f.lit = (key >> 16) & 1;
+  f.pre = !f.lit && ((key >> 15) & 1);
   f.val = key & 0xff;
-  f.si = (i32)x - (i32)((key & 0x7fff) + 1);
+  f.si = f.pre ? (i32)x : (i32)x - (i32)((key & 0x7fff) + 1);
 #ifndef AHIP_ABLATE_FAR
-  if (f.act && !f.lit && f.si < 0) f.val = hist[f.si];
+  if (f.act && !f.lit && f.si < 0) f.val = hist[f.si];  // far sources pass 1 did not take (long, or too close to the window)
 #endif
   return f;
 }
@@ -255,8 +275,8 @@ AHIP_DEVINL void resolve_back(ParLds &P, const GroupFront &f, u32 g0, u8 *ob, in
   u32 val = f.val;
   const bool copy = f.act && !f.lit;
   wave_sync();  // bytes of earlier groups were stored by other lanes
-  if (copy && f.si >= 0 && f.si < (i32)g0) val = ob[f.si];
-  const bool dep = copy && f.si >= (i32)g0;
+  if (copy && f.si >= 0 && (f.si < (i32)g0 || f.pre)) val = ob[f.si];  // pre: its own deposited byte (lower lanes may copy from it)
+  const bool dep = copy && !f.pre && f.si >= (i32)g0;
   if (__any(dep)) {
     u32 srcl = dep ? (u32)(f.si - (i32)g0) : (u32)lane;
     bool res = !dep;
@@ -271,25 +291,10 @@ AHIP_DEVINL void resolve_back(ParLds &P, const GroupFront &f, u32 g0, u8 *ob, in
       }
     } while (__any(!res) && ++guard < 8);
   }
-  if (f.act) ob[g0 + lane] = (u8)val;
+  if (f.act && !f.pre) ob[g0 + lane] = (u8)val;
 }
-AHIP_DEVINL void resolve_window(ParLds &P, u32 ntok, u32 nbytes, const u8 *hist, u32 A, int lane) {
-  // pass 1: tokens -> keys
-  u32 run = 0;
-  for (u32 c = 0; c < ntok; c += 64) {
-    const u32 idx = c + lane;
-    const bool in = idx < ntok;
-    const u32 t = in ? P.tok[idx] : 0u;
-    const bool lit = t >> 31;
-    const u32 len = in ? (lit ? 1u : (t >> 16)) : 0u;
-    u32 total;
-    const u32 off = run + wave_excl_sum(len, total);
-    const u32 key = (1u << 30) | (off << 17) | (lit ? (0x10000u | (t & 0xff)) : ((t & 0xffff) - 1));
-    if (in) P.tok[idx] = key;
-    run += total;
-  }
-  wave_sync();
-  // pass 2: bytes
+// pass 2 of the resolver: keys are already in the queue (resolve_member builds them)
+AHIP_DEVINL void resolve_bytes(ParLds &P, u32 ntok, u32 nbytes, const u8 *hist, u32 A, int lane) {
   u8 *ob = P.obuf + A;
   u32 tcur = 0, carry = 0;
   if (nbytes == 0 || nbytes > (u32)OB_CAP || ntok > (u32)TOK_CAP) return;  // never spin on corrupt bookkeeping
@@ -318,46 +323,107 @@ AHIP_DEVINL void flush_window(const ParLds &P, u8 *g, u32 A, u32 nbytes, int lan
   if (tail0 + lane < nbytes) g[tail0 + lane] = P.obuf[A + tail0 + lane];
 }
 
-// Move the tokens of lanes [la, lb) from the slab into the LDS queue in stream order, checking
-// every distance against the bytes that exist before the token.  Returns false when a
-// back-reference reaches before the member start (the serial decoder then decides).
-//  T/B: exclusive prefix sums of tokens / bytes over the window's lanes; Ta/Ba: their values at la.
-AHIP_DEVINL bool gather_batch(ParLds &P, const u32 *slab, int la, int lb, u32 n, u32 T, u32 B, u32 Ta, u32 Ba,
-                              u64 hist0, int lane) {
-  const bool mine = lane >= la && lane < lb;
-  const u32 cnt = mine ? n : 0u;
-  const u32 steps = wave_umax(cnt);
-  u32 *q = P.tok + (T - Ta);
-  u64 avail = hist0 + (B - Ba);  // bytes of this member that precede the lane's first token
-  bool far = false;
-  for (u32 k = 0; k < steps; k += 8) {
-    u32 t[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) t[u] = (k + u < cnt) ? slab[(k + u) * 64 + lane] : 0u;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      if (k + u < cnt) {
-        const bool lit = t[u] >> 31;
-        if (!lit && (u64)(t[u] & 0xffff) > avail) far = true;
-        avail += lit ? 1u : (t[u] >> 16);
-        q[k + u] = t[u];
-      }
+// ------------------------------------------------------------------------------------------
+// Tokenizer side
+// ------------------------------------------------------------------------------------------
+
+// Serial decode of one Huffman block that EMITS tokens instead of writing bytes: the checked path
+// for everything irregular (same decisions, in the same order, as huffman_token<WRITE, CAREFUL>).
+template <bool CAREFUL>
+AHIP_DEVINL u32 huffman_token_emit(WaveLds &L, BitCursor &b, OutCursor &o, TokSink &sink, u32 ll_max, u32 d_max, int lane) {
+  if (CAREFUL && b.pos + ll_max > b.total_bits) return 100 + MS_FALSE_EOS;
+  u64 w = peek_bits(b);
+  u32 e = uniform(L.ll[(u32)w & ((1u << LL_ROOT) - 1)]);
+  if (e & E_LONG) e = uniform(long_lookup<false>(L.lld, L.ll_sorted, (u32)w, LL_ROOT));
+  u32 cl = e & 15;
+  if (e & (E_LIT | E_EOB | E_BAD | E_HOLE)) {
+    if (e & E_LIT) {
+      if (o.pos >= o.limit) return 100 + MS_CAP;
+      if (sink.base && lane == 0) sink.base[sink.w] = TK_LIT | (e >> 16);
+      sink.w += 1;
+      o.pos += 1;
+      b.pos += cl;
+      return 0;
+    }
+    if (e & E_EOB) { b.pos += cl; return 1; }
+    if (e & E_BAD) return 100 + MS_FALSE;
+    return 100 + MS_HANG;
+  }
+  u32 used = cl;
+  w >>= cl;
+  u32 xb = (e >> 4) & 15;
+  i32 len = (i32)(e >> 16);
+  if (CAREFUL && xb && b.pos + used + xb > b.total_bits) len -= 1;
+  else { len += (i32)((u32)w & ((1u << xb) - 1)); w >>= xb; used += xb; }
+  if (CAREFUL && b.pos + used + d_max > b.total_bits) return 100 + MS_FALSE_EOS;
+  u32 d = uniform(L.dt[(u32)w & ((1u << D_ROOT) - 1)]);
+  if (d & E_LONG) d = uniform(long_lookup<true>(L.dd, L.d_sorted, (u32)w, D_ROOT));
+  if (d & E_BAD) return 100 + MS_FALSE;
+  u32 dl = d & 15;
+  w >>= dl;
+  used += dl;
+  u32 dxb = (d >> 4) & 15;
+  i32 dist = (i32)(d >> 16);
+  if (CAREFUL && dxb && b.pos + used + dxb > b.total_bits) dist -= 1;
+  else { dist += (i32)((u32)w & ((1u << dxb) - 1)); used += dxb; }
+  b.pos += used;
+  if ((u64)dist > o.pos) return 100 + MS_FARREF;
+  if (o.pos + (u64)len > o.limit) return 100 + MS_CAP;
+  if (sink.base && lane == 0) sink.base[sink.w] = ((u32)len << 16) | (u32)dist;
+  sink.w += 1;
+  o.pos += (u64)len;
+  return 0;
+}
+AHIP_DEVINL u32 huffman_block_emit(WaveLds &L, BitCursor &b, OutCursor &o, TokSink &sink, int lane) {
+  const u32 ll_max = L.lld.maxlen, d_max = L.dd.maxlen;
+  for (;;) {
+    u32 r;
+    if ((b.pos >> 3) + 16 <= b.in_len) r = huffman_token_emit<false>(L, b, o, sink, ll_max, d_max, lane);
+    else r = huffman_token_emit<true>(L, b, o, sink, ll_max, d_max, lane);
+    if (r == 0) continue;
+    if (r == 1) return MS_OK;
+    return r - 100;
+  }
+}
+// _parseUncompressedBlock as tokens: runs of >= 3 bytes become one TK_STORED record (3 words)
+AHIP_DEVINL u32 stored_block_emit(BitCursor &b, OutCursor &o, TokSink &sink, int lane) {
+  b.pos = (b.pos + 7) & ~7ull;
+  int len = read_bits(b, 16);
+  int nlen_raw = read_bits(b, 16);
+  int nlen = nlen_raw ^ 0xffff;
+  if (len != 0 && len != nlen) return (len < 0 || nlen_raw < 0) ? MS_FALSE_EOS : MS_FALSE;
+  u64 byte = b.pos >> 3;
+  if ((u64)len > b.in_len - byte) return MS_FALSE;
+  if (o.pos + (u64)len > o.limit) return MS_CAP;
+  if (len >= 3) {
+    if (sink.base && lane == 0) {
+      sink.base[sink.w] = TK_STORED | (u32)len;
+      sink.base[sink.w + 1] = (u32)byte;
+      sink.base[sink.w + 2] = (u32)(byte >> 32);
+    }
+    sink.w += 3;
+  } else {
+    for (int i = 0; i < len; ++i) {
+      if (sink.base && lane == 0) sink.base[sink.w] = TK_LIT | b.in[byte + i];
+      sink.w += 1;
     }
   }
-  return !__any(far);
+  o.pos += (u64)len;
+  b.pos += 8ull * (u64)len;
+  return MS_OK;
 }
 
-// Decode one Huffman block (tables already built in L) starting at b.pos.
+// Decode one Huffman block (tables already built in L) starting at b.pos into tokens.
 // Returns MS_* exactly like huffman_block().
-template <bool WRITE>
-AHIP_DEVINL u32 huffman_block_parallel(WaveLds &L, ParLds &P, u32 *slab, BitCursor &b, OutCursor &o, int lane,
-                                       ParStats &st) {
+AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, u32 *slab, BitCursor &b, OutCursor &o, TokSink &sink,
+                                       int lane, ParStats &st) {
   BlockMeta M;
   load_long_meta(M.ll, L.lld, LL_ROOT);
   load_long_meta(M.d, L.dd, D_ROOT);
+  const bool emit = sink.base != nullptr;
   u32 wguard = 0;
   for (;;) {
-    if (++wguard > 4096) { st.dbg |= 1; break; }
+    if (++wguard > (1u << 20)) { st.dbg |= 1; break; }
     const u64 gbyte = (b.pos >> 3) & ~3ull;
     if (gbyte + (u64)IN_DWORDS * 4 > b.in_len) break;  // too close to the end: checked serial path
     // ---- stage the window ----
@@ -376,7 +442,8 @@ AHIP_DEVINL u32 huffman_block_parallel(WaveLds &L, ParLds &P, u32 *slab, BitCurs
     const u32 s0 = (u32)(b.pos - gbyte * 8);
     const u32 boundary = (u32)(lane + 1) * SUB_BITS;
     // ---- pass A: lane 0 from the true boundary (recording), the others blind ----
-    LaneRun R = run_lane<true>(true, lane == 0, lane == 0 ? s0 : (u32)lane * SUB_BITS, boundary, L, M, P.inbuf, slab, lane);
+    LaneRun R = run_lane<true>(true, emit && lane == 0, lane == 0 ? s0 : (u32)lane * SUB_BITS, boundary, L, M, P.inbuf,
+                               slab, lane);
     AHIP_TICK(t_c);
     AHIP_ACC(st.cyc[2], t_b, t_c);
     // ---- pass B rounds: restart from the predecessor's end until the chain is consistent ----
@@ -391,7 +458,7 @@ AHIP_DEVINL u32 huffman_block_parallel(WaveLds &L, ParLds &P, u32 *slab, BitCurs
       u32 prev_end = lane_prev(R.end);
       u32 prev_flags = lane_prev(R.flags);
       bool act = lane > final_upto && prev_flags == 0;
-      LaneRun R2 = run_lane<true>(act, true, prev_end, boundary, L, M, P.inbuf, slab, lane);
+      LaneRun R2 = run_lane<true>(act, emit, prev_end, boundary, L, M, P.inbuf, slab, lane);
       bool mism = act && (R2.end != R.end || R2.flags != R.flags);
       if (act) R = R2;
       u64 mm = __ballot(mism);
@@ -413,71 +480,49 @@ AHIP_DEVINL u32 huffman_block_parallel(WaveLds &L, ParLds &P, u32 *slab, BitCurs
     const u32 T = wave_excl_sum(valid ? R.ntok : 0u, tot_tok);
     const u32 B = wave_excl_sum(valid ? R.nbytes : 0u, tot_bytes);
     if ((u64)tot_bytes > o.limit - o.pos) { st.fallbacks++; break; }  // output window exhausted: serial path reports it
+    // a back-reference reaching before the member start: dist > bytes before the token
+    if (__any(valid && (i64)R.need > (i64)(o.pos + B))) { st.fallbacks++; break; }
     const u32 next_pos = lane_bcast(R.end, kstop < 64 ? kstop : 63);  // past the EOB code, or lane 63's end
-    const u32 lane_start = lane == 0 ? s0 : lane_prev(R.end);
-    // ---- resolve in batches of whole lanes that fit the LDS token queue / output window ----
-    bool bail = false;
-    int la = 0;
-    u32 bguard = 0;
-    while (la < nlanes) {
-      if (++bguard > 80) { st.dbg |= 4; bail = true; break; }
-      const u32 Ta = lane_bcast(T, la), Ba = lane_bcast(B, la);
-      const bool fits = valid && lane >= la && (T + R.ntok - Ta <= (u32)TOK_CAP) && (B + R.nbytes - Ba <= (u32)OB_CAP);
-      const u64 fm = __ballot(fits) >> la;            // lanes la, la+1, ... as bits 0, 1, ...
-      const int take = fm == ~0ull ? 64 : (__ffsll((long long)~fm) - 1);  // leading run of fitting lanes
-      if (take == 0) {  // one lane alone exceeds the queue (very dense or very long tokens)
-        b.pos = gbyte * 8 + lane_bcast(lane_start, la);
-        bail = true;
-        break;
+    // ---- slab (lane-major rows) -> the member's token stream (stream order) ----
+    AHIP_TICK(t_e0);
+    if (emit) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      const u32 cnt = valid ? R.ntok : 0u;
+      const u32 steps = wave_umax(cnt);
+      u32 *q = sink.base + sink.w + T;
+      for (u32 k = 0; k < steps; k += 8) {
+        u32 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = (k + u < cnt) ? slab[(k + u) * 64 + lane] : 0u;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (k + u < cnt) q[k + u] = t[u];
       }
-      const int lb = la + take;
-      const u32 Tb = lb < 64 ? lane_bcast(T, lb < 64 ? lb : 63) : tot_tok;
-      const u32 Bb = lb < 64 ? lane_bcast(B, lb < 64 ? lb : 63) : tot_bytes;
-      const u32 ntok = (lb < nlanes ? Tb : tot_tok) - Ta, nbytes = (lb < nlanes ? Bb : tot_bytes) - Ba;
-      AHIP_TICK(t_e0);
-      if (!gather_batch(P, slab, la, lb, R.ntok, T, B, Ta, Ba, o.pos, lane)) {
-        b.pos = gbyte * 8 + lane_bcast(lane_start, la);
-        bail = true;
-        break;
-      }
-      wave_sync();
-      AHIP_TICK(t_f);
-      AHIP_ACC(st.cyc[4], t_e0, t_f);
-      if (WRITE && nbytes) {
-        u8 *g = o.base + o.pos;
-        const u32 A = (u32)((uintptr_t)g & 15);
-        resolve_window(P, ntok, nbytes, g, A, lane);
-        wave_sync();
-        AHIP_TICK(t_g);
-        AHIP_ACC(st.cyc[5], t_f, t_g);
-        flush_window(P, g, A, nbytes, lane);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // later batches read this output back
-        AHIP_TICK(t_h);
-        AHIP_ACC(st.cyc[6], t_g, t_h);
-      }
-      o.pos += nbytes;
-      la = lb;
-      if (la < nlanes) st.partial++;
     }
-    if (bail) { st.fallbacks++; break; }
+    AHIP_TICK(t_f);
+    AHIP_ACC(st.cyc[4], t_e0, t_f);
+    sink.w += tot_tok;
+    o.pos += tot_bytes;
     b.pos = gbyte * 8 + next_pos;
     if (kstop < 64) return MS_OK;
   }
   AHIP_TICK(t_s0);
-  u32 rs = huffman_block<WRITE>(L, b, o, lane);
+  u32 rs = huffman_block_emit(L, b, o, sink, lane);
   AHIP_TICK(t_s1);
   AHIP_ACC(st.cyc[7], t_s0, t_s1);
   return rs;
 }
 
 // Inflate one stream.  Mirrors Inflate._inflate(): loop blocks until BFINAL, an error, or EOS.
-//  PAR: Huffman blocks go through huffman_block_parallel (P must be valid), else the serial decoder.
+//  PAR = false: the serial byte-writing decoder (A/B baseline, single kernel).
+//  PAR = true : tokenizer -- no bytes are written; tokens go to `tokens` (nullptr = sizing run).
 template <bool WRITE, bool PAR>
-AHIP_DEVINL void inflate_member(WaveLds &L, ParLds *P, u32 *slab, const u8 *in, u64 in_len, const MemberDesc &m,
-                                u8 *out, MemberResult &res, int lane) {
+AHIP_DEVINL void inflate_member(WaveLds &L, TokLds *P, u32 *slab, const u8 *in, u64 in_len, const MemberDesc &m,
+                                u8 *out, u32 *tokens, MemberResult &res, int lane) {
   ParStats st{};
   BitCursor b{in, in_len, in_len * 8, m.in_off * 8, nullptr, 0, 0};
   OutCursor o{out + m.out_off, 0, m.out_limit};
+  TokSink sink{tokens, 0};
   u32 status = MS_EOS, blocks = 0;
   for (;;) {
     if (((b.pos + 7) >> 3) >= in_len) { status = MS_EOS; break; }
@@ -487,7 +532,7 @@ AHIP_DEVINL void inflate_member(WaveLds &L, ParLds *P, u32 *slab, const u8 *in, 
     const int btype = hdr >> 1;
     u32 r;
     if (btype == 0) {
-      r = stored_block<WRITE>(b, o, lane);
+      r = PAR ? stored_block_emit(b, o, sink, lane) : stored_block<WRITE>(b, o, lane);
     } else if (btype == 3) {
       r = MS_FALSE;
     } else {
@@ -515,7 +560,7 @@ AHIP_DEVINL void inflate_member(WaveLds &L, ParLds *P, u32 *slab, const u8 *in, 
         AHIP_TICK(t_h1);
         AHIP_ACC(st.cyc[0], t_h0, t_h1);
         if (!ok) r = MS_OVERSUB;
-        else if (PAR) r = huffman_block_parallel<WRITE>(L, *P, slab, b, o, lane, st);
+        else if (PAR) r = huffman_block_tokenize(L, *P, slab, b, o, sink, lane, st);
         else r = huffman_block<WRITE>(L, b, o, lane);
       }
     }
@@ -539,6 +584,118 @@ AHIP_DEVINL void inflate_member(WaveLds &L, ParLds *P, u32 *slab, const u8 *in, 
     res.partial = st.partial;
     for (int k = 0; k < 8; ++k) res.cyc[k] = st.cyc[k];
     if (st.dbg) res.cyc[7] = 0xdead0000u | st.dbg;
+    res.tok_words = sink.w;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Resolver side: replay one member's token stream into its output window
+// ------------------------------------------------------------------------------------------
+AHIP_DEVINL void resolve_member(ParLds &P, const u8 *in, const u32 *tokens, u64 nwords, u8 *out_base, u32 *cyc, int lane) {
+  u64 cur = 0, opos = 0;
+  if (lane == 0) P.misc[0] = 0xffffffffu;
+  wave_sync();
+  while (cur < nwords) {
+    AHIP_TICK(t_0);
+    // ---- fetch up to TOK_CAP words; a stored-run record ends the batch (it is handled at a batch head) ----
+    const u32 want = (nwords - cur) < (u64)TOK_CAP ? (u32)(nwords - cur) : (u32)TOK_CAP;
+    u32 first_stored = want;
+    for (u32 k = lane; k < want; k += 64) {
+      const u32 t = tokens[cur + k];
+      P.tok[k] = t;
+      if ((t & 0xe0000000u) == TK_STORED) atomicMin(&P.misc[0], k);  // lowest index wins
+    }
+    wave_sync();
+    first_stored = uniform(P.misc[0]) < want ? uniform(P.misc[0]) : want;
+    // NOTE: the two words after a TK_STORED header are raw offsets and may alias the pattern; only the
+    // FIRST hit is trusted, and the scan restarts after it.
+    if (first_stored == 0) {
+      // stored run at the head: input -> output copy
+      const u32 len = P.tok[0] & 0xffff;
+      const u64 src = (u64)P.tok[1] | ((u64)P.tok[2] << 32);
+      for (u32 i = lane; i < len; i += 64) out_base[opos + i] = in[src + i];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      opos += len;
+      cur += 3;
+      if (lane == 0) P.misc[0] = 0xffffffffu;
+      wave_sync();
+      continue;
+    }
+    u32 ntok = first_stored;
+    wave_sync();
+    if (lane == 0) P.misc[0] = 0xffffffffu;
+    // ---- pass 1 (keys) with the byte cut at OB_CAP; matches whose whole source is flushed history (and
+    //      at most 16 bytes long) are fetched per TOKEN with two 8-byte loads and deposited into the window
+    //      right here -- one vector-memory instruction per 64 tokens instead of one byte gather per 64 bytes ----
+    u8 *g = out_base + opos;
+    const u32 A = (u32)((uintptr_t)g & 15);
+    u8 *obw = P.obuf + A;
+    // software-pipelined by one chunk of 64 tokens: the history loads of chunk c+1 are in flight while
+    // chunk c is deposited
+    struct Chunk { u32 idx, len, off, key, total, nf, nin; bool fits, pre, cut; u64 w0, w1; };
+    auto prep = [&](u32 c, u32 run) -> Chunk {
+      Chunk q;
+      q.idx = c + lane;
+      const bool inb = q.idx < ntok;
+      const u32 t = inb ? P.tok[q.idx] : 0u;
+      const bool lit = t >> 31;
+      q.len = inb ? (lit ? 1u : (t >> 16)) : 0u;
+      q.off = run + wave_excl_sum(q.len, q.total);
+      q.fits = inb && q.off + q.len <= (u32)OB_CAP;
+      q.key = (1u << 30) | (q.off << 17) | (lit ? (0x10000u | (t & 0xff)) : ((t & 0xffff) - 1));
+      const i32 srel = (i32)q.off - (i32)(t & 0xffff);  // source start relative to the window
+      q.pre = q.fits && !lit && q.len <= 16 && srel + 16 <= 0;
+      q.w0 = q.w1 = 0;
+#ifndef AHIP_NO_FAR_DEPOSIT
+      if (q.pre) { const u8 *sp = g + srel; q.w0 = load_u64_unaligned(sp); q.w1 = load_u64_unaligned(sp + 8); }
+#else
+      q.pre = false;
+#endif
+      const u64 fm = __ballot(q.fits), im = __ballot(inb);
+      q.nf = (u32)__popcll(fm);
+      q.nin = (u32)__popcll(im);
+      q.cut = fm != im;  // the window is full: cut after the last fitting token
+      return q;
+    };
+    u32 run = 0, kept = 0, c = 0;
+    Chunk ck = prep(0, 0);
+    for (;;) {
+      const bool more = !ck.cut && c + 64 < ntok;
+      Chunk nxt = ck;
+      if (more) nxt = prep(c + 64, run + ck.total);
+      if (ck.pre) {
+        u8 *dp = obw + ck.off;
+#pragma unroll
+        for (u32 k = 0; k < 16; ++k)
+          if (k < ck.len) dp[k] = (u8)((k < 8 ? ck.w0 : ck.w1) >> (8 * (k & 7)));
+      }
+      if (ck.fits) P.tok[ck.idx] = ck.key | (ck.pre ? 0x8000u : 0u);
+      if (ck.cut) {
+        kept = c + ck.nf;
+        run = ck.nf ? lane_bcast(ck.off + ck.len, (int)ck.nf - 1) : run;
+        break;
+      }
+      run += ck.total;
+      kept = c + ck.nin;
+      if (!more) break;
+      ck = nxt;
+      c += 64;
+    }
+    ntok = kept;
+    wave_sync();
+    AHIP_TICK(t_1);
+    AHIP_ACC(cyc[4], t_0, t_1);
+    const u32 nbytes = run;
+    resolve_bytes(P, ntok, nbytes, g, A, lane);
+    wave_sync();
+    AHIP_TICK(t_2);
+    AHIP_ACC(cyc[5], t_1, t_2);
+    flush_window(P, g, A, nbytes, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // later batches read this output back
+    AHIP_TICK(t_3);
+    AHIP_ACC(cyc[6], t_2, t_3);
+    opos += nbytes;
+    cur += ntok;
   }
 }
 

@@ -87,8 +87,8 @@ int32_t ahip_gzip_plan_run(ahip_gzip_plan *plan, void *d_out, size_t out_cap, vo
 /* After the stream is synchronised: per-run verdict (AHIP_OK / AHIP_FALSE / ...). */
 int32_t ahip_gzip_plan_status(ahip_gzip_plan *plan, size_t *out_len);
 void ahip_gzip_plan_destroy(ahip_gzip_plan *plan);
-/* Diagnostics only: per-member results of the last run, 18 u32 words per member
- * {end_pos lo,hi, out_len lo,hi, status, blocks, windows, rounds, fallbacks, partial, cyc[8]}
+/* Diagnostics only: per-member results of the last run, 20 u32 words per member
+ * {end_pos lo,hi, out_len lo,hi, status, blocks, windows, rounds, fallbacks, partial, cyc[8], tok_words lo,hi}
  * (cyc: per-phase shader-clock cycles / 16, filled by -DAHIP_PROFILE builds only). */
 int32_t ahip_debug_plan_results(ahip_gzip_plan *plan, uint32_t *host_words, size_t max_members, size_t *n_members);
 

@@ -21,9 +21,9 @@ torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); L.ahip_gzip_plan_run(plan, d_out.data_ptr(), d_out.numel(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)); e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1)
-buf = np.zeros(members * 18, dtype=np.uint32); n = ctypes.c_size_t()
+buf = np.zeros(members * 20, dtype=np.uint32); n = ctypes.c_size_t()
 assert L.ahip_debug_plan_results(plan, buf.ctypes.data, members, ctypes.byref(n)) == 0
-r = buf.reshape(-1, 18)
+r = buf.reshape(-1, 20)
 print("kernel %.3f ms  %.1f GB/s out  ok=%s" % (ms, len(plain) / ms / 1e6, bool(np.array_equal(d_out[:len(plain)].cpu().numpy(), plain))))
 print("per member: blocks %.2f windows %.2f rounds %.2f (%.3f per window) fallbacks %.3f partial %.2f" % (
     r[:, 5].mean(), r[:, 6].mean(), r[:, 7].mean(), r[:, 7].sum() / max(1, r[:, 6].sum()), r[:, 8].mean(), r[:, 9].mean()))
