@@ -55,7 +55,10 @@ __global__ __launch_bounds__(64) void inflate_tokenize_kernel(const u8 *__restri
     d.out_off = uniform64(d.out_off);
     d.out_limit = uniform64(d.out_limit);
     u32 *tk = tokens ? tokens + (d.out_off - group_out0) : nullptr;
-    inflate_member<false, true>(lds.w, &lds.p, slab, in, in_len, d, (u8 *)nullptr, tk, results[m], lane);
+    // header scratch lives in the upper part of the window buffer (the staged header bytes use the first 640)
+    static_assert(sizeof(HeaderLds) + 1024 <= sizeof(TokLds), "header scratch must fit behind the staged header");
+    HeaderLds &hdr = *(HeaderLds *)((u8 *)lds.p.inbuf + 1024);
+    inflate_member<false, true>(lds.w, hdr, &lds.p, slab, in, in_len, d, (u8 *)nullptr, tk, results[m], lane);
   }
 }
 
@@ -85,6 +88,7 @@ __global__ __launch_bounds__(64) void inflate_members_serial_kernel(const u8 *__
                                                                    u32 n_members, u8 *out,
                                                                    MemberResult *__restrict__ results) {
   __shared__ WaveLds lds;
+  __shared__ HeaderLds hdr;
   const int lane = threadIdx.x;
   const u32 m = blockIdx.x;
   if (m >= n_members) return;
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(64) void inflate_members_serial_kernel(const u8 *__
   d.in_off = uniform64(d.in_off);
   d.out_off = uniform64(d.out_off);
   d.out_limit = uniform64(d.out_limit);
-  inflate_member<WRITE, false>(lds, nullptr, nullptr, in, in_len, d, out, nullptr, results[m], lane);
+  inflate_member<WRITE, false>(lds, hdr, nullptr, nullptr, in, in_len, d, out, nullptr, results[m], lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -191,6 +195,13 @@ hipError_t launch_inflate_group(const u8 *in, u64 n, const MemberDesc *members, 
     if (e != hipSuccess) return e;
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, inflate_resolve_kernel, 64, 0);
     if (e != hipSuccess) return e;
+    // hipOccupancyMaxActiveBlocksPerMultiprocessor over-reports these kernels by one workgroup per CU
+    // on gfx950 / ROCm 7.2 (MI355X_MICROARCH.md, "Residency"): with the API's number the surplus
+    // workgroups only start when resident ones finish, which cost 15-25 % here.  One less is what fits.
+    a = a > 1 ? a - 1 : a;
+    b = b > 1 ? b - 1 : b;
+    if (const char *e1 = getenv("AHIP_TOK_WGS_PER_CU")) a = atoi(e1);  // tuning overrides
+    if (const char *e2 = getenv("AHIP_RES_WGS_PER_CU")) b = atoi(e2);
     tok_resident = cus * (a > 0 ? a : 1);
     res_resident = cus * (b > 0 ? b : 1);
   }

@@ -124,7 +124,7 @@ AHIP_DEVINL void load_long_meta(LongMeta<N> &m, const CodeDesc &cd, int root) {
   }
 }
 template <bool IS_DIST, int N>
-AHIP_DEVINL u32 long_resolve(const LongMeta<N> &m, const u16 *sorted, u32 bits, int root) {
+AHIP_DEVINL u32 long_resolve(const LongMeta<N> &m, const u32 *sorted, u32 bits, int root) {
   const u32 rev = __brev(bits);
   u32 pos = 0, len = 0;
 #pragma unroll
@@ -135,8 +135,7 @@ AHIP_DEVINL u32 long_resolve(const LongMeta<N> &m, const u16 *sorted, u32 bits, 
     pos = hit ? m.offset[k] + idx : pos;
     len = hit ? Lk : len;
   }
-  const u32 sym = sorted[pos];
-  const u32 e = IS_DIST ? dist_entry(sym, len) : litlen_entry(sym, len);
+  const u32 e = sorted[pos];
   const u32 hole = IS_DIST ? dist_entry(0, 0) : (u32)E_HOLE;  // unfilled entry: symbol 0, length 0
   return len ? e : hole;
 }
@@ -155,6 +154,7 @@ AHIP_DEVINL u32 decode_token(LaneBits &d, const WaveLds &L, const BlockMeta &M, 
   const u32 w = lb_peek32(d);  // 32 valid bits; litlen code + extra <= 20
   u32 e = L.ll[w & ((1u << LL_ROOT) - 1)];
   if (__any(e & E_LONG)) {
+    asm volatile("; long litlen code" ::: "memory");  // keep this a real branch: if-converted, its LDS read would sit on every step's critical path
     const u32 e2 = long_resolve<false>(M.ll, L.ll_sorted, w, LL_ROOT);
     e = (e & E_LONG) ? e2 : e;
   }
@@ -169,6 +169,7 @@ AHIP_DEVINL u32 decode_token(LaneBits &d, const WaveLds &L, const BlockMeta &M, 
   const u32 w2 = lb_peek32(d);  // distance code + extra <= 28
   u32 t = L.dt[w2 & ((1u << D_ROOT) - 1)];
   if (__any(is_match && (t & E_LONG))) {
+    asm volatile("; long distance code" ::: "memory");
     const u32 t2 = long_resolve<true>(M.d, L.d_sorted, w2, D_ROOT);
     t = (t & E_LONG) ? t2 : t;
   }
@@ -441,7 +442,9 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, u32 *slab, BitCurs
     st.windows++;
     const u32 s0 = (u32)(b.pos - gbyte * 8);
     const u32 boundary = (u32)(lane + 1) * SUB_BITS;
-    // ---- pass A: lane 0 from the true boundary (recording), the others blind ----
+    // ---- pass A: lane 0 from the true boundary (recording), the others blind.  The SAME loop body as
+    //      the pass-B rounds on purpose: a separate "ends only" variant was measured 8 % slower
+    //      (code size / instruction cache) ----
     LaneRun R = run_lane<true>(true, emit && lane == 0, lane == 0 ? s0 : (u32)lane * SUB_BITS, boundary, L, M, P.inbuf,
                                slab, lane);
     AHIP_TICK(t_c);
@@ -455,8 +458,8 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, u32 *slab, BitCurs
       u64 final_mask = (final_upto >= 63) ? ~0ull : ((2ull << final_upto) - 1);
       if (flagged & final_mask) break;  // a final lane ended the block (or hit an error)
       if (final_upto >= 63) break;
-      u32 prev_end = lane_prev(R.end);
-      u32 prev_flags = lane_prev(R.flags);
+      // DPP reads need the SOURCE lane active: take lane-1's values with every lane enabled
+      const u32 prev_end = lane_prev(R.end), prev_flags = lane_prev(R.flags);
       bool act = lane > final_upto && prev_flags == 0;
       LaneRun R2 = run_lane<true>(act, emit, prev_end, boundary, L, M, P.inbuf, slab, lane);
       bool mism = act && (R2.end != R.end || R2.flags != R.flags);
@@ -517,8 +520,8 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, u32 *slab, BitCurs
 //  PAR = false: the serial byte-writing decoder (A/B baseline, single kernel).
 //  PAR = true : tokenizer -- no bytes are written; tokens go to `tokens` (nullptr = sizing run).
 template <bool WRITE, bool PAR>
-AHIP_DEVINL void inflate_member(WaveLds &L, TokLds *P, u32 *slab, const u8 *in, u64 in_len, const MemberDesc &m,
-                                u8 *out, u32 *tokens, MemberResult &res, int lane) {
+AHIP_DEVINL void inflate_member(WaveLds &L, HeaderLds &H, TokLds *P, u32 *slab, const u8 *in, u64 in_len,
+                                const MemberDesc &m, u8 *out, u32 *tokens, MemberResult &res, int lane) {
   ParStats st{};
   BitCursor b{in, in_len, in_len * 8, m.in_off * 8, nullptr, 0, 0};
   OutCursor o{out + m.out_off, 0, m.out_limit};
@@ -539,7 +542,7 @@ AHIP_DEVINL void inflate_member(WaveLds &L, TokLds *P, u32 *slab, const u8 *in, 
       int hlit = 288, hdist = 30;
       r = MS_OK;
       AHIP_TICK(t_h0);
-      if (btype == 1) fixed_lengths(L.lens, lane);
+      if (btype == 1) fixed_lengths(H.lens, lane);
       else {
         if (PAR) {  // stage the (at most 569-byte) dynamic header into the idle window buffer
           const u64 sb = (b.pos >> 3) & ~3ull;
@@ -551,12 +554,12 @@ AHIP_DEVINL void inflate_member(WaveLds &L, TokLds *P, u32 *slab, const u8 *in, 
             b.stage = P->inbuf; b.stage_byte = sb; b.stage_len = HDR_STAGE;
           }
         }
-        r = dynamic_header(L, b, lane, hlit, hdist);
+        r = dynamic_header(H, b, lane, hlit, hdist);
         b.stage = nullptr;
       }
       if (r == MS_OK) {
-        bool ok = build_decode_table<false>(L.lens, hlit, L.ll, LL_ROOT, L.lld, L.ll_sorted, lane);
-        ok &= build_decode_table<true>(L.lens + hlit, hdist, L.dt, D_ROOT, L.dd, L.d_sorted, lane);
+        bool ok = build_decode_table<false>(H.lens, hlit, L.ll, LL_ROOT, L.lld, L.ll_sorted, lane);
+        ok &= build_decode_table<true>(H.lens + hlit, hdist, L.dt, D_ROOT, L.dd, L.d_sorted, lane);
         AHIP_TICK(t_h1);
         AHIP_ACC(st.cyc[0], t_h0, t_h1);
         if (!ok) r = MS_OVERSUB;

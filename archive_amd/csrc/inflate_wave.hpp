@@ -62,14 +62,18 @@ struct CodeDesc {
   u32 pad;
 };
 
+// Block-header scratch: only alive between a block's 3-bit header and the end of its table build,
+// so the tokenizer overlays it on the (then idle) bitstream window.
+struct HeaderLds {
+  u32 cl[128];        // code-length code: single level, built exactly like the reference
+  u8 lens[320 + 8];
+};
 struct WaveLds {
   u32 ll[1 << LL_ROOT];
   u32 dt[1 << D_ROOT];
-  u32 cl[128];        // code-length code: single level, built exactly like the reference
   CodeDesc lld, dd;
-  u16 ll_sorted[288];
-  u16 d_sorted[32];
-  u8 lens[320 + 8];
+  u32 ll_sorted[288];  // decode-table ENTRY of every symbol in canonical (length, symbol) order
+  u32 d_sorted[32];
 };
 
 struct BitCursor {
@@ -117,15 +121,14 @@ AHIP_DEVINL int read_bits(BitCursor &b, u32 n) {
 
 // Resolve a bit pattern against the canonical description (codes longer than `root`).
 template <bool IS_DIST>
-AHIP_DEVINL u32 long_lookup(const CodeDesc &cd, const u16 *sorted, u32 bits, int root) {
+AHIP_DEVINL u32 long_lookup(const CodeDesc &cd, const u32 *sorted, u32 bits, int root) {
   u32 rev = __brev(bits);
   u32 maxlen = cd.maxlen;
   for (u32 L = root + 1; L <= maxlen; ++L) {
     u32 code = rev >> (32 - L);
     u32 idx = code - cd.first[L];
     if (idx < cd.count[L]) {
-      u32 sym = sorted[cd.offset[L] + idx];
-      return IS_DIST ? dist_entry(sym, L) : litlen_entry(sym, L);
+      return sorted[cd.offset[L] + idx];
     }
   }
   return IS_DIST ? dist_entry(0, 0) : E_HOLE;  // unfilled entry: symbol 0, length 0
@@ -134,7 +137,7 @@ AHIP_DEVINL u32 long_lookup(const CodeDesc &cd, const u16 *sorted, u32 bits, int
 // Build primary table + canonical description from `n` code lengths in LDS (wave-cooperative).
 // Returns false for an over-subscribed set (not reproduced).
 template <bool IS_DIST>
-AHIP_DEVINL bool build_decode_table(const u8 *lens, int n, u32 *primary, int root, CodeDesc &cd, u16 *sorted,
+AHIP_DEVINL bool build_decode_table(const u8 *lens, int n, u32 *primary, int root, CodeDesc &cd, u32 *sorted,
                                     int lane) {
   constexpr int CHUNKS = IS_DIST ? 1 : 5;
   u32 mylen[CHUNKS], myrank[CHUNKS];
@@ -191,10 +194,10 @@ AHIP_DEVINL bool build_decode_table(const u8 *lens, int n, u32 *primary, int roo
     if (l) {
       u32 s = c * 64 + lane;
       u32 cde = cd.first[l] + myrank[c];
-      sorted[cd.offset[l] + myrank[c]] = (u16)s;
+      const u32 e = IS_DIST ? dist_entry(s, l) : litlen_entry(s, l);
+      sorted[cd.offset[l] + myrank[c]] = e;
       if ((int)l <= root) {
         u32 rev = __brev(cde) >> (32 - l);
-        u32 e = IS_DIST ? dist_entry(s, l) : litlen_entry(s, l);
         for (u32 j = rev; j < (1u << root); j += (1u << l)) primary[j] = e;
       }
     }
@@ -322,7 +325,7 @@ AHIP_DEVINL u32 stored_block(BitCursor &b, OutCursor &o, int lane) {
 }
 
 // _parseDynamicHuffmanBlock header + _decode; leaves litlen/dist lengths in L.lens
-AHIP_DEVINL u32 dynamic_header(WaveLds &L, BitCursor &b, int lane, int &hlit_out, int &hdist_out) {
+AHIP_DEVINL u32 dynamic_header(HeaderLds &L, BitCursor &b, int lane, int &hlit_out, int &hdist_out) {
   int hlit = read_bits(b, 5);
   if (hlit < 0) return MS_FALSE_EOS;
   hlit += 257;
