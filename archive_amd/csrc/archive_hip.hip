@@ -228,14 +228,14 @@ hipError_t launch_inflate_group(const u8 *in, u64 n, const MemberDesc *members, 
 // the whole range is known to be small / a sizing run.
 template <bool WRITE>
 hipError_t launch_inflate(const u8 *in, u64 n, const MemberDesc *members, u32 M, u8 *out, MemberResult *res,
-                          hipStream_t st, const u64 *host_out_off = nullptr) {
+                          hipStream_t st, const u64 *host_out_off = nullptr, u64 total_out = 0) {
   if (M == 0) return hipSuccess;
   if (use_serial_kernel()) {
     hipLaunchKernelGGL(inflate_members_serial_kernel<WRITE>, dim3(M), dim3(64), 0, st, in, n, members, M, out, res);
     return hipGetLastError();
   }
   if (!WRITE || !host_out_off) {
-    const u64 total = host_out_off ? host_out_off[M] : 0;
+    const u64 total = host_out_off ? host_out_off[M] : total_out;
     return launch_inflate_group<WRITE>(in, n, members, 0, M, 0, total, out, res, st);
   }
   u32 first = 0;
@@ -341,7 +341,7 @@ int32_t plan_build(ahip_gzip_plan *pl, bool force_sizing, hipStream_t st) {
   if (!pl->sum.first_is_gzip) { pl->sum.members = 0; pl->sum.total_out = 0; pl->sum.tail_pos = start; }
   // output offsets on the host: the decode is launched in groups whose token streams fit the scratch
   pl->host_out_off.clear();
-  if (pl->sum.members) {
+  if (pl->sum.members && pl->sum.total_out > GROUP_OUT_MAX) {
     std::vector<MemberDesc> md(pl->sum.members);
     HIP_TRY(hipMemcpy(md.data(), pl->members.p, md.size() * sizeof(MemberDesc), hipMemcpyDeviceToHost));
     pl->host_out_off.resize(md.size() + 1);
@@ -364,8 +364,10 @@ int32_t plan_run(ahip_gzip_plan *pl, u8 *d_out, size_t out_cap, hipStream_t st) 
   pl->ran = true;
   if (M == 0) return AHIP_OK;
   HIP_TRY(pl->results.reserve((size_t)M * sizeof(MemberResult)));
+  const u64 whole[2] = {0, pl->sum.total_out};  // one group: only its total is needed
   HIP_TRY(launch_inflate<true>(pl->d_in, pl->in_len, pl->members.as<MemberDesc>(), M, d_out,
-                               pl->results.as<MemberResult>(), st, pl->host_out_off.data()));
+                               pl->results.as<MemberResult>(), st,
+                               pl->host_out_off.empty() ? nullptr : pl->host_out_off.data(), whole[1]));
   hipLaunchKernelGGL(gz_verify, dim3(cdiv(M, 256)), dim3(256), 0, st, pl->members.as<MemberDesc>(),
                      pl->expect_status.as<u32>(), pl->results.as<MemberResult>(), M, pl->drun.as<RunSummary>());
   HIP_TRY(hipGetLastError());

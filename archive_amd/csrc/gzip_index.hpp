@@ -19,7 +19,7 @@
 
 namespace ahip {
 
-constexpr u32 TILE_BYTES = 4096;  // 256 threads x 16 bytes
+constexpr u32 TILE_BYTES = 16384;  // 256 threads x 4 x 16 bytes
 constexpr u64 POS_UNKNOWN = ~0ull;
 
 constexpr u32 HF_BC = 1;     // size known from the BC subfield
@@ -86,8 +86,12 @@ AHIP_DEVINL u32 block_reduce_add_256(u32 v, u32 *sm) {
 
 __global__ __launch_bounds__(256) void gz_count_candidates(const u8 *in, u64 start, u64 n, u32 *tile_counts) {
   __shared__ u32 sm[4];
-  u64 base = start + (u64)blockIdx.x * TILE_BYTES + threadIdx.x * 16;
-  u32 c = __popc(candidate_mask16(in, n, base));
+  u32 c = 0;
+#pragma unroll
+  for (u32 r = 0; r < TILE_BYTES / 4096; ++r) {
+    u64 base = start + (u64)blockIdx.x * TILE_BYTES + r * 4096 + threadIdx.x * 16;
+    c += __popc(candidate_mask16(in, n, base));
+  }
   u32 t = block_reduce_add_256(c, sm);
   if (threadIdx.x == 0) tile_counts[blockIdx.x] = t;
 }
@@ -121,19 +125,24 @@ __global__ __launch_bounds__(256) void gz_write_candidates(const u8 *in, u64 sta
                                                            const u32 *tile_offsets, u64 *cand_pos) {
   if (tile_counts[blockIdx.x] == 0) return;  // uniform per block
   __shared__ u32 wsum[4];
-  u64 base = start + (u64)blockIdx.x * TILE_BYTES + threadIdx.x * 16;
-  u32 mask = candidate_mask16(in, n, base);
-  u32 c = __popc(mask), x = c;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int o = 1; o < 64; o <<= 1) { u32 y = __shfl_up(x, o); if (lane >= o) x += y; }
-  if (lane == 63) wsum[w] = x;
-  __syncthreads();
-  u32 off = tile_offsets[blockIdx.x] + x - c;
-  for (int k = 0; k < w; ++k) off += wsum[k];
-  while (mask) {
-    int k = __ffs(mask) - 1;
-    mask &= mask - 1;
-    cand_pos[off++] = base + k;
+  u32 tile_off = tile_offsets[blockIdx.x];
+  for (u32 r = 0; r < TILE_BYTES / 4096; ++r) {  // sub-tiles in position order
+    u64 base = start + (u64)blockIdx.x * TILE_BYTES + r * 4096 + threadIdx.x * 16;
+    u32 mask = candidate_mask16(in, n, base);
+    u32 c = __popc(mask), x = c;
+    for (int o = 1; o < 64; o <<= 1) { u32 y = __shfl_up(x, o); if (lane >= o) x += y; }
+    __syncthreads();
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    u32 off = tile_off + x - c;
+    for (int k = 0; k < w; ++k) off += wsum[k];
+    while (mask) {
+      int k = __ffs(mask) - 1;
+      mask &= mask - 1;
+      cand_pos[off++] = base + k;
+    }
+    tile_off += wsum[0] + wsum[1] + wsum[2] + wsum[3];
   }
 }
 
@@ -239,9 +248,23 @@ __global__ __launch_bounds__(1024) void gz_chain(const u64 *cand_pos, const GzHe
   }
   if (tid == 0) { nxt[K] = K; jmp[K] = K; jmp2[K] = K; reach[K] = 0; }
   __syncthreads();
-  // B: reachability by pointer doubling
+  // B: reachability.  Common case first: every candidate's successor is simply the next candidate
+  // (no false magic inside compressed data, no garbage) -- then all K are on the chain.
+  __shared__ u32 not_consecutive;
+  if (tid == 0) not_consecutive = first_ok ? 0u : 1u;
+  __syncthreads();
+  {
+    bool bad = false;
+    for (u32 i = tid; i + 1 < K; i += 1024) bad |= nxt[i] != i + 1;
+    if (bad) not_consecutive = 1;
+  }
+  __syncthreads();
+  const bool all_chained = not_consecutive == 0;
+  if (all_chained) for (u32 i = tid; i < K; i += 1024) reach[i] = 1;
+  __syncthreads();
+  // otherwise pointer doubling from candidate 0
   u32 *ja = jmp, *jb = jmp2;
-  for (u64 span = 1; span < (u64)K; span <<= 1) {
+  for (u64 span = 1; span < (u64)K && !all_chained; span <<= 1) {
     for (u32 i = tid; i < K; i += 1024) {
       u32 j = ja[i];
       if (reach[i] && j < K) reach[j] = 1;
