@@ -233,45 +233,87 @@ __global__ __launch_bounds__(1024) void gz_chain(const u64 *cand_pos, const GzHe
   __shared__ u64 wsum_a[16], wsum_b[16], wsum_c[16];
   __shared__ u64 carry_a, carry_b, carry_c;
   const bool first_ok = K > 0 && cand_pos[0] == start;
-  // A: successor index of every candidate
+  // A: successor index of every candidate (the next candidate in position order, nearly always)
   for (u32 i = tid; i < K; i += 1024) {
     u64 np = hdr[i].next_pos;
     u32 j = K;
     if (!(hdr[i].flags & HF_RANGE) && np < n) {
-      u32 lo = i + 1, hi = K;  // candidates are sorted; next_pos > pos
-      while (lo < hi) { u32 mid = (lo + hi) >> 1; if (cand_pos[mid] < np) lo = mid + 1; else hi = mid; }
-      if (lo < K && cand_pos[lo] == np) j = lo;
+      if (i + 1 < K && cand_pos[i + 1] == np) j = i + 1;
+      else {
+        u32 lo = i + 1, hi = K;  // candidates are sorted; next_pos > pos
+        while (lo < hi) { u32 mid = (lo + hi) >> 1; if (cand_pos[mid] < np) lo = mid + 1; else hi = mid; }
+        if (lo < K && cand_pos[lo] == np) j = lo;
+      }
     }
     nxt[i] = j;
-    jmp[i] = j;
-    reach[i] = (i == 0 && first_ok) ? 1u : 0u;
+    reach[i] = 0;
   }
-  if (tid == 0) { nxt[K] = K; jmp[K] = K; jmp2[K] = K; reach[K] = 0; }
+  if (tid == 0) { nxt[K] = K; reach[K] = 0; }
   __syncthreads();
-  // B: reachability.  Common case first: every candidate's successor is simply the next candidate
-  // (no false magic inside compressed data, no garbage) -- then all K are on the chain.
-  __shared__ u32 not_consecutive;
-  if (tid == 0) not_consecutive = first_ok ? 0u : 1u;
+  // B: reachability from candidate 0.  The chain runs through consecutive candidates except where a
+  // false magic inside compressed data (about one per 16 MiB) or garbage interrupts it, so: list the
+  // exceptions (nxt[i] != i+1) in index order in LDS, let one thread hop between them, and mark the
+  // runs in between with all threads.  Pointer doubling remains for adversarial inputs.
+  constexpr u32 EXC_CAP = 3072;
+  __shared__ u32 exc_idx[EXC_CAP], exc_nxt[EXC_CAP];
+  __shared__ u32 run_lo[EXC_CAP + 1], run_hi[EXC_CAP + 1];
+  __shared__ u32 cnt_scan[1024];
+  __shared__ u32 n_exc, n_runs;
+  const u32 chunk = (K + 1023) / 1024;
+  const u32 c0 = tid * chunk < K ? tid * chunk : K, c1 = c0 + chunk < K ? c0 + chunk : K;
+  u32 mine = 0;
+  for (u32 i = c0; i < c1; ++i) mine += nxt[i] != i + 1;
+  cnt_scan[tid] = mine;
   __syncthreads();
-  {
-    bool bad = false;
-    for (u32 i = tid; i + 1 < K; i += 1024) bad |= nxt[i] != i + 1;
-    if (bad) not_consecutive = 1;
+  for (u32 o = 1; o < 1024; o <<= 1) {  // inclusive scan of the per-thread counts
+    u32 v = tid >= o ? cnt_scan[tid - o] : 0;
+    __syncthreads();
+    cnt_scan[tid] += v;
+    __syncthreads();
   }
+  if (tid == 1023) n_exc = cnt_scan[1023];
   __syncthreads();
-  const bool all_chained = not_consecutive == 0;
-  if (all_chained) for (u32 i = tid; i < K; i += 1024) reach[i] = 1;
-  __syncthreads();
-  // otherwise pointer doubling from candidate 0
-  u32 *ja = jmp, *jb = jmp2;
-  for (u64 span = 1; span < (u64)K && !all_chained; span <<= 1) {
-    for (u32 i = tid; i < K; i += 1024) {
-      u32 j = ja[i];
-      if (reach[i] && j < K) reach[j] = 1;
-      jb[i] = (j < K) ? ja[j] : K;
+  const bool listed = n_exc <= EXC_CAP;
+  if (listed) {
+    u32 slot = cnt_scan[tid] - mine;
+    for (u32 i = c0; i < c1; ++i) {
+      u32 j = nxt[i];
+      if (j != i + 1) { exc_idx[slot] = i; exc_nxt[slot] = j; ++slot; }
     }
     __syncthreads();
-    u32 *t = ja; ja = jb; jb = t;
+    if (tid == 0) {
+      u32 r = 0;
+      if (first_ok) {
+        u32 i = 0, p = 0;
+        const u32 E = n_exc;
+        for (;;) {
+          while (p < E && exc_idx[p] < i) ++p;
+          if (p == E) { run_lo[r] = i; run_hi[r] = K - 1; ++r; break; }  // consecutive to the last candidate
+          run_lo[r] = i; run_hi[r] = exc_idx[p]; ++r;
+          i = exc_nxt[p];
+          if (i >= K) break;
+        }
+      }
+      n_runs = r;
+    }
+    __syncthreads();
+    for (u32 r = 0; r < n_runs; ++r)
+      for (u32 i = run_lo[r] + tid; i <= run_hi[r]; i += 1024) reach[i] = 1;
+    __syncthreads();
+  } else {
+    for (u32 i = tid; i <= K; i += 1024) { jmp[i] = nxt[i]; if (i == 0 && first_ok) reach[0] = 1; }
+    if (tid == 0) jmp2[K] = K;
+    __syncthreads();
+    u32 *ja = jmp, *jb = jmp2;
+    for (u64 span = 1; span < (u64)K; span <<= 1) {
+      for (u32 i = tid; i < K; i += 1024) {
+        u32 j = ja[i];
+        if (reach[i] && j < K) reach[j] = 1;
+        jb[i] = (j < K) ? ja[j] : K;
+      }
+      __syncthreads();
+      u32 *t = ja; ja = jb; jb = t;
+    }
   }
   // C: ordered member list + output offsets (exclusive scans over the reach flags)
   if (tid == 0) { carry_a = 0; carry_b = 0; carry_c = 0; }

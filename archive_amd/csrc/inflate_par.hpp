@@ -489,17 +489,33 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, u32 *slab, BitCurs
     // ---- slab (lane-major rows) -> the member's token stream (stream order) ----
     AHIP_TICK(t_e0);
     if (emit) {
+      // Transposed through LDS (the idle bitstream window) so that the stream is written with
+      // coalesced stores: per-lane 4-byte stores to 64 different lines ran at one line per cycle in
+      // the address coalescer and cost more than either decode pass.
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      constexpr u32 QCAP = 1024;
+      static_assert(IN_DWORDS >= (int)QCAP, "token transpose buffer lives in the window buffer");
       const u32 cnt = valid ? R.ntok : 0u;
-      const u32 steps = wave_umax(cnt);
-      u32 *q = sink.base + sink.w + T;
-      for (u32 k = 0; k < steps; k += 8) {
-        u32 t[8];
+      u32 *q = sink.base + sink.w;
+      for (u32 lo = 0; lo < tot_tok; lo += QCAP) {
+        // rows of this lane whose stream index T + r falls into [lo, lo + QCAP)
+        const u32 rb = lo > T ? lo - T : 0u;
+        const u32 re = lo + QCAP > T ? (cnt < lo + QCAP - T ? cnt : lo + QCAP - T) : 0u;
+        const bool any_rows = rb < re;
+        const u32 rmin = ~wave_umax(any_rows ? ~rb : 0u), rmax = wave_umax(any_rows ? re : 0u);
+        const u32 tb = T - lo;  // wraps for lanes that start before the batch; only used when in range
+        for (u32 r = rmin; r < rmax; r += 16) {  // 16 row loads in flight: this loop is latency-bound
+          u32 t[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = (k + u < cnt) ? slab[(k + u) * 64 + lane] : 0u;
+          for (int u = 0; u < 16; ++u) t[u] = (r + u >= rb && r + u < re) ? slab[(r + u) * 64 + lane] : 0u;
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (k + u < cnt) q[k + u] = t[u];
+          for (int u = 0; u < 16; ++u)
+            if (r + u >= rb && r + u < re) P.inbuf[tb + r + u] = t[u];
+        }
+        wave_sync();
+        const u32 nq = tot_tok - lo < QCAP ? tot_tok - lo : QCAP;
+        for (u32 k = lane; k < nq; k += 64) q[lo + k] = P.inbuf[k];
+        wave_sync();
       }
     }
     AHIP_TICK(t_f);
@@ -687,7 +703,7 @@ AHIP_DEVINL void resolve_member(ParLds &P, const u8 *in, const u32 *tokens, u64 
     ntok = kept;
     wave_sync();
     AHIP_TICK(t_1);
-    AHIP_ACC(cyc[4], t_0, t_1);
+    AHIP_ACC(cyc[6], t_0, t_1);
     const u32 nbytes = run;
     resolve_bytes(P, ntok, nbytes, g, A, lane);
     wave_sync();
@@ -696,7 +712,7 @@ AHIP_DEVINL void resolve_member(ParLds &P, const u8 *in, const u32 *tokens, u64 
     flush_window(P, g, A, nbytes, lane);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // later batches read this output back
     AHIP_TICK(t_3);
-    AHIP_ACC(cyc[6], t_2, t_3);
+    AHIP_ACC(cyc[5], t_2, t_3);
     opos += nbytes;
     cur += ntok;
   }

@@ -143,19 +143,22 @@ def main():
                 "gen_seconds": round(gen_s, 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
-                         "kernel": "inflate_members_kernel<true>", "kernel_ms": round(kern_ms, 4),
-                         "algorithmic_bytes": int(algo_bytes)},
+                         "kernel": "inflate_tokenize_kernel + inflate_resolve_kernel (one launch each per decode; "
+                                   "HIP events on the launch stream around ahip_gzip_plan_run)",
+                         "kernel_ms": round(kern_ms, 4), "algorithmic_bytes": int(algo_bytes)},
         }
-        # HBM-side traffic of the dominant kernel: PMC counters cannot be read from inside this
+        # HBM-side traffic of the inflate stage: PMC counters cannot be read from inside this
         # process; the figure measured by rocprofv3 (separate --pmc passes, profiles/) is attached
         # when this run uses the profiled workload.
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            import glob
+            latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))[-1]
+            with open(latest) as f:
                 pmc = json.load(f)
             w = pmc["workload"]
             if (w["members"], w["member_bytes"], w["kind"], w["bc"]) == (args.members, args.member_bytes, args.kind, not args.no_bc):
                 line["roofline"]["traffic"] = round(pmc["traffic_bytes_per_launch"] / 1e9, 2)
-                line["roofline"]["traffic_unit"] = "GB per launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, raw, profiles/r01_pmc_traffic.md)"
+                line["roofline"]["traffic_unit"] = ("GB per decode (rocprofv3 FETCH_SIZE+WRITE_SIZE, calibrated, profiles/%s)" % os.path.basename(latest))
         except Exception:
             pass
         if args.cpu_seconds > 0 and world >= 1:

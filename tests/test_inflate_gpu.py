@@ -167,6 +167,18 @@ def test_ragged_members(amd):
     assert gzip.decompress(g) == b"".join(parts)
 
 
+@pytest.mark.parametrize("n_members", [40, 3500])
+def test_false_member_magics_inside_payloads(amd, orc, n_members):
+    """`1f 8b 08` inside stored payloads creates false member candidates; the chain must hop over them
+    (few: exception list; thousands: pointer-doubling fallback of gz_chain)."""
+    parts = [b"\x1f\x8b\x08\x00" + bytes([i & 255, i >> 8]) * 9 + streams.text(40 + i % 7, i) for i in range(n_members)]
+    g = b"".join(streams.gz_member(p, level=0) if i % 3 else streams.bgzf_member(p) for i, p in enumerate(parts))
+    want = b"".join(parts)
+    assert _gz(amd, g) == (0, want)
+    if n_members < 100:
+        assert orc.gzip_decode(g, cap=len(want) + 8) == (0, want)
+
+
 def test_device_resident_plan_api(amd):
     import torch
     from archive_amd import _native as N

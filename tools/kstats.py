@@ -31,11 +31,11 @@ print("status histogram", np.bincount(r[:, 4]))
 print("debug codes", sorted(set(hex(v) for v in r[:, 17] if (v >> 16) == 0xdead)))
 cyc = r[:, 10:18].astype(np.float64).mean(axis=0) * 16
 if cyc.sum() > 0:
-    names = ["header+tables", "stage", "passA", "passB", "emit", "resolve", "flush", "serial"]
+    names = ["tok header+tables", "tok stage", "tok passA", "tok passB", "tok emit", "res bytes+flush", "res keys+deposit", "tok serial"]
     tot = cyc.sum()
     print("cycles per member: total %.0f" % tot)
     for nme, c in zip(names, cyc):
-        print("  %-14s %10.0f  %5.1f%%" % (nme, c, 100 * c / tot))
+        print("  %-18s %10.0f  %5.1f%%" % (nme, c, 100 * c / tot))
 got = d_out[:len(plain)].cpu().numpy()
 if not np.array_equal(got, plain):
     bad = np.nonzero(got != plain)[0]

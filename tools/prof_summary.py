@@ -1,0 +1,155 @@
+"""Dev tool: turn the rocprofv3 CSVs that tools/run_prof.sh leaves under gpurun_out/ into the
+committed summaries profiles/<round>_kernel_stats.{md,csv} and profiles/<round>_pmc_traffic.{md,json}.
+
+    python tools/prof_summary.py r01
+"""
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out")
+PROF = os.path.join(ROOT, "profiles")
+STAGE = ("inflate_tokenize_kernel", "inflate_resolve_kernel")
+
+
+def short(name):
+    name = re.sub(r"\(.*$", "", name).strip()
+    name = re.sub(r"^void ", "", name)
+    return name
+
+
+def one(pattern):
+    hits = sorted(glob.glob(os.path.join(OUT, pattern), recursive=True))
+    if not hits:
+        raise SystemExit("missing " + pattern)
+    return hits[0]
+
+
+def counter_by_kernel(path, counter):
+    """kernel short name -> (mean counter value per dispatch, dispatches). rocprofv3 emits one row per
+    dispatch per counter (values already summed over XCDs/instances)."""
+    acc = {}
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] != counter:
+                continue
+            k = short(row["Kernel_Name"])
+            s, n = acc.get(k, (0.0, 0))
+            acc[k] = (s + float(row["Counter_Value"]), n + 1)
+    return {k: (s / n, n) for k, (s, n) in acc.items()}
+
+
+def main():
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    os.makedirs(PROF, exist_ok=True)
+
+    # ---- kernel-trace stats
+    stats_csv = one("prof_%s/**/*kernel_stats.csv" % rnd)
+    shutil.copy(stats_csv, os.path.join(PROF, "%s_kernel_stats.csv" % rnd))
+    rows = list(csv.DictReader(open(stats_csv)))
+    bench_line = None
+    for cand in ("prof_%s.log" % rnd, "bench_%s.log" % rnd):
+        p = os.path.join(OUT, cand)
+        if os.path.exists(p):
+            for ln in open(p):
+                if ln.startswith("{") and '"metric"' in ln:
+                    bench_line = json.loads(ln)
+            if bench_line:
+                break
+    stage_ns = 0.0
+    with open(os.path.join(PROF, "%s_kernel_stats.md" % rnd), "w") as f:
+        f.write("# Round %s -- rocprofv3 --kernel-trace --stats of the bench command\n\n" % rnd[1:].lstrip("0"))
+        f.write("    cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_%s -o %s -- "
+                "python bench.py --steps 5 --warmup 1 --cpu-seconds 0\n\n" % (rnd, rnd))
+        f.write("Raw CSV: `profiles/%s_kernel_stats.csv`.\n\n" % rnd)
+        f.write("| kernel | calls | avg (ms) | min (ms) | max (ms) | % of GPU time |\n|---|---|---|---|---|---|\n")
+        for r in rows:
+            k = short(r["Name"])
+            f.write("| `%s` | %s | %.4f | %.4f | %.4f | %s |\n" % (
+                k, r["Calls"], float(r["AverageNs"]) / 1e6, float(r["MinNs"]) / 1e6, float(r["MaxNs"]) / 1e6, r["Percentage"]))
+            if any(k.startswith(s) or s in k for s in STAGE):
+                stage_ns += float(r["AverageNs"])
+        f.write("\nInflate stage (`inflate_tokenize_kernel` + `inflate_resolve_kernel`, one launch each per decode): "
+                "%.3f ms average per decode.\n" % (stage_ns / 1e6))
+        if bench_line:
+            rl = bench_line["roofline"]
+            f.write("\nThe same run's own HIP-event figure (bench.py `roofline.kernel_ms`, events around `ahip_gzip_plan_run`, "
+                    "which also holds the ~20 us `gz_verify`): %.3f ms -- under the profiler.  Bench line of that run:\n\n    %s\n"
+                    % (rl["kernel_ms"], json.dumps(bench_line)))
+
+    # ---- PMC traffic
+    fetch = counter_by_kernel(one("pmc_fetch/**/*counter_collection.csv"), "FETCH_SIZE")
+    write = counter_by_kernel(one("pmc_write/**/*counter_collection.csv"), "WRITE_SIZE")
+    cal_n = 2 << 30
+    cal = {}
+    try:
+        cf = counter_by_kernel(one("cal_fetch/**/*counter_collection.csv"), "FETCH_SIZE")
+        cw = counter_by_kernel(one("cal_write/**/*counter_collection.csv"), "WRITE_SIZE")
+        for k in set(cf) | set(cw):
+            cal[k] = (cf.get(k, (0, 0))[0] * 1024, cw.get(k, (0, 0))[0] * 1024, cf.get(k, (0, 0))[1])
+    except SystemExit:
+        pass
+    # scale factors: true bytes / reported bytes for pure streaming kernels of known size
+    rscale = wscale = None
+    for k, (fb, wb, n) in cal.items():
+        if "FillFunctor" in k and wb > 0.2 * cal_n:
+            wscale = cal_n / wb
+        if ("copy" in k.lower() or "Copy" in k) and fb > 0.2 * cal_n:
+            rscale = cal_n / fb
+            if wscale is None and wb > 0.2 * cal_n:
+                wscale = cal_n / wb
+    info = bench_line["config"] if bench_line else {}
+    algo = bench_line["roofline"]["algorithmic_bytes"] if bench_line else None
+    kernels = {}
+    for k in sorted(set(fetch) | set(write)):
+        kernels[k] = {"fetch_kb_raw": fetch.get(k, (0, 0))[0], "write_kb_raw": write.get(k, (0, 0))[0],
+                      "dispatches": fetch.get(k, (0, 0))[1]}
+    stage_f = sum(v["fetch_kb_raw"] for k, v in kernels.items() if any(s in k for s in STAGE)) * 1024
+    stage_w = sum(v["write_kb_raw"] for k, v in kernels.items() if any(s in k for s in STAGE)) * 1024
+    rs = rscale if rscale else 2.0   # guide: FETCH_SIZE reports 1/2 of wide coalesced reads on gfx950
+    ws = wscale if wscale else 1.0
+    js = {
+        "stage": "inflate_tokenize_kernel + inflate_resolve_kernel",
+        "workload": {"members": info.get("members_per_gpu"), "member_bytes": info.get("member_bytes"),
+                     "kind": "log", "bc": True},
+        "kernels": kernels,
+        "calibration": {"bytes": cal_n, "kernels": {k: {"fetch_bytes_raw": v[0], "write_bytes_raw": v[1]} for k, v in cal.items()},
+                        "read_scale": rscale, "write_scale": wscale},
+        "fetch_bytes_raw": stage_f, "write_bytes_raw": stage_w,
+        "fetch_bytes": stage_f * rs, "write_bytes": stage_w * ws,
+        "traffic_bytes_per_launch": stage_f * rs + stage_w * ws,
+        "algorithmic_bytes": algo,
+        "note": "separate --pmc passes (FETCH_SIZE, WRITE_SIZE); per-dispatch means; KB x 1024; read side scaled by "
+                "read_scale and write side by write_scale, both measured on 2 GiB streaming fill/copy kernels in the same "
+                "session (tools/pmc_calib.py); MI355X_MICROARCH.md HBM section documents the 2x FETCH_SIZE under-count.",
+    }
+    json.dump(js, open(os.path.join(PROF, "%s_pmc_traffic.json" % rnd), "w"), indent=1)
+    with open(os.path.join(PROF, "%s_pmc_traffic.md" % rnd), "w") as f:
+        f.write("# Round %s -- HBM-side traffic (rocprofv3 PMC, separate passes)\n\n" % rnd[1:].lstrip("0"))
+        f.write("    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv ... -- python bench.py --steps 3 --warmup 1 --cpu-seconds 0\n"
+                "    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv ... -- python bench.py --steps 3 --warmup 1 --cpu-seconds 0\n"
+                "    (same two passes over tools/pmc_calib.py: 2 GiB fill + 2 GiB device copy, for the scale factors)\n\n")
+        f.write("| kernel | dispatches | FETCH_SIZE (KB, raw, per dispatch) | WRITE_SIZE (KB, raw, per dispatch) |\n|---|---|---|---|\n")
+        for k, v in sorted(kernels.items(), key=lambda kv: -(kv[1]["fetch_kb_raw"] + kv[1]["write_kb_raw"])):
+            f.write("| `%s` | %d | %.1f | %.1f |\n" % (k, v["dispatches"], v["fetch_kb_raw"], v["write_kb_raw"]))
+        f.write("\nCalibration (2 GiB = %d B per kernel):\n\n| kernel | FETCH_SIZE bytes (raw) | WRITE_SIZE bytes (raw) |\n|---|---|---|\n" % cal_n)
+        for k, v in cal.items():
+            f.write("| `%s` | %.0f | %.0f |\n" % (k, v[0], v[1]))
+        f.write("\nread scale = %s, write scale = %s (true bytes / reported bytes).\n\n" % (
+            "%.3f" % rscale if rscale else "n/a (guide's 2.0 used)", "%.3f" % wscale if wscale else "n/a (1.0 used)"))
+        if algo:
+            f.write("Inflate stage per decode: read %.2f GB (raw %.2f), written %.2f GB (raw %.2f), total **%.2f GB** against "
+                    "%.2f GB algorithmic (C + U): %.2fx.\n" % (
+                        stage_f * rs / 1e9, stage_f / 1e9, stage_w * ws / 1e9, stage_w / 1e9,
+                        (stage_f * rs + stage_w * ws) / 1e9, algo / 1e9, (stage_f * rs + stage_w * ws) / algo))
+    print(open(os.path.join(PROF, "%s_pmc_traffic.md" % rnd)).read())
+    print(open(os.path.join(PROF, "%s_kernel_stats.md" % rnd)).read())
+
+
+if __name__ == "__main__":
+    main()

@@ -1,10 +1,18 @@
+# Round profile recipe (run on the GPU box through gpurun; every step under its own timeout).
+#   1. GPU parity tests, 2. the bench line, 3. rocprofv3 kernel-trace stats of the bench command,
+#   4./5. FETCH_SIZE and WRITE_SIZE in separate --pmc passes (bench + a known-byte-count calibration).
+# tools/prof_summary.py turns gpurun_out/ into the committed profiles/rNN_* summaries.
 set -x
+R=${1:-r01}
 cd /root/repo
 timeout 300 python -m pytest tests -m gpu -q 2>&1 | tail -2
-timeout 280 python bench.py --steps 10 --warmup 2 --cpu-seconds 12 > gpurun_out/bench_r01.log 2>&1; tail -1 gpurun_out/bench_r01.log
+timeout 280 python bench.py --steps 10 --warmup 2 --cpu-seconds 12 > gpurun_out/bench_$R.log 2>&1; tail -1 gpurun_out/bench_$R.log
 cd /tmp && export TMPDIR=/tmp
-timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/prof_r01 -o r01 -- python /root/repo/bench.py --steps 5 --warmup 1 --cpu-seconds 0 > /root/repo/gpurun_out/prof_r01.log 2>&1
-ls -R /root/repo/gpurun_out/prof_r01 | head
-timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /root/repo/gpurun_out/pmc_fetch -o f -- python /root/repo/bench.py --steps 3 --warmup 1 --cpu-seconds 0 > /root/repo/gpurun_out/pmc_fetch.log 2>&1
-timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /root/repo/gpurun_out/pmc_write -o w -- python /root/repo/bench.py --steps 3 --warmup 1 --cpu-seconds 0 > /root/repo/gpurun_out/pmc_write.log 2>&1
-ls /root/repo/gpurun_out/pmc_fetch /root/repo/gpurun_out/pmc_write
+O=/root/repo/gpurun_out
+rm -rf $O/prof_$R $O/pmc_fetch $O/pmc_write $O/cal_fetch $O/cal_write
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$R -o $R -- python /root/repo/bench.py --steps 5 --warmup 1 --cpu-seconds 0 > $O/prof_$R.log 2>&1
+timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python /root/repo/bench.py --steps 3 --warmup 1 --cpu-seconds 0 > $O/pmc_fetch.log 2>&1
+timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python /root/repo/bench.py --steps 3 --warmup 1 --cpu-seconds 0 > $O/pmc_write.log 2>&1
+timeout 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/cal_fetch -o f -- python /root/repo/tools/pmc_calib.py > $O/cal_fetch.log 2>&1
+timeout 120 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/cal_write -o w -- python /root/repo/tools/pmc_calib.py > $O/cal_write.log 2>&1
+find $O/prof_$R $O/pmc_fetch $O/pmc_write $O/cal_fetch $O/cal_write -type f | head -30
