@@ -94,15 +94,14 @@ def main():
             cal[k] = (cf.get(k, (0, 0))[0] * 1024, cw.get(k, (0, 0))[0] * 1024, cf.get(k, (0, 0))[1])
     except SystemExit:
         pass
-    # scale factors: true bytes / reported bytes for pure streaming kernels of known size
+    # scale factors: true bytes / reported bytes.  Reads: the 2 GiB streaming copy.  Writes: WRITE_SIZE turned
+    # out to depend on the store pattern (the 16-B/lane fill kernel reports 1/2, the blit copy 1/1), so the
+    # write side is calibrated on our own store pattern instead: inflate_resolve_kernel writes exactly U bytes
+    # (the output, 16-B stores from LDS) and nothing else.
     rscale = wscale = None
     for k, (fb, wb, n) in cal.items():
-        if "FillFunctor" in k and wb > 0.2 * cal_n:
-            wscale = cal_n / wb
-        if ("copy" in k.lower() or "Copy" in k) and fb > 0.2 * cal_n:
+        if ("copy" in k.lower()) and fb > 0.2 * cal_n:
             rscale = cal_n / fb
-            if wscale is None and wb > 0.2 * cal_n:
-                wscale = cal_n / wb
     info = bench_line["config"] if bench_line else {}
     algo = bench_line["roofline"]["algorithmic_bytes"] if bench_line else None
     kernels = {}
@@ -111,6 +110,11 @@ def main():
                       "dispatches": fetch.get(k, (0, 0))[1]}
     stage_f = sum(v["fetch_kb_raw"] for k, v in kernels.items() if any(s in k for s in STAGE)) * 1024
     stage_w = sum(v["write_kb_raw"] for k, v in kernels.items() if any(s in k for s in STAGE)) * 1024
+    if bench_line:
+        U = info["members_per_gpu"] * info["member_bytes"]
+        rw = sum(v["write_kb_raw"] for k, v in kernels.items() if "inflate_resolve_kernel" in k) * 1024
+        if rw > 0:
+            wscale = U / rw
     rs = rscale if rscale else 2.0   # guide: FETCH_SIZE reports 1/2 of wide coalesced reads on gfx950
     ws = wscale if wscale else 1.0
     js = {
@@ -125,8 +129,10 @@ def main():
         "traffic_bytes_per_launch": stage_f * rs + stage_w * ws,
         "algorithmic_bytes": algo,
         "note": "separate --pmc passes (FETCH_SIZE, WRITE_SIZE); per-dispatch means; KB x 1024; read side scaled by "
-                "read_scale and write side by write_scale, both measured on 2 GiB streaming fill/copy kernels in the same "
-                "session (tools/pmc_calib.py); MI355X_MICROARCH.md HBM section documents the 2x FETCH_SIZE under-count.",
+                "read_scale (2 GiB streaming copy, tools/pmc_calib.py; MI355X_MICROARCH.md documents the 2x "
+                "FETCH_SIZE under-count of 16-B/lane reads -- byte gathers may be counted differently, so the read figure "
+                "is an upper bound) and write side by write_scale (inflate_resolve_kernel's WRITE_SIZE against the U bytes "
+                "it is known to write).",
     }
     json.dump(js, open(os.path.join(PROF, "%s_pmc_traffic.json" % rnd), "w"), indent=1)
     with open(os.path.join(PROF, "%s_pmc_traffic.md" % rnd), "w") as f:
@@ -140,6 +146,8 @@ def main():
         f.write("\nCalibration (2 GiB = %d B per kernel):\n\n| kernel | FETCH_SIZE bytes (raw) | WRITE_SIZE bytes (raw) |\n|---|---|---|\n" % cal_n)
         for k, v in cal.items():
             f.write("| `%s` | %.0f | %.0f |\n" % (k, v[0], v[1]))
+        f.write("\nWRITE_SIZE depends on the store pattern (fill: 1/2, blit copy: 1/1), so the write scale is taken from "
+                "`inflate_resolve_kernel`, which writes exactly U bytes with 16-B stores.\n")
         f.write("\nread scale = %s, write scale = %s (true bytes / reported bytes).\n\n" % (
             "%.3f" % rscale if rscale else "n/a (guide's 2.0 used)", "%.3f" % wscale if wscale else "n/a (1.0 used)"))
         if algo:
