@@ -545,9 +545,10 @@ uint32_t ahip_adler32(const uint8_t *data, size_t len, uint32_t adler) {
   return (uint32_t)((s2 << 16) | s1);
 }
 
-int32_t ahip_bzip2_decode(const uint8_t *in, size_t in_len, int32_t verify, uint8_t *out, size_t out_cap,
-                          size_t *out_len) {
-  std::lock_guard<std::recursive_mutex> lk(g_mu);
+// bzip2 on device memory.  `in` = the first bytes of the stream on the host (header checks), d_in = the whole
+// stream on the device, d_out = device output of out_cap bytes.
+static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, int32_t verify, u8 *d_out, size_t out_cap,
+                                 size_t *out_len) {
   if (out_len) *out_len = 0;
   // BZh + level, read through the bit reader: fewer than 4 bytes is a RangeError in the reference
   if (in_len < 4) {
@@ -558,19 +559,15 @@ int32_t ahip_bzip2_decode(const uint8_t *in, size_t in_len, int32_t verify, uint
   const int level = (int)in[3] - 0x30;
   if (level < 0 || level > 9) return AHIP_FALSE;
   if (in_len == 4) return AHIP_OK;  // while (!input.isEOS) never runs
-  int32_t rc = ensure_init();
-  if (rc != AHIP_OK) return rc;
   if (level == 0) return AHIP_FALSE;  // zero-sized tt: the first symbol already fails nblock >= nblockMAX
-  static DevBuf din, dcand, dcount, dtt, dsel, dslabs, dres, dcrc, dord, doff, dlen, dout;
+  static DevBuf dcand, dcount, dtt, dsel, dres, dcrc, doff;
   hipStream_t st = nullptr;
-  HIP_TRY(din.reserve(in_len + 16));
-  HIP_TRY(hipMemcpy(din.p, in, in_len, hipMemcpyHostToDevice));
   // B0: block / end-of-stream magics at any bit offset
   const u32 cap_c = (u32)(in_len / 32 + 64);
   HIP_TRY(dcand.reserve((size_t)cap_c * sizeof(BzCand)));
   HIP_TRY(dcount.reserve(16));
   HIP_TRY(hipMemsetAsync(dcount.p, 0, 4, st));
-  hipLaunchKernelGGL(bz_scan_magic, dim3(cdiv(in_len, 256)), dim3(256), 0, st, din.as<u8>(), (u64)in_len,
+  hipLaunchKernelGGL(bz_scan_magic, dim3(cdiv(in_len, 256)), dim3(256), 0, st, d_in, (u64)in_len,
                      dcand.as<BzCand>(), dcount.as<u32>(), cap_c);
   u32 ncand = 0;
   HIP_TRY(hipMemcpy(&ncand, dcount.p, 4, hipMemcpyDeviceToHost));
@@ -584,94 +581,165 @@ int32_t ahip_bzip2_decode(const uint8_t *in, size_t in_len, int32_t verify, uint
   }
   HIP_TRY(hipMemcpy(dcand.p, cands.data(), (size_t)ncand * sizeof(BzCand), hipMemcpyHostToDevice));
   const u64 nblock_max = 100000ull * (u64)level;
-  const u64 slab_cap = nblock_max + nblock_max / 4 + 4096;
+  const u64 wstride = nblock_max / BZ_G + 2;
+  static DevBuf dpre, dwalk, drank, dspans;
   HIP_TRY(dtt.reserve((size_t)ncand * nblock_max * 4));
   HIP_TRY(dsel.reserve((size_t)ncand * BZ_MAX_SELECTORS));
-  HIP_TRY(dslabs.reserve((size_t)ncand * slab_cap));
+  HIP_TRY(dpre.reserve((size_t)ncand * nblock_max));
+  HIP_TRY(dwalk.reserve((size_t)ncand * wstride * sizeof(BzWalk)));
+  HIP_TRY(drank.reserve((size_t)ncand * wstride * 4));
+  HIP_TRY(dspans.reserve((size_t)ncand * BZ_SPANS * sizeof(BzSpan)));
   HIP_TRY(dres.reserve((size_t)ncand * sizeof(BzResult)));
   {
-    u32 table[256];
+    u32 table[256 + 64];
     for (u32 i = 0; i < 256; ++i) {
       u32 c = i << 24;
       for (int k = 0; k < 8; ++k) c = (c & 0x80000000u) ? ((c << 1) ^ 0x04c11db7u) : (c << 1);
       table[i] = c;
     }
-    HIP_TRY(dcrc.reserve(1024));
-    HIP_TRY(hipMemcpy(dcrc.p, table, 1024, hipMemcpyHostToDevice));
+    auto mulmod = [](u32 a, u32 b) {
+      u32 r = 0;
+      for (int i = 31; i >= 0; --i) { r = (r << 1) ^ ((r >> 31) ? 0x04c11db7u : 0u); if ((b >> i) & 1) r ^= a; }
+      return r;
+    };
+    u32 pw = 0x100;  // x^8
+    for (int k = 0; k < 64; ++k) { table[256 + k] = pw; pw = mulmod(pw, pw); }
+    HIP_TRY(dcrc.reserve(sizeof(table)));
+    HIP_TRY(hipMemcpy(dcrc.p, table, sizeof(table), hipMemcpyHostToDevice));
   }
-  hipLaunchKernelGGL(bz_decode_block, dim3(ncand), dim3(64), 0, st, din.as<u8>(), (u64)in_len, dcand.as<BzCand>(), ncand,
-                     (u32)level, dtt.as<u32>(), dsel.as<u8>(), dslabs.as<u8>(), slab_cap, dres.as<BzResult>());
-  hipLaunchKernelGGL(bz_tinv_scatter, dim3(ncand), dim3(64), 0, st, dtt.as<u32>(), (u32)level, dcand.as<BzCand>(),
+  const u32 wgrid = (u32)cdiv(wstride, 256);
+  hipLaunchKernelGGL(bz_decode_block, dim3(ncand), dim3(64), 0, st, d_in, (u64)in_len, dcand.as<BzCand>(), ncand,
+                     (u32)level, dtt.as<u32>(), dsel.as<u8>(), dres.as<BzResult>());
+  hipLaunchKernelGGL(bz_tinv_scatter, dim3(ncand), dim3(1024), 0, st, dtt.as<u32>(), (u32)level, dcand.as<BzCand>(),
                      dres.as<BzResult>());
+  hipLaunchKernelGGL(bz_walk<false>, dim3(wgrid, ncand), dim3(256), 0, st, dtt.as<u32>(), (u32)level, dcand.as<BzCand>(),
+                     dres.as<BzResult>(), dwalk.as<BzWalk>(), drank.as<u32>(), dpre.as<u8>());
+  hipLaunchKernelGGL(bz_rank, dim3(ncand), dim3(256), 0, st, (u32)level, dcand.as<BzCand>(), dres.as<BzResult>(),
+                     dwalk.as<BzWalk>(), drank.as<u32>());
+  hipLaunchKernelGGL(bz_walk<true>, dim3(wgrid, ncand), dim3(256), 0, st, dtt.as<u32>(), (u32)level, dcand.as<BzCand>(),
+                     dres.as<BzResult>(), dwalk.as<BzWalk>(), drank.as<u32>(), dpre.as<u8>());
+  hipLaunchKernelGGL(bz_rle_scan, dim3(ncand), dim3(1024), 0, st, (u32)level, dcand.as<BzCand>(), dres.as<BzResult>(),
+                     dpre.as<u8>(), dspans.as<BzSpan>());
+  // blocks the parallel path handed back (BZ_ST_SERIAL): the reference loop, counting only (no slab)
   hipLaunchKernelGGL(bz_unbwt, dim3(cdiv(ncand, 64)), dim3(64), 0, st, dtt.as<u32>(), (u32)level, ncand,
-                     dcand.as<BzCand>(), dslabs.as<u8>(), slab_cap, dres.as<BzResult>(), dcrc.as<u32>(),
+                     dcand.as<BzCand>(), (u8 *)nullptr, (u64)0, dres.as<BzResult>(), dcrc.as<u32>(),
                      (const u64 *)nullptr, (u8 *)nullptr);
   std::vector<BzResult> res(ncand);
   HIP_TRY(hipMemcpy(res.data(), dres.p, (size_t)ncand * sizeof(BzResult), hipMemcpyDeviceToHost));
   HIP_TRY(hipGetLastError());
-  // follow the chain of blocks exactly like decodeStream: a block ends where the next magic starts
-  std::vector<u32> order;
-  std::vector<u64> off, len;
+  // follow the chain of blocks exactly like decodeStream: a block ends where the next magic starts.
+  // Sizes are known here; block CRCs only after the expansion, so the walk is done for placement first and
+  // the verdict (first CRC mismatch stops the stream, its bytes already written) afterwards.
+  struct Placed { u32 cand; u64 off, len; };
+  std::vector<Placed> placed;
   u64 total = 0;
-  u32 combined = 0;
   int32_t verdict = AHIP_OK;
-  size_t i = 0;
-  u64 byte_pos_after = 0;  // reference InputStream position (bytes pulled into the bit reader)
-  for (;;) {
-    const BzResult &r = res[i];
-    if (cands[i].kind == 2) {  // end of stream: combined CRC, then decodeStream returns true
+  bool saw_eos = false;
+  u32 eos_stored = 0;
+  {
+    size_t i = 0;
+    for (;;) {
+      const BzResult &r = res[i];
+      if (cands[i].kind == 2) {  // end of stream: combined CRC, then decodeStream returns true
+        if (r.status == BZ_ST_RANGE) { verdict = AHIP_RANGE; break; }
+        saw_eos = true; eos_stored = r.stored_crc;
+        break;
+      }
       if (r.status == BZ_ST_RANGE) { verdict = AHIP_RANGE; break; }
-      if (verify && r.stored_crc != combined) verdict = AHIP_FALSE;
-      break;
+      if (r.status == BZ_ST_UNSUPPORTED) return fail(AHIP_E_UNSUPPORTED, "randomised bzip2 block");
+      if (r.status != BZ_ST_OK && r.status != BZ_ST_OVERFLOW) { verdict = AHIP_FALSE; break; }
+      placed.push_back({(u32)i, total, r.out_len});
+      total += r.out_len;
+      // next block type is read at r.end_bit
+      if ((r.end_bit + 7) / 8 >= in_len) break;  // while (!input.isEOS): clean end without an end-of-stream block
+      size_t j = i + 1;
+      while (j < ncand && cands[j].bit < r.end_bit) ++j;
+      if (j >= ncand || cands[j].bit != r.end_bit) {
+        // not a block magic there: _readBlockType returns -1 (or runs off the end)
+        verdict = (r.end_bit + 48 > (u64)in_len * 8) ? AHIP_RANGE : AHIP_FALSE;
+        break;
+      }
+      i = j;
     }
-    if (r.status == BZ_ST_RANGE) { verdict = AHIP_RANGE; break; }
-    if (r.status == BZ_ST_UNSUPPORTED) return fail(AHIP_E_UNSUPPORTED, "randomised bzip2 block");
-    if (r.status != BZ_ST_OK && r.status != BZ_ST_OVERFLOW) { verdict = AHIP_FALSE; break; }
-    order.push_back((u32)i); off.push_back(total); len.push_back(r.out_len);
-    total += r.out_len;
-    if (verify && r.crc != r.stored_crc) { verdict = AHIP_FALSE; break; }  // the block's bytes were already written
-    combined = ((combined << 1) | (combined >> 31)) ^ r.crc;
-    // next block type is read at r.end_bit
-    byte_pos_after = (r.end_bit + 7) / 8;
-    if (byte_pos_after >= in_len) break;  // while (!input.isEOS): clean end without an end-of-stream block
-    size_t j = i + 1;
-    while (j < ncand && cands[j].bit < r.end_bit) ++j;
-    if (j >= ncand || cands[j].bit != r.end_bit) {
-      // not a block magic there: _readBlockType returns -1 (or runs off the end)
-      verdict = (r.end_bit + 48 > (u64)in_len * 8) ? AHIP_RANGE : AHIP_FALSE;
-      break;
-    }
-    i = j;
   }
-  if (out_len) *out_len = total;
-  if (verdict == AHIP_RANGE) return AHIP_RANGE;
-  if (total > out_cap) return fail(AHIP_E_CAP, "output buffer too small");
-  if (!order.empty() && total) {
-    const u32 nb = (u32)order.size();
-    HIP_TRY(dord.reserve(nb * 4)); HIP_TRY(doff.reserve(nb * 8)); HIP_TRY(dlen.reserve(nb * 8)); HIP_TRY(dout.reserve(total));
-    HIP_TRY(hipMemcpy(dord.p, order.data(), nb * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(doff.p, off.data(), nb * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dlen.p, len.data(), nb * 8, hipMemcpyHostToDevice));
-    // blocks that outgrew their slab (long runs) are un-BWT'ed a second time straight into place
-    std::vector<u64> direct(ncand, ~0ull);
-    bool any_direct = false;
-    for (u32 k = 0; k < nb; ++k)
-      if (res[order[k]].status == BZ_ST_OVERFLOW) { direct[order[k]] = off[k]; len[k] = 0; any_direct = true; }
-    HIP_TRY(hipMemcpy(dlen.p, len.data(), nb * 8, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(bz_gather, dim3(64, nb), dim3(256), 0, st, dslabs.as<u8>(), slab_cap, dord.as<u32>(), doff.as<u64>(),
-                       dlen.as<u64>(), dout.as<u8>());
-    if (any_direct) {
+  if (verdict == AHIP_RANGE) { if (out_len) *out_len = total; return AHIP_RANGE; }
+  if (total > out_cap) { if (out_len) *out_len = total; return fail(AHIP_E_CAP, "output buffer too small"); }
+  if (!placed.empty()) {
+    std::vector<u64> par_off(ncand, ~0ull), ser_off(ncand, ~0ull);
+    bool any_serial = false;
+    for (const Placed &pl : placed) {
+      if (res[pl.cand].status == BZ_ST_OK) par_off[pl.cand] = pl.off;
+      else { ser_off[pl.cand] = pl.off; any_serial = true; }
+    }
+    HIP_TRY(doff.reserve((size_t)ncand * 8));
+    HIP_TRY(hipMemcpy(doff.p, par_off.data(), (size_t)ncand * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(bz_rle_expand, dim3(BZ_SPANS / 256, ncand), dim3(256), 0, st, (u32)level, dcand.as<BzCand>(),
+                       dres.as<BzResult>(), dpre.as<u8>(), dspans.as<BzSpan>(), doff.as<u64>(), d_out,
+                       dcrc.as<u32>());
+    if (any_serial) {
       static DevBuf ddir;
       HIP_TRY(ddir.reserve((size_t)ncand * 8));
-      HIP_TRY(hipMemcpy(ddir.p, direct.data(), (size_t)ncand * 8, hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(ddir.p, ser_off.data(), (size_t)ncand * 8, hipMemcpyHostToDevice));
       hipLaunchKernelGGL(bz_unbwt, dim3(cdiv(ncand, 64)), dim3(64), 0, st, dtt.as<u32>(), (u32)level, ncand,
-                         dcand.as<BzCand>(), dslabs.as<u8>(), slab_cap, dres.as<BzResult>(), dcrc.as<u32>(),
-                         ddir.as<u64>(), dout.as<u8>());
+                         dcand.as<BzCand>(), (u8 *)nullptr, (u64)0, dres.as<BzResult>(), dcrc.as<u32>(),
+                         ddir.as<u64>(), d_out);
     }
-    HIP_TRY(hipMemcpy(out, dout.p, total, hipMemcpyDeviceToHost));
+    std::vector<BzResult> res2(ncand);
+    HIP_TRY(hipMemcpy(res2.data(), dres.p, (size_t)ncand * sizeof(BzResult), hipMemcpyDeviceToHost));
     HIP_TRY(hipGetLastError());
+    // verdict: block CRCs in stream order, then the combined CRC
+    u32 combined = 0;
+    u64 keep = total;
+    for (const Placed &pl : placed) {
+      const u32 crc = res[pl.cand].status == BZ_ST_OK ? (res2[pl.cand].crc ^ 0xffffffffu) : res[pl.cand].crc;
+      if (verify && crc != res[pl.cand].stored_crc) {  // the block's bytes were already written
+        verdict = AHIP_FALSE; keep = pl.off + pl.len; saw_eos = false;
+        break;
+      }
+      combined = ((combined << 1) | (combined >> 31)) ^ crc;
+    }
+    if (saw_eos && verify && eos_stored != combined && verdict == AHIP_OK) verdict = AHIP_FALSE;
+    total = keep;
+    HIP_TRY(hipStreamSynchronize(st));
+  } else if (saw_eos && verify && eos_stored != 0) {
+    verdict = AHIP_FALSE;
   }
+  if (out_len) *out_len = total;
   return verdict;
+}
+
+int32_t ahip_bzip2_decode_device(const void *d_in, size_t in_len, int32_t verify, void *d_out, size_t out_cap,
+                                 size_t *out_len, void *stream) {
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  (void)stream;  // the bzip2 path reads verdicts back between phases: it runs on the default stream
+  if (out_len) *out_len = 0;
+  u8 hdr[4] = {0, 0, 0, 0};
+  if (in_len >= 4 || in_len > 0) {
+    int32_t rc = ensure_init();
+    if (rc != AHIP_OK) return rc;
+    HIP_TRY(hipMemcpy(hdr, d_in, in_len < 4 ? in_len : 4, hipMemcpyDeviceToHost));
+  }
+  return bzip2_device_impl(hdr, (const u8 *)d_in, in_len, verify, (u8 *)d_out, out_cap, out_len);
+}
+
+int32_t ahip_bzip2_decode(const uint8_t *in, size_t in_len, int32_t verify, uint8_t *out, size_t out_cap,
+                          size_t *out_len) {
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  if (out_len) *out_len = 0;
+  static DevBuf din, dout;
+  // the header-only outcomes need no device
+  if (in_len <= 4 || in[0] != 'B' || in[1] != 'Z' || in[2] != 'h' || in[3] < '1' || in[3] > '9')
+    return bzip2_device_impl(in, nullptr, in_len, verify, nullptr, 0, out_len);
+  int32_t rc = ensure_init();
+  if (rc != AHIP_OK) return rc;
+  HIP_TRY(din.reserve(in_len + 16));
+  HIP_TRY(hipMemcpy(din.p, in, in_len, hipMemcpyHostToDevice));
+  HIP_TRY(dout.reserve(out_cap + 16));
+  size_t n = 0;
+  rc = bzip2_device_impl(in, din.as<u8>(), in_len, verify, dout.as<u8>(), out_cap, &n);
+  if (out_len) *out_len = n;
+  if ((rc == AHIP_OK || rc == AHIP_FALSE) && n && n <= out_cap) HIP_TRY(hipMemcpy(out, dout.p, n, hipMemcpyDeviceToHost));
+  return rc;
 }
 
 size_t ahip_deflate_bound(size_t in_len) {

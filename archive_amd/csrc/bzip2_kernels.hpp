@@ -9,13 +9,24 @@
 //        phase 1  header, selectors, code lengths, limit/base/perm tables (:114-246, :774-813) and the
 //                 Huffman + MTF + RUNA/RUNB loop into tt[] (:267-388) -- serial by nature, executed
 //                 wave-uniformly with tables in LDS;
-//        phase 2  T^-1 (:406-439) as a 64-lane counting sort: every lane histograms its 1/64 of tt[],
-//                 a per-symbol scan across lanes gives each lane its write cursors, then lanes scatter
-//                 -- same result as the reference's stable serial loop;
-//        phase 3  inverse-BWT pointer chase + run-length undo + MSB-first CRC-32 (:610-727) into the
-//                 block's output slab (serial: every step depends on the previous load).
-//   The host then follows the chain of blocks (a block's end bit must be the next block's magic),
-//   verifies CRCs when asked, and a gather kernel packs the slabs into the caller's buffer.
+//        phase 2  T^-1 (:406-439) as a stable counting sort over 16 waves (bz_tinv_scatter) -- same
+//                 result as the reference's serial loop;
+//        phase 3  inverse BWT (:610-727).  The pointer chase tt[t] -> t is one cycle through the block;
+//                 walked serially every step waits for the previous load (~1 us x 900 000).  Instead
+//                 it is list-ranked: every 128th index (and the chain head) is a splitter; one thread
+//                 per splitter walks to the next splitter counting steps (bz_walk<false>), one thread
+//                 orders the <= 7 033 splitters in LDS (bz_rank), and the splitter threads walk again
+//                 writing their bytes at their rank (bz_walk<true>) -- ~500 dependent loads per
+//                 thread instead of 900 000.
+//        phase 4  run-length undo + MSB-first CRC-32 as a scan: 1 024 spans per block, each span's
+//                 effect on the 5 possible entry states of the "4 equal bytes, then a count" machine
+//                 (bz_rle_scan), composed in order; then every span expands at its own offset and the
+//                 block CRC is assembled from per-span remainders times x^(8*suffix) in GF(2)
+//                 (bz_rle_expand).
+//   The host follows the chain of blocks (a block's end bit must be the next block's magic) between
+//   phases 4a and 4b to place blocks, and verifies CRCs when asked.  Blocks the parallel path cannot
+//   represent exactly (pointer cycle shorter than the block, data ending inside a run-length escape:
+//   corrupt input only) go through the serial bz_unbwt, which restates the reference loop 1:1.
 // The obsolete randomised-block mode is not implemented (BZ_ST_UNSUPPORTED).
 #pragma once
 #include "common.hpp"
@@ -23,14 +34,16 @@
 namespace ahip {
 
 constexpr u32 BZ_MAX_SELECTORS = 18002;
-constexpr u32 BZ_ST_OK = 0, BZ_ST_FALSE = 1, BZ_ST_RANGE = 2, BZ_ST_OVERFLOW = 16, BZ_ST_UNSUPPORTED = 17;
+constexpr u32 BZ_ST_OK = 0, BZ_ST_FALSE = 1, BZ_ST_RANGE = 2, BZ_ST_OVERFLOW = 16, BZ_ST_UNSUPPORTED = 17, BZ_ST_SERIAL = 18;
+constexpr u32 BZ_G = 128;      // splitter stride of the list ranking
+constexpr u32 BZ_SPANS = 1024;  // run-length spans per block
 
 struct BzCand { u64 bit; u32 kind; u32 pad; };  // kind 0 = compressed block, 2 = end of stream
 struct BzResult {
   u64 end_bit;   // bit position just after the block
   u64 out_len;
   u32 status, crc, stored_crc, nblock;
-  u32 pad_orig_ptr, pad;  // origPtr kept for the second (direct) un-BWT pass of oversized blocks
+  u32 pad_orig_ptr, pad;  // origPtr (phases 2-4 need it)
 };
 
 // ---- B0: magic scan ----
@@ -91,19 +104,72 @@ AHIP_DEVINL u32 bz_bits(BzBits &b, u32 nb) {  // nb <= 24
   return v;
 }
 
+constexpr u32 BZ_FAST_BITS = 10;
 struct BzLds {
   i32 limit[6][24], base[6][24];
   u16 perm[6][258];
   u8 len[6][258];
   i32 min_len[6];
-  u8 mtf[256], seq2unseq[256];
-  u32 unzftab[256];
+  u8 seq2unseq[256];
+  // fast[t][p]: what the reference's limit/base/perm loop does with the 10-bit pattern p, precomputed:
+  // symbol << 5 | length; 0 = no code of <= 10 bits matches (or an invalid index): take the exact loop
+  u16 fast[6][1u << BZ_FAST_BITS];
 };
+
+// Wave-uniform bit reader for the symbol loop: the stream is fetched 64 dwords at a time (one per lane,
+// coalesced, the next batch already in flight), words are pulled out with v_readlane, and the bit buffer
+// itself lives in scalar registers -- no memory latency on the decode path.
+struct BzFast {
+  const u8 *in; u64 n;   // bytes
+  u64 nbits, bit;        // stream length in bits, next unread bit
+  u64 base;              // dword index held by lane 0 of `cur`
+  u32 cur, nxt;          // this lane's dword (big-endian value) of the current / next batch
+  u32 wi;                // next dword of `cur` to pull
+  u64 buf; u32 cnt;      // unread bits, MSB first
+  bool fault;
+};
+AHIP_DEVINL u32 bzf_word(const BzFast &f, u64 idx) {
+  const u64 off = idx * 4;
+  if (off + 4 <= f.n) return __builtin_bswap32(*(const u32 *)(f.in + off));  // `in` is device-allocated: aligned
+  u32 w = 0;
+  for (int k = 0; k < 4; ++k) w = (w << 8) | (off + k < f.n ? f.in[off + k] : 0u);
+  return w;
+}
+AHIP_DEVINL void bzf_refill(BzFast &f, int lane) {  // afterwards cnt >= 33
+  if (f.cnt > 32) return;
+  const u32 w = lane_bcast(f.cur, (int)uniform(f.wi));
+  f.buf |= (u64)w << (32 - f.cnt);
+  f.cnt += 32;
+  if (++f.wi == 64) {
+    f.cur = f.nxt;
+    f.base += 64;
+    f.nxt = bzf_word(f, f.base + 64 + lane);
+    f.wi = 0;
+  }
+}
+AHIP_DEVINL void bzf_init(BzFast &f, const u8 *in, u64 n, u64 bit, int lane) {
+  f.in = in; f.n = n; f.nbits = n * 8; f.bit = bit; f.fault = false;
+  f.base = bit >> 5;
+  f.cur = bzf_word(f, f.base + lane);
+  f.nxt = bzf_word(f, f.base + 64 + lane);
+  f.wi = 0; f.buf = 0; f.cnt = 0;
+  bzf_refill(f, lane);
+  const u32 skip = (u32)bit & 31;
+  f.buf <<= skip; f.cnt -= skip;
+}
+AHIP_DEVINL u32 bzf_bits(BzFast &f, u32 nb, int lane) {  // nb <= 24; the reference's readBits
+  if (nb == 0) return 0;
+  if (f.bit + nb > f.nbits) { f.fault = true; f.bit += nb; return 0; }
+  bzf_refill(f, lane);
+  const u32 v = (u32)(f.buf >> (64 - nb));
+  f.buf <<= nb; f.cnt -= nb; f.bit += nb;
+  return v;
+}
 
 // one wave per candidate block
 __global__ __launch_bounds__(64) void bz_decode_block(const u8 *__restrict__ in, u64 n, const BzCand *__restrict__ cands,
                                                       u32 ncand, u32 block_size100k, u32 *__restrict__ tt_all,
-                                                      u8 *__restrict__ sel_all, u8 *__restrict__ slabs, u64 slab_cap,
+                                                      u8 *__restrict__ sel_all,
                                                       BzResult *__restrict__ results) {
   __shared__ BzLds L;
   const u32 blk = blockIdx.x, lane = threadIdx.x;
@@ -111,7 +177,6 @@ __global__ __launch_bounds__(64) void bz_decode_block(const u8 *__restrict__ in,
   const u32 nblock_max = 100000u * block_size100k;
   u32 *tt = tt_all + (u64)blk * nblock_max;
   u8 *sel = sel_all + (u64)blk * BZ_MAX_SELECTORS;
-  u8 *slab = slabs + (u64)blk * slab_cap;
   BzResult R{0, 0, BZ_ST_OK, 0, 0, 0, 0, 0};
   BzBits b{in, n, 0, false, 0, 0, 0};
   bz_seek(b, cands[blk].bit + 48);
@@ -209,9 +274,32 @@ __global__ __launch_bounds__(64) void bz_decode_block(const u8 *__restrict__ in,
         L.min_len[t] = minl;
       }
     }
-    for (u32 i = lane; i < 256; i += 64) { L.mtf[i] = (u8)i; L.unzftab[i] = 0; }
     wave_sync();
-    // MTF / RUNA / RUNB loop
+    // fast tables: run the reference's decode loop on every 10-bit pattern once
+    for (u32 t = 0; t < ngroups; ++t) {
+      const i32 minl = L.min_len[t];
+      for (u32 pat = lane; pat < (1u << BZ_FAST_BITS); pat += 64) {
+        u32 e = 0;
+        for (i32 zn = minl; zn <= (i32)BZ_FAST_BITS; ++zn) {
+          const i32 zvec = (i32)(pat >> (BZ_FAST_BITS - zn));
+          if (zvec <= L.limit[t][zn]) {
+            const i32 idx = zvec - L.base[t][zn];
+            if (idx >= 0 && idx < 258) e = ((u32)L.perm[t][idx] << 5) | (u32)zn;
+            break;  // an index out of range is the reference's error: the exact loop reports it
+          }
+        }
+        L.fast[t][pat] = (u16)e;
+      }
+    }
+    wave_sync();
+    // MTF list and seqToUnseq in registers: lane l holds entries 4l .. 4l+3 (byte j = entry 4l + j)
+    u32 mtf = (4u * lane) | ((4u * lane + 1) << 8) | ((4u * lane + 2) << 16) | ((4u * lane + 3) << 24);
+    const u32 s2u = L.seq2unseq[4 * lane] | ((u32)L.seq2unseq[4 * lane + 1] << 8) | ((u32)L.seq2unseq[4 * lane + 2] << 16) |
+                    ((u32)L.seq2unseq[4 * lane + 3] << 24);
+    BzFast f;
+    bzf_init(f, in, n, b.bit, lane);
+    // selectors: 64 at a time, one per lane
+    u32 selv = sel[lane < nsel ? lane : 0];
     const u32 eob = num_in_use + 1;
     i32 group_no = -1;
     u32 group_pos = 0, gsel = 0;
@@ -221,25 +309,41 @@ __global__ __launch_bounds__(64) void bz_decode_block(const u8 *__restrict__ in,
         group_no++;
         if (group_no >= (i32)nsel) return -1;
         group_pos = 50;
-        gsel = sel[group_no];
-        gmin = L.min_len[gsel];
+        if (group_no && (group_no & 63) == 0) selv = sel[(u32)group_no + lane < nsel ? (u32)group_no + lane : 0];
+        gsel = lane_bcast(selv, group_no & 63);
+        gmin = (i32)uniform((u32)L.min_len[gsel]);
       }
       group_pos--;
+      bzf_refill(f, lane);
+      const u32 e = uniform(L.fast[gsel][(u32)(f.buf >> (64 - BZ_FAST_BITS))]);
+      const u32 el = e & 31;
+      if (e != 0 && f.bit + el <= f.nbits) {
+        f.buf <<= el; f.cnt -= el; f.bit += el;
+        return (i32)(e >> 5);
+      }
+      // the reference loop, bit by bit (long codes, invalid indices, end of input)
       i32 zn = gmin;
-      i32 zvec = (i32)bz_bits(b, (u32)zn);
+      i32 zvec = (i32)bzf_bits(f, (u32)zn, lane);
       for (;;) {
         if (zn > 20) return -1;
-        if (zvec <= L.limit[gsel][zn]) break;
+        if (zvec <= (i32)uniform((u32)L.limit[gsel][zn])) break;
         zn++;
-        zvec = (zvec << 1) | (i32)bz_bits(b, 1);
+        zvec = (zvec << 1) | (i32)bzf_bits(f, 1, lane);
       }
-      const i32 idx = zvec - L.base[gsel][zn];
+      const i32 idx = zvec - (i32)uniform((u32)L.base[gsel][zn]);
       if (idx < 0 || idx >= 258) return -1;
-      return (i32)L.perm[gsel][idx];
+      return (i32)uniform(L.perm[gsel][idx]);
+    };
+    // tt[] stores are gathered 64 at a time (lane k keeps the symbol for index 64j + k)
+    u32 pend = 0, pend_lo = 0;
+    auto flush_partial = [&]() {
+      const u32 idx = (nblock & ~63u) + lane;
+      if (idx >= pend_lo && idx < nblock) tt[idx] = pend;
+      pend_lo = nblock;
     };
     i32 next_sym = get_mtf_val();
     bool bad = next_sym < 0;
-    while (!bad && !b.fault && (u32)next_sym != eob) {
+    while (!bad && !f.fault && (u32)next_sym != eob) {
       if (next_sym == 0 || next_sym == 1) {
         i32 es = -1, N = 1;
         do {
@@ -250,91 +354,112 @@ __global__ __launch_bounds__(64) void bz_decode_block(const u8 *__restrict__ in,
         } while (next_sym == 0 || next_sym == 1);
         if (bad) break;
         es++;
-        const u32 uc = L.seq2unseq[L.mtf[0]];
+        const u32 front = lane_bcast(mtf, 0) & 0xff;
+        const u32 ucv = (lane_bcast(s2u, (int)(front >> 2)) >> (8 * (front & 3))) & 0xff;
         if (nblock + (u32)es > nblock_max) { bad = true; break; }
-        if (lane == 0) L.unzftab[uc] += (u32)es;
-        for (u32 k = lane; k < (u32)es; k += 64) tt[nblock + k] = uc;
+        flush_partial();
+        for (u32 k = lane; k < (u32)es; k += 64) tt[nblock + k] = ucv;
         nblock += (u32)es;
+        pend_lo = nblock;
         if (next_sym < 0) { bad = true; break; }
         continue;
       }
       if (nblock >= nblock_max) { bad = true; break; }
       const u32 nn = (u32)next_sym - 1;
-      const u32 v = L.mtf[nn];
-      wave_sync();
-      // move to front: lanes shift the first nn entries up by one, highest 64-entry piece first
-      for (i32 k0 = (i32)((nn ? nn - 1 : 0) & ~63u); k0 >= 0 && nn; k0 -= 64) {
-        const u32 k = (u32)k0 + lane;
-        const u8 x = k < nn ? L.mtf[k] : 0;
-        wave_sync();
-        if (k < nn) L.mtf[k + 1] = x;
-        wave_sync();
-      }
-      if (lane == 0) {
-        L.mtf[0] = (u8)v;
-        const u32 uc = L.seq2unseq[v];
-        L.unzftab[uc]++;
-        tt[nblock] = uc;
-      }
-      wave_sync();
+      next_sym = get_mtf_val();  // independent of the list update below: its table read overlaps it
+      // move to front, in registers
+      const u32 q = nn >> 2, r = nn & 3;
+      const u32 v = (lane_bcast(mtf, (int)q) >> (8 * r)) & 0xff;
+      const u32 up = lane_prev(mtf) >> 24;
+      const u32 shifted = (mtf << 8) | (lane == 0 ? v : up);
+      const u32 mask = r == 3 ? 0xffffffffu : ((1u << (8 * (r + 1))) - 1);
+      if ((u32)lane < q) mtf = shifted;
+      else if ((u32)lane == q) mtf = (shifted & mask) | (mtf & ~mask);
+      const u32 ucv = (lane_bcast(s2u, (int)(v >> 2)) >> (8 * (v & 3))) & 0xff;
+      if ((u32)lane == (nblock & 63)) pend = ucv;
       nblock++;
-      next_sym = get_mtf_val();
+      if ((nblock & 63) == 0) {
+        const u32 idx = nblock - 64 + lane;
+        if (idx >= pend_lo) tt[idx] = pend;
+        pend_lo = nblock;
+      }
       if (next_sym < 0) bad = true;
     }
+    flush_partial();
+    b.bit = f.bit;
+    b.fault = f.fault;
     if (b.fault) { status = BZ_ST_RANGE; break; }
     if (bad) { status = BZ_ST_FALSE; break; }
     if (orig_ptr >= nblock) { status = BZ_ST_FALSE; break; }
   } while (0);
 
-  // phases 2 and 3 are separate launches (bz_tinv_scatter needs a 64 x 256 x u32 cursor table in LDS)
+  // phases 2-4 are separate launches
   R.status = status;
   R.nblock = nblock;
   R.end_bit = b.bit;
-  R.crc = orig_ptr;  // carried to the next kernels
+  R.crc = 0;
+  R.pad_orig_ptr = orig_ptr;
   if (lane == 0) results[blk] = R;
 }
 
 // ---- phase 2 (own launch): T^-1 ----
-// tt[i] holds the block's bytes (low 8 bits).  Result: tt[j] |= i << 8 for the j-th smallest (byte, i).
-__global__ __launch_bounds__(64) void bz_tinv_scatter(u32 *__restrict__ tt_all, u32 block_size100k,
-                                                      const BzCand *__restrict__ cands, BzResult *__restrict__ results) {
-  __shared__ u32 cur[64 * 256];  // 64 KiB: cursor of (lane, symbol)
-  const u32 blk = blockIdx.x, lane = threadIdx.x;
+// tt[i] holds the block's bytes (low 8 bits).  Result: tt[j] |= i << 8 for the j-th smallest (byte, i) --
+// a stable counting sort, i.e. the reference's serial loop (:406-439).  16 waves per block, each owning a
+// contiguous sixteenth: per-wave histograms, a (symbol, wave) exclusive scan, then 64 elements per step:
+// eight ballots give every lane the set of lanes holding the same byte, so its rank inside the step is a
+// popcount and only the first lane of each byte value bumps the wave's cursor.
+__global__ __launch_bounds__(1024) void bz_tinv_scatter(u32 *__restrict__ tt_all, u32 block_size100k,
+                                                        const BzCand *__restrict__ cands, BzResult *__restrict__ results) {
+  __shared__ u32 cur[16][256];
+  __shared__ u32 tot[256];
+  const u32 blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (cands[blk].kind != 0 || results[blk].status != BZ_ST_OK) return;
   const u32 nblock = results[blk].nblock;
   u32 *tt = tt_all + (u64)blk * (100000u * block_size100k);
-  for (u32 i = lane; i < 64 * 256; i += 64) cur[i] = 0;
-  wave_sync();
-  const u32 seg = (nblock + 63) / 64;
-  const u32 lo = lane * seg < nblock ? lane * seg : nblock;
+  for (u32 i = tid; i < 16 * 256; i += 1024) (&cur[0][0])[i] = 0;
+  __syncthreads();
+  const u32 seg = (((nblock + 15) / 16) + 63) & ~63u;
+  const u32 lo = w * seg < nblock ? w * seg : nblock;
   const u32 hi = lo + seg < nblock ? lo + seg : nblock;
-  for (u32 i = lo; i < hi; ++i) cur[lane * 256 + (tt[i] & 0xff)]++;
-  wave_sync();
-  // symbol-major exclusive scan: position of the first (sym, lane) element in sorted order
-  u32 sym_total[4];
-  for (u32 g = 0; g < 4; ++g) {  // lane handles symbol g*64 + lane: sum over lanes l
-    const u32 s = g * 64 + lane;
+  for (u32 i = lo + lane; i < hi; i += 64) atomicAdd(&cur[w][tt[i] & 0xff], 1u);
+  __syncthreads();
+  if (tid < 256) {
     u32 acc = 0;
-    for (u32 l = 0; l < 64; ++l) { const u32 c = cur[l * 256 + s]; cur[l * 256 + s] = acc; acc += c; }
-    sym_total[g] = acc;
+    for (u32 k = 0; k < 16; ++k) { const u32 c = cur[k][tid]; cur[k][tid] = acc; acc += c; }
+    tot[tid] = acc;
   }
-  wave_sync();
-  // exclusive scan of symbol totals over all 256 symbols (cftab)
-  u32 run = 0;
-  for (u32 g = 0; g < 4; ++g) {
-    u32 tot;
-    const u32 ex = wave_excl_sum(sym_total[g], tot);
-    const u32 basep = run + ex;
-    const u32 s = g * 64 + lane;
-    for (u32 l = 0; l < 64; ++l) cur[l * 256 + s] += basep;
-    run += tot;
+  __syncthreads();
+  if (tid < 64) {  // cftab: exclusive scan of the 256 symbol totals, 4 per lane
+    u32 t0 = tot[4 * tid], t1 = tot[4 * tid + 1], t2 = tot[4 * tid + 2], t3 = tot[4 * tid + 3];
+    u32 total;
+    const u32 ex = wave_excl_sum(t0 + t1 + t2 + t3, total);
+    tot[4 * tid] = ex; tot[4 * tid + 1] = ex + t0; tot[4 * tid + 2] = ex + t0 + t1; tot[4 * tid + 3] = ex + t0 + t1 + t2;
   }
-  wave_sync();
-  // scatter: stable within a lane's segment, lanes ordered by segment -> identical to the serial loop
-  for (u32 i = lo; i < hi; ++i) {
-    const u32 s = tt[i] & 0xff;
-    const u32 pos = cur[lane * 256 + s]++;
-    atomicOr(&tt[pos], i << 8);  // pos may lie in another lane's segment that is still being read (low byte untouched)
+  __syncthreads();
+  if (tid < 256) {
+    const u32 basep = tot[tid];
+    for (u32 k = 0; k < 16; ++k) cur[k][tid] += basep;
+  }
+  __syncthreads();
+  const u64 below = (1ull << lane) - 1;
+  for (u32 i0 = lo; i0 < hi; i0 += 64) {
+    const u32 i = i0 + lane;
+    const bool act = i < hi;
+    const u32 sym = act ? (tt[i] & 0xff) : 0u;
+    u64 same = __ballot(act);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const u64 bal = __ballot((sym >> k) & 1);
+      same &= ((sym >> k) & 1) ? bal : ~bal;
+    }
+    const u32 rank = (u32)__popcll(same & below);
+    u32 pos = 0;
+    if (act) pos = cur[w][sym] + rank;
+    wave_sync();  // every lane has read its cursor before the leaders move them
+    if (act && rank == 0) cur[w][sym] += (u32)__popcll(same);
+    wave_sync();
+    // pos may lie in a part of tt[] another wave has not read yet: only the upper 24 bits are touched
+    if (act) atomicOr(&tt[pos], i << 8);
   }
 }
 
@@ -350,12 +475,12 @@ __global__ __launch_bounds__(64) void bz_unbwt(const u32 *__restrict__ tt_all, u
   if (blk >= ncand) return;
   if (cands[blk].kind != 0) return;
   if (direct_off) { if (direct_off[blk] == ~0ull) return; }
-  else if (results[blk].status != BZ_ST_OK) return;
+  else if (results[blk].status != BZ_ST_SERIAL) return;
   const u32 nblock_max = 100000u * block_size100k;
   const u32 *tt = tt_all + (u64)blk * nblock_max;
   u8 *out = direct_off ? direct_out + direct_off[blk] : slabs + (u64)blk * slab_cap;
   if (direct_off) slab_cap = ~0ull;
-  const u32 nblock = results[blk].nblock, orig_ptr = direct_off ? results[blk].pad_orig_ptr : results[blk].crc;
+  const u32 nblock = results[blk].nblock, orig_ptr = results[blk].pad_orig_ptr;
   u32 crc = 0xffffffffu;
   u64 olen = 0;
   u32 status = BZ_ST_OK;
@@ -409,16 +534,223 @@ fin:
   results[blk].status = status;
   results[blk].out_len = olen;
   results[blk].crc = crc ^ 0xffffffffu;
-  if (status == BZ_ST_OVERFLOW) results[blk].pad_orig_ptr = orig_ptr;
 }
 
-__global__ __launch_bounds__(256) void bz_gather(const u8 *__restrict__ slabs, u64 slab_cap, const u32 *__restrict__ order,
-                                                 const u64 *__restrict__ off, const u64 *__restrict__ len, u8 *__restrict__ out) {
-  const u32 k = blockIdx.y;
-  const u8 *src = slabs + (u64)order[k] * slab_cap;
-  u8 *dst = out + off[k];
-  const u64 n = len[k];
-  for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) dst[i] = src[i];
+// ---- phase 3 (parallel): list-ranked inverse BWT ----
+// Splitter s < S sits at index s * BZ_G; splitter S is the chain head p0 = tt[origPtr] >> 8.
+struct BzWalk { u32 next, len; };
+AHIP_DEVINL u32 bz_nsplit(u32 nblock) { return (nblock + BZ_G - 1) / BZ_G; }
+
+template <bool WRITE>
+__global__ __launch_bounds__(256) void bz_walk(const u32 *__restrict__ tt_all, u32 block_size100k,
+                                               const BzCand *__restrict__ cands, const BzResult *__restrict__ results,
+                                               BzWalk *__restrict__ walk_all, const u32 *__restrict__ rank_all,
+                                               u8 *__restrict__ pre_all) {
+  const u32 blk = blockIdx.y;
+  if (cands[blk].kind != 0 || results[blk].status != BZ_ST_OK) return;
+  const u32 nblock = results[blk].nblock;
+  const u32 nblock_max = 100000u * block_size100k;
+  const u32 S = bz_nsplit(nblock), stride = nblock_max / BZ_G + 2;
+  const u32 s = blockIdx.x * 256 + threadIdx.x;
+  if (s > S || nblock == 0) return;
+  const u32 *tt = tt_all + (u64)blk * nblock_max;
+  const u32 p0 = tt[results[blk].pad_orig_ptr] >> 8;
+  u32 cur = s == S ? p0 : s * BZ_G;
+  u32 k = 0;
+  if (WRITE) {
+    k = rank_all[(u64)blk * stride + s];
+    if (k == ~0u) return;  // not on the head's cycle (duplicate of the head, or corrupt data)
+  }
+  u8 *pre = pre_all + (u64)blk * nblock_max;
+  u32 len = 0;
+  do {
+    const u32 w = tt[cur];
+    if (WRITE) pre[k + len] = (u8)w;
+    cur = w >> 8;
+    ++len;
+  } while ((cur & (BZ_G - 1)) != 0 && cur != p0 && len < nblock);
+  if (!WRITE) {
+    BzWalk r;
+    r.next = cur == p0 ? S : cur / BZ_G;
+    r.len = len;
+    walk_all[(u64)blk * stride + s] = r;
+  }
+}
+
+// one workgroup per block: order the splitters along the cycle, starting at the head
+__global__ __launch_bounds__(256) void bz_rank(u32 block_size100k, const BzCand *__restrict__ cands,
+                                               BzResult *__restrict__ results, const BzWalk *__restrict__ walk_all,
+                                               u32 *__restrict__ rank_all) {
+  constexpr u32 S_MAX = 900000 / BZ_G + 2;
+  __shared__ u16 nxt[S_MAX];
+  __shared__ u32 ln[S_MAX];  // sublist length; overwritten by 0x80000000 | rank once the splitter is placed
+  const u32 blk = blockIdx.x;
+  if (cands[blk].kind != 0 || results[blk].status != BZ_ST_OK) return;
+  const u32 nblock = results[blk].nblock;
+  if (nblock == 0) return;
+  const u32 nblock_max = 100000u * block_size100k;
+  const u32 S = bz_nsplit(nblock), stride = nblock_max / BZ_G + 2;
+  const BzWalk *walk = walk_all + (u64)blk * stride;
+  for (u32 i = threadIdx.x; i <= S; i += 256) { nxt[i] = (u16)walk[i].next; ln[i] = walk[i].len & 0x7fffffffu; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 s = S, pos = 0, hops = 0;
+    do {
+      const u32 l = ln[s];
+      if (l & 0x80000000u) break;  // already placed: not a simple cycle through the head
+      ln[s] = 0x80000000u | pos;
+      pos += l;
+      s = nxt[s];
+    } while (s != S && ++hops <= S && pos < nblock);
+    // a valid block is ONE cycle of length nblock; anything else takes the serial path
+    if (s != S || pos != nblock) results[blk].status = BZ_ST_SERIAL;
+  }
+  __syncthreads();
+  for (u32 i = threadIdx.x; i <= S; i += 256) {
+    const u32 v = ln[i];
+    rank_all[(u64)blk * stride + i] = (v & 0x80000000u) ? (v & 0x7fffffffu) : ~0u;
+  }
+}
+
+// ---- phase 4: run-length undo as a scan ----
+// Machine (bzip2_decoder.dart:640-727): a byte is output as it comes; after 4 equal bytes in a row the
+// next byte is a repeat count (that many more copies), and the run detector starts afresh.
+// State: prev byte + cnt (0 fresh, 1..3 equal bytes so far, 4 = next byte is a count).
+struct RleState { u32 prev, cnt; };
+AHIP_DEVINL u32 rle_class(const RleState &s, u32 x0) {  // what a span starting with byte x0 sees
+  if (s.cnt == 4) return 4;
+  return (s.cnt > 0 && s.prev == x0) ? s.cnt : 0u;
+}
+AHIP_DEVINL RleState rle_entry(u32 cls, u32 x0, u32 prev_if_count) {
+  RleState s;
+  s.cnt = cls;
+  s.prev = cls == 4 ? prev_if_count : x0;
+  if (cls == 0) s.prev = 0x100;  // fresh: matches no byte
+  return s;
+}
+// advance by one input byte; returns the number of bytes it puts out (the byte value is s.prev afterwards,
+// except for a count, where it is the run byte)
+AHIP_DEVINL u32 rle_step(RleState &s, u32 x) {
+  if (s.cnt == 4) { s.cnt = 0; return x; }  // prev stays the run byte for the caller; state is fresh
+  if (s.cnt > 0 && x == s.prev) { s.cnt += 1; return 1; }
+  s.prev = x; s.cnt = 1;
+  return 1;
+}
+
+struct BzSpan { u32 prev, cnt; u64 off; };  // entry state and output offset of a span
+
+__global__ __launch_bounds__(1024) void bz_rle_scan(u32 block_size100k, const BzCand *__restrict__ cands,
+                                                    BzResult *__restrict__ results, const u8 *__restrict__ pre_all,
+                                                    BzSpan *__restrict__ spans_all) {
+  __shared__ u32 t_state[BZ_SPANS][5];  // packed prev << 8 | cnt
+  __shared__ u32 t_len[BZ_SPANS][5];
+  __shared__ u16 x0s[BZ_SPANS];
+  const u32 blk = blockIdx.x, t = threadIdx.x;
+  if (cands[blk].kind != 0 || results[blk].status != BZ_ST_OK) return;
+  const u32 nblock = results[blk].nblock;
+  const u32 nblock_max = 100000u * block_size100k;
+  const u8 *pre = pre_all + (u64)blk * nblock_max;
+  const u32 sp = (nblock + BZ_SPANS - 1) / BZ_SPANS;
+  const u32 lo = t * sp < nblock ? t * sp : nblock, hi = lo + sp < nblock ? lo + sp : nblock;
+  const u32 x0 = lo < hi ? pre[lo] : 0x100u;
+  x0s[t] = (u16)x0;
+  // the run byte of an entering "count" state is unknown here; it only matters for the output bytes, not for
+  // lengths or exit states (after a count the machine is fresh), so 0 stands in
+  RleState st[5];
+  u32 len[5];
+#pragma unroll
+  for (u32 c = 0; c < 5; ++c) { st[c] = rle_entry(c, x0, 0); len[c] = 0; }
+  for (u32 i = lo; i < hi; ++i) {
+    const u32 x = pre[i];
+#pragma unroll
+    for (u32 c = 0; c < 5; ++c) len[c] += rle_step(st[c], x);
+  }
+#pragma unroll
+  for (u32 c = 0; c < 5; ++c) {
+    t_state[t][c] = (st[c].prev << 8) | st[c].cnt;
+    t_len[t][c] = len[c];
+  }
+  __syncthreads();
+  __shared__ u32 e_prev[BZ_SPANS], e_cnt[BZ_SPANS];
+  __shared__ u64 e_off[BZ_SPANS];
+  if (t == 0) {
+    RleState s{0x100, 0};
+    u64 off = 0;
+    for (u32 k = 0; k < BZ_SPANS; ++k) {
+      e_prev[k] = s.prev; e_cnt[k] = s.cnt; e_off[k] = off;
+      const u32 x = x0s[k];
+      if (x == 0x100u) continue;  // empty span
+      const u32 c = rle_class(s, x);
+      const u32 ps = t_state[k][c];
+      off += t_len[k][c];
+      // a span entered in "count" state consumes its first byte as the count and is fresh right after, so
+      // its recorded exit state does not depend on the (here unknown) run byte
+      s.prev = ps >> 8; s.cnt = ps & 0xff;
+    }
+    results[blk].out_len = off;
+    if (s.cnt == 4) results[blk].status = BZ_ST_SERIAL;  // data ends inside an escape: the reference reads on (serial path)
+  }
+  __syncthreads();
+  BzSpan o;
+  o.prev = e_prev[t]; o.cnt = e_cnt[t]; o.off = e_off[t];
+  spans_all[(u64)blk * BZ_SPANS + t] = o;
+}
+
+// GF(2) helpers for the MSB-first CRC-32 (polynomial 0x04c11db7)
+AHIP_DEVINL u32 gf_mulmod(u32 a, u32 b) {
+  u32 r = 0;
+  for (int i = 31; i >= 0; --i) {
+    r = (r << 1) ^ ((r >> 31) ? 0x04c11db7u : 0u);
+    if ((b >> i) & 1) r ^= a;
+  }
+  return r;
+}
+// x^(8 * nbytes) mod P; pw[k] = x^(8 * 2^k) mod P
+AHIP_DEVINL u32 gf_xpow8(u64 nbytes, const u32 *pw) {
+  u32 r = 1;  // the polynomial "1"
+  bool first = true;
+  for (u32 k = 0; nbytes; ++k, nbytes >>= 1)
+    if (nbytes & 1) { r = first ? pw[k] : gf_mulmod(r, pw[k]); first = false; }
+  return r;
+}
+
+// crc_tab: 256 table entries followed by 64 powers pw[k]
+__global__ __launch_bounds__(256) void bz_rle_expand(u32 block_size100k, const BzCand *__restrict__ cands,
+                                                     BzResult *__restrict__ results, const u8 *__restrict__ pre_all,
+                                                     const BzSpan *__restrict__ spans_all, const u64 *__restrict__ dst_off,
+                                                     u8 *__restrict__ out, const u32 *__restrict__ crc_tab) {
+  __shared__ u32 tab[256];
+  tab[threadIdx.x] = crc_tab[threadIdx.x];
+  __syncthreads();
+  const u32 blk = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
+  if (cands[blk].kind != 0 || results[blk].status != BZ_ST_OK || dst_off[blk] == ~0ull) return;
+  const u32 nblock = results[blk].nblock;
+  const u32 nblock_max = 100000u * block_size100k;
+  const u8 *pre = pre_all + (u64)blk * nblock_max;
+  const u32 sp = (nblock + BZ_SPANS - 1) / BZ_SPANS;
+  const u32 lo = t * sp < nblock ? t * sp : nblock, hi = lo + sp < nblock ? lo + sp : nblock;
+  const BzSpan e = spans_all[(u64)blk * BZ_SPANS + t];
+  const u64 total = results[blk].out_len;
+  RleState s{e.prev, e.cnt};
+  u8 *dst = out + dst_off[blk] + e.off;
+  u64 n = 0;
+  u32 crc = 0;  // remainder of this span's bytes alone (initial value 0)
+  for (u32 i = lo; i < hi; ++i) {
+    const u32 x = pre[i];
+    const bool is_count = s.cnt == 4;
+    const u32 run_byte = s.prev;
+    u32 reps = rle_step(s, x);
+    const u32 ch = is_count ? run_byte : x;
+    if (is_count) s.prev = 0x100;  // fresh
+    for (; reps; --reps) {
+      dst[n++] = (u8)ch;
+      crc = (crc << 8) ^ tab[(crc >> 24) ^ ch];
+    }
+  }
+  u32 term = 0;
+  if (n) term = gf_mulmod(crc, gf_xpow8(total - e.off - n, crc_tab + 256));
+  if (t == 0) term ^= gf_mulmod(0xffffffffu, gf_xpow8(total, crc_tab + 256));  // the 0xffffffff initial value
+  if (term) atomicXor(&results[blk].crc, term);
 }
 
 }  // namespace ahip

@@ -119,6 +119,10 @@ size_t ahip_deflate_bound(size_t in_len);
  * The obsolete randomised-block mode returns AHIP_E_UNSUPPORTED. */
 int32_t ahip_bzip2_decode(const uint8_t *in, size_t in_len, int32_t verify, uint8_t *out, size_t out_cap,
                           size_t *out_len);
+/* device-resident form (no reference counterpart): d_in/d_out on the current device.  Blocks are placed by the
+ * host between two kernel phases, so the call synchronises; `stream` is reserved (default stream is used). */
+int32_t ahip_bzip2_decode_device(const void *d_in, size_t in_len, int32_t verify, void *d_out, size_t out_cap,
+                                 size_t *out_len, void *stream);
 
 /* ---- checksums (ref: util/crc32.dart:6-27, util/adler32.dart:29-52), chainable ---- */
 uint32_t ahip_crc32(const uint8_t *data, size_t len, uint32_t crc /* 0 to start */);

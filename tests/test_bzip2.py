@@ -18,6 +18,9 @@ def _corpora():
         "random": bytes(rnd.getrandbits(8) for _ in range(250000)),
         "runs": b"".join(bytes([rnd.randrange(4)]) * rnd.randrange(1, 600) for _ in range(3000)),
         "empty": b"", "one": b"x", "text": streams.text(99999, 4),
+        # run-length escapes of every shape, also with the count byte equal to the run byte (4 + 97 x 'a')
+        "escapes": b"".join(bytes([c]) * n + b"." for c in (0, 4, 97, 255) for n in (1, 2, 3, 4, 5, 7, 8, 9, 4 + c, 258, 259, 260, 263, 1000) for _ in range(3)),
+        "fours": (b"aaaa" + b"bbbb" + b"aaaab" + b"\x04\x04\x04\x04" + b"\x00\x00\x00\x00\x00") * 2000,
     }
 
 
@@ -25,7 +28,14 @@ def _malformed():
     c = bz2.compress(b"hello world" * 1000)
     bad_block = bytearray(bz2.compress(streams.text(50000, 1), 1))
     bad_block[len(bad_block) // 2] ^= 0x10
-    return {"truncated_tail": c[:-3], "truncated_mid": c[:50], "no_magic": b"BZh9" + bytes(20), "not_bz": b"hello",
+    flips = {}
+    small = bz2.compress(streams.text(20000, 2) + bytes(300) + b"abcd" * 50, 9)
+    for k in range(24):  # single-bit damage all over one block: whatever the oracle makes of it, so must the GPU
+        b = bytearray(small)
+        pos = 40 + (k * 7919) % (len(small) - 60)
+        b[pos] ^= 1 << (k % 8)
+        flips["flip%d" % k] = bytes(b)
+    return {**flips, "truncated_tail": c[:-3], "truncated_mid": c[:50], "no_magic": b"BZh9" + bytes(20), "not_bz": b"hello",
             "short": b"BZ", "header_only": b"BZh9", "bad_level": b"BZhx" + c[4:], "two_streams": c + c,
             "corrupt_block": bytes(bad_block)}
 
@@ -75,3 +85,24 @@ def test_gpu_matches_oracle(native_built):
             st, out = orc.bzip2_decode(c, verify=verify)
             got = run(c, verify)
             assert got == ((2, None) if st == 2 else (st, out)), (name, verify, got[0], st)
+
+
+@pytest.mark.gpu
+def test_gpu_device_resident_api(native_built):
+    import ctypes
+
+    import torch
+    from archive_amd import _native as N
+    from tools import corpus
+    assert N.lib().ahip_init(0) == 0
+    data = bytes(corpus.text(corpus.WIKI, 8, 0, 2500000))
+    comp = bz2.compress(data, 9)  # three 900k blocks
+    d_in = torch.frombuffer(bytearray(comp), dtype=torch.uint8).cuda()
+    olen = ctypes.c_size_t()
+    small = torch.empty(100, dtype=torch.uint8, device="cuda")
+    assert N.lib().ahip_bzip2_decode_device(d_in.data_ptr(), d_in.numel(), 1, small.data_ptr(), 100, ctypes.byref(olen), None) == -1
+    assert olen.value == len(data)
+    d_out = torch.empty(len(data), dtype=torch.uint8, device="cuda")
+    assert N.lib().ahip_bzip2_decode_device(d_in.data_ptr(), d_in.numel(), 1, d_out.data_ptr(), d_out.numel(),
+                                            ctypes.byref(olen), None) == 0
+    assert olen.value == len(data) and bytes(d_out.cpu().numpy()) == data
