@@ -750,7 +750,7 @@ size_t ahip_deflate_bound(size_t in_len) {
 // Deflate on device memory.  Returns the compressed size through *out_len.
 static int32_t deflate_device_impl(const u8 *d_in, size_t n, int level, u8 *d_out, size_t cap, size_t *out_len,
                                    hipStream_t st) {
-  static DevBuf b_mlen, b_mdist, b_tok, b_ntok, b_slabs, b_csize, b_coff;
+  static DevBuf b_match, b_tok, b_ntok, b_slabs, b_csize, b_coff;
   if (out_len) *out_len = 0;
   if (level < 0 || level > 9) return AHIP_OK;  // the reference's _init fails silently: no output
   if (n == 0) {  // reference: one fixed-Huffman block holding only the end-of-block code (level >= 1), or an empty stored block
@@ -769,17 +769,16 @@ static int32_t deflate_device_impl(const u8 *d_in, size_t n, int level, u8 *d_ou
   P.lazy = level >= 4 ? 1u : 0u;
   P.store = level == 0 ? 1u : 0u;
   P.max_cmp = 258;
-  HIP_TRY(b_mlen.reserve(n * 2 + 64));
-  HIP_TRY(b_mdist.reserve(n * 2 + 64));
+  HIP_TRY(b_match.reserve(n * 4 + 64));
   HIP_TRY(b_tok.reserve(n * 4 + 64));
   HIP_TRY(b_ntok.reserve((size_t)P.chunks * 4));
   HIP_TRY(b_slabs.reserve((size_t)P.chunks * DF_SLAB));
   HIP_TRY(b_csize.reserve((size_t)P.chunks * 4));
   HIP_TRY(b_coff.reserve((size_t)P.chunks * 8));
   if (!P.store)
-    hipLaunchKernelGGL(deflate_match_kernel, dim3(P.chunks), dim3(256), 0, st, d_in, P, b_mlen.as<u16>(), b_mdist.as<u16>());
-  hipLaunchKernelGGL(deflate_parse_kernel, dim3(cdiv(P.chunks, 64)), dim3(64), 0, st, d_in, P, b_mlen.as<u16>(),
-                     b_mdist.as<u16>(), b_tok.as<u32>(), b_ntok.as<u32>());
+    hipLaunchKernelGGL(deflate_match_kernel, dim3(P.chunks), dim3(256), 0, st, d_in, P, b_match.as<u32>());
+  hipLaunchKernelGGL(deflate_parse_kernel, dim3(P.chunks), dim3(64), 0, st, d_in, P, b_match.as<u32>(), b_tok.as<u32>(),
+                     b_ntok.as<u32>());
   hipLaunchKernelGGL(deflate_encode_kernel, dim3(P.chunks), dim3(256), 0, st, d_in, P, b_tok.as<u32>(), b_ntok.as<u32>(),
                      b_slabs.as<u8>(), b_csize.as<u32>());
   std::vector<u32> csize(P.chunks);

@@ -12,13 +12,13 @@
 // by an empty stored block so that it ends on a byte boundary (the Z_SYNC_FLUSH marker the
 // reference itself emits through _trStoredBlock(0, 0, false), deflate.dart:219):
 //
-//   D1 deflate_match_kernel   one workgroup per chunk.  4-way bucketed hash of 4-byte strings in
-//                             LDS; positions are processed 256 at a time (probe, then insert), so
-//                             every probe sees exactly the strings before its own sub-block.
-//                             Candidates are verified with 4-byte compares; best (len, dist) per
-//                             position goes to scratch.
-//   D2 deflate_parse_kernel   one lane per chunk walks the match arrays with the reference's
-//                             one-step lazy rule and writes the token list.
+//   D1 deflate_match_kernel   one workgroup per chunk.  Sliding window (36 KiB ring) and a 4-way bucketed
+//                             hash of 4-byte strings in LDS; positions are processed 256 at a time
+//                             (probe, then insert), so every probe sees exactly the strings before
+//                             its own sub-block.  Best (len, dist) per position goes to scratch.
+//   D2 deflate_parse_kernel   one wave per chunk follows the reference's one-step lazy rule as the
+//                             orbit of position 0 (scalar hops over a 64-position block) and writes
+//                             the token list.
 //   D3 deflate_encode_kernel  one workgroup per chunk: symbol histogram (LDS atomics), zlib's
 //                             heap Huffman construction with the 15/7-bit limit (restated from
 //                             deflate.dart:2567-2784, run by one lane), dynamic header, then the
@@ -43,6 +43,10 @@ constexpr u32 DF_HASH_BITS = AHIP_DF_HASH_BITS, DF_WAYS = AHIP_DF_WAYS;
 constexpr u32 DF_SUB = 256;              // positions probed, then inserted, per step (one workgroup)
 constexpr u32 DF_MINLEN = 4;             // 4-byte hash: 3-byte matches are not searched
 constexpr u32 DF_EMPTY = 0xffff;
+#ifndef AHIP_DF_CAP
+#define AHIP_DF_CAP 32
+#endif
+constexpr u32 DF_CAP = AHIP_DF_CAP;      // the match kernel compares this far; the parse extends the matches it uses
 
 struct DeflateParams {
   u64 n;        // input bytes
@@ -57,51 +61,104 @@ AHIP_DEVINL u32 df_hash4(u32 w) { return (w * 2654435761u) >> (32 - DF_HASH_BITS
 // ------------------------------------------------------------------------------------------
 // D1: per-position best match
 // ------------------------------------------------------------------------------------------
-// longest common prefix of the strings at window offsets c < p, both known to share 4 bytes
-AHIP_DEVINL u32 df_match_len(const u8 *win, u32 c, u32 p, u32 maxl) {
-  u32 l = 4;
-  while (l + 4 <= maxl) {
-    const u32 x = load_u32_unaligned(win + c + l) ^ load_u32_unaligned(win + p + l);
-    if (x) return l + ((u32)__builtin_ctz(x) >> 3);
-    l += 4;
+// The sliding window lives in LDS: a 36 KiB ring (32 KiB of history + 1.25 KiB of lookahead + slack) whose
+// first 272 bytes are mirrored behind its end, so a compare that starts near the end of the ring reads
+// straight on.  Candidate verification and match extension are LDS reads (two aligned dwords + v_alignbyte
+// per unaligned 4 bytes) instead of scattered global loads -- the first version spent its time in the
+// address coalescer (64 different lines per load instruction).
+constexpr u32 DF_RING = 36864, DF_MIRROR = 272, DF_AHEAD = 1024;
+AHIP_DEVINL u32 df_rc(u32 x) { return x >= DF_RING ? x - DF_RING : x; }  // window position -> ring offset (x < 2 * DF_RING)
+AHIP_DEVINL u32 df_rd4(const u32 *ring, u32 r) {
+  const u32 i = r >> 2;
+  return __builtin_amdgcn_alignbyte(ring[i + 1], ring[i], r & 3);
+}
+AHIP_DEVINL u64 df_rd8(const u32 *ring, u32 r) {
+  const u32 i = r >> 2;
+  const u32 a = ring[i], b = ring[i + 1], c = ring[i + 2];
+  return (u64)__builtin_amdgcn_alignbyte(b, a, r & 3) | ((u64)__builtin_amdgcn_alignbyte(c, b, r & 3) << 32);
+}
+// Lengths of up to NW candidate matches at once.  rc[k] = ring offset of candidate k (alive[k] says it shares
+// the first 4 bytes with the string at rp).  The candidates advance together, 8 bytes per round, so one
+// round costs ONE LDS round trip for all of them -- the kernel is bound by dependent LDS latency (two waves
+// per SIMD), not by LDS bandwidth.
+template <int NW>
+AHIP_DEVINL void df_match_lens(const u32 *ring, const u32 (&rc)[NW], u32 rp, u32 maxl, bool (&alive)[NW], u32 (&len)[NW]) {
+  bool any = false;
+#pragma unroll
+  for (int k = 0; k < NW; ++k) { len[k] = alive[k] ? (maxl < 4 ? maxl : 4u) : 0u; alive[k] = alive[k] && maxl > 4; any |= alive[k]; }
+  for (u32 l = 4; any; l += 8) {
+    const u64 pw = df_rd8(ring, rp + l);
+    u64 cw[NW];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) cw[k] = df_rd8(ring, rc[k] + l);  // dead candidates read too: no branch, no extra round trip
+    any = false;
+    const u32 room = maxl - l;  // > 0
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+      const u64 x = cw[k] ^ pw;
+      u32 n = x ? ((u32)__builtin_ctzll(x) >> 3) : 8u;
+      n = n < room ? n : room;
+      if (alive[k]) { len[k] = l + n; alive[k] = n == 8 && room > 8; }
+      any |= alive[k];
+    }
   }
-  while (l < maxl && win[c + l] == win[p + l]) ++l;
-  return l;
 }
 
+// match[] holds len << 16 | dist per input position (0 = no match of >= 4 bytes)
 __global__ __launch_bounds__(256) void deflate_match_kernel(const u8 *__restrict__ in, DeflateParams P,
-                                                            u16 *__restrict__ mlen, u16 *__restrict__ mdist) {
+                                                            u32 *__restrict__ match) {
   __shared__ u16 tbl[(1u << DF_HASH_BITS) * DF_WAYS];
+  __shared__ u32 ring[(DF_RING + DF_MIRROR) / 4 + 2];
   const u32 chunk = blockIdx.x, tid = threadIdx.x;
   const u64 cstart = (u64)chunk * DF_CHUNK;
   const u32 clen = (u32)((P.n - cstart) < DF_CHUNK ? (P.n - cstart) : DF_CHUNK);
   const u32 dict = cstart >= DF_CHUNK ? DF_CHUNK : (u32)cstart;  // raw bytes before the chunk that may be referenced
   const u8 *win = in + cstart - dict;                            // window base; positions are relative to it
   const u32 wlen = dict + clen;
-  for (u32 i = tid; i < (1u << DF_HASH_BITS) * DF_WAYS; i += 256) tbl[i] = (u16)DF_EMPTY;
-  __syncthreads();
   if (P.store) return;
+  for (u32 i = tid; i < (1u << DF_HASH_BITS) * DF_WAYS; i += 256) tbl[i] = (u16)DF_EMPTY;
+  // bytes [q, q + 4) of the window into the ring (zero past the end)
+  auto stage = [&](u32 q) {
+    u32 v = 0;
+    if (q + 4 <= wlen) v = load_u32_unaligned(win + q);
+    else for (u32 k = 0; k < 4; ++k) v |= (q + k < wlen ? (u32)win[q + k] : 0u) << (8 * k);
+    const u32 r = df_rc(q);
+    ring[r >> 2] = v;
+    if (r < DF_MIRROR) ring[(DF_RING + r) >> 2] = v;
+  };
+  stage(4 * tid);  // [0, DF_AHEAD)
+  __syncthreads();
   // 256 positions per step: probe everything inserted by earlier steps, insert (slot = step number
   // mod ways, so a bucket keeps its most recent strings), then probe the slot just written for a
   // lower position of the SAME step (distances below 256: runs and short periods).
   for (u32 base = 0; base < wlen; base += DF_SUB) {
+    if (tid < 64) stage(base + DF_AHEAD + 4 * tid);  // nobody reads these slots during this step
     const u32 p = base + tid;
     const bool has4 = p + 4 <= wlen;
     const bool search = has4 && p >= dict;
+    const u32 rp = df_rc(p);
     u32 w = 0, h = 0, best_len = 0, best_dist = 0;
-    const u32 maxl = (wlen - p) < P.max_cmp ? (wlen - p) : P.max_cmp;
-    if (has4) { w = load_u32_unaligned(win + p); h = df_hash4(w); }
+    // Compares stop at DF_CAP bytes: a wave waits for its longest compare, and neighbouring positions inside
+    // one long match would each walk (nearly) all of it.  The parse extends the few matches it actually emits.
+    u32 maxl = (wlen - p) < P.max_cmp ? (wlen - p) : P.max_cmp;
+    maxl = maxl < DF_CAP ? maxl : DF_CAP;
+    if (has4) { w = df_rd4(ring, rp); h = df_hash4(w); }
     if (search) {
+      u32 rc[DF_WAYS], dist[DF_WAYS], len[DF_WAYS];
+      bool alive[DF_WAYS];
 #pragma unroll
       for (u32 way = 0; way < DF_WAYS; ++way) {
         const u32 c = tbl[h * DF_WAYS + way];
-        if (c == DF_EMPTY) continue;
-        const u32 dist = p - c;  // c < p: inserted by an earlier step
-        if (dist > 32768) continue;
-        if (load_u32_unaligned(win + c) != w) continue;
-        const u32 l = df_match_len(win, c, p, maxl);
-        if (l > best_len || (l == best_len && dist < best_dist)) { best_len = l; best_dist = dist; }
+        dist[way] = p - c;  // c < p: inserted by an earlier step
+        alive[way] = c != DF_EMPTY && dist[way] <= 32768;
+        rc[way] = alive[way] ? df_rc(c) : rp;
       }
+#pragma unroll
+      for (u32 way = 0; way < DF_WAYS; ++way) alive[way] = alive[way] && df_rd4(ring, rc[way]) == w;
+      df_match_lens<DF_WAYS>(ring, rc, rp, maxl, alive, len);
+#pragma unroll
+      for (u32 way = 0; way < DF_WAYS; ++way)
+        if (len[way] > best_len || (len[way] == best_len && len[way] && dist[way] < best_dist)) { best_len = len[way]; best_dist = dist[way]; }
     }
     const u32 slot = h * DF_WAYS + ((base / DF_SUB) & (DF_WAYS - 1));
     __syncthreads();
@@ -109,50 +166,93 @@ __global__ __launch_bounds__(256) void deflate_match_kernel(const u8 *__restrict
     __syncthreads();
     if (search) {
       const u32 c = tbl[slot];
-      if (c < p && c >= base && load_u32_unaligned(win + c) == w) {
-        const u32 l = df_match_len(win, c, p, maxl);
-        if (l > best_len) { best_len = l; best_dist = p - c; }
-      }
+      u32 rc[1], len[1];
+      bool alive[1];
+      alive[0] = c < p && c >= base;
+      rc[0] = alive[0] ? df_rc(c) : rp;
+      alive[0] = alive[0] && df_rd4(ring, rc[0]) == w;
+      df_match_lens<1>(ring, rc, rp, maxl, alive, len);
+      if (len[0] > best_len) { best_len = len[0]; best_dist = p - c; }
     }
-    if (p >= dict && p < wlen) {
-      const bool ok = best_len >= DF_MINLEN;
-      mlen[cstart + (p - dict)] = ok ? (u16)best_len : (u16)0;
-      if (ok) mdist[cstart + (p - dict)] = (u16)best_dist;  // 32768 fits
-    }
+    if (p >= dict && p < wlen) match[cstart + (p - dict)] = best_len >= DF_MINLEN ? ((best_len << 16) | best_dist) : 0u;
   }
 }
 
 // ------------------------------------------------------------------------------------------
-// D2: parse (one lane per chunk)
+// D2: parse -- one wave per chunk
 // ------------------------------------------------------------------------------------------
+// The reference's decision at a position depends only on the matches at that position and the next
+// (one-step lazy rule), so every position has a well-defined "next position"; the parse is the orbit of
+// position 0.  64 positions at a time: the lanes compute step and token, a scalar loop hops through the
+// block with v_readlane, and the visited lanes write their tokens compacted.
+// true length (<= maxl) of a match known to hold for DF_CAP bytes: one wave-wide step, 4 bytes per lane
+AHIP_DEVINL u32 df_extend(const u8 *a, u32 dist, u32 maxl, u32 lane) {
+  const u32 o = DF_CAP + 4 * lane;
+  const u8 *src = a - dist;  // (a[x - dist] with unsigned x would wrap)
+  u32 same = 4, nb = 0;
+  if (o < maxl) {
+    nb = maxl - o < 4 ? maxl - o : 4;
+    same = nb;
+    for (u32 k = nb; k-- > 0;)
+      if (a[o + k] != src[o + k]) same = k;
+  }
+  const u64 stop = __ballot(o < maxl && same < 4);  // a mismatch, or the end of the allowed range, inside this lane
+  if (!stop) return maxl;
+  const int f = __ffsll((long long)stop) - 1;
+  return DF_CAP + 4 * (u32)f + lane_bcast(same, f);
+}
+
 __global__ __launch_bounds__(64) void deflate_parse_kernel(const u8 *__restrict__ in, DeflateParams P,
-                                                           const u16 *__restrict__ mlen, const u16 *__restrict__ mdist,
-                                                           u32 *__restrict__ tok, u32 *__restrict__ ntok) {
-  const u32 chunk = blockIdx.x * 64 + threadIdx.x;
+                                                           const u32 *__restrict__ match, u32 *__restrict__ tok,
+                                                           u32 *__restrict__ ntok) {
+  const u32 chunk = blockIdx.x, lane = threadIdx.x;
   if (chunk >= P.chunks) return;
   const u64 cstart = (u64)chunk * DF_CHUNK;
   const u32 clen = (u32)((P.n - cstart) < DF_CHUNK ? (P.n - cstart) : DF_CHUNK);
   u32 *t = tok + cstart;  // at most one token per byte
-  u32 k = 0, i = 0;
+  u32 k = 0, pos = 0;
   if (!P.store) {
-    while (i < clen) {
-      u32 l = mlen[cstart + i];
-      if (l > clen - i) l = clen - i;
-      if (l >= DF_MINLEN) {
-        if (P.lazy && i + 1 < clen && mlen[cstart + i + 1] > l) {  // a longer match starts at the next byte
-          t[k++] = 0x80000000u | in[cstart + i];
-          i += 1;
-          continue;
+    const u64 below = (1ull << lane) - 1;
+    for (u32 base = 0; base < clen; base += 64) {
+      const u32 i = base + lane;
+      const bool inb = i < clen;
+      const u32 m = inb ? match[cstart + i] : 0u;
+      const u32 m1 = (i + 1 < clen) ? match[cstart + i + 1] : 0u;
+      const u32 l = m >> 16;  // <= min(DF_CAP, clen - i) by construction
+      bool is_match = inb && l >= DF_MINLEN;
+      if (is_match && P.lazy && (m1 >> 16) > l) is_match = false;  // a longer match starts at the next byte
+      u32 step = is_match ? l : 1u;
+      u32 token = is_match ? m : (0x80000000u | (inb ? (u32)in[cstart + i] : 0u));
+      const bool capped = inb && l >= DF_CAP;  // true length unknown: settled when (if) the parse lands here
+      u64 visited = 0;
+      const u64 cap_mask = __ballot(capped);
+      const u32 lim = base + 64 < clen ? base + 64 : clen;
+      while (pos < lim) {
+        const u32 j = pos - base;
+        visited |= 1ull << j;
+        u32 st = lane_bcast(step, (int)j);
+        if ((cap_mask >> j) & 1) {
+          const u8 *a = in + cstart + pos;
+          const u32 rem = clen - pos;
+          const u32 d0 = lane_bcast(m, (int)j) & 0xffff;
+          const u32 L0 = df_extend(a, d0, rem < P.max_cmp ? rem : P.max_cmp, lane);
+          bool take = true;
+          if (P.lazy && pos + 1 < clen) {
+            const u32 mm1 = lane_bcast(m1, (int)j);
+            u32 L1 = mm1 >> 16;
+            if (L1 >= DF_CAP) L1 = df_extend(a + 1, mm1 & 0xffff, (rem - 1) < P.max_cmp ? (rem - 1) : P.max_cmp, lane);
+            take = !(L1 > L0);
+          }
+          st = take ? L0 : 1u;
+          if (lane == j) token = take ? ((L0 << 16) | d0) : (0x80000000u | (u32)a[0]);
         }
-        t[k++] = (l << 16) | mdist[cstart + i];
-        i += l;
-      } else {
-        t[k++] = 0x80000000u | in[cstart + i];
-        i += 1;
+        pos += st;
       }
+      if ((visited >> lane) & 1) t[k + (u32)__popcll(visited & below)] = token;
+      k += (u32)__popcll(visited);
     }
   }
-  ntok[chunk] = k;
+  if (lane == 0) ntok[chunk] = k;
 }
 
 // ------------------------------------------------------------------------------------------
