@@ -769,7 +769,7 @@ static int32_t deflate_device_impl(const u8 *d_in, size_t n, int level, u8 *d_ou
   P.lazy = level >= 4 ? 1u : 0u;
   P.store = level == 0 ? 1u : 0u;
   P.max_cmp = 258;
-  HIP_TRY(b_match.reserve(n * 4 + 64));
+  HIP_TRY(b_match.reserve(n * 4 + 64 + (size_t)P.chunks * 32 + 64));
   HIP_TRY(b_tok.reserve(n * 4 + 64));
   HIP_TRY(b_ntok.reserve((size_t)P.chunks * 4));
   HIP_TRY(b_slabs.reserve((size_t)P.chunks * DF_SLAB));
@@ -777,6 +777,17 @@ static int32_t deflate_device_impl(const u8 *d_in, size_t n, int level, u8 *d_ou
   HIP_TRY(b_coff.reserve((size_t)P.chunks * 8));
   if (!P.store)
     hipLaunchKernelGGL(deflate_match_kernel, dim3(P.chunks), dim3(256), 0, st, d_in, P, b_match.as<u32>());
+#ifdef AHIP_PROFILE
+  if (!P.store && getenv("AHIP_DEBUG")) {
+    std::vector<u32> pc((size_t)P.chunks * 8);
+    hipMemcpy(pc.data(), b_match.as<u32>() + n + 16, pc.size() * 4, hipMemcpyDeviceToHost);
+    double s[8] = {0};
+    for (u32 c = 0; c < P.chunks; ++c) for (int k = 0; k < 8; ++k) s[k] += pc[(size_t)c * 8 + k] * 16.0;
+    fprintf(stderr, "[ahip] match kernel cycles per chunk (wave 0): pre-sync %.0f  barriers+insert %.0f  verify %.0f  compare %.0f  "
+            "post-sync total %.0f  search loop %.0f\n", s[0] / P.chunks, s[1] / P.chunks, s[2] / P.chunks, s[3] / P.chunks,
+            s[4] / P.chunks, s[5] / P.chunks);
+  }
+#endif
   hipLaunchKernelGGL(deflate_parse_kernel, dim3(P.chunks), dim3(64), 0, st, d_in, P, b_match.as<u32>(), b_tok.as<u32>(),
                      b_ntok.as<u32>());
   hipLaunchKernelGGL(deflate_encode_kernel, dim3(P.chunks), dim3(256), 0, st, d_in, P, b_tok.as<u32>(), b_ntok.as<u32>(),

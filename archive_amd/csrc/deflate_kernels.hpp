@@ -90,7 +90,7 @@ AHIP_DEVINL void df_match_lens(const u32 *ring, const u32 (&rc)[NW], u32 rp, u32
     const u64 pw = df_rd8(ring, rp + l);
     u64 cw[NW];
 #pragma unroll
-    for (int k = 0; k < NW; ++k) cw[k] = df_rd8(ring, rc[k] + l);  // dead candidates read too: no branch, no extra round trip
+    for (int k = 0; k < NW; ++k) cw[k] = df_rd8(ring, rc[k] + l);  // dead candidates read too: masking them was measured slower
     any = false;
     const u32 room = maxl - l;  // > 0
 #pragma unroll
@@ -103,6 +103,10 @@ AHIP_DEVINL void df_match_lens(const u32 *ring, const u32 (&rc)[NW], u32 rp, u32
     }
   }
 }
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for the wave's outstanding
+// GLOBAL loads and stores (the match[] store of the previous step, the window prefetch), ~1-2 us each step.
+AHIP_DEVINL void df_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // match[] holds len << 16 | dist per input position (0 = no match of >= 4 bytes)
 __global__ __launch_bounds__(256) void deflate_match_kernel(const u8 *__restrict__ in, DeflateParams P,
@@ -117,22 +121,51 @@ __global__ __launch_bounds__(256) void deflate_match_kernel(const u8 *__restrict
   const u32 wlen = dict + clen;
   if (P.store) return;
   for (u32 i = tid; i < (1u << DF_HASH_BITS) * DF_WAYS; i += 256) tbl[i] = (u16)DF_EMPTY;
-  // bytes [q, q + 4) of the window into the ring (zero past the end)
-  auto stage = [&](u32 q) {
+  // bytes [q, q + 4) of the window (zero past the end) ...
+  auto fetch = [&](u32 q) -> u32 {
     u32 v = 0;
     if (q + 4 <= wlen) v = load_u32_unaligned(win + q);
     else for (u32 k = 0; k < 4; ++k) v |= (q + k < wlen ? (u32)win[q + k] : 0u) << (8 * k);
+    return v;
+  };
+  // ... into the ring
+  auto put = [&](u32 q, u32 v) {
     const u32 r = df_rc(q);
     ring[r >> 2] = v;
     if (r < DF_MIRROR) ring[(DF_RING + r) >> 2] = v;
   };
+  auto stage = [&](u32 q) { put(q, fetch(q)); };
   stage(4 * tid);  // [0, DF_AHEAD)
   __syncthreads();
-  // 256 positions per step: probe everything inserted by earlier steps, insert (slot = step number
-  // mod ways, so a bucket keeps its most recent strings), then probe the slot just written for a
-  // lower position of the SAME step (distances below 256: runs and short periods).
-  for (u32 base = 0; base < wlen; base += DF_SUB) {
-    if (tid < 64) stage(base + DF_AHEAD + 4 * tid);  // nobody reads these slots during this step
+  // History before the chunk is only inserted.  Four consecutive steps write four different ways, so they
+  // are done as one (same table as step by step, a quarter of the barriers).
+  u32 base = 0;
+  for (; base + 4 * DF_SUB <= dict; base += 4 * DF_SUB) {
+    stage(base + DF_AHEAD + 4 * tid);
+    __syncthreads();  // the last position's 4 bytes reach into what was just staged
+#pragma unroll
+    for (u32 k = 0; k < 4; ++k) {
+      const u32 p = base + k * DF_SUB + tid;  // p + 4 <= wlen: the chunk follows
+      tbl[df_hash4(df_rd4(ring, df_rc(p))) * DF_WAYS + (((base / DF_SUB) + k) & (DF_WAYS - 1))] = (u16)p;
+    }
+    __syncthreads();
+  }
+  // 256 positions per step.  A position is compared with the strings earlier steps left in its bucket
+  // (read before this step's insertion) and with the string this step put into the bucket's current slot
+  // if that one lies below it (distances under 256: runs and short periods) -- five candidates, one batch.
+#ifdef AHIP_PROFILE
+  u32 pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  AHIP_TICK(t_dict);
+  // window prefetch: wave 0 loads the 256 bytes at base + DF_AHEAD during one step and stores them into the
+  // ring at the top of the next, so the load's latency is never waited for
+  u32 pf = tid < 64 ? fetch(base + DF_AHEAD + 4 * tid) : 0u;
+  for (; base < wlen; base += DF_SUB) {
+    AHIP_TICK(t0);
+    if (tid < 64) {  // nobody reads these slots during this step
+      put(base + DF_AHEAD + 4 * tid, pf);
+      pf = fetch(base + DF_SUB + DF_AHEAD + 4 * tid);
+    }
     const u32 p = base + tid;
     const bool has4 = p + 4 <= wlen;
     const bool search = has4 && p >= dict;
@@ -143,39 +176,49 @@ __global__ __launch_bounds__(256) void deflate_match_kernel(const u8 *__restrict
     u32 maxl = (wlen - p) < P.max_cmp ? (wlen - p) : P.max_cmp;
     maxl = maxl < DF_CAP ? maxl : DF_CAP;
     if (has4) { w = df_rd4(ring, rp); h = df_hash4(w); }
-    if (search) {
-      u32 rc[DF_WAYS], dist[DF_WAYS], len[DF_WAYS];
-      bool alive[DF_WAYS];
+    u32 cand[DF_WAYS + 1];
 #pragma unroll
-      for (u32 way = 0; way < DF_WAYS; ++way) {
-        const u32 c = tbl[h * DF_WAYS + way];
-        dist[way] = p - c;  // c < p: inserted by an earlier step
-        alive[way] = c != DF_EMPTY && dist[way] <= 32768;
-        rc[way] = alive[way] ? df_rc(c) : rp;
+    for (u32 way = 0; way < DF_WAYS; ++way) cand[way] = search ? tbl[h * DF_WAYS + way] : DF_EMPTY;
+    const u32 slot = h * DF_WAYS + ((base / DF_SUB) & (DF_WAYS - 1));
+    AHIP_TICK(t1);
+    df_lds_barrier();
+    if (has4) tbl[slot] = (u16)p;  // same-hash writers of one step race: any winner is valid
+    df_lds_barrier();
+    AHIP_TICK(t2);
+    AHIP_ACC(pc[0], t0, t1);
+    AHIP_ACC(pc[1], t1, t2);
+    if (search) {
+      cand[DF_WAYS] = tbl[slot];
+      u32 rc[DF_WAYS + 1], dist[DF_WAYS + 1], len[DF_WAYS + 1];
+      bool alive[DF_WAYS + 1];
+#pragma unroll
+      for (u32 k = 0; k <= DF_WAYS; ++k) {
+        const u32 c = cand[k];
+        dist[k] = p - c;
+        alive[k] = k < DF_WAYS ? (c != DF_EMPTY && dist[k] <= 32768) : (c < p && c >= base);
+        rc[k] = alive[k] ? df_rc(c) : rp;
       }
 #pragma unroll
-      for (u32 way = 0; way < DF_WAYS; ++way) alive[way] = alive[way] && df_rd4(ring, rc[way]) == w;
-      df_match_lens<DF_WAYS>(ring, rc, rp, maxl, alive, len);
+      for (u32 k = 0; k <= DF_WAYS; ++k) alive[k] = alive[k] && df_rd4(ring, rc[k]) == w;  // (dead ones read rp: one address, a broadcast)
+      AHIP_TICK(t3);
+      AHIP_ACC(pc[2], t2, t3);
+      df_match_lens<DF_WAYS + 1>(ring, rc, rp, maxl, alive, len);
+      AHIP_TICK(t4);
+      AHIP_ACC(pc[3], t3, t4);
 #pragma unroll
-      for (u32 way = 0; way < DF_WAYS; ++way)
-        if (len[way] > best_len || (len[way] == best_len && len[way] && dist[way] < best_dist)) { best_len = len[way]; best_dist = dist[way]; }
-    }
-    const u32 slot = h * DF_WAYS + ((base / DF_SUB) & (DF_WAYS - 1));
-    __syncthreads();
-    if (has4) tbl[slot] = (u16)p;  // same-hash writers of one step race: any winner is valid
-    __syncthreads();
-    if (search) {
-      const u32 c = tbl[slot];
-      u32 rc[1], len[1];
-      bool alive[1];
-      alive[0] = c < p && c >= base;
-      rc[0] = alive[0] ? df_rc(c) : rp;
-      alive[0] = alive[0] && df_rd4(ring, rc[0]) == w;
-      df_match_lens<1>(ring, rc, rp, maxl, alive, len);
-      if (len[0] > best_len) { best_len = len[0]; best_dist = p - c; }
+      for (u32 k = 0; k < DF_WAYS; ++k)
+        if (len[k] > best_len || (len[k] == best_len && len[k] && dist[k] < best_dist)) { best_len = len[k]; best_dist = dist[k]; }
+      if (len[DF_WAYS] > best_len) { best_len = len[DF_WAYS]; best_dist = dist[DF_WAYS]; }
     }
     if (p >= dict && p < wlen) match[cstart + (p - dict)] = best_len >= DF_MINLEN ? ((best_len << 16) | best_dist) : 0u;
+    AHIP_TICK(t5);
+    AHIP_ACC(pc[4], t2, t5);
   }
+#ifdef AHIP_PROFILE
+  AHIP_TICK(t_end);
+  AHIP_ACC(pc[5], t_dict, t_end);
+  if (tid == 0) for (int k = 0; k < 8; ++k) match[P.n + 16 + (u64)chunk * 8 + k] = pc[k];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
