@@ -16,6 +16,7 @@
 #include "common.hpp"
 #include "gzip_index.hpp"
 #include "bzip2_kernels.hpp"
+#include "checksum_kernels.hpp"
 #include "deflate_kernels.hpp"
 #include "inflate_par.hpp"
 
@@ -397,6 +398,62 @@ int32_t plan_verdict(ahip_gzip_plan *pl, hipStream_t st, bool *needs_sizing) {
 // Runs a sizing pass first when `cap` may be too small.  Single wave: the serial path of the
 // reference has no member parallelism to offer.
 struct OneResult { MemberResult r; };
+// ---- checksums of device-resident data (checksum_kernels.hpp) ----
+static u32 g_ck_tables[CK_TAB_WORDS];
+static bool g_ck_ready = false;
+static hipError_t ck_prepare(DevBuf &dtab, DevBuf &dacc) {
+  if (!g_ck_ready) { ck_build_tables(g_ck_tables); g_ck_ready = true; }
+  hipError_t e = dacc.reserve(64);
+  if (e != hipSuccess) return e;
+  if (!dtab.p) {
+    e = dtab.reserve(sizeof(g_ck_tables));
+    if (e != hipSuccess) return e;
+    e = hipMemcpy(dtab.p, g_ck_tables, sizeof(g_ck_tables), hipMemcpyHostToDevice);
+  }
+  return e;
+}
+static u32 ck_grid(size_t n) {
+  const size_t nseg = (n + CK_SEG - 1) / CK_SEG;
+  const size_t waves = nseg < 8192 ? nseg : 8192;
+  return (u32)((waves + 3) / 4 ? (waves + 3) / 4 : 1);
+}
+// getCrc32(d[0, n), crc0)  (util/crc32.dart:6-27)
+static int32_t crc32_device_impl(const u8 *d, size_t n, u32 crc0, u32 *out, hipStream_t st) {
+  static DevBuf dtab, dacc;
+  HIP_TRY(ck_prepare(dtab, dacc));
+  u32 raw = 0;
+  if (n) {
+    HIP_TRY(hipMemsetAsync(dacc.p, 0, 4, st));
+    hipLaunchKernelGGL(crc32_kernel, dim3(ck_grid(n)), dim3(256), 0, st, d, (u64)n, dtab.as<u32>(), dacc.as<u32>());
+    HIP_TRY(hipMemcpyAsync(&raw, dacc.p, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+  }
+  // the register starts at ~crc0, runs over n bytes (x^(8n)) and is inverted at the end
+  const u32 state = ck_mulmod(ck_xpow8(n, g_ck_tables + 1280), ~crc0) ^ raw;
+  *out = ~state;
+  return AHIP_OK;
+}
+// getAdler32(d[0, n), adler0)  (util/adler32.dart:29-52)
+static int32_t adler32_device_impl(const u8 *d, size_t n, u32 adler0, u32 *out, hipStream_t st) {
+  static DevBuf dtab, dacc;
+  HIP_TRY(ck_prepare(dtab, dacc));
+  unsigned long long acc[2] = {0, 0};
+  if (n) {
+    HIP_TRY(hipMemsetAsync(dacc.p, 0, 16, st));
+    hipLaunchKernelGGL(adler32_kernel, dim3(ck_grid(n)), dim3(256), 0, st, d, (u64)n, dacc.as<unsigned long long>());
+    HIP_TRY(hipMemcpyAsync(acc, dacc.p, 16, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+  }
+  const u64 M = 65521, a0 = adler0 & 0xffff, b0 = adler0 >> 16;
+  const u64 A = acc[0] % M, T = acc[1] % M, nm = (u64)n % M;
+  const u64 s1 = (a0 + A) % M;
+  const u64 s2 = (b0 + nm * a0 % M + nm * A % M + M - T) % M;
+  *out = (u32)((s2 << 16) | s1);
+  return AHIP_OK;
+}
+
 int32_t inflate_one(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool write, MemberResult *res,
                     hipStream_t st) {
   static DevBuf dd, dr;
@@ -479,10 +536,11 @@ int32_t zlib_stream_device(const u8 *host_in, const u8 *d_in, u64 n, u64 pos, bo
       u32 a = host_in[pos], b = host_in[pos + 1], c = host_in[pos + 2], d = host_in[pos + 3];
       u32 want = big_endian ? ((a << 24) | (b << 16) | (c << 8) | d) : ((d << 24) | (c << 16) | (b << 8) | a);
       pos += 4;
-      if (verify) {
-        tmp.resize(buf_len);
-        if (buf_len) HIP_TRY(hipMemcpy(tmp.data(), outbuf.as<u8>() + committed, buf_len, hipMemcpyDeviceToHost));
-        if (ahip_adler32(tmp.data(), buf_len, 1) != want) { *committed_io = committed; return AHIP_FALSE; }
+      if (verify) {  // Adler-32 of the member's bytes where they are: in HBM
+        u32 got = 0;
+        rc = adler32_device_impl(outbuf.as<u8>() + committed, buf_len, 1, &got, st);
+        if (rc != AHIP_OK) return rc;
+        if (got != want) { *committed_io = committed; return AHIP_FALSE; }
       }
     }
   }
@@ -817,11 +875,13 @@ int32_t ahip_deflate_raw_device(const void *d_in, size_t in_len, int32_t level, 
   return deflate_device_impl((const u8 *)d_in, in_len, level, (u8 *)d_out, out_cap, out_len, (hipStream_t)stream);
 }
 
-int32_t ahip_deflate_raw(const uint8_t *in, size_t in_len, int32_t level, int32_t window_bits, uint8_t *out,
-                         size_t out_cap, size_t *out_len, uint32_t *crc32) {
+// host-pointer Deflate; the checksums of the input are taken from its device copy
+static int32_t deflate_host_impl(const uint8_t *in, size_t in_len, int32_t level, int32_t window_bits, uint8_t *out,
+                                 size_t out_cap, size_t *out_len, uint32_t *crc32, uint32_t *adler32) {
   std::lock_guard<std::recursive_mutex> lk(g_mu);
   if (out_len) *out_len = 0;
   if (crc32) *crc32 = 0;
+  if (adler32) *adler32 = 1;
   if (window_bits < 9 || window_bits > 15 || level < 0 || level > 9) return AHIP_OK;  // reference: silent no-op
   if (window_bits != 15) return fail(AHIP_E_UNSUPPORTED, "only windowBits 15 is implemented");
   int32_t rc = ensure_init();
@@ -835,10 +895,32 @@ int32_t ahip_deflate_raw(const uint8_t *in, size_t in_len, int32_t level, int32_
   rc = deflate_device_impl(din.as<u8>(), in_len, level, dout.as<u8>(), bound, &produced, nullptr);
   if (rc != AHIP_OK) return rc;
   if (out_len) *out_len = produced;
-  if (crc32) *crc32 = ahip_crc32(in, in_len, 0);
+  if (crc32) { rc = crc32_device_impl(din.as<u8>(), in_len, 0, crc32, nullptr); if (rc != AHIP_OK) return rc; }
+  if (adler32) { rc = adler32_device_impl(din.as<u8>(), in_len, 1, adler32, nullptr); if (rc != AHIP_OK) return rc; }
   if (produced > out_cap) return fail(AHIP_E_CAP, "output buffer too small");
   if (produced) HIP_TRY(hipMemcpy(out, dout.p, produced, hipMemcpyDeviceToHost));
   return AHIP_OK;
+}
+
+int32_t ahip_deflate_raw(const uint8_t *in, size_t in_len, int32_t level, int32_t window_bits, uint8_t *out,
+                         size_t out_cap, size_t *out_len, uint32_t *crc32) {
+  return deflate_host_impl(in, in_len, level, window_bits, out, out_cap, out_len, crc32, nullptr);
+}
+
+int32_t ahip_crc32_device(const void *d_data, size_t len, uint32_t crc, uint32_t *out, void *stream) {
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  if (!out) return fail(AHIP_E_ARG, "out == NULL");
+  int32_t rc = ensure_init();
+  if (rc != AHIP_OK) return rc;
+  return crc32_device_impl((const u8 *)d_data, len, crc, out, (hipStream_t)stream);
+}
+
+int32_t ahip_adler32_device(const void *d_data, size_t len, uint32_t adler, uint32_t *out, void *stream) {
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  if (!out) return fail(AHIP_E_ARG, "out == NULL");
+  int32_t rc = ensure_init();
+  if (rc != AHIP_OK) return rc;
+  return adler32_device_impl((const u8 *)d_data, len, adler, out, (hipStream_t)stream);
 }
 
 int32_t ahip_gzip_encode(const uint8_t *in, size_t in_len, int32_t level, uint32_t mtime, uint8_t *out, size_t out_cap,
@@ -847,7 +929,7 @@ int32_t ahip_gzip_encode(const uint8_t *in, size_t in_len, int32_t level, uint32
   if (out_cap < 18) { if (out_len) *out_len = ahip_deflate_bound(in_len) + 18; return fail(AHIP_E_CAP, "output buffer too small"); }
   size_t clen = 0;
   uint32_t crc = 0;
-  int32_t rc = ahip_deflate_raw(in, in_len, level, 15, out + 10, out_cap - 18, &clen, &crc);
+  int32_t rc = deflate_host_impl(in, in_len, level, 15, out + 10, out_cap - 18, &clen, &crc, nullptr);
   if (out_len) *out_len = clen + 18;
   if (rc != AHIP_OK) return rc;
   const uint8_t h[10] = {0x1f, 0x8b, 8, 0, (uint8_t)mtime, (uint8_t)(mtime >> 8), (uint8_t)(mtime >> 16), (uint8_t)(mtime >> 24), 0, 0xff};
@@ -861,11 +943,11 @@ int32_t ahip_zlib_encode(const uint8_t *in, size_t in_len, int32_t level, uint8_
   if (out_len) *out_len = 0;
   if (out_cap < 6) { if (out_len) *out_len = ahip_deflate_bound(in_len) + 6; return fail(AHIP_E_CAP, "output buffer too small"); }
   size_t clen = 0;
-  int32_t rc = ahip_deflate_raw(in, in_len, level, 15, out + 2, out_cap - 6, &clen, nullptr);
+  uint32_t a = 1;
+  int32_t rc = deflate_host_impl(in, in_len, level, 15, out + 2, out_cap - 6, &clen, nullptr, &a);
   if (out_len) *out_len = clen + 6;
   if (rc != AHIP_OK) return rc;
   out[0] = 0x78; out[1] = 0x01;
-  const uint32_t a = ahip_adler32(in, in_len, 1);
   uint8_t *t = out + 2 + clen;
   t[0] = (uint8_t)(a >> 24); t[1] = (uint8_t)(a >> 16); t[2] = (uint8_t)(a >> 8); t[3] = (uint8_t)a;
   return AHIP_OK;

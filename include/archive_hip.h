@@ -127,6 +127,10 @@ int32_t ahip_bzip2_decode_device(const void *d_in, size_t in_len, int32_t verify
 /* ---- checksums (ref: util/crc32.dart:6-27, util/adler32.dart:29-52), chainable ---- */
 uint32_t ahip_crc32(const uint8_t *data, size_t len, uint32_t crc /* 0 to start */);
 uint32_t ahip_adler32(const uint8_t *data, size_t len, uint32_t adler /* 1 to start */);
+/* the same two on device-resident data (HIP kernels; used internally for the gzip/zlib trailers of the encoders
+ * and for `verify: true` of the zlib decoder, _zlib_decoder_web.dart:90-99); synchronise `stream` */
+int32_t ahip_crc32_device(const void *d_data, size_t len, uint32_t crc, uint32_t *out, void *stream);
+int32_t ahip_adler32_device(const void *d_data, size_t len, uint32_t adler, uint32_t *out, void *stream);
 
 #ifdef __cplusplus
 }
