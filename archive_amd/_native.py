@@ -18,7 +18,7 @@ EXPORTS = [
     "ahip_inflate_raw", "ahip_gzip_decode", "ahip_zlib_decode",
     "ahip_gzip_decode_device", "ahip_gzip_plan_create", "ahip_gzip_plan_info", "ahip_gzip_plan_run",
     "ahip_gzip_plan_status", "ahip_gzip_plan_destroy", "ahip_debug_plan_results",
-    "ahip_bzip2_decode", "ahip_bzip2_decode_device", "ahip_crc32_device", "ahip_adler32_device", "ahip_deflate_raw", "ahip_gzip_encode", "ahip_zlib_encode", "ahip_deflate_raw_device", "ahip_deflate_bound",
+    "ahip_bzip2_decode", "ahip_bzip2_decode_device", "ahip_crc32_device", "ahip_adler32_device", "ahip_inflate_batch", "ahip_inflate_batch_device", "ahip_deflate_raw", "ahip_gzip_encode", "ahip_zlib_encode", "ahip_deflate_raw_device", "ahip_deflate_bound",
     "ahip_crc32", "ahip_adler32",
 ]
 
@@ -63,6 +63,8 @@ def lib():
     L.ahip_gzip_plan_destroy.argtypes = [vp]; L.ahip_gzip_plan_destroy.restype = None
     L.ahip_debug_plan_results.argtypes = [vp, vp, sz, szp]; L.ahip_debug_plan_results.restype = i32
     L.ahip_bzip2_decode.argtypes = [vp, sz, i32, vp, sz, szp]; L.ahip_bzip2_decode.restype = i32
+    L.ahip_inflate_batch.argtypes = [vp, sz, u32, vp, vp, vp, vp, sz, vp, vp, vp, szp]; L.ahip_inflate_batch.restype = i32
+    L.ahip_inflate_batch_device.argtypes = [vp, sz, u32, vp, vp, vp, vp, sz, vp, vp, vp, szp, vp]; L.ahip_inflate_batch_device.restype = i32
     L.ahip_crc32_device.argtypes = [vp, sz, u32, ctypes.POINTER(u32), vp]; L.ahip_crc32_device.restype = i32
     L.ahip_adler32_device.argtypes = [vp, sz, u32, ctypes.POINTER(u32), vp]; L.ahip_adler32_device.restype = i32
     L.ahip_bzip2_decode_device.argtypes = [vp, sz, i32, vp, sz, szp, vp]; L.ahip_bzip2_decode_device.restype = i32

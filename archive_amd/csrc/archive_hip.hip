@@ -59,7 +59,8 @@ __global__ __launch_bounds__(64) void inflate_tokenize_kernel(const u8 *__restri
     // header scratch lives in the upper part of the window buffer (the staged header bytes use the first 640)
     static_assert(sizeof(HeaderLds) + 1024 <= sizeof(TokLds), "header scratch must fit behind the staged header");
     HeaderLds &hdr = *(HeaderLds *)((u8 *)lds.p.inbuf + 1024);
-    inflate_member<false, true>(lds.w, hdr, &lds.p, slab, in, in_len, d, (u8 *)nullptr, tk, results[m], lane);
+    const u64 lim = uniform64(d.in_end) ? uniform64(d.in_end) : in_len;
+    inflate_member<false, true>(lds.w, hdr, &lds.p, slab, in, lim, d, (u8 *)nullptr, tk, results[m], lane);
   }
 }
 
@@ -97,7 +98,8 @@ __global__ __launch_bounds__(64) void inflate_members_serial_kernel(const u8 *__
   d.in_off = uniform64(d.in_off);
   d.out_off = uniform64(d.out_off);
   d.out_limit = uniform64(d.out_limit);
-  inflate_member<WRITE, false>(lds, hdr, nullptr, nullptr, in, in_len, d, out, nullptr, results[m], lane);
+  const u64 lim = uniform64(d.in_end) ? uniform64(d.in_end) : in_len;
+  inflate_member<WRITE, false>(lds, hdr, nullptr, nullptr, in, lim, d, out, nullptr, results[m], lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -459,7 +461,7 @@ int32_t inflate_one(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool
   static DevBuf dd, dr;
   HIP_TRY(dd.reserve(sizeof(MemberDesc)));
   HIP_TRY(dr.reserve(sizeof(MemberResult)));
-  MemberDesc d{off, 0, out_cap, POS_UNKNOWN};
+  MemberDesc d{off, 0, out_cap, POS_UNKNOWN, 0};
   HIP_TRY(hipMemcpyAsync(dd.p, &d, sizeof d, hipMemcpyHostToDevice, st));
   const u64 one_off[2] = {0, out_cap};
   if (write) HIP_TRY(launch_inflate<true>(d_in, n, dd.as<MemberDesc>(), 1u, d_out, dr.as<MemberResult>(), st, one_off));
@@ -1152,6 +1154,85 @@ int32_t ahip_inflate_raw(const uint8_t *in, size_t in_len, uint8_t *out, size_t 
     HIP_TRY(hipMemcpy(out, dout.p, r.out_len, hipMemcpyDeviceToHost));
   }
   return st;
+}
+
+// Many independent raw DEFLATE streams in one call (the ZIP entry path).  Device-level worker.
+static int32_t inflate_batch_impl(const u8 *d_in, size_t in_len, u32 n, const uint64_t *in_off, const uint64_t *in_size,
+                                  const uint64_t *size_hint, u8 *d_out, size_t out_cap, uint64_t *out_off, uint64_t *out_len,
+                                  int32_t *status, size_t *out_total, hipStream_t st, DevBuf *own_out) {
+  if (out_total) *out_total = 0;
+  if (n == 0) return AHIP_OK;
+  if (!in_off || !in_size || !out_off || !out_len || !status) return fail(AHIP_E_ARG, "NULL entry table");
+  for (u32 i = 0; i < n; ++i)
+    if (in_off[i] > in_len || in_size[i] > in_len - in_off[i]) return fail(AHIP_E_ARG, "entry outside the input");
+  static DevBuf ddesc, dres;
+  std::vector<MemberDesc> md(n);
+  std::vector<MemberResult> res(n);
+  HIP_TRY(ddesc.reserve((size_t)n * sizeof(MemberDesc)));
+  HIP_TRY(dres.reserve((size_t)n * sizeof(MemberResult)));
+  // in_end = 0 means "unbounded", so an empty slice is expressed as a stream starting at the end of the input
+  auto entry_desc = [&](u32 i, u64 ooff, u64 olim) {
+    return in_size[i] ? MemberDesc{in_off[i], ooff, olim, POS_UNKNOWN, in_off[i] + in_size[i]}
+                      : MemberDesc{(u64)in_len, ooff, olim, POS_UNKNOWN, 0};
+  };
+  std::vector<u64> size(n);
+  if (size_hint) {
+    for (u32 i = 0; i < n; ++i) size[i] = size_hint[i];
+  } else {  // sizing run: every entry's true length
+    for (u32 i = 0; i < n; ++i) md[i] = entry_desc(i, 0, ~0ull);
+    HIP_TRY(hipMemcpyAsync(ddesc.p, md.data(), (size_t)n * sizeof(MemberDesc), hipMemcpyHostToDevice, st));
+    HIP_TRY(launch_inflate<false>(d_in, in_len, ddesc.as<MemberDesc>(), n, (u8 *)nullptr, dres.as<MemberResult>(), st));
+    HIP_TRY(hipMemcpyAsync(res.data(), dres.p, (size_t)n * sizeof(MemberResult), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (u32 i = 0; i < n; ++i) size[i] = res[i].out_len;
+  }
+  std::vector<u64> off(n + 1);
+  u64 total = 0;
+  for (u32 i = 0; i < n; ++i) { off[i] = total; total += size[i]; }
+  off[n] = total;
+  if (out_total) *out_total = total;
+  if (total > out_cap) return fail(AHIP_E_CAP, "output buffer too small");
+  if (own_out) { HIP_TRY(own_out->reserve(total + 16)); d_out = own_out->as<u8>(); }
+  for (u32 i = 0; i < n; ++i) md[i] = entry_desc(i, off[i], size[i]);
+  HIP_TRY(hipMemcpyAsync(ddesc.p, md.data(), (size_t)n * sizeof(MemberDesc), hipMemcpyHostToDevice, st));
+  HIP_TRY(launch_inflate<true>(d_in, in_len, ddesc.as<MemberDesc>(), n, d_out, dres.as<MemberResult>(), st, off.data()));
+  HIP_TRY(hipMemcpyAsync(res.data(), dres.p, (size_t)n * sizeof(MemberResult), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipGetLastError());
+  for (u32 i = 0; i < n; ++i) {
+    out_off[i] = off[i];
+    out_len[i] = res[i].out_len;
+    status[i] = res[i].status == MS_CAP ? AHIP_E_CAP : member_status_to_abi(res[i].status);
+  }
+  return AHIP_OK;
+}
+
+int32_t ahip_inflate_batch_device(const void *d_in, size_t in_len, uint32_t n_entries, const uint64_t *in_off,
+                                  const uint64_t *in_size, const uint64_t *size_hint, void *d_out, size_t out_cap,
+                                  uint64_t *out_off, uint64_t *out_len, int32_t *status, size_t *out_total, void *stream) {
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  int32_t rc = ensure_init();
+  if (rc != AHIP_OK) return rc;
+  return inflate_batch_impl((const u8 *)d_in, in_len, n_entries, in_off, in_size, size_hint, (u8 *)d_out, out_cap, out_off,
+                            out_len, status, out_total, (hipStream_t)stream, nullptr);
+}
+
+int32_t ahip_inflate_batch(const uint8_t *in, size_t in_len, uint32_t n_entries, const uint64_t *in_off,
+                           const uint64_t *in_size, const uint64_t *size_hint, uint8_t *out, size_t out_cap,
+                           uint64_t *out_off, uint64_t *out_len, int32_t *status, size_t *out_total) {
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  int32_t rc = ensure_init();
+  if (rc != AHIP_OK) return rc;
+  static DevBuf din, dout;
+  HIP_TRY(din.reserve(in_len + 16));
+  if (in_len) HIP_TRY(hipMemcpy(din.p, in, in_len, hipMemcpyHostToDevice));
+  size_t total = 0;
+  rc = inflate_batch_impl(din.as<u8>(), in_len, n_entries, in_off, in_size, size_hint, nullptr, out_cap, out_off, out_len,
+                          status, &total, nullptr, &dout);
+  if (out_total) *out_total = total;
+  if (rc != AHIP_OK) return rc;
+  if (total) HIP_TRY(hipMemcpy(out, dout.p, total, hipMemcpyDeviceToHost));
+  return AHIP_OK;
 }
 
 }  // extern "C"

@@ -32,6 +32,7 @@ struct MemberDesc {
   u64 out_off;    // byte offset of this member's output window in the output buffer
   u64 out_limit;  // size of that window
   u64 expect_end; // expected reference stream position after the deflate data (~0 = unknown)
+  u64 in_end;     // end of the bytes this stream may read (0 = the end of the whole input): a ZIP entry's slice
 };
 
 struct MemberResult {

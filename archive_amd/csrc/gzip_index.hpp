@@ -208,6 +208,7 @@ __global__ __launch_bounds__(256) void gz_make_sizing_descs(const GzHeader *hdr,
   d.out_off = 0;
   d.out_limit = ~0ull;
   d.expect_end = POS_UNKNOWN;
+  d.in_end = 0;
   descs[i] = d;
 }
 __global__ __launch_bounds__(256) void gz_apply_sizing(GzHeader *hdr, u32 K, const MemberResult *res, u64 n) {
@@ -343,6 +344,7 @@ __global__ __launch_bounds__(1024) void gz_chain(const u64 *cand_pos, const GzHe
       d.out_off = ob + xb - b;
       d.out_limit = h.size;
       d.expect_end = (h.flags & HF_RANGE) ? POS_UNKNOWN : h.next_pos - 8;
+      d.in_end = 0;
       members[m] = d;
       expect_status[m] = h.status;
       if (nxt[i] == K) {  // last member of the chain

@@ -113,6 +113,23 @@ int32_t ahip_deflate_raw_device(const void *d_in, size_t in_len, int32_t level, 
 /* upper bound of the compressed size for in_len input bytes */
 size_t ahip_deflate_bound(size_t in_len);
 
+/* ---- many raw DEFLATE streams in one call: the ZIP entry path ----
+ * ref: codecs/zip/zip_file.dart:184,229,232 -- each compressed entry is `Inflate(bytes, uncompressedSize).getBytes()`
+ * on its own slice of the archive.  Entry i is the slice in[in_off[i], in_off[i] + in_size[i]) (the stream sees the
+ * slice end as end of input, like the reference's InputStream over the sub-list) and is decoded exactly like
+ * ahip_inflate_raw.  size_hint[i] = the directory's uncompressed size (the reference only uses it to size its
+ * buffer; here it sizes entry i's output window: an entry that produces more gets status AHIP_E_CAP and can be
+ * redone alone) or NULL to measure every entry first.  out_off/out_len/status: n_entries elements each, filled on
+ * return; entry i's bytes are out[out_off[i], out_off[i] + out_len[i]).  Returns AHIP_OK when the batch ran (per
+ * entry verdicts in status[]), AHIP_E_CAP with *out_total = required bytes when out_cap is too small. */
+int32_t ahip_inflate_batch(const uint8_t *in, size_t in_len, uint32_t n_entries, const uint64_t *in_off,
+                           const uint64_t *in_size, const uint64_t *size_hint, uint8_t *out, size_t out_cap,
+                           uint64_t *out_off, uint64_t *out_len, int32_t *status, size_t *out_total);
+/* device-resident form: d_in/d_out on the device, the entry tables on the host */
+int32_t ahip_inflate_batch_device(const void *d_in, size_t in_len, uint32_t n_entries, const uint64_t *in_off,
+                                  const uint64_t *in_size, const uint64_t *size_hint, void *d_out, size_t out_cap,
+                                  uint64_t *out_off, uint64_t *out_len, int32_t *status, size_t *out_total, void *stream);
+
 /* ---- BZip2 ----
  * ref: codecs/bzip2_decoder.dart:13-88 `BZip2Decoder().decodeBytes(data, verify: false)`: ONE bzip2
  * stream (the reference returns at the first end-of-stream block); blocks are decoded in parallel.
