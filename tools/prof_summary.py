@@ -44,9 +44,33 @@ def counter_by_kernel(path, counter):
     return {k: (s / n, n) for k, (s, n) in acc.items()}
 
 
+def side_profile(rnd, tag, title, cmd):
+    """kernel-stats table of a secondary workload (gpurun_out/prof_<tag>/ + prof_<tag>.log) -> profiles/"""
+    try:
+        stats_csv = one("prof_%s/**/*kernel_stats.csv" % tag)
+    except SystemExit:
+        return
+    rows = list(csv.DictReader(open(stats_csv)))
+    with open(os.path.join(PROF, "%s_%s_kernel_stats.md" % (rnd, tag)), "w") as f:
+        f.write("# Round %s -- %s (rocprofv3 --kernel-trace --stats)\n\n    %s\n\n" % (rnd[1:].lstrip("0"), title, cmd))
+        f.write("| kernel | calls | avg (ms) | min (ms) | max (ms) | % of GPU time |\n|---|---|---|---|---|---|\n")
+        for r in rows:
+            f.write("| `%s` | %s | %.4f | %.4f | %.4f | %s |\n" % (
+                short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e6, float(r["MinNs"]) / 1e6, float(r["MaxNs"]) / 1e6, r["Percentage"]))
+        log = os.path.join(OUT, "prof_%s.log" % tag)
+        if os.path.exists(log):
+            keep = [ln.rstrip() for ln in open(log) if not ln.startswith(("E2026", "W2026", "I2026")) and "amdgpu.ids" not in ln and ln.strip()]
+            f.write("\nOutput of the profiled command (calls with small inputs are included in the averages above; the\n"
+                    "`max` column is the full-size call):\n\n")
+            for ln in keep[-16:]:
+                f.write("    " + ln + "\n")
+
+
 def main():
     rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
     os.makedirs(PROF, exist_ok=True)
+    side_profile(rnd, "df", "Deflate level 6, 1 GiB log text (config 3)", "python tools/deflate_stats.py 1024")
+    side_profile(rnd, "bz", "BZip2 decode, 384 MiB of wiki-like text in 900k blocks (config 5)", "python tools/bzip2_stats.py 384")
 
     # ---- kernel-trace stats
     stats_csv = one("prof_%s/**/*kernel_stats.csv" % rnd)
