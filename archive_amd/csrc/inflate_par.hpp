@@ -450,25 +450,24 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, u32 *slab, BitCurs
     AHIP_TICK(t_c);
     AHIP_ACC(st.cyc[2], t_b, t_c);
     // ---- pass B rounds: restart from the predecessor's end until the chain is consistent ----
-    int final_upto = 0;
+    // A lane decodes again only when the start it was given last time is no longer its predecessor's end, so
+    // after the first round (every lane once, recording) a round usually keeps one or two lanes busy and the
+    // lock-step loop is as long as THEIR token count, not the longest of 64.  At the fixpoint every lane
+    // started where its predecessor ended and lane 0 started at the true boundary: the chain is the true path
+    // up to the first flagged lane.
+    u32 used_start = lane == 0 ? s0 : ~0u;
     u32 rguard = 0;
     for (;;) {
       if (++rguard > 80) { st.dbg |= 2; break; }
-      u64 flagged = __ballot(R.flags != 0);
-      u64 final_mask = (final_upto >= 63) ? ~0ull : ((2ull << final_upto) - 1);
-      if (flagged & final_mask) break;  // a final lane ended the block (or hit an error)
-      if (final_upto >= 63) break;
       // DPP reads need the SOURCE lane active: take lane-1's values with every lane enabled
       const u32 prev_end = lane_prev(R.end), prev_flags = lane_prev(R.flags);
-      bool act = lane > final_upto && prev_flags == 0;
+      const bool act = lane > 0 && prev_flags == 0 && prev_end != used_start;
+      if (!__any(act)) break;
       LaneRun R2 = run_lane<true>(act, emit, prev_end, boundary, L, M, P.inbuf, slab, lane);
-      bool mism = act && (R2.end != R.end || R2.flags != R.flags);
-      if (act) R = R2;
-      u64 mm = __ballot(mism);
-      int f = mm ? (__ffsll((long long)mm) - 1) : 63;
-      final_upto = f > final_upto ? f : final_upto + 1;
+      if (act) { R = R2; used_start = prev_end; }
       st.rounds++;
     }
+    const int final_upto = 63;
     AHIP_TICK(t_d);
     AHIP_ACC(st.cyc[3], t_c, t_d);
     // ---- who is on the true path ----

@@ -161,7 +161,7 @@ def main():
                 line["roofline"]["traffic_unit"] = ("GB per decode (rocprofv3 FETCH_SIZE+WRITE_SIZE, calibrated, profiles/%s)" % os.path.basename(latest))
         except Exception:
             pass
-        if args.cpu_seconds > 0 and world >= 1:
+        if args.cpu_seconds > 0 and world == 1:  # the CPU baseline is reported at N=1 only
             line["cpu_baseline"] = cpu_baseline(comp, args, out_bytes)
         print(json.dumps(line), flush=True)
     if world > 1:
