@@ -836,7 +836,11 @@ static int32_t deflate_device_impl(const u8 *d_in, size_t n, int level, u8 *d_ou
   HIP_TRY(b_csize.reserve((size_t)P.chunks * 4));
   HIP_TRY(b_coff.reserve((size_t)P.chunks * 8));
   if (!P.store)
-    hipLaunchKernelGGL(deflate_match_kernel, dim3(P.chunks), dim3(256), 0, st, d_in, P, b_match.as<u32>());
+  {
+    if (level <= 3) hipLaunchKernelGGL((deflate_match_kernel<12, 2>), dim3(P.chunks), dim3(256), 0, st, d_in, P, b_match.as<u32>());
+    else if (level <= 6) hipLaunchKernelGGL((deflate_match_kernel<12, 4>), dim3(P.chunks), dim3(256), 0, st, d_in, P, b_match.as<u32>());
+    else hipLaunchKernelGGL((deflate_match_kernel<13, 4>), dim3(P.chunks), dim3(256), 0, st, d_in, P, b_match.as<u32>());
+  }
 #ifdef AHIP_PROFILE
   if (!P.store && getenv("AHIP_DEBUG")) {
     std::vector<u32> pc((size_t)P.chunks * 8);

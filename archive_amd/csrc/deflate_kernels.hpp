@@ -33,13 +33,12 @@ namespace ahip {
 
 constexpr u32 DF_CHUNK = 32768;          // bytes per chunk = one DEFLATE block
 constexpr u32 DF_SLAB = DF_CHUNK + 512;  // per-chunk output slab (a stored block needs CHUNK + 5 + flush)
-#ifndef AHIP_DF_HASH_BITS
-#define AHIP_DF_HASH_BITS 12
-#endif
-#ifndef AHIP_DF_WAYS
-#define AHIP_DF_WAYS 4
-#endif
-constexpr u32 DF_HASH_BITS = AHIP_DF_HASH_BITS, DF_WAYS = AHIP_DF_WAYS;
+// Hash table shape per level group (the reference's level table, deflate.dart:1253-1272, trades chain
+// depth for speed; here the knob is how many window positions the LDS table can index -- measured on the
+// benchmark text, compressed size follows the ENTRY COUNT, not the associativity):
+//   levels 1-3: 4096 x 2 ( 8 K entries, 16 KiB, three workgroups per CU)   fastest
+//   levels 4-6: 4096 x 4 (16 K entries, 32 KiB, two workgroups per CU)
+//   levels 7-9: 8192 x 4 (32 K entries, 64 KiB, one workgroup per CU)      every window position indexed
 constexpr u32 DF_SUB = 256;              // positions probed, then inserted, per step (one workgroup)
 constexpr u32 DF_MINLEN = 4;             // 4-byte hash: 3-byte matches are not searched
 constexpr u32 DF_EMPTY = 0xffff;
@@ -56,7 +55,7 @@ struct DeflateParams {
   u32 max_cmp;  // longest match searched (258)
 };
 
-AHIP_DEVINL u32 df_hash4(u32 w) { return (w * 2654435761u) >> (32 - DF_HASH_BITS); }
+template <u32 HB> AHIP_DEVINL u32 df_hash4(u32 w) { return (w * 2654435761u) >> (32 - HB); }
 
 // ------------------------------------------------------------------------------------------
 // D1: per-position best match
@@ -109,9 +108,11 @@ AHIP_DEVINL void df_match_lens(const u32 *ring, const u32 (&rc)[NW], u32 rp, u32
 AHIP_DEVINL void df_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // match[] holds len << 16 | dist per input position (0 = no match of >= 4 bytes)
+template <u32 DF_HASH_BITS, u32 DF_WAYS>
 __global__ __launch_bounds__(256) void deflate_match_kernel(const u8 *__restrict__ in, DeflateParams P,
                                                             u32 *__restrict__ match) {
   __shared__ u16 tbl[(1u << DF_HASH_BITS) * DF_WAYS];
+  constexpr u32 MERGE = DF_WAYS < 4 ? DF_WAYS : 4;  // history steps inserted per barrier (distinct ways)
   __shared__ u32 ring[(DF_RING + DF_MIRROR) / 4 + 2];
   const u32 chunk = blockIdx.x, tid = threadIdx.x;
   const u64 cstart = (u64)chunk * DF_CHUNK;
@@ -137,16 +138,16 @@ __global__ __launch_bounds__(256) void deflate_match_kernel(const u8 *__restrict
   auto stage = [&](u32 q) { put(q, fetch(q)); };
   stage(4 * tid);  // [0, DF_AHEAD)
   __syncthreads();
-  // History before the chunk is only inserted.  Four consecutive steps write four different ways, so they
-  // are done as one (same table as step by step, a quarter of the barriers).
+  // History before the chunk is only inserted.  Consecutive steps write different ways, so up to four are
+  // done as one (same table as step by step, a quarter of the barriers).
   u32 base = 0;
-  for (; base + 4 * DF_SUB <= dict; base += 4 * DF_SUB) {
-    stage(base + DF_AHEAD + 4 * tid);
+  for (; base + MERGE * DF_SUB <= dict; base += MERGE * DF_SUB) {
+    if (tid < MERGE * 64) stage(base + DF_AHEAD + 4 * tid);
     __syncthreads();  // the last position's 4 bytes reach into what was just staged
 #pragma unroll
-    for (u32 k = 0; k < 4; ++k) {
+    for (u32 k = 0; k < MERGE; ++k) {
       const u32 p = base + k * DF_SUB + tid;  // p + 4 <= wlen: the chunk follows
-      tbl[df_hash4(df_rd4(ring, df_rc(p))) * DF_WAYS + (((base / DF_SUB) + k) & (DF_WAYS - 1))] = (u16)p;
+      tbl[df_hash4<DF_HASH_BITS>(df_rd4(ring, df_rc(p))) * DF_WAYS + (((base / DF_SUB) + k) & (DF_WAYS - 1))] = (u16)p;
     }
     __syncthreads();
   }
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256) void deflate_match_kernel(const u8 *__restrict
     // one long match would each walk (nearly) all of it.  The parse extends the few matches it actually emits.
     u32 maxl = (wlen - p) < P.max_cmp ? (wlen - p) : P.max_cmp;
     maxl = maxl < DF_CAP ? maxl : DF_CAP;
-    if (has4) { w = df_rd4(ring, rp); h = df_hash4(w); }
+    if (has4) { w = df_rd4(ring, rp); h = df_hash4<DF_HASH_BITS>(w); }
     u32 cand[DF_WAYS + 1];
 #pragma unroll
     for (u32 way = 0; way < DF_WAYS; ++way) cand[way] = search ? tbl[h * DF_WAYS + way] : DF_EMPTY;

@@ -10,7 +10,7 @@ from tests import streams
 L = N.lib(); L.ahip_init(0)
 cs = {"text": streams.text(200000, 2), "log": bytes(corpus.text(corpus.LOG, 1234, 0, 1 << 20)), "wiki": bytes(corpus.text(corpus.WIKI, 8, 0, 1 << 20))}
 for name, d in cs.items():
-    for lvl in (1, 6):
+    for lvl in (1, 6, 9):
         ours = len(archive_amd.Deflate(d, level=lvl).get_bytes()); ref = len(orc.deflate_raw(d, lvl)[0])
         print("%-5s L%d ours %8d ref %8d  %+.1f%%  ratio %.3f vs %.3f" % (name, lvl, ours, ref, 100.0 * (ours - ref) / ref, len(d) / ours, len(d) / ref))
 mb = int(sys.argv[1]) if len(sys.argv) > 1 else 256
