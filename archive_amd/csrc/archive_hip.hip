@@ -856,6 +856,17 @@ static int32_t deflate_device_impl(const u8 *d_in, size_t n, int level, u8 *d_ou
                      b_ntok.as<u32>());
   hipLaunchKernelGGL(deflate_encode_kernel, dim3(P.chunks), dim3(256), 0, st, d_in, P, b_tok.as<u32>(), b_ntok.as<u32>(),
                      b_slabs.as<u8>(), b_csize.as<u32>());
+#ifdef AHIP_PROFILE
+  if (!P.store && getenv("AHIP_DEBUG")) {
+    hipStreamSynchronize(st);
+    std::vector<u8> sl((size_t)P.chunks * DF_SLAB);
+    hipMemcpy(sl.data(), b_slabs.p, sl.size(), hipMemcpyDeviceToHost);
+    double s4[4] = {0, 0, 0, 0};
+    for (u32 c = 0; c < P.chunks; ++c) { const u32 *pc = (const u32 *)(sl.data() + (size_t)c * DF_SLAB + DF_SLAB - 32); for (int k = 0; k < 4; ++k) s4[k] += pc[k] * 16.0; }
+    fprintf(stderr, "[ahip] encode kernel cycles per chunk: zero+histogram %.0f  trees+header (one lane) %.0f  size pass %.0f  token rounds %.0f\n",
+            s4[0] / P.chunks, s4[1] / P.chunks, s4[2] / P.chunks, s4[3] / P.chunks);
+  }
+#endif
   std::vector<u32> csize(P.chunks);
   HIP_TRY(hipMemcpyAsync(csize.data(), b_csize.p, (size_t)P.chunks * 4, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));

@@ -307,10 +307,11 @@ constexpr int DF_LCODES = 286, DF_DCODES = 30, DF_BLCODES = 19, DF_HEAP = 573;
 struct EncLds {
   u32 fl[288], fd[32];
   u16 ltree[DF_HEAP * 2], dtree[(2 * DF_DCODES + 1) * 2], bltree[(2 * DF_BLCODES + 1) * 2];
-  u16 heap[DF_HEAP];
-  u8 depth[DF_HEAP];
-  u16 bl_count[16];
-  int heap_len, heap_max;
+  u32 keys[512], iw[512];  // sort keys freq << 9 | symbol; weights of the internal nodes
+  u16 par[1024];           // parent of leaf r (sorted rank) / of internal node m + k
+  u32 bl_count[16];
+  u32 t_m, t_kraft;
+  int t_maxcode;
   u32 opt_len;
   u32 wsum[4];
   u32 run_bits;
@@ -341,103 +342,124 @@ AHIP_DEVINL void df_dist_code(u32 dist, u32 &code, u32 &xb, u32 &xv) {
   xv = d & ((1u << xb) - 1);
 }
 
-struct DfTreeDesc { u16 *tree; int elems, max_length, max_code; const u8 *extra; int extra_base; };
-
-AHIP_DEVINL bool df_smaller(const u16 *tree, int n, int m, const u8 *depth) {
-  return tree[n * 2] < tree[m * 2] || (tree[n * 2] == tree[m * 2] && depth[n] <= depth[m]);
-}
-__device__ inline void df_pqdownheap(EncLds &E, const u16 *tree, int k) {
-  const int v = E.heap[k];
-  int j = k << 1;
-  while (j <= E.heap_len) {
-    if (j < E.heap_len && df_smaller(tree, E.heap[j + 1], E.heap[j], E.depth)) j++;
-    if (df_smaller(tree, v, E.heap[j], E.depth)) break;
-    E.heap[k] = E.heap[j];
-    k = j;
-    j <<= 1;
-  }
-  E.heap[k] = (u16)v;
-}
 AHIP_DEVINL u32 df_bi_reverse(u32 code, int len) { return __brev(code) >> (32 - len); }
 
-// zlib's build_tree / gen_bitlen / gen_codes (deflate.dart:2567-2784), run by ONE lane on LDS arrays.
-__device__ inline void df_build_tree(EncLds &E, DfTreeDesc &d) {
-  u16 *tree = d.tree;
-  int n, m, max_code = -1, node;
-  E.heap_len = 0;
-  E.heap_max = DF_HEAP;
-  for (n = 0; n < d.elems; n++) {
-    if (tree[n * 2] != 0) { E.heap[++E.heap_len] = (u16)(max_code = n); E.depth[n] = 0; }
-    else tree[n * 2 + 1] = 0;
+// Code lengths and codes of one Huffman tree, built by the whole workgroup (256 threads).
+//
+// The reference (deflate.dart:2567-2784 = zlib's build_tree / gen_bitlen / gen_codes) is a heap algorithm run
+// by one thread; on a single lane its ~10^4 dependent LDS accesses cost ~0.3 ms per block and were 83 % of this
+// kernel.  Compressed BYTES are not pinned by the reference, only validity and size, so the
+// same optimal lengths are reached a parallel way:
+//   sort (freq, symbol) ascending (bitonic, in LDS)  ->  two-queue Huffman merge (one lane, ~2 LDS reads per
+//   step, the only serial part)  ->  leaf depths by walking parents (a thread per leaf)  ->  clip to the length
+//   limit and repair the Kraft sum with zlib's own move (one leaf from the deepest non-full level down, one
+//   from the limit up next to it)  ->  hand the multiset of lengths out by frequency rank  ->  canonical codes
+//   (zlib's gen_codes order: by symbol index within a length, bit-reversed).
+// Like zlib, a tree with fewer than two used symbols gets dummy ones so that the code is complete.
+template <int NP>
+__device__ inline void df_build_tree_wg(EncLds &E, u16 *tree, int elems, int max_length, int &max_code_out, u32 tid) {
+  u32 *keys = E.keys;
+  // ---- keys + used count ----
+  if (tid == 0) { E.t_m = 0; E.t_maxcode = -1; E.t_kraft = 0; }
+  for (u32 i = tid; i < 16; i += 256) E.bl_count[i] = 0;
+  __syncthreads();
+  for (u32 i = tid; i < (u32)NP; i += 256) {
+    const bool used = i < (u32)elems && tree[i * 2] != 0;
+    keys[i] = used ? (((u32)tree[i * 2] << 9) | i) : 0xffffffffu;
+    if (i < (u32)elems) tree[i * 2 + 1] = 0;
+    if (used) { atomicAdd(&E.t_m, 1u); atomicMax(&E.t_maxcode, (int)i); }
   }
-  while (E.heap_len < 2) {
-    node = E.heap[++E.heap_len] = (u16)(max_code < 2 ? ++max_code : 0);
-    tree[node * 2] = 1;
-    E.depth[node] = 0;
-  }
-  d.max_code = max_code;
-  for (n = E.heap_len / 2; n >= 1; n--) df_pqdownheap(E, tree, n);
-  node = d.elems;
-  do {
-    n = E.heap[1];
-    E.heap[1] = E.heap[E.heap_len--];
-    df_pqdownheap(E, tree, 1);
-    m = E.heap[1];
-    E.heap[--E.heap_max] = (u16)n;
-    E.heap[--E.heap_max] = (u16)m;
-    tree[node * 2] = (u16)(tree[n * 2] + tree[m * 2]);
-    E.depth[node] = (u8)((E.depth[n] > E.depth[m] ? E.depth[n] : E.depth[m]) + 1);
-    tree[n * 2 + 1] = tree[m * 2 + 1] = (u16)node;
-    E.heap[1] = (u16)node++;
-    df_pqdownheap(E, tree, 1);
-  } while (E.heap_len >= 2);
-  E.heap[--E.heap_max] = E.heap[1];
-  // gen_bitlen
-  int h, bits, overflow = 0;
-  for (bits = 0; bits <= 15; bits++) E.bl_count[bits] = 0;
-  tree[E.heap[E.heap_max] * 2 + 1] = 0;
-  for (h = E.heap_max + 1; h < DF_HEAP; h++) {
-    n = E.heap[h];
-    bits = tree[tree[n * 2 + 1] * 2 + 1] + 1;
-    if (bits > d.max_length) { bits = d.max_length; overflow++; }
-    tree[n * 2 + 1] = (u16)bits;
-    if (n > max_code) continue;
-    E.bl_count[bits]++;
-    int xbits = n >= d.extra_base ? d.extra[n - d.extra_base] : 0;
-    E.opt_len += (u32)tree[n * 2] * (u32)(bits + xbits);
-  }
-  if (overflow > 0) {
-    do {
-      bits = d.max_length - 1;
-      while (E.bl_count[bits] == 0) bits--;
-      E.bl_count[bits]--;
-      E.bl_count[bits + 1] = (u16)(E.bl_count[bits + 1] + 2);
-      E.bl_count[d.max_length]--;
-      overflow -= 2;
-    } while (overflow > 0);
-    for (bits = d.max_length; bits != 0; bits--) {
-      n = E.bl_count[bits];
-      while (n != 0) {
-        m = E.heap[--h];
-        if (m > max_code) continue;
-        if (tree[m * 2 + 1] != bits) {
-          E.opt_len += (u32)((bits - (int)tree[m * 2 + 1]) * (int)tree[m * 2]);
-          tree[m * 2 + 1] = (u16)bits;
-        }
-        n--;
-      }
+  __syncthreads();
+  if (tid == 0) {
+    while (E.t_m < 2) {  // zlib: force at least two codes of non-zero frequency
+      const int node = E.t_maxcode < 2 ? ++E.t_maxcode : 0;
+      tree[node * 2] = 1;
+      keys[node] = (1u << 9) | (u32)node;
+      E.t_m++;
     }
   }
-  // gen_codes
-  u16 next_code[16];
-  u32 code = 0;
-  next_code[0] = 0;
-  for (bits = 1; bits <= 15; bits++) { code = (code + E.bl_count[bits - 1]) << 1; next_code[bits] = (u16)code; }
-  for (n = 0; n <= max_code; n++) {
+  __syncthreads();
+  const int m = (int)E.t_m;
+  max_code_out = E.t_maxcode;
+  // ---- bitonic sort, ascending ----
+  for (u32 k = 2; k <= (u32)NP; k <<= 1) {
+    for (u32 j = k >> 1; j > 0; j >>= 1) {
+      for (u32 t = tid; t < (u32)NP / 2; t += 256) {
+        const u32 i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // index with bit j clear
+        const u32 l = i | j;
+        const u32 a = keys[i], b = keys[l];
+        const bool up = (i & k) == 0;
+        if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  // ---- two-queue merge: leaves 0..m-1 (sorted), internal nodes m..2m-2 in creation (= weight) order ----
+  if (tid == 0) {
+    u32 *iw = E.iw;
+    u16 *par = E.par;
+    int li = 0, ii = 0, ic = 0;
+    u32 lw = keys[0] >> 9, nw = 0xffffffffu;  // heads of the two queues
+    for (int step = 0; step < m - 1; ++step) {
+      u32 w2 = 0;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const bool leaf = li < m && (ii >= ic || lw <= nw);  // ties: the leaf first (smaller depth)
+        if (leaf) { par[li] = (u16)(m + ic); w2 += lw; ++li; lw = li < m ? keys[li] >> 9 : 0xffffffffu; }
+        else { par[m + ii] = (u16)(m + ic); w2 += nw; ++ii; nw = ii < ic ? iw[ii] : 0xffffffffu; }
+      }
+      iw[ic] = w2;
+      if (ii == ic) nw = w2;  // the internal queue was empty: the new node is its head
+      ++ic;
+    }
+  }
+  __syncthreads();
+  // ---- leaf depths (thread per leaf), clipped; level histogram and Kraft sum ----
+  const int root = 2 * m - 2;
+  for (int r = (int)tid; r < m; r += 256) {
+    int d = 0, x = r;
+    while (x != root) { x = E.par[x]; ++d; }
+    if (d > max_length) d = max_length;
+    if (d == 0) d = 1;  // (m >= 2, so this cannot happen; keeps a lone code at length 1)
+    atomicAdd(&E.bl_count[d], 1u);
+    atomicAdd(&E.t_kraft, 1u << (max_length - d));
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int excess = (int)E.t_kraft - (1 << max_length);
+    while (excess > 0 && E.bl_count[max_length] > 0) {
+      int bits = max_length - 1;
+      while (bits > 0 && E.bl_count[bits] == 0) bits--;
+      if (bits == 0) break;
+      E.bl_count[bits]--;
+      E.bl_count[bits + 1] += 2;
+      E.bl_count[max_length]--;
+      excess--;
+    }
+  }
+  __syncthreads();
+  // ---- lengths by frequency rank: the rarest symbols take the longest codes ----
+  for (int r = (int)tid; r < m; r += 256) {
+    int run = 0, len = 1;
+    for (int bits = max_length; bits >= 1; --bits) {
+      const int c = (int)E.bl_count[bits];
+      if (r < run + c) { len = bits; break; }
+      run += c;
+    }
+    tree[(keys[r] & 511) * 2 + 1] = (u16)len;
+  }
+  __syncthreads();
+  // ---- canonical codes ----
+  for (int n = (int)tid; n < elems; n += 256) {
     const int len = tree[n * 2 + 1];
     if (len == 0) continue;
-    tree[n * 2] = (u16)df_bi_reverse(next_code[len]++, len);
+    u32 code = 0;
+    for (int bits = 1; bits <= len; ++bits) code = (code + E.bl_count[bits - 1]) << 1;  // next_code[len]
+    u32 rank = 0;
+    for (int t = 0; t < n; ++t) rank += tree[t * 2 + 1] == len;
+    tree[n * 2] = (u16)df_bi_reverse(code + rank, len);
   }
+  __syncthreads();
 }
 
 // serial LSB-first bit writer into the LDS output image (one lane, before the parallel phase)
@@ -500,6 +522,7 @@ __global__ __launch_bounds__(256) void deflate_encode_kernel(const u8 *__restric
   const u32 nt = ntok[chunk];
   const u32 *t = tok + cstart;
   u8 *slab = slabs + (u64)chunk * DF_SLAB;
+  AHIP_TICK(e0);
   for (u32 i = tid; i < DF_SLAB / 4; i += 256) E.obuf[i] = 0;
   for (u32 i = tid; i < 288; i += 256) E.fl[i] = 0;
   if (tid < 32) E.fd[tid] = 0;
@@ -527,32 +550,35 @@ __global__ __launch_bounds__(256) void deflate_encode_kernel(const u8 *__restric
     for (u32 i = tid; i < 286; i += 256) E.ltree[i * 2] = (u16)E.fl[i];
     if (tid < 30) E.dtree[tid * 2] = (u16)E.fd[tid];
     __syncthreads();
-    // ---- trees + header (one lane) ----
+    AHIP_TICK(e1);
+    // ---- trees (whole workgroup), then run-length scan of the lengths and the header (one lane) ----
+    if (tid == 0) E.ltree[256 * 2] = 1;  // end of block
+    __syncthreads();
+    int l_max_code, d_max_code, b_max_code;
+    df_build_tree_wg<512>(E, E.ltree, DF_LCODES, 15, l_max_code, tid);
+    df_build_tree_wg<32>(E, E.dtree, DF_DCODES, 15, d_max_code, tid);
     if (tid == 0) {
-      E.ltree[256 * 2] = 1;  // end of block
-      E.opt_len = 0;
-      DfTreeDesc ld{E.ltree, DF_LCODES, 15, 0, k_extra_lbits, 257};
-      DfTreeDesc dd{E.dtree, DF_DCODES, 15, 0, k_extra_dbits, 0};
-      DfTreeDesc bd{E.bltree, DF_BLCODES, 7, 0, k_extra_blbits, 0};
-      df_build_tree(E, ld);
-      df_build_tree(E, dd);
-      df_scan_tree(E, E.ltree, ld.max_code);
-      df_scan_tree(E, E.dtree, dd.max_code);
-      df_build_tree(E, bd);
+      df_scan_tree(E, E.ltree, l_max_code);
+      df_scan_tree(E, E.dtree, d_max_code);
+    }
+    __syncthreads();
+    df_build_tree_wg<32>(E, E.bltree, DF_BLCODES, 7, b_max_code, tid);
+    if (tid == 0) {
       int max_blindex;
       for (max_blindex = DF_BLCODES - 1; max_blindex >= 3; max_blindex--)
         if (E.bltree[k_bl_order[max_blindex] * 2 + 1] != 0) break;
       DfBits b{E.obuf, 0};
       df_put(b, (2u << 1) | (last ? 1u : 0u), 3);  // dynamic block, BFINAL on the last chunk
-      df_put(b, (u32)(ld.max_code + 1 - 257), 5);
-      df_put(b, (u32)(dd.max_code + 1 - 1), 5);
+      df_put(b, (u32)(l_max_code + 1 - 257), 5);
+      df_put(b, (u32)(d_max_code + 1 - 1), 5);
       df_put(b, (u32)(max_blindex + 1 - 4), 4);
       for (int r = 0; r <= max_blindex; r++) df_put(b, E.bltree[k_bl_order[r] * 2 + 1], 3);
-      df_send_tree(E, b, E.ltree, ld.max_code);
-      df_send_tree(E, b, E.dtree, dd.max_code);
+      df_send_tree(E, b, E.ltree, l_max_code);
+      df_send_tree(E, b, E.dtree, d_max_code);
       E.run_bits = b.pos;
     }
     __syncthreads();
+    AHIP_TICK(e2);
     // ---- exact size first: a chunk that does not shrink (or would not fit the LDS image) is stored ----
     {
       u32 mybits = 0;
@@ -574,6 +600,10 @@ __global__ __launch_bounds__(256) void deflate_encode_kernel(const u8 *__restric
       const u32 need = (E.run_bits + E.opt_len + E.ltree[256 * 2 + 1] + 3 + 7 + 32 + 7) / 8;
       if (need > clen + 5 || need > DF_SLAB - 16) stored = true;
     }
+    AHIP_TICK(e3);
+#ifdef AHIP_PROFILE
+    if (tid == 0) { u32 *pc = (u32 *)(slab + DF_SLAB - 32); pc[0] = (u32)((e1 - e0) >> 4); pc[1] = (u32)((e2 - e1) >> 4); pc[2] = (u32)((e3 - e2) >> 4); }
+#endif
     if (!stored) {
     // ---- tokens, 256 per round ----
     for (u32 base = 0; base < nt; base += 256) {
@@ -629,6 +659,9 @@ __global__ __launch_bounds__(256) void deflate_encode_kernel(const u8 *__restric
     }
     __syncthreads();
     total_bits = E.run_bits;
+#ifdef AHIP_PROFILE
+    { AHIP_TICK(e4); if (tid == 0) { u32 *pc = (u32 *)(slab + DF_SLAB - 32); pc[3] = (u32)((e4 - e3) >> 4); } }
+#endif
     }
   }
   if (stored) {
