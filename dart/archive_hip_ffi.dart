@@ -17,6 +17,41 @@ typedef _InflateNative = Int32 Function(Pointer<Uint8> input, IntPtr inLen, Poin
 typedef _InflateDart = int Function(
     Pointer<Uint8> input, int inLen, Pointer<Uint8> out, int outCap, Pointer<IntPtr> outLen, Pointer<IntPtr> consumed);
 
+typedef _BatchNative = Int32 Function(
+    Pointer<Uint8> input,
+    IntPtr inLen,
+    Uint32 nEntries,
+    Pointer<Uint64> inOff,
+    Pointer<Uint64> inSize,
+    Pointer<Uint64> sizeHint,
+    Pointer<Uint8> out,
+    IntPtr outCap,
+    Pointer<Uint64> outOff,
+    Pointer<Uint64> outLen,
+    Pointer<Int32> status,
+    Pointer<IntPtr> outTotal);
+typedef _BatchDart = int Function(
+    Pointer<Uint8> input,
+    int inLen,
+    int nEntries,
+    Pointer<Uint64> inOff,
+    Pointer<Uint64> inSize,
+    Pointer<Uint64> sizeHint,
+    Pointer<Uint8> out,
+    int outCap,
+    Pointer<Uint64> outOff,
+    Pointer<Uint64> outLen,
+    Pointer<Int32> status,
+    Pointer<IntPtr> outTotal);
+typedef _EncodeNative = Int32 Function(
+    Pointer<Uint8> input, IntPtr inLen, Int32 level, Pointer<Uint8> out, IntPtr outCap, Pointer<IntPtr> outLen);
+typedef _EncodeDart = int Function(
+    Pointer<Uint8> input, int inLen, int level, Pointer<Uint8> out, int outCap, Pointer<IntPtr> outLen);
+typedef _BzNative = Int32 Function(
+    Pointer<Uint8> input, IntPtr inLen, Int32 verify, Pointer<Uint8> out, IntPtr outCap, Pointer<IntPtr> outLen);
+typedef _BzDart = int Function(
+    Pointer<Uint8> input, int inLen, int verify, Pointer<Uint8> out, int outCap, Pointer<IntPtr> outLen);
+
 class ArchiveHip {
   static const ok = 0, stoppedEarly = 1, rangeError = 2, wouldHang = 3, eCap = -1;
 
@@ -24,6 +59,9 @@ class ArchiveHip {
   late final _DecodeDart _gzip = _lib.lookupFunction<_DecodeNative, _DecodeDart>('ahip_gzip_decode');
   late final _DecodeDart _zlib = _lib.lookupFunction<_DecodeNative, _DecodeDart>('ahip_zlib_decode');
   late final _InflateDart _inflate = _lib.lookupFunction<_InflateNative, _InflateDart>('ahip_inflate_raw');
+  late final _BatchDart _batch = _lib.lookupFunction<_BatchNative, _BatchDart>('ahip_inflate_batch');
+  late final _EncodeDart _zlibEncode = _lib.lookupFunction<_EncodeNative, _EncodeDart>('ahip_zlib_encode');
+  late final _BzDart _bzip2 = _lib.lookupFunction<_BzNative, _BzDart>('ahip_bzip2_decode');
   late final int Function(int) _init =
       _lib.lookupFunction<Int32 Function(Int32), int Function(int)>('ahip_init');
   late final Pointer<Utf8> Function() _lastError =
@@ -81,6 +119,57 @@ class ArchiveHip {
       return _run(data, (i, n, o, c, l) => _inflate(i, n, o, c, l, consumed), sizeHint: uncompressedSize);
     } finally {
       malloc.free(consumed);
+    }
+  }
+
+  /// ZLibEncoder().encodeBytes(data, level: level)  (zlib/_zlib_encoder_web.dart:27-73)
+  Uint8List zlibEncode(List<int> data, {int level = 6}) =>
+      _run(data, (i, n, o, c, l) => _zlibEncode(i, n, level, o, c, l), sizeHint: data.length + data.length ~/ 512 + 128);
+
+  /// BZip2Decoder().decodeBytes(data, verify: verify)  (bzip2_decoder.dart:13-88)
+  Uint8List bzip2Decode(List<int> data, {bool verify = false}) =>
+      _run(data, (i, n, o, c, l) => _bzip2(i, n, verify ? 1 : 0, o, c, l), sizeHint: 8 * data.length + 1024);
+
+  /// All DEFLATE entries of a ZIP archive in one call (zip/zip_file.dart:182-248 does them one by one):
+  /// entry k is archive[offsets[k], offsets[k] + sizes[k]); uncompressedSizes come from the directory.
+  /// Returns the entries' bytes in order; an entry the reference would stop early on keeps what it produced.
+  List<Uint8List> inflateEntries(Uint8List archive, List<int> offsets, List<int> sizes, List<int> uncompressedSizes) {
+    final k = offsets.length;
+    final inp = malloc<Uint8>(archive.isEmpty ? 1 : archive.length);
+    inp.asTypedList(archive.length).setAll(0, archive);
+    final off = malloc<Uint64>(k), sz = malloc<Uint64>(k), hint = malloc<Uint64>(k);
+    final oOff = malloc<Uint64>(k), oLen = malloc<Uint64>(k);
+    final st = malloc<Int32>(k);
+    final total = malloc<IntPtr>();
+    var cap = 0;
+    for (var i = 0; i < k; ++i) {
+      off[i] = offsets[i];
+      sz[i] = sizes[i];
+      hint[i] = uncompressedSizes[i];
+      cap += uncompressedSizes[i];
+    }
+    final out = malloc<Uint8>(cap == 0 ? 1 : cap);
+    try {
+      final rc = _batch(inp, archive.length, k, off, sz, hint, out, cap, oOff, oLen, st, total);
+      if (rc != ok) throw StateError('archive_hip $rc: ${_lastError().toDartString()}');
+      final view = out.asTypedList(cap);
+      return [
+        for (var i = 0; i < k; ++i)
+          if (st[i] == eCap)
+            inflateRaw(archive.sublist(offsets[i], offsets[i] + sizes[i])) // the directory understated it
+          else if (st[i] == rangeError)
+            throw RangeError('archive_hip: entry $i reads before its first byte')
+          else
+            Uint8List.fromList(view.sublist(oOff[i], oOff[i] + oLen[i]))
+      ];
+    } finally {
+      for (final p in [off, sz, hint, oOff, oLen]) {
+        malloc.free(p);
+      }
+      malloc.free(inp);
+      malloc.free(out);
+      malloc.free(st);
+      malloc.free(total);
     }
   }
 }
