@@ -1,0 +1,92 @@
+"""BASELINE.json's full sizes through size-independent properties (the byte-for-byte oracle comparisons run at
+sizes the CPU oracle finishes in seconds; here the checks are checksums and round trips):
+
+  config 4   65 536 gzip members x 64 KiB (4 GiB out): decode verdict, size, and CRC-32 of the 4 GiB taken on the
+             device == CRC-32 of the generator's plain text taken by zlib on the host.
+  config 3   1 GiB of log text, Deflate level 6: the stream inflates to the input through zlib (CRC-32 and length),
+             its size is within the stated tolerance of what the reference's level 6 produces on a sample, and the
+             device CRC-32 of the input equals the host's.
+"""
+import ctypes
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config4_4gib_multimember_crc(native_built):
+    import torch
+    from archive_amd import _native as N
+    from tools import corpus
+    L = N.lib()
+    assert L.ahip_init(0) == 0
+    members, mb = 65536, 65536
+    comp, plain = corpus.make_gzip(kind=corpus.LOG, seed=1234, n_members=members, member_bytes=mb, level=6, bc=True,
+                                   want_plain=True)
+    want_crc = 0
+    for off in range(0, len(plain), 1 << 28):  # zlib.crc32 takes < 4 GiB at a time
+        want_crc = zlib.crc32(plain[off:off + (1 << 28)], want_crc)
+    d_in = torch.from_numpy(comp).cuda()
+    d_out = torch.empty(members * mb + 64, dtype=torch.uint8, device="cuda")
+    olen = ctypes.c_size_t()
+    assert L.ahip_gzip_decode_device(d_in.data_ptr(), d_in.numel(), d_out.data_ptr(), d_out.numel(), ctypes.byref(olen), None) == 0, N.last_error()
+    assert olen.value == members * mb
+    crc = ctypes.c_uint32()
+    assert L.ahip_crc32_device(d_out.data_ptr(), olen.value, 0, ctypes.byref(crc), None) == 0
+    assert crc.value == want_crc
+    # spot diff: first, middle and last member byte for byte
+    for m in (0, members // 2, members - 1):
+        assert bytes(d_out[m * mb:(m + 1) * mb].cpu().numpy()) == bytes(plain[m * mb:(m + 1) * mb])
+
+
+def test_config3_1gib_deflate_roundtrip(native_built):
+    import torch
+    from archive_amd import _native as N
+    from oracle import pyoracle as orc
+    from tools import corpus
+    L = N.lib()
+    assert L.ahip_init(0) == 0
+    n = 1 << 30
+    buf = np.empty(n, dtype=np.uint8)
+    for c in range(n >> 20):
+        corpus.lib().corpus_log_text(1234, c * 16, buf[c << 20:].ctypes.data, 1 << 20)
+    d_in = torch.from_numpy(buf).cuda()
+    d_out = torch.empty(L.ahip_deflate_bound(n), dtype=torch.uint8, device="cuda")
+    olen = ctypes.c_size_t()
+    assert L.ahip_deflate_raw_device(d_in.data_ptr(), n, 6, d_out.data_ptr(), d_out.numel(), ctypes.byref(olen), None) == 0
+    comp = d_out[:olen.value].cpu().numpy().tobytes()
+    # inflates to the input (zlib on the host: streaming, CRC + length)
+    z = zlib.decompressobj(-15)
+    crc, total = 0, 0
+    for off in range(0, len(comp), 1 << 24):
+        piece = z.decompress(comp[off:off + (1 << 24)])
+        crc = zlib.crc32(piece, crc)
+        total += len(piece)
+    tail = z.flush()
+    crc = zlib.crc32(tail, crc)
+    total += len(tail)
+    want_crc = 0
+    for off in range(0, n, 1 << 28):
+        want_crc = zlib.crc32(buf[off:off + (1 << 28)].tobytes(), want_crc)
+    assert total == n and crc == want_crc and z.eof
+    dcrc = ctypes.c_uint32()
+    assert L.ahip_crc32_device(d_in.data_ptr(), n, 0, ctypes.byref(dcrc), None) == 0 and dcrc.value == want_crc
+    # size against the reference's level 6 on the first 4 MiB (the oracle is ~50 s per GiB per thread)
+    sample = buf[:4 << 20].tobytes()
+    ref = len(orc.deflate_raw(sample, 6)[0])
+    so = ctypes.c_size_t()
+    assert L.ahip_deflate_raw_device(d_in.data_ptr(), len(sample), 6, d_out.data_ptr(), d_out.numel(), ctypes.byref(so), None) == 0
+    assert so.value <= ref * 1.10, (so.value, ref)  # <= +10 % at level 6 on the benchmark corpora
+    # the first 64 MiB of the stream's source also survive the HIP inflate (one wave: a single member)
+    piece = 64 << 20
+    po = ctypes.c_size_t()
+    assert L.ahip_deflate_raw_device(d_in.data_ptr(), piece, 6, d_out.data_ptr(), d_out.numel(), ctypes.byref(po), None) == 0
+    u64s = ctypes.c_uint64 * 1
+    back = torch.empty(piece + 64, dtype=torch.uint8, device="cuda")
+    out_off, out_len, status, tot = u64s(), u64s(), (ctypes.c_int32 * 1)(), ctypes.c_size_t()
+    assert L.ahip_inflate_batch_device(d_out.data_ptr(), po.value, 1, u64s(0), u64s(po.value), u64s(piece), back.data_ptr(),
+                                       back.numel(), out_off, out_len, status, ctypes.byref(tot), None) == 0, N.last_error()
+    assert status[0] in (0, 1) and out_len[0] == piece
+    assert torch.equal(back[:piece], d_in[:piece])
