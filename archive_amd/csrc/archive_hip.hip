@@ -181,7 +181,17 @@ hipError_t scratch_reserve(size_t bytes, void **p);
 hipError_t tokens_reserve(size_t bytes, void **p);
 
 // Largest output (bytes) decoded per tokenize/resolve launch pair: its token streams take 4x that.
-constexpr u64 GROUP_OUT_MAX = 6ull << 30;
+// Output bytes decoded per tokenize/resolve launch pair (the token scratch is 4 B per output byte).
+// AHIP_GROUP_OUT_MAX (bytes) shrinks it so that tests can drive the multi-group path with small streams.
+static u64 group_out_max() {
+  static u64 v = 0;
+  if (!v) {
+    const char *e = getenv("AHIP_GROUP_OUT_MAX");
+    v = e && atoll(e) > 0 ? (u64)atoll(e) : (6ull << 30);
+  }
+  return v;
+}
+#define GROUP_OUT_MAX group_out_max()
 
 // members[first .. first+count) with output offsets [out0, out1): tokenize (+ resolve when WRITE)
 template <bool WRITE>
@@ -844,7 +854,7 @@ static int32_t deflate_device_impl(const u8 *d_in, size_t n, int level, u8 *d_ou
 #ifdef AHIP_PROFILE
   if (!P.store && getenv("AHIP_DEBUG")) {
     std::vector<u32> pc((size_t)P.chunks * 8);
-    hipMemcpy(pc.data(), b_match.as<u32>() + n + 16, pc.size() * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(pc.data(), b_match.as<u32>() + n + 16, pc.size() * 4, hipMemcpyDeviceToHost);
     double s[8] = {0};
     for (u32 c = 0; c < P.chunks; ++c) for (int k = 0; k < 8; ++k) s[k] += pc[(size_t)c * 8 + k] * 16.0;
     fprintf(stderr, "[ahip] match kernel cycles per chunk (wave 0): pre-sync %.0f  barriers+insert %.0f  verify %.0f  compare %.0f  "
@@ -858,9 +868,9 @@ static int32_t deflate_device_impl(const u8 *d_in, size_t n, int level, u8 *d_ou
                      b_slabs.as<u8>(), b_csize.as<u32>());
 #ifdef AHIP_PROFILE
   if (!P.store && getenv("AHIP_DEBUG")) {
-    hipStreamSynchronize(st);
+    (void)hipStreamSynchronize(st);
     std::vector<u8> sl((size_t)P.chunks * DF_SLAB);
-    hipMemcpy(sl.data(), b_slabs.p, sl.size(), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(sl.data(), b_slabs.p, sl.size(), hipMemcpyDeviceToHost);
     double s4[4] = {0, 0, 0, 0};
     for (u32 c = 0; c < P.chunks; ++c) { const u32 *pc = (const u32 *)(sl.data() + (size_t)c * DF_SLAB + DF_SLAB - 32); for (int k = 0; k < 4; ++k) s4[k] += pc[k] * 16.0; }
     fprintf(stderr, "[ahip] encode kernel cycles per chunk: zero+histogram %.0f  trees+header (one lane) %.0f  size pass %.0f  token rounds %.0f\n",

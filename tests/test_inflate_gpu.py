@@ -3,6 +3,7 @@ committed golden vectors and size-independent properties."""
 import ctypes
 import gzip
 import hashlib
+import os
 import zlib
 
 import pytest
@@ -10,6 +11,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 from tests import streams  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -177,6 +180,30 @@ def test_false_member_magics_inside_payloads(amd, orc, n_members):
     assert _gz(amd, g) == (0, want)
     if n_members < 100:
         assert orc.gzip_decode(g, cap=len(want) + 8) == (0, want)
+
+
+def test_output_groups(native_built):
+    """Streams larger than one launch's output budget are decoded group by group (6 GiB in production; shrunk here
+    through AHIP_GROUP_OUT_MAX, in a fresh process because the library reads it once)."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, ctypes
+sys.path.insert(0, %r)
+import archive_amd
+from tests import streams
+from tools import corpus
+comp, plain = corpus.make_gzip(n_members=300, want_plain=True)            # 300 x 64 KiB, groups of <= 1 MiB
+st_out = archive_amd.GZipDecoder().decode_bytes(bytes(comp))
+assert st_out == bytes(plain)
+big = streams.text(3000000, 9)                                             # one member larger than a group
+g = streams.gz_member(b"head") + streams.gz_member(big) + streams.gz_member(b"tail")
+assert archive_amd.GZipDecoder().decode_bytes(g) == b"head" + big + b"tail"
+print("groups ok")
+''' % ROOT
+    env = dict(os.environ, AHIP_GROUP_OUT_MAX=str(1 << 20))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "groups ok" in r.stdout, r.stdout + r.stderr
 
 
 def test_device_resident_plan_api(amd):
