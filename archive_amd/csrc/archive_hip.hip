@@ -13,12 +13,14 @@
 #include <string>
 #include <vector>
 
+#include <chrono>
 #include "common.hpp"
 #include "gzip_index.hpp"
 #include "bzip2_kernels.hpp"
 #include "checksum_kernels.hpp"
 #include "deflate_kernels.hpp"
 #include "inflate_par.hpp"
+#include "sm_inflate.hpp"
 
 using namespace ahip;
 
@@ -286,6 +288,8 @@ struct ahip_gzip_plan {
       sizing_results, dsum, drun;
   bool ran = false;
   std::vector<u64> host_out_off;  // M + 1 entries: output offset of every member, then the total
+  struct Big { u32 cand, member; u64 in_off, out_off, out_len; };
+  std::vector<Big> big;           // long members decoded by many waves each (sm_inflate), outside the member launch
   ~ahip_gzip_plan() {
     for (DevBuf *b : {&tile_counts, &tile_offsets, &cand_pos, &hdr, &scratch_u32, &members, &expect_status, &results,
                       &sizing_descs, &sizing_results, &dsum, &drun})
@@ -294,6 +298,11 @@ struct ahip_gzip_plan {
 };
 
 namespace {
+
+int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool write, MemberResult *res, bool *handled,
+                   hipStream_t st);
+int32_t inflate_one_wave(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool write, MemberResult *res, hipStream_t st);
+u64 sm_min_bytes();
 
 // Build (or rebuild with force_sizing) the member index for d_in[start..n).
 int32_t plan_build(ahip_gzip_plan *pl, bool force_sizing, hipStream_t st) {
@@ -335,8 +344,41 @@ int32_t plan_build(ahip_gzip_plan *pl, bool force_sizing, hipStream_t st) {
     HIP_TRY(pl->sizing_results.reserve((size_t)K * sizeof(MemberResult)));
     hipLaunchKernelGGL(gz_make_sizing_descs, dim3(cdiv(K, 256)), dim3(256), 0, st, pl->hdr.as<GzHeader>(), K,
                        pl->sizing_descs.as<MemberDesc>());
+    // Long members (a file that is ONE gzip member is the common case) are measured by many waves each; the
+    // member launch skips them (their descriptor is pointed at the end of the input).
+    pl->big.clear();
+    if (K <= 256 && n >= sm_min_bytes() && !getenv("AHIP_NO_SM")) {
+      std::vector<GzHeader> hh(K);
+      std::vector<u64> cp(K);
+      std::vector<MemberDesc> sd(K);
+      HIP_TRY(hipMemcpyAsync(hh.data(), pl->hdr.p, (size_t)K * sizeof(GzHeader), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(cp.data(), pl->cand_pos.p, (size_t)K * 8, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(sd.data(), pl->sizing_descs.p, (size_t)K * sizeof(MemberDesc), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      for (u32 i = 0; i < K; ++i) {
+        const u64 lim = i + 1 < K ? cp[i + 1] : n;
+        if (!(hh[i].flags & HF_RANGE) && hh[i].payload_off < lim && lim - hh[i].payload_off >= sm_min_bytes()) {
+          pl->big.push_back({i, 0xffffffffu, hh[i].payload_off, 0, 0});
+          sd[i].in_off = n;  // nothing to read: the member launch is done with it at once
+        }
+      }
+      if (!pl->big.empty())
+        HIP_TRY(hipMemcpyAsync(pl->sizing_descs.p, sd.data(), (size_t)K * sizeof(MemberDesc), hipMemcpyHostToDevice, st));
+    }
     HIP_TRY(launch_inflate<false>(in, n, pl->sizing_descs.as<MemberDesc>(), K, (u8 *)nullptr,
                                   pl->sizing_results.as<MemberResult>(), st));
+    u64 covered_until = 0;  // candidates inside a member that has just been measured are false ones: skip them
+    for (auto &bg : pl->big) {
+      if (bg.in_off < covered_until) continue;
+      MemberResult r{};
+      bool handled = false;
+      int32_t rc = sm_inflate(in, n, bg.in_off, nullptr, 0, false, &r, &handled, st);
+      if (rc != AHIP_OK) return rc;
+      if (!handled) { rc = inflate_one_wave(in, n, bg.in_off, nullptr, ~0ull, false, &r, st); if (rc != AHIP_OK) return rc; }
+      HIP_TRY(hipMemcpyAsync(pl->sizing_results.as<MemberResult>() + bg.cand, &r, sizeof r, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      if (r.status == MS_OK) covered_until = r.end_pos;
+    }
     hipLaunchKernelGGL(gz_apply_sizing, dim3(cdiv(K, 256)), dim3(256), 0, st, pl->hdr.as<GzHeader>(), K,
                        pl->sizing_results.as<MemberResult>(), n);
     pl->sized = true;
@@ -352,6 +394,25 @@ int32_t plan_build(ahip_gzip_plan *pl, bool force_sizing, hipStream_t st) {
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipGetLastError());
   if (!pl->sum.first_is_gzip) { pl->sum.members = 0; pl->sum.total_out = 0; pl->sum.tail_pos = start; }
+  if (force_sizing && !pl->big.empty() && pl->sum.members) {
+    // which members are the long ones (false candidates among them never reach the chain); neutralise those
+    // descriptors for the member launch and remember where their output goes
+    std::vector<MemberDesc> md(pl->sum.members);
+    HIP_TRY(hipMemcpy(md.data(), pl->members.p, md.size() * sizeof(MemberDesc), hipMemcpyDeviceToHost));
+    std::vector<ahip_gzip_plan::Big> keep;
+    for (auto bg : pl->big)
+      for (size_t m = 0; m < md.size(); ++m)
+        if (md[m].in_off == bg.in_off) {
+          bg.member = (u32)m; bg.out_off = md[m].out_off; bg.out_len = md[m].out_limit;
+          keep.push_back(bg);
+          md[m].in_off = n;
+          HIP_TRY(hipMemcpy(pl->members.as<MemberDesc>() + m, &md[m], sizeof(MemberDesc), hipMemcpyHostToDevice));
+          break;
+        }
+    pl->big = keep;
+  } else if (!force_sizing) {
+    pl->big.clear();
+  }
   // output offsets on the host: the decode is launched in groups whose token streams fit the scratch
   pl->host_out_off.clear();
   if (pl->sum.members && pl->sum.total_out > GROUP_OUT_MAX) {
@@ -381,6 +442,15 @@ int32_t plan_run(ahip_gzip_plan *pl, u8 *d_out, size_t out_cap, hipStream_t st) 
   HIP_TRY(launch_inflate<true>(pl->d_in, pl->in_len, pl->members.as<MemberDesc>(), M, d_out,
                                pl->results.as<MemberResult>(), st,
                                pl->host_out_off.empty() ? nullptr : pl->host_out_off.data(), whole[1]));
+  for (const auto &bg : pl->big) {  // long members: many waves each, straight into place
+    MemberResult r{};
+    bool handled = false;
+    int32_t rc = sm_inflate(pl->d_in, pl->in_len, bg.in_off, d_out + bg.out_off, bg.out_len, true, &r, &handled, st);
+    if (rc != AHIP_OK) return rc;
+    if (!handled) { rc = inflate_one_wave(pl->d_in, pl->in_len, bg.in_off, d_out + bg.out_off, bg.out_len, true, &r, st); if (rc != AHIP_OK) return rc; }
+    HIP_TRY(hipMemcpyAsync(pl->results.as<MemberResult>() + bg.member, &r, sizeof r, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
   hipLaunchKernelGGL(gz_verify, dim3(cdiv(M, 256)), dim3(256), 0, st, pl->members.as<MemberDesc>(),
                      pl->expect_status.as<u32>(), pl->results.as<MemberResult>(), M, pl->drun.as<RunSummary>());
   HIP_TRY(hipGetLastError());
@@ -466,8 +536,166 @@ static int32_t adler32_device_impl(const u8 *d, size_t n, u32 adler0, u32 *out, 
   return AHIP_OK;
 }
 
+// ---- one long stream on many waves (sm_inflate.hpp) ----
+u64 sm_min_bytes() {
+  static u64 v = 0;
+  if (!v) { const char *e = getenv("AHIP_SM_MIN"); v = e && atoll(e) > 0 ? (u64)atoll(e) : (2ull << 20); }
+  return v;
+}
+static u64 sm_chunk_bytes() {
+  static u64 v = 0;
+  if (!v) { const char *e = getenv("AHIP_SM_CHUNK"); v = e && atoll(e) >= 4096 ? (u64)atoll(e) : (64ull << 10); }
+  return v;
+}
+struct SmPlan {  // what the sizing pass learned, kept for the write pass of the same stream
+  const u8 *d_in = nullptr;
+  u64 n = 0, off = 0;
+  std::vector<u64> cand;        // every candidate block start (bits), sorted
+  std::vector<ChunkDesc> chain; // the chunks on the true path, exact offsets
+  std::vector<MemberResult> sized;
+  u64 total_out = 0, end_pos = 0;
+  u32 blocks = 0;
+  bool valid = false;
+};
+static SmPlan g_sm;
+
+static int sm_resident_waves() {
+  static int v = 0;
+  if (!v) {
+    int dev = 0, cus = 0, a = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 1024;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, sm_tokenize_kernel, 64, 0) != hipSuccess || a < 1) a = 8;
+    v = cus * (a > 1 ? a - 1 : a);
+  }
+  return v;
+}
+
+// *handled = false: not a case for this path (too short, no block found, chain broken, an error inside a chunk) --
+// the caller decodes the stream on one wave, which restates the reference exactly.
+int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool write, MemberResult *res, bool *handled,
+                   hipStream_t st) {
+  *handled = false;
+  if (getenv("AHIP_NO_SM") || n <= off || n - off < sm_min_bytes()) return AHIP_OK;
+  const auto t_start = std::chrono::steady_clock::now();
+  static DevBuf dcand, dchunks, dres, dsym, dwin;
+  const bool dbg = getenv("AHIP_DEBUG") != nullptr;
+  // the plan of a sizing call serves exactly one following write call on the same stream (device buffers are reused
+  // between API calls, so a pointer match alone proves nothing)
+  if (!write || !(g_sm.valid && g_sm.d_in == d_in && g_sm.n == n && g_sm.off == off)) {
+    g_sm = SmPlan{};
+    const u64 cb = sm_chunk_bytes();
+    const u32 n_chunks = (u32)((n - off + cb - 1) / cb);
+    if (n_chunks < 4) return AHIP_OK;
+    HIP_TRY(dcand.reserve((size_t)n_chunks * 8));
+    hipLaunchKernelGGL(sm_find_kernel, dim3(n_chunks - 1), dim3(64), 0, st, d_in, n, off, cb, n_chunks, dcand.as<u64>());
+    std::vector<u64> found(n_chunks);
+    HIP_TRY(hipMemcpyAsync(found.data(), dcand.p, (size_t)n_chunks * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    std::vector<u64> cand;
+    cand.push_back(off * 8);
+    for (u32 k = 1; k < n_chunks; ++k)
+      if (found[k] != ~0ull && found[k] > cand.back()) cand.push_back(found[k]);
+    if (dbg) fprintf(stderr, "[ahip] sm: %u cuts, %zu block starts found\n", n_chunks, cand.size());
+    if (cand.size() < 4) return AHIP_OK;
+    const u32 nc = (u32)cand.size();
+    // sizing: every candidate decodes (no tokens stored) until a block starts on a later candidate
+    std::vector<ChunkDesc> cd(nc);
+    for (u32 i = 0; i < nc; ++i) cd[i] = ChunkDesc{cand[i], 0, 1ull << 62, i ? SM_WINDOW : 0u, 0};
+    HIP_TRY(dcand.reserve((size_t)nc * 8));
+    HIP_TRY(dchunks.reserve((size_t)nc * sizeof(ChunkDesc)));
+    HIP_TRY(dres.reserve((size_t)nc * sizeof(MemberResult)));
+    HIP_TRY(hipMemcpyAsync(dcand.p, cand.data(), (size_t)nc * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dchunks.p, cd.data(), (size_t)nc * sizeof(ChunkDesc), hipMemcpyHostToDevice, st));
+    const u32 grid = nc < (u32)sm_resident_waves() ? nc : (u32)sm_resident_waves();
+    void *sp = nullptr;
+    HIP_TRY(scratch_reserve((size_t)grid * SLAB_WORDS * 4, &sp));
+    hipLaunchKernelGGL(sm_tokenize_kernel, dim3(grid), dim3(64), 0, st, d_in, n, dchunks.as<ChunkDesc>(), nc, dcand.as<u64>(), nc,
+                       (u32 *)nullptr, dres.as<MemberResult>(), (u32 *)sp);
+    std::vector<MemberResult> rs(nc);
+    HIP_TRY(hipMemcpyAsync(rs.data(), dres.p, (size_t)nc * sizeof(MemberResult), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    // the chain of chunks: each ends exactly where the next one starts
+    u32 i = 0;
+    u64 total = 0;
+    for (;;) {
+      const MemberResult &r = rs[i];
+      g_sm.chain.push_back(ChunkDesc{cand[i], total, r.out_len, (u32)(total < SM_WINDOW ? total : SM_WINDOW), 0});
+      g_sm.sized.push_back(r);
+      total += r.out_len;
+      g_sm.blocks += r.blocks;
+      if (r.status == MS_OK) { g_sm.end_pos = r.end_pos; break; }
+      if (r.status != MS_CHUNK_END) { if (dbg) fprintf(stderr, "[ahip] sm: chunk %u ended with status %u: one-wave path\n", i, r.status); return AHIP_OK; }
+      auto it = std::lower_bound(cand.begin(), cand.end(), r.end_pos);
+      if (it == cand.end() || *it != r.end_pos || (u32)(it - cand.begin()) <= i) return fail(AHIP_E_DEVICE, "internal: chunk chain broken");
+      i = (u32)(it - cand.begin());
+    }
+    g_sm.cand = cand;
+    g_sm.total_out = total;
+    g_sm.d_in = d_in; g_sm.n = n; g_sm.off = off;
+    g_sm.valid = true;
+    if (dbg) fprintf(stderr, "[ahip] sm: %zu chunks on the chain, %llu bytes out (find + sizing + chain: %.2f ms)\n", g_sm.chain.size(),
+                     (unsigned long long)total, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
+  }
+  *res = MemberResult{};
+  res->status = MS_OK;
+  res->out_len = g_sm.total_out;
+  res->end_pos = g_sm.end_pos;
+  res->blocks = g_sm.blocks;
+  if (!write) { *handled = true; return AHIP_OK; }
+  if (g_sm.total_out > out_cap) { res->status = MS_CAP; *handled = true; return AHIP_OK; }
+  // ---- tokens (exact offsets), symbols, windows, bytes ----
+  const u32 nch = (u32)g_sm.chain.size(), nc = (u32)g_sm.cand.size();
+  const u64 total = g_sm.total_out;
+  void *tp = nullptr, *sp = nullptr;
+  HIP_TRY(tokens_reserve((size_t)total * 4 + 64, &tp));
+  HIP_TRY(dsym.reserve((size_t)total * 2 + 64));
+  HIP_TRY(dwin.reserve((size_t)nch * SM_WINDOW));
+  HIP_TRY(dcand.reserve((size_t)nc * 8));
+  HIP_TRY(dchunks.reserve((size_t)nch * sizeof(ChunkDesc)));
+  HIP_TRY(dres.reserve((size_t)nch * sizeof(MemberResult)));
+  HIP_TRY(hipMemcpyAsync(dcand.p, g_sm.cand.data(), (size_t)nc * 8, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(dchunks.p, g_sm.chain.data(), (size_t)nch * sizeof(ChunkDesc), hipMemcpyHostToDevice, st));
+  const u32 grid = nch < (u32)sm_resident_waves() ? nch : (u32)sm_resident_waves();
+  HIP_TRY(scratch_reserve((size_t)grid * SLAB_WORDS * 4, &sp));
+  hipLaunchKernelGGL(sm_tokenize_kernel, dim3(grid), dim3(64), 0, st, d_in, n, dchunks.as<ChunkDesc>(), nch, dcand.as<u64>(), nc,
+                     (u32 *)tp, dres.as<MemberResult>(), (u32 *)sp);
+  std::vector<MemberResult> rs(nch);
+  HIP_TRY(hipMemcpyAsync(rs.data(), dres.p, (size_t)nch * sizeof(MemberResult), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipGetLastError());
+  for (u32 i = 0; i < nch; ++i)
+    if (rs[i].status != g_sm.sized[i].status || rs[i].out_len != g_sm.sized[i].out_len || rs[i].end_pos != g_sm.sized[i].end_pos) {
+      // e.g. a back-reference into the void in front of the stream that the permissive sizing pass let through
+      if (dbg) fprintf(stderr, "[ahip] sm: chunk %u differs from its sizing run (status %u vs %u): one-wave path\n", i, rs[i].status, g_sm.sized[i].status);
+      g_sm.valid = false;
+      return AHIP_OK;
+    }
+  hipLaunchKernelGGL(sm_resolve_kernel, dim3(grid), dim3(64), 0, st, d_in, dchunks.as<ChunkDesc>(), nch, dsym.as<u16>(), (const u32 *)tp,
+                     dres.as<MemberResult>());
+  hipLaunchKernelGGL(sm_windows_kernel, dim3(1), dim3(1024), 0, st, dchunks.as<ChunkDesc>(), dres.as<MemberResult>(), nch, dsym.as<u16>(),
+                     dwin.as<u8>());
+  hipLaunchKernelGGL(sm_translate_kernel, dim3(32, nch), dim3(256), 0, st, dchunks.as<ChunkDesc>(), dres.as<MemberResult>(), dsym.as<u16>(),
+                     dwin.as<u8>(), d_out);
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipGetLastError());
+  g_sm.valid = false;
+  *handled = true;
+  if (dbg) fprintf(stderr, "[ahip] sm: write pass %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
+  return AHIP_OK;
+}
+
+int32_t inflate_one_wave(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool write, MemberResult *res, hipStream_t st);
 int32_t inflate_one(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool write, MemberResult *res,
                     hipStream_t st) {
+  bool handled = false;
+  int32_t rc = sm_inflate(d_in, n, off, d_out, out_cap, write, res, &handled, st);
+  if (rc != AHIP_OK) return rc;
+  if (handled) return AHIP_OK;
+  return inflate_one_wave(d_in, n, off, d_out, out_cap, write, res, st);
+}
+int32_t inflate_one_wave(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool write, MemberResult *res, hipStream_t st) {
   static DevBuf dd, dr;
   HIP_TRY(dd.reserve(sizeof(MemberDesc)));
   HIP_TRY(dr.reserve(sizeof(MemberResult)));

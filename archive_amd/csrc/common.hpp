@@ -25,6 +25,7 @@ enum : u32 {
   MS_CAP = 16,      // member wanted to write past its output window
   MS_FARREF = 17,   // back-reference reaches before this member's first byte
   MS_OVERSUB = 18,  // over-subscribed Huffman code lengths (not reproduced)
+  MS_CHUNK_END = 19, // chunked single-stream decode: stopped at the next chunk's first block (end_pos is a BIT position)
 };
 
 struct MemberDesc {
@@ -33,6 +34,23 @@ struct MemberDesc {
   u64 out_limit;  // size of that window
   u64 expect_end; // expected reference stream position after the deflate data (~0 = unknown)
   u64 in_end;     // end of the bytes this stream may read (0 = the end of the whole input): a ZIP entry's slice
+};
+
+// Chunked decode of ONE long stream (sm_inflate): a chunk starts at a block header found by the block finder
+// (any bit offset), may refer to `hist` bytes of output before its own, and stops in front of the first block
+// that starts at one of the candidate positions.
+struct ChunkDesc {
+  u64 start_bit;  // absolute bit position of the chunk's first block header
+  u64 out_off;    // token-stream / output offset (in elements) of the chunk
+  u64 out_limit;  // output window size
+  u32 hist;       // bytes of earlier output a back-reference may reach into (<= 32768)
+  u32 pad;
+};
+struct ChunkCtx {
+  const u64 *cand_bits;  // sorted candidate block-start bit positions
+  u32 n_cand;
+  u32 start_bit;         // 0..7 within the first byte
+  u32 hist;
 };
 
 struct MemberResult {

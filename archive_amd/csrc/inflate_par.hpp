@@ -64,12 +64,24 @@ struct TokLds {
   u32 inbuf[IN_DWORDS] __attribute__((aligned(16)));
 };
 // LDS of the resolver: token queue, output window, start-slot rows
-struct ParLds {
+// E = u8: bytes.  E = u16: symbols of the chunked single-stream decode -- a byte value, or 0x8000 + j for "byte j
+// of the 32 KiB of output in front of this chunk" (not known yet when the chunk is resolved).
+template <typename E>
+struct ParLdsT {
   u32 tok[TOK_CAP];
-  u8 obuf[OB_CAP + 32] __attribute__((aligned(16)));
+  E obuf[OB_CAP + 32] __attribute__((aligned(16)));
   u32 slot[3 * 64];  // two alternating 64-entry start-slot rows + one dump row
   u32 misc[4];       // [0] index of the first stored-run record in the current batch
 };
+using ParLds = ParLdsT<u8>;
+constexpr u32 SYM_MARK = 0x8000;
+// history element at window-relative offset si < 0; opos = elements of this chunk in front of the window
+template <typename E>
+AHIP_DEVINL u32 hist_get(const E *hist, i32 si, u64 opos) {
+  if (sizeof(E) == 1) return hist[si];
+  const i64 a = (i64)opos + si;
+  return a >= 0 ? (u32)hist[si] : (u32)(SYM_MARK + 32768 + a);
+}
 
 constexpr u32 TK_STORED = 0x60000000u;  // | len (3..65535), followed by two words: absolute input byte offset lo, hi
 
@@ -242,8 +254,9 @@ struct GroupFront {
   bool act, lit;
   bool pre;   // byte of a far match already deposited into the window by pass 1
 };
-AHIP_DEVINL GroupFront resolve_front(ParLds &P, u32 ntok, u32 nbytes, const u8 *hist, u32 g0, u32 &tcur, u32 &carry,
-                                     int lane) {
+template <typename E>
+AHIP_DEVINL GroupFront resolve_front(ParLdsT<E> &P, u32 ntok, u32 nbytes, const E *hist, u64 opos, u32 g0, u32 &tcur,
+                                     u32 &carry, int lane) {
   u32 *slot = P.slot + ((g0 >> 6) & 1) * 64;  // two slot arrays alternate: no write-after-read stall
   wave_sync();
   slot[lane] = 0;
@@ -268,11 +281,12 @@ AHIP_DEVINL GroupFront resolve_front(ParLds &P, u32 ntok, u32 nbytes, const u8 *
   f.val = key & 0xff;
   f.si = f.pre ? (i32)x : (i32)x - (i32)((key & 0x7fff) + 1);
 #ifndef AHIP_ABLATE_FAR
-  if (f.act && !f.lit && f.si < 0) f.val = hist[f.si];  // far sources pass 1 did not take (long, or too close to the window)
+  if (f.act && !f.lit && f.si < 0) f.val = hist_get(hist, f.si, opos);  // far sources pass 1 did not take (long, or too close to the window)
 #endif
   return f;
 }
-AHIP_DEVINL void resolve_back(ParLds &P, const GroupFront &f, u32 g0, u8 *ob, int lane) {
+template <typename E>
+AHIP_DEVINL void resolve_back(ParLdsT<E> &P, const GroupFront &f, u32 g0, E *ob, int lane) {
   u32 val = f.val;
   const bool copy = f.act && !f.lit;
   wave_sync();  // bytes of earlier groups were stored by other lanes
@@ -292,17 +306,18 @@ AHIP_DEVINL void resolve_back(ParLds &P, const GroupFront &f, u32 g0, u8 *ob, in
       }
     } while (__any(!res) && ++guard < 8);
   }
-  if (f.act && !f.pre) ob[g0 + lane] = (u8)val;
+  if (f.act && !f.pre) ob[g0 + lane] = (E)val;
 }
 // pass 2 of the resolver: keys are already in the queue (resolve_member builds them)
-AHIP_DEVINL void resolve_bytes(ParLds &P, u32 ntok, u32 nbytes, const u8 *hist, u32 A, int lane) {
-  u8 *ob = P.obuf + A;
+template <typename E>
+AHIP_DEVINL void resolve_bytes(ParLdsT<E> &P, u32 ntok, u32 nbytes, const E *hist, u64 opos, u32 A, int lane) {
+  E *ob = P.obuf + A;
   u32 tcur = 0, carry = 0;
   if (nbytes == 0 || nbytes > (u32)OB_CAP || ntok > (u32)TOK_CAP) return;  // never spin on corrupt bookkeeping
-  GroupFront cur = resolve_front(P, ntok, nbytes, hist, 0, tcur, carry, lane);
+  GroupFront cur = resolve_front(P, ntok, nbytes, hist, opos, 0, tcur, carry, lane);
   u32 g0 = 0;
   for (; g0 + 64 < nbytes; g0 += 64) {  // front of the next group and back of this one: one straight-line body
-    GroupFront nxt = resolve_front(P, ntok, nbytes, hist, g0 + 64, tcur, carry, lane);
+    GroupFront nxt = resolve_front(P, ntok, nbytes, hist, opos, g0 + 64, tcur, carry, lane);
     resolve_back(P, cur, g0, ob, lane);
     cur = nxt;
   }
@@ -312,6 +327,9 @@ AHIP_DEVINL void resolve_bytes(ParLds &P, u32 ntok, u32 nbytes, const u8 *hist, 
 // Flush the assembled window to HBM: byte head up to 16-byte alignment, 16-byte body, byte tail.
 // obuf index A + i holds output byte i, with A = (address of byte 0) & 15, so LDS and global
 // addresses are congruent mod 16.
+AHIP_DEVINL void flush_window(const ParLdsT<u16> &P, u16 *g, u32 A, u32 n, int lane) {  // symbols: plain copy
+  for (u32 i = lane; i < n; i += 64) g[i] = P.obuf[A + i];
+}
 AHIP_DEVINL void flush_window(const ParLds &P, u8 *g, u32 A, u32 nbytes, int lane) {
   u32 head = (16 - A) & 15;
   if (head > nbytes) head = nbytes;
@@ -534,16 +552,26 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, u32 *slab, BitCurs
 // Inflate one stream.  Mirrors Inflate._inflate(): loop blocks until BFINAL, an error, or EOS.
 //  PAR = false: the serial byte-writing decoder (A/B baseline, single kernel).
 //  PAR = true : tokenizer -- no bytes are written; tokens go to `tokens` (nullptr = sizing run).
-template <bool WRITE, bool PAR>
+//  CHUNK = true: one chunk of a long stream (ChunkCtx): bit-granular start, `hist` bytes of earlier output count
+//  as already produced (so the back-reference range check holds across the chunk boundary), and the loop stops
+//  in front of a block header that sits on a candidate position; end_pos is then reported in BITS.
+template <bool WRITE, bool PAR, bool CHUNK = false>
 AHIP_DEVINL void inflate_member(WaveLds &L, HeaderLds &H, TokLds *P, u32 *slab, const u8 *in, u64 in_len,
-                                const MemberDesc &m, u8 *out, u32 *tokens, MemberResult &res, int lane) {
+                                const MemberDesc &m, u8 *out, u32 *tokens, MemberResult &res, int lane,
+                                const ChunkCtx *cx = nullptr) {
   ParStats st{};
-  BitCursor b{in, in_len, in_len * 8, m.in_off * 8, nullptr, 0, 0};
-  OutCursor o{out + m.out_off, 0, m.out_limit};
+  BitCursor b{in, in_len, in_len * 8, m.in_off * 8 + (CHUNK ? cx->start_bit : 0u), nullptr, 0, 0};
+  const u64 hist = CHUNK ? cx->hist : 0u;
+  OutCursor o{out + m.out_off, hist, m.out_limit + hist};
   TokSink sink{tokens, 0};
   u32 status = MS_EOS, blocks = 0;
   for (;;) {
     if (((b.pos + 7) >> 3) >= in_len) { status = MS_EOS; break; }
+    if (CHUNK && blocks) {  // a later chunk takes over at this block?
+      u32 lo = 0, hi = cx->n_cand;
+      while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (cx->cand_bits[mid] < b.pos) lo = mid + 1; else hi = mid; }
+      if (lo < cx->n_cand && cx->cand_bits[lo] == b.pos) { status = MS_CHUNK_END; break; }
+    }
     int hdr = read_bits(b, 3);
     ++blocks;
     const bool final_block = hdr & 1;
@@ -593,7 +621,8 @@ AHIP_DEVINL void inflate_member(WaveLds &L, HeaderLds &H, TokLds *P, u32 *slab, 
     u64 end = (b.pos + 7) >> 3;
     if (status == MS_FALSE_EOS) { end = in_len; status = MS_FALSE; }  // every byte was pulled into the accumulator
     res.end_pos = end > in_len ? in_len : end;
-    res.out_len = o.pos;
+    if (CHUNK && status == MS_CHUNK_END) res.end_pos = b.pos;
+    res.out_len = o.pos - hist;
     res.status = status;
     res.blocks = blocks;
     res.windows = st.windows;
@@ -609,7 +638,9 @@ AHIP_DEVINL void inflate_member(WaveLds &L, HeaderLds &H, TokLds *P, u32 *slab, 
 // ------------------------------------------------------------------------------------------
 // Resolver side: replay one member's token stream into its output window
 // ------------------------------------------------------------------------------------------
-AHIP_DEVINL void resolve_member(ParLds &P, const u8 *in, const u32 *tokens, u64 nwords, u8 *out_base, u32 *cyc, int lane) {
+template <typename E>
+AHIP_DEVINL void resolve_member(ParLdsT<E> &P, const u8 *in, const u32 *tokens, u64 nwords, E *out_base, u32 *cyc, int lane) {
+  constexpr bool MARK = sizeof(E) == 2;
   u64 cur = 0, opos = 0;
   if (lane == 0) P.misc[0] = 0xffffffffu;
   wave_sync();
@@ -631,7 +662,7 @@ AHIP_DEVINL void resolve_member(ParLds &P, const u8 *in, const u32 *tokens, u64 
       // stored run at the head: input -> output copy
       const u32 len = P.tok[0] & 0xffff;
       const u64 src = (u64)P.tok[1] | ((u64)P.tok[2] << 32);
-      for (u32 i = lane; i < len; i += 64) out_base[opos + i] = in[src + i];
+      for (u32 i = lane; i < len; i += 64) out_base[opos + i] = (E)in[src + i];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       opos += len;
       cur += 3;
@@ -645,9 +676,9 @@ AHIP_DEVINL void resolve_member(ParLds &P, const u8 *in, const u32 *tokens, u64 
     // ---- pass 1 (keys) with the byte cut at OB_CAP; matches whose whole source is flushed history (and
     //      at most 16 bytes long) are fetched per TOKEN with two 8-byte loads and deposited into the window
     //      right here -- one vector-memory instruction per 64 tokens instead of one byte gather per 64 bytes ----
-    u8 *g = out_base + opos;
-    const u32 A = (u32)((uintptr_t)g & 15);
-    u8 *obw = P.obuf + A;
+    E *g = out_base + opos;
+    const u32 A = MARK ? 0u : (u32)((uintptr_t)g & 15);
+    E *obw = P.obuf + A;
     // software-pipelined by one chunk of 64 tokens: the history loads of chunk c+1 are in flight while
     // chunk c is deposited
     struct Chunk { u32 idx, len, off, key, total, nf, nin; bool fits, pre, cut; u64 w0, w1; };
@@ -662,13 +693,9 @@ AHIP_DEVINL void resolve_member(ParLds &P, const u8 *in, const u32 *tokens, u64 
       q.fits = inb && q.off + q.len <= (u32)OB_CAP;
       q.key = (1u << 30) | (q.off << 17) | (lit ? (0x10000u | (t & 0xff)) : ((t & 0xffff) - 1));
       const i32 srel = (i32)q.off - (i32)(t & 0xffff);  // source start relative to the window
-      q.pre = q.fits && !lit && q.len <= 16 && srel + 16 <= 0;
+      q.pre = !MARK && q.fits && !lit && q.len <= 16 && srel + 16 <= 0;  // (symbols take the per-element path)
       q.w0 = q.w1 = 0;
-#ifndef AHIP_NO_FAR_DEPOSIT
-      if (q.pre) { const u8 *sp = g + srel; q.w0 = load_u64_unaligned(sp); q.w1 = load_u64_unaligned(sp + 8); }
-#else
-      q.pre = false;
-#endif
+      if (q.pre) { const u8 *sp = (const u8 *)g + srel; q.w0 = load_u64_unaligned(sp); q.w1 = load_u64_unaligned(sp + 8); }
       const u64 fm = __ballot(q.fits), im = __ballot(inb);
       q.nf = (u32)__popcll(fm);
       q.nin = (u32)__popcll(im);
@@ -682,10 +709,10 @@ AHIP_DEVINL void resolve_member(ParLds &P, const u8 *in, const u32 *tokens, u64 
       Chunk nxt = ck;
       if (more) nxt = prep(c + 64, run + ck.total);
       if (ck.pre) {
-        u8 *dp = obw + ck.off;
+        E *dp = obw + ck.off;
 #pragma unroll
         for (u32 k = 0; k < 16; ++k)
-          if (k < ck.len) dp[k] = (u8)((k < 8 ? ck.w0 : ck.w1) >> (8 * (k & 7)));
+          if (k < ck.len) dp[k] = (E)(u8)((k < 8 ? ck.w0 : ck.w1) >> (8 * (k & 7)));
       }
       if (ck.fits) P.tok[ck.idx] = ck.key | (ck.pre ? 0x8000u : 0u);
       if (ck.cut) {
@@ -704,7 +731,7 @@ AHIP_DEVINL void resolve_member(ParLds &P, const u8 *in, const u32 *tokens, u64 
     AHIP_TICK(t_1);
     AHIP_ACC(cyc[6], t_0, t_1);
     const u32 nbytes = run;
-    resolve_bytes(P, ntok, nbytes, g, A, lane);
+    resolve_bytes(P, ntok, nbytes, (const E *)g, opos, A, lane);
     wave_sync();
     AHIP_TICK(t_2);
     AHIP_ACC(cyc[5], t_1, t_2);

@@ -1,0 +1,259 @@
+// sm_inflate.hpp -- ONE long DEFLATE stream decoded by many waves.
+//
+// The reference (lib/src/codecs/zlib/inflate.dart) walks a stream block after block; nothing in the format
+// says where a block starts, and a back-reference may reach 32 KiB into what the previous block produced.
+// Multi-member input side-steps both (members are independent).  For a single long stream:
+//
+//   S1 sm_find_kernel      the compressed data is cut every `chunk_bytes`; one wave per cut looks for the first
+//                          DYNAMIC block header behind it: 64 bit positions per step pass a cheap filter (BTYPE,
+//                          HLIT/HDIST range, complete code-length code), survivors get the full header parse and
+//                          table build the decoder itself uses.  Stored / fixed blocks are not searched; a cut
+//                          without a find simply extends the previous chunk.
+//   S2 sm_tokenize_kernel  the ordinary tokenizer (inflate_member<.., CHUNK>) from each find to the block that
+//                          starts on the next find.  Run twice: sizes first (a false find decodes garbage and is
+//                          dropped when the host follows the chain of ends == starts), then recording tokens at
+//                          exact offsets.  A back-reference may reach `hist` bytes in front of its chunk.
+//   S3 sm_resolve_kernel   the ordinary resolver on 16-bit symbols: a byte, or a marker "byte j of the 32 KiB in
+//                          front of this chunk" for what is not known yet.
+//   S4 sm_windows_kernel   chunk after chunk, the last 32 KiB of each chunk are made concrete with the window of
+//                          the chunk before (the only serial step: 32 K look-ups per chunk, one workgroup).
+//   S5 sm_translate_kernel every chunk turns its symbols into bytes with its (now known) window.
+//
+// Anything unexpected (no finds, a broken chain, an error status inside a chunk) makes the host fall back to the
+// one-wave path, which restates the reference exactly; so malformed streams keep their reference verdicts.
+#pragma once
+#include "inflate_par.hpp"
+
+namespace ahip {
+
+constexpr u32 SM_WINDOW = 32768;
+
+struct SmLds {
+  WaveLds w;
+  TokLds p;
+};
+
+// bits [q, q + 64) of the stream (zero past the end)
+AHIP_DEVINL u64 sm_bits64(const u8 *in, u64 in_len, u64 q) {
+  const u64 byte = q >> 3;
+  u64 lo = 0, hi = 0;
+  if (byte + 16 <= in_len) { lo = load_u64_unaligned(in + byte); hi = load_u64_unaligned(in + byte + 8); }
+  else {
+    for (u32 k = 0; k < 8; ++k) { if (byte + k < in_len) lo |= (u64)in[byte + k] << (8 * k); if (byte + 8 + k < in_len) hi |= (u64)in[byte + 8 + k] << (8 * k); }
+  }
+  const u32 s = (u32)q & 7;
+  return s ? (lo >> s) | (hi << (64 - s)) : lo;
+}
+
+// Second filter, one candidate per lane: build the code-length code (canonical, LSB-first table like the
+// reference's), run-length decode the HLIT + HDIST code lengths and keep only headers whose literal/length code
+// has an end-of-block code and is complete and whose distance code is complete or has at most one code -- what
+// every compressor writes and random bits almost never do.  Nothing is stored: only the Kraft sums are kept.
+AHIP_DEVINL bool sm_header_plausible(const u8 *in, u64 in_len, u64 q, u8 *tab /* this lane's 128 entries */) {
+  const u64 v = sm_bits64(in, in_len, q);
+  const u32 hlit = ((u32)(v >> 3) & 31) + 257, hdist = ((u32)(v >> 8) & 31) + 1, ncl = ((u32)(v >> 13) & 15) + 4;
+  const u64 w = sm_bits64(in, in_len, q + 17);
+  // position of symbol s in the transmitted order 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
+  const u8 inv[19] = {3, 17, 15, 13, 11, 9, 7, 5, 4, 6, 8, 10, 12, 14, 16, 18, 0, 1, 2};
+  u32 code = 0;
+  for (u32 bl = 1; bl <= 7; ++bl) {
+#pragma unroll
+    for (u32 sym = 0; sym < 19; ++sym) {
+      const u32 l = inv[sym] < ncl ? (u32)(w >> (3 * inv[sym])) & 7 : 0u;
+      if (l == bl) {
+        const u32 rev = __brev(code) >> (32 - bl);
+        for (u32 j = rev; j < 128; j += 1u << bl) tab[j] = (u8)((bl << 5) | sym);
+        ++code;
+      }
+    }
+    code <<= 1;
+  }
+  const u32 total = hlit + hdist;
+  const u64 end_bits = in_len * 8;
+  u64 pos = q + 17 + 3 * ncl;
+  u64 buf = 0;
+  u32 have = 0, idx = 0, prev = 0, kl = 0, kd = 0, nd = 0;
+  bool eob = false;
+  while (idx < total) {
+    if (have < 16) { if (pos + 16 > end_bits) return false; buf = sm_bits64(in, in_len, pos); have = 64; }
+    const u32 e = tab[(u32)buf & 127];
+    u32 len = e >> 5;
+    const u32 sym = e & 31;
+    if (len == 0) return false;
+    u32 rep = 1, val = sym;
+    if (sym >= 16) {
+      const u32 xb = sym == 16 ? 2u : (sym == 17 ? 3u : 7u);
+      const u32 x = (u32)(buf >> len) & ((1u << xb) - 1);
+      len += xb;
+      if (sym == 16) { if (idx == 0) return false; rep = 3 + x; val = prev; }
+      else { rep = (sym == 17 ? 3u : 11u) + x; val = 0; }
+    }
+    buf >>= len; have -= len; pos += len;
+    if (idx + rep > total) return false;
+    if (val) {
+      const u32 nl = idx < hlit ? (idx + rep <= hlit ? rep : hlit - idx) : 0u;  // how many of them are literal/length codes
+      kl += nl * (32768u >> val);
+      kd += (rep - nl) * (32768u >> val);
+      nd += rep - nl;
+      if (idx <= 256 && idx + rep > 256) eob = true;
+    }
+    prev = val;
+    idx += rep;
+  }
+  return eob && kl == 32768u && (kd == 32768u || nd <= 1);
+}
+
+// cand[k] (k >= 1): bit position of the first dynamic block header at or behind data_start + k * chunk_bytes
+// (searched up to the next cut), ~0 if there is none.
+__global__ __launch_bounds__(64) void sm_find_kernel(const u8 *__restrict__ in, u64 in_len, u64 data_start, u64 chunk_bytes,
+                                                     u32 n_chunks, u64 *__restrict__ cand) {
+  __shared__ SmLds lds;
+  __shared__ u8 cl_tab[64][128];
+  __shared__ u64 queue[128];
+  const int lane = threadIdx.x;
+  const u32 k = blockIdx.x + 1;
+  if (k >= n_chunks) return;
+  HeaderLds &H = *(HeaderLds *)((u8 *)lds.p.inbuf + 1024);
+  const u64 q0 = (data_start + (u64)k * chunk_bytes) * 8, q1 = q0 + chunk_bytes * 8;
+  const u64 below = (1ull << lane) - 1;
+  u64 found = ~0ull;
+  u32 qn = 0;
+  for (u64 base = q0; found == ~0ull && (base < q1 || qn); base += 64) {
+    const bool scanning = base < q1;
+    if (scanning) {
+      // ---- first filter, 64 positions: BTYPE, HLIT/HDIST range, complete code-length code ----
+      const u64 q = base + lane;
+      bool ok = q + 3 + 14 + 12 <= in_len * 8 && q < q1;
+      if (ok) {
+        const u64 v = sm_bits64(in, in_len, q);
+        const u32 hlit = (u32)(v >> 3) & 31, hdist = (u32)(v >> 8) & 31, ncl = ((u32)(v >> 13) & 15) + 4;
+        ok = ((v >> 1) & 3) == 2 && hlit <= 29 && hdist <= 29;
+        if (ok) {  // sum of 2^(7 - len) over the used lengths == 2^7
+          const u64 w = sm_bits64(in, in_len, q + 17);  // 19 x 3 = 57 bits
+          u32 kraft = 0;
+#pragma unroll
+          for (u32 i = 0; i < 19; ++i) {
+            const u32 l = i < ncl ? (u32)(w >> (3 * i)) & 7 : 0u;
+            kraft += l ? (128u >> l) : 0u;
+          }
+          ok = kraft == 128;
+        }
+      }
+      const u64 m = __ballot(ok);
+      if (ok) queue[qn + (u32)__popcll(m & below)] = q;
+      qn += (u32)__popcll(m);
+      wave_sync();
+    }
+    if (qn < 64 && scanning && base + 64 < q1) continue;  // collect a full batch first (or drain at the end)
+    // ---- second filter, one queued position per lane ----
+    const u32 nb = qn < 64 ? qn : 64;
+    bool pass = false;
+    if ((u32)lane < nb) pass = sm_header_plausible(in, in_len, queue[lane], cl_tab[lane]);
+    u64 pm = __ballot(pass);
+    while (pm && found == ~0ull) {  // lowest position first: the decoder's own header parse and table build decide
+      const int l = __ffsll((long long)pm) - 1;
+      pm &= pm - 1;
+      const u64 q = queue[l];
+      BitCursor b{in, in_len, in_len * 8, q + 3, nullptr, 0, 0};
+      int hl = 0, hd = 0;
+      const u32 r = dynamic_header(H, b, lane, hl, hd);
+      wave_sync();
+      if (r != MS_OK || H.lens[256] == 0) continue;
+      bool good = build_decode_table<false>(H.lens, hl, lds.w.ll, LL_ROOT, lds.w.lld, lds.w.ll_sorted, lane);
+      good &= build_decode_table<true>(H.lens + hl, hd, lds.w.dt, D_ROOT, lds.w.dd, lds.w.d_sorted, lane);
+      wave_sync();
+      if (good) found = q;
+    }
+    // drop the batch
+    wave_sync();
+    const u64 moved = (u32)lane + nb < qn ? queue[lane + nb] : 0;
+    wave_sync();
+    if ((u32)lane + nb < qn) queue[lane] = moved;
+    qn -= nb;
+    wave_sync();
+  }
+  if (lane == 0) cand[k] = found;
+}
+
+// the tokenizer on chunks (persistent grid like inflate_tokenize_kernel)
+__global__ __launch_bounds__(64) void sm_tokenize_kernel(const u8 *__restrict__ in, u64 in_len,
+                                                        const ChunkDesc *__restrict__ chunks, u32 n_chunks,
+                                                        const u64 *__restrict__ cand_bits, u32 n_cand,
+                                                        u32 *__restrict__ tokens, MemberResult *__restrict__ results,
+                                                        u32 *__restrict__ scratch) {
+  __shared__ SmLds lds;
+  const int lane = threadIdx.x;
+  u32 *slab = scratch + (size_t)blockIdx.x * SLAB_WORDS;
+  for (u32 k = blockIdx.x; k < n_chunks; k += gridDim.x) {
+    const ChunkDesc c = chunks[k];
+    MemberDesc d;
+    d.in_off = uniform64(c.start_bit) >> 3;
+    d.out_off = uniform64(c.out_off);
+    d.out_limit = uniform64(c.out_limit);
+    d.expect_end = POS_UNKNOWN;
+    d.in_end = 0;
+    ChunkCtx cx{cand_bits, n_cand, (u32)uniform64(c.start_bit) & 7, uniform(c.hist)};
+    u32 *tk = tokens ? tokens + d.out_off : nullptr;
+    HeaderLds &hdr = *(HeaderLds *)((u8 *)lds.p.inbuf + 1024);
+    inflate_member<false, true, true>(lds.w, hdr, &lds.p, slab, in, in_len, d, (u8 *)nullptr, tk, results[k], lane, &cx);
+  }
+}
+
+// tokens -> symbols
+__global__ __launch_bounds__(64) void sm_resolve_kernel(const u8 *__restrict__ in, const ChunkDesc *__restrict__ chunks,
+                                                       u32 n_chunks, u16 *sym, const u32 *__restrict__ tokens,
+                                                       const MemberResult *__restrict__ results) {
+  __shared__ ParLdsT<u16> lds;
+  const int lane = threadIdx.x;
+  for (u32 k = blockIdx.x; k < n_chunks; k += gridDim.x) {
+    const u64 out_off = uniform64(chunks[k].out_off);
+    const u64 nwords = uniform64(results[k].tok_words);
+    u32 cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    resolve_member<u16>(lds, in, tokens + out_off, nwords, sym + out_off, cyc, lane);
+  }
+}
+
+// windows[k] = the 32 KiB of output that end with chunk k (bytes; positions before the stream start are unused)
+__global__ __launch_bounds__(1024) void sm_windows_kernel(const ChunkDesc *__restrict__ chunks, const MemberResult *__restrict__ results,
+                                                          u32 n_chunks, const u16 *__restrict__ sym, u8 *__restrict__ windows) {
+  __shared__ u8 W[2][SM_WINDOW];
+  const u32 tid = threadIdx.x;
+  constexpr u32 PER = SM_WINDOW / 1024;  // 32 window elements per thread
+  for (u32 k = 0; k < n_chunks; ++k) {
+    const u8 *prev = W[(k + 1) & 1];
+    u8 *cur = W[k & 1];
+    const u64 off = chunks[k].out_off, len = results[k].out_len;
+    // window element j = output position (end - 32768 + j) of the stream; all loads first, they are independent
+    u32 s[PER];
+#pragma unroll
+    for (u32 u = 0; u < PER; ++u) {
+      const u32 j = tid + u * 1024;
+      s[u] = len >= SM_WINDOW - j ? (u32)sym[off + len - (SM_WINDOW - j)] : 0xffffffffu;
+    }
+#pragma unroll
+    for (u32 u = 0; u < PER; ++u) {
+      const u32 j = tid + u * 1024;
+      u8 v = 0;
+      if (s[u] != 0xffffffffu) v = s[u] < SYM_MARK ? (u8)s[u] : prev[s[u] - SYM_MARK];
+      else if (k) v = prev[j + len];  // this chunk is shorter than the window: the rest slides over from the previous one
+      cur[j] = v;
+      windows[(u64)k * SM_WINDOW + j] = v;
+    }
+    __syncthreads();
+  }
+}
+
+// symbols -> bytes, every chunk with the window of the chunk before it
+__global__ __launch_bounds__(256) void sm_translate_kernel(const ChunkDesc *__restrict__ chunks, const MemberResult *__restrict__ results,
+                                                           const u16 *__restrict__ sym, const u8 *__restrict__ windows,
+                                                           u8 *__restrict__ out) {
+  const u32 k = blockIdx.y;
+  const u64 off = chunks[k].out_off, len = results[k].out_len;
+  const u8 *w = k ? windows + (u64)(k - 1) * SM_WINDOW : windows;
+  for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < len; i += (u64)gridDim.x * 256) {
+    const u32 s = sym[off + i];
+    out[off + i] = s < SYM_MARK ? (u8)s : w[s - SYM_MARK];
+  }
+}
+
+}  // namespace ahip
