@@ -586,16 +586,20 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
     const u64 cb = sm_chunk_bytes();
     const u32 n_chunks = (u32)((n - off + cb - 1) / cb);
     if (n_chunks < 4) return AHIP_OK;
-    HIP_TRY(dcand.reserve((size_t)n_chunks * 8));
-    hipLaunchKernelGGL(sm_find_kernel, dim3(n_chunks - 1), dim3(64), 0, st, d_in, n, off, cb, n_chunks, dcand.as<u64>());
-    std::vector<u64> found(n_chunks);
-    HIP_TRY(hipMemcpyAsync(found.data(), dcand.p, (size_t)n_chunks * 8, hipMemcpyDeviceToHost, st));
+    constexpr u32 SPLIT = 4;  // waves searching behind each cut
+    HIP_TRY(dcand.reserve((size_t)n_chunks * SPLIT * 8));
+    hipLaunchKernelGGL(sm_find_kernel, dim3((n_chunks - 1) * SPLIT), dim3(64), 0, st, d_in, n, off, cb, n_chunks, SPLIT, dcand.as<u64>());
+    std::vector<u64> found((size_t)n_chunks * SPLIT);
+    HIP_TRY(hipMemcpyAsync(found.data(), dcand.p, (size_t)n_chunks * SPLIT * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipGetLastError());
     std::vector<u64> cand;
     cand.push_back(off * 8);
     for (u32 k = 1; k < n_chunks; ++k)
-      if (found[k] != ~0ull && found[k] > cand.back()) cand.push_back(found[k]);
+      for (u32 part = 0; part < SPLIT; ++part) {
+        const u64 f = found[(size_t)k * SPLIT + part];
+        if (f != ~0ull) { if (f > cand.back()) cand.push_back(f); break; }  // the first find behind the cut
+      }
     if (dbg) fprintf(stderr, "[ahip] sm: %u cuts, %zu block starts found\n", n_chunks, cand.size());
     if (cand.size() < 4) return AHIP_OK;
     const u32 nc = (u32)cand.size();
@@ -674,8 +678,18 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
     }
   hipLaunchKernelGGL(sm_resolve_kernel, dim3(grid), dim3(64), 0, st, d_in, dchunks.as<ChunkDesc>(), nch, dsym.as<u16>(), (const u32 *)tp,
                      dres.as<MemberResult>());
-  hipLaunchKernelGGL(sm_windows_kernel, dim3(1), dim3(1024), 0, st, dchunks.as<ChunkDesc>(), dres.as<MemberResult>(), nch, dsym.as<u16>(),
-                     dwin.as<u8>());
+  {
+    static DevBuf dwsym, dgwin;
+    u32 gs = 1;
+    while ((u64)gs * gs < nch) ++gs;  // about sqrt(chunks) groups of sqrt(chunks) chunks: both serial parts equally short
+    const u32 ng = (nch + gs - 1) / gs;
+    HIP_TRY(dwsym.reserve((size_t)nch * SM_WINDOW * 2));
+    HIP_TRY(dgwin.reserve((size_t)ng * SM_WINDOW));
+    hipLaunchKernelGGL(sm_windows_group, dim3(ng), dim3(1024), 0, st, dchunks.as<ChunkDesc>(), dres.as<MemberResult>(), nch, gs,
+                       dsym.as<u16>(), dwsym.as<u16>());
+    hipLaunchKernelGGL(sm_windows_link, dim3(1), dim3(1024), 0, st, nch, gs, dwsym.as<u16>(), dgwin.as<u8>());
+    hipLaunchKernelGGL(sm_windows_apply, dim3(8, nch), dim3(256), 0, st, gs, dwsym.as<u16>(), dgwin.as<u8>(), dwin.as<u8>());
+  }
   hipLaunchKernelGGL(sm_translate_kernel, dim3(32, nch), dim3(256), 0, st, dchunks.as<ChunkDesc>(), dres.as<MemberResult>(), dsym.as<u16>(),
                      dwin.as<u8>(), d_out);
   HIP_TRY(hipStreamSynchronize(st));

@@ -15,8 +15,9 @@
 //                          exact offsets.  A back-reference may reach `hist` bytes in front of its chunk.
 //   S3 sm_resolve_kernel   the ordinary resolver on 16-bit symbols: a byte, or a marker "byte j of the 32 KiB in
 //                          front of this chunk" for what is not known yet.
-//   S4 sm_windows_kernel   chunk after chunk, the last 32 KiB of each chunk are made concrete with the window of
-//                          the chunk before (the only serial step: 32 K look-ups per chunk, one workgroup).
+//   S4 sm_windows_*        the last 32 KiB behind every chunk: window k is a function of window k-1, composed in
+//                          groups (symbolic inside a group, groups in parallel), linked group after group by one
+//                          workgroup (the only serial step), then made concrete per chunk.
 //   S5 sm_translate_kernel every chunk turns its symbols into bytes with its (now known) window.
 //
 // Anything unexpected (no finds, a broken chain, an error status inside a chunk) makes the host fall back to the
@@ -105,16 +106,19 @@ AHIP_DEVINL bool sm_header_plausible(const u8 *in, u64 in_len, u64 q, u8 *tab /*
 
 // cand[k] (k >= 1): bit position of the first dynamic block header at or behind data_start + k * chunk_bytes
 // (searched up to the next cut), ~0 if there is none.
+// The range behind a cut is searched by `split` waves (equal parts, cand[k * split + part]); the host keeps the
+// first find of each cut.
 __global__ __launch_bounds__(64) void sm_find_kernel(const u8 *__restrict__ in, u64 in_len, u64 data_start, u64 chunk_bytes,
-                                                     u32 n_chunks, u64 *__restrict__ cand) {
+                                                     u32 n_chunks, u32 split, u64 *__restrict__ cand) {
   __shared__ SmLds lds;
   __shared__ u8 cl_tab[64][128];
   __shared__ u64 queue[128];
   const int lane = threadIdx.x;
-  const u32 k = blockIdx.x + 1;
+  const u32 k = blockIdx.x / split + 1, part = blockIdx.x % split;
   if (k >= n_chunks) return;
   HeaderLds &H = *(HeaderLds *)((u8 *)lds.p.inbuf + 1024);
-  const u64 q0 = (data_start + (u64)k * chunk_bytes) * 8, q1 = q0 + chunk_bytes * 8;
+  const u64 part_bits = chunk_bytes * 8 / split;
+  const u64 q0 = (data_start + (u64)k * chunk_bytes) * 8 + part * part_bits, q1 = q0 + part_bits;
   const u64 below = (1ull << lane) - 1;
   u64 found = ~0ull;
   u32 qn = 0;
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(64) void sm_find_kernel(const u8 *__restrict__ in, 
     qn -= nb;
     wave_sync();
   }
-  if (lane == 0) cand[k] = found;
+  if (lane == 0) cand[(u64)k * split + part] = found;
 }
 
 // the tokenizer on chunks (persistent grid like inflate_tokenize_kernel)
@@ -213,15 +217,25 @@ __global__ __launch_bounds__(64) void sm_resolve_kernel(const u8 *__restrict__ i
   }
 }
 
-// windows[k] = the 32 KiB of output that end with chunk k (bytes; positions before the stream start are unused)
-__global__ __launch_bounds__(1024) void sm_windows_kernel(const ChunkDesc *__restrict__ chunks, const MemberResult *__restrict__ results,
-                                                          u32 n_chunks, const u16 *__restrict__ sym, u8 *__restrict__ windows) {
-  __shared__ u8 W[2][SM_WINDOW];
-  const u32 tid = threadIdx.x;
+// Windows.  windows[k] = the 32 KiB of output that end with chunk k (bytes; positions before the stream start are
+// unused).  Window k is a function of window k-1 (every element is a byte of chunk k or a look-up into window k-1),
+// and such functions compose, so the chain is cut into groups:
+//   A  sm_windows_group   every group walks its chunks with the group's (unknown) input window as markers:
+//                         symbolic windows wsym[k], groups in parallel;
+//   B  sm_windows_link    one workgroup makes the groups' last windows concrete, group after group;
+//   C  sm_windows_apply   every chunk's symbolic window becomes bytes with its group's input window.
+__global__ __launch_bounds__(1024) void sm_windows_group(const ChunkDesc *__restrict__ chunks, const MemberResult *__restrict__ results,
+                                                         u32 n_chunks, u32 group_size, const u16 *__restrict__ sym,
+                                                         u16 *__restrict__ wsym) {
+  __shared__ u16 W[2][SM_WINDOW];
+  const u32 tid = threadIdx.x, k0 = blockIdx.x * group_size;
   constexpr u32 PER = SM_WINDOW / 1024;  // 32 window elements per thread
-  for (u32 k = 0; k < n_chunks; ++k) {
-    const u8 *prev = W[(k + 1) & 1];
-    u8 *cur = W[k & 1];
+  for (u32 j = tid; j < SM_WINDOW; j += 1024) W[1][j] = (u16)(SYM_MARK + j);  // identity: "element j of the group's input window"
+  __syncthreads();
+  for (u32 g = 0; g < group_size && k0 + g < n_chunks; ++g) {
+    const u32 k = k0 + g;
+    const u16 *prev = W[(g + 1) & 1];
+    u16 *cur = W[g & 1];
     const u64 off = chunks[k].out_off, len = results[k].out_len;
     // window element j = output position (end - 32768 + j) of the stream; all loads first, they are independent
     u32 s[PER];
@@ -233,13 +247,41 @@ __global__ __launch_bounds__(1024) void sm_windows_kernel(const ChunkDesc *__res
 #pragma unroll
     for (u32 u = 0; u < PER; ++u) {
       const u32 j = tid + u * 1024;
-      u8 v = 0;
-      if (s[u] != 0xffffffffu) v = s[u] < SYM_MARK ? (u8)s[u] : prev[s[u] - SYM_MARK];
-      else if (k) v = prev[j + len];  // this chunk is shorter than the window: the rest slides over from the previous one
+      u16 v;
+      if (s[u] != 0xffffffffu) v = s[u] < SYM_MARK ? (u16)s[u] : prev[s[u] - SYM_MARK];
+      else v = prev[j + len];  // this chunk is shorter than the window: the rest slides over from the one before
       cur[j] = v;
-      windows[(u64)k * SM_WINDOW + j] = v;
+      wsym[(u64)k * SM_WINDOW + j] = v;
     }
     __syncthreads();
+  }
+}
+// gwin[g] = concrete window at the END of group g
+__global__ __launch_bounds__(1024) void sm_windows_link(u32 n_chunks, u32 group_size, const u16 *__restrict__ wsym, u8 *__restrict__ gwin) {
+  __shared__ u8 W[2][SM_WINDOW];
+  const u32 tid = threadIdx.x, n_groups = (n_chunks + group_size - 1) / group_size;
+  for (u32 j = tid; j < SM_WINDOW; j += 1024) W[1][j] = 0;  // in front of the stream: never referenced
+  __syncthreads();
+  for (u32 g = 0; g < n_groups; ++g) {
+    const u32 last = (g + 1) * group_size - 1 < n_chunks ? (g + 1) * group_size - 1 : n_chunks - 1;
+    const u8 *prev = W[(g + 1) & 1];
+    u8 *cur = W[g & 1];
+    for (u32 j = tid; j < SM_WINDOW; j += 1024) {
+      const u32 s = wsym[(u64)last * SM_WINDOW + j];
+      const u8 v = s < SYM_MARK ? (u8)s : prev[s - SYM_MARK];
+      cur[j] = v;
+      gwin[(u64)g * SM_WINDOW + j] = v;
+    }
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void sm_windows_apply(u32 group_size, const u16 *__restrict__ wsym, const u8 *__restrict__ gwin,
+                                                        u8 *__restrict__ windows) {
+  const u32 k = blockIdx.y, g = k / group_size;
+  const u8 *in_win = g ? gwin + (u64)(g - 1) * SM_WINDOW : nullptr;
+  for (u32 j = blockIdx.x * 256 + threadIdx.x; j < SM_WINDOW; j += gridDim.x * 256) {
+    const u32 s = wsym[(u64)k * SM_WINDOW + j];
+    windows[(u64)k * SM_WINDOW + j] = s < SYM_MARK ? (u8)s : (in_win ? in_win[s - SYM_MARK] : (u8)0);
   }
 }
 
