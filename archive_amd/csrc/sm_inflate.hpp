@@ -6,9 +6,10 @@
 //
 //   S1 sm_find_kernel      the compressed data is cut every `chunk_bytes`; one wave per cut looks for the first
 //                          DYNAMIC block header behind it: 64 bit positions per step pass a cheap filter (BTYPE,
-//                          HLIT/HDIST range, complete code-length code), survivors get the full header parse and
-//                          table build the decoder itself uses.  Stored / fixed blocks are not searched; a cut
-//                          without a find simply extends the previous chunk.
+//                          HLIT/HDIST range, complete code-length code), survivors are run-length decoded one per
+//                          lane and must describe complete trees with an end-of-block code.  What still slips
+//                          through is judged by S2.  Stored / fixed blocks are not searched; a cut without a find
+//                          simply extends the previous chunk.
 //   S2 sm_tokenize_kernel  the ordinary tokenizer (inflate_member<.., CHUNK>) from each find to the block that
 //                          starts on the next find.  Run twice: sizes first (a false find decodes garbage and is
 //                          dropped when the host follows the chain of ends == starts), then recording tokens at
@@ -110,13 +111,18 @@ AHIP_DEVINL bool sm_header_plausible(const u8 *in, u64 in_len, u64 q, u8 *tab /*
 // first find of each cut.
 __global__ __launch_bounds__(64) void sm_find_kernel(const u8 *__restrict__ in, u64 in_len, u64 data_start, u64 chunk_bytes,
                                                      u32 n_chunks, u32 split, u64 *__restrict__ cand) {
-  __shared__ SmLds lds;
   __shared__ u8 cl_tab[64][128];
   __shared__ u64 queue[128];
+  __shared__ u16 kraft4[4096];  // sum of 128 >> len over four 3-bit code-length fields (len 0 counts nothing)
   const int lane = threadIdx.x;
   const u32 k = blockIdx.x / split + 1, part = blockIdx.x % split;
   if (k >= n_chunks) return;
-  HeaderLds &H = *(HeaderLds *)((u8 *)lds.p.inbuf + 1024);
+  for (u32 i = lane; i < 4096; i += 64) {
+    u32 t = 0;
+    for (u32 f = 0; f < 4; ++f) { const u32 l = (i >> (3 * f)) & 7; t += l ? (128u >> l) : 0u; }
+    kraft4[i] = (u16)t;
+  }
+  wave_sync();
   const u64 part_bits = chunk_bytes * 8 / split;
   const u64 q0 = (data_start + (u64)k * chunk_bytes) * 8 + part * part_bits, q1 = q0 + part_bits;
   const u64 below = (1ull << lane) - 1;
@@ -132,16 +138,12 @@ __global__ __launch_bounds__(64) void sm_find_kernel(const u8 *__restrict__ in, 
         const u64 v = sm_bits64(in, in_len, q);
         const u32 hlit = (u32)(v >> 3) & 31, hdist = (u32)(v >> 8) & 31, ncl = ((u32)(v >> 13) & 15) + 4;
         ok = ((v >> 1) & 3) == 2 && hlit <= 29 && hdist <= 29;
-        if (ok) {  // sum of 2^(7 - len) over the used lengths == 2^7
-          const u64 w = sm_bits64(in, in_len, q + 17);  // 19 x 3 = 57 bits
-          u32 kraft = 0;
-#pragma unroll
-          for (u32 i = 0; i < 19; ++i) {
-            const u32 l = i < ncl ? (u32)(w >> (3 * i)) & 7 : 0u;
-            kraft += l ? (128u >> l) : 0u;
-          }
-          ok = kraft == 128;
-        }
+        // sum of 2^(7 - len) over the transmitted lengths == 2^7 (19 x 3 = 57 bits, five table look-ups)
+        u64 w = sm_bits64(in, in_len, q + 17);
+        w &= (1ull << (3 * ncl)) - 1;
+        const u32 kraft = kraft4[(u32)w & 4095] + kraft4[(u32)(w >> 12) & 4095] + kraft4[(u32)(w >> 24) & 4095] +
+                          kraft4[(u32)(w >> 36) & 4095] + kraft4[(u32)(w >> 48) & 4095];
+        ok = ok && kraft == 128;
       }
       const u64 m = __ballot(ok);
       if (ok) queue[qn + (u32)__popcll(m & below)] = q;
@@ -149,25 +151,12 @@ __global__ __launch_bounds__(64) void sm_find_kernel(const u8 *__restrict__ in, 
       wave_sync();
     }
     if (qn < 64 && scanning && base + 64 < q1) continue;  // collect a full batch first (or drain at the end)
-    // ---- second filter, one queued position per lane ----
+    // ---- second filter, one queued position per lane; the sizing pass is the final judge of what it lets through ----
     const u32 nb = qn < 64 ? qn : 64;
     bool pass = false;
     if ((u32)lane < nb) pass = sm_header_plausible(in, in_len, queue[lane], cl_tab[lane]);
-    u64 pm = __ballot(pass);
-    while (pm && found == ~0ull) {  // lowest position first: the decoder's own header parse and table build decide
-      const int l = __ffsll((long long)pm) - 1;
-      pm &= pm - 1;
-      const u64 q = queue[l];
-      BitCursor b{in, in_len, in_len * 8, q + 3, nullptr, 0, 0};
-      int hl = 0, hd = 0;
-      const u32 r = dynamic_header(H, b, lane, hl, hd);
-      wave_sync();
-      if (r != MS_OK || H.lens[256] == 0) continue;
-      bool good = build_decode_table<false>(H.lens, hl, lds.w.ll, LL_ROOT, lds.w.lld, lds.w.ll_sorted, lane);
-      good &= build_decode_table<true>(H.lens + hl, hd, lds.w.dt, D_ROOT, lds.w.dd, lds.w.d_sorted, lane);
-      wave_sync();
-      if (good) found = q;
-    }
+    const u64 pm = __ballot(pass);
+    if (pm) found = queue[__ffsll((long long)pm) - 1];  // lowest position first
     // drop the batch
     wave_sync();
     const u64 moved = (u32)lane + nb < qn ? queue[lane + nb] : 0;
