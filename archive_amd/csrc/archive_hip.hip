@@ -583,7 +583,8 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
   // between API calls, so a pointer match alone proves nothing)
   if (!write || !(g_sm.valid && g_sm.d_in == d_in && g_sm.n == n && g_sm.off == off)) {
     g_sm = SmPlan{};
-    const u64 cb = sm_chunk_bytes();
+    u64 cb = sm_chunk_bytes();
+    while ((n - off + cb - 1) / cb > 32768) cb *= 2;  // grid.y of the per-chunk kernels; 32 Ki chunks are plenty
     const u32 n_chunks = (u32)((n - off + cb - 1) / cb);
     if (n_chunks < 4) return AHIP_OK;
     constexpr u32 SPLIT = 4;  // waves searching behind each cut
