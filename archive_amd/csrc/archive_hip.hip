@@ -1443,16 +1443,22 @@ static int32_t inflate_batch_impl(const u8 *d_in, size_t in_len, u32 n, const ui
     return in_size[i] ? MemberDesc{in_off[i], ooff, olim, POS_UNKNOWN, in_off[i] + in_size[i]}
                       : MemberDesc{(u64)in_len, ooff, olim, POS_UNKNOWN, 0};
   };
+  // long entries are decoded by many waves each (sm_inflate), outside the batch launch
+  auto big = [&](u32 i) { return in_size[i] >= sm_min_bytes() && !getenv("AHIP_NO_SM"); };
+  auto skip_desc = [&](u64 ooff, u64 olim) { return MemberDesc{(u64)in_len, ooff, olim, POS_UNKNOWN, 0}; };
   std::vector<u64> size(n);
   if (size_hint) {
     for (u32 i = 0; i < n; ++i) size[i] = size_hint[i];
   } else {  // sizing run: every entry's true length
-    for (u32 i = 0; i < n; ++i) md[i] = entry_desc(i, 0, ~0ull);
+    for (u32 i = 0; i < n; ++i) md[i] = big(i) ? skip_desc(0, 0) : entry_desc(i, 0, ~0ull);
     HIP_TRY(hipMemcpyAsync(ddesc.p, md.data(), (size_t)n * sizeof(MemberDesc), hipMemcpyHostToDevice, st));
     HIP_TRY(launch_inflate<false>(d_in, in_len, ddesc.as<MemberDesc>(), n, (u8 *)nullptr, dres.as<MemberResult>(), st));
     HIP_TRY(hipMemcpyAsync(res.data(), dres.p, (size_t)n * sizeof(MemberResult), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    for (u32 i = 0; i < n; ++i) size[i] = res[i].out_len;
+    for (u32 i = 0; i < n; ++i) {
+      if (big(i)) { int32_t rc = inflate_one(d_in, in_off[i] + in_size[i], in_off[i], nullptr, ~0ull, false, &res[i], st); if (rc != AHIP_OK) return rc; }
+      size[i] = res[i].out_len;
+    }
   }
   std::vector<u64> off(n + 1);
   u64 total = 0;
@@ -1461,12 +1467,17 @@ static int32_t inflate_batch_impl(const u8 *d_in, size_t in_len, u32 n, const ui
   if (out_total) *out_total = total;
   if (total > out_cap) return fail(AHIP_E_CAP, "output buffer too small");
   if (own_out) { HIP_TRY(own_out->reserve(total + 16)); d_out = own_out->as<u8>(); }
-  for (u32 i = 0; i < n; ++i) md[i] = entry_desc(i, off[i], size[i]);
+  for (u32 i = 0; i < n; ++i) md[i] = big(i) ? skip_desc(off[i], 0) : entry_desc(i, off[i], size[i]);
   HIP_TRY(hipMemcpyAsync(ddesc.p, md.data(), (size_t)n * sizeof(MemberDesc), hipMemcpyHostToDevice, st));
   HIP_TRY(launch_inflate<true>(d_in, in_len, ddesc.as<MemberDesc>(), n, d_out, dres.as<MemberResult>(), st, off.data()));
   HIP_TRY(hipMemcpyAsync(res.data(), dres.p, (size_t)n * sizeof(MemberResult), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipGetLastError());
+  for (u32 i = 0; i < n; ++i)
+    if (big(i)) {  // the slice end is this stream's end of input
+      int32_t rc = inflate_one(d_in, in_off[i] + in_size[i], in_off[i], d_out + off[i], size[i], true, &res[i], st);
+      if (rc != AHIP_OK) return rc;
+    }
   for (u32 i = 0; i < n; ++i) {
     out_off[i] = off[i];
     out_len[i] = res[i].out_len;

@@ -129,3 +129,20 @@ def test_reference_zip_fixture(native_built):
         ost, oout, _ = orc.inflate_raw(comp)
         assert oout == want  # the reference's own expectation (zip_test.dart:11-28)
         assert (status[0], obuf.raw[:out_len[0]]) == (ost, want)  # verdict included (quirk q2: false, output complete)
+
+
+def test_long_entries_take_the_chunked_path(native_built):
+    """Entries of >= 2 MiB compressed are decoded by many waves each; bytes must not depend on that."""
+    from archive_amd import zip_entries
+    from tools import corpus
+    big1 = bytes(corpus.text(corpus.LOG, 5, 0, 8 << 20))
+    big2 = bytes(corpus.text(corpus.WIKI, 6, 0, 7 << 20))
+    files = [("a.txt", streams.text(3000, 1), zipfile.ZIP_DEFLATED), ("big1.log", big1, zipfile.ZIP_DEFLATED),
+             ("b.txt", streams.text(70000, 2), zipfile.ZIP_DEFLATED), ("big2.xml", big2, zipfile.ZIP_DEFLATED),
+             ("c.bin", b"\x00" * 10, zipfile.ZIP_STORED)]
+    z = _make_zip(files)
+    for trust in (True, False):
+        got = zip_entries.read_zip(z, trust_sizes=trust)
+        assert [g[0] for g in got] == [f[0] for f in files]
+        for (name, data), (_, want, _) in zip(got, files):
+            assert data == want, (name, trust)
