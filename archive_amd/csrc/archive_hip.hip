@@ -362,6 +362,17 @@ int32_t plan_build(ahip_gzip_plan *pl, bool force_sizing, hipStream_t st) {
           sd[i].in_off = n;  // nothing to read: the member launch is done with it at once
         }
       }
+      // Long members are taken one after another (each on the whole GPU): with many of them, the ordinary launch
+      // -- all members at once, one wave each -- wins unless a member is really long.
+      if (pl->big.size() > 8) {
+        std::vector<ahip_gzip_plan::Big> keep;
+        for (const auto &bg : pl->big) {
+          const u64 lim = bg.cand + 1 < K ? cp[bg.cand + 1] : n;
+          if (lim - bg.in_off >= (32ull << 20)) keep.push_back(bg);
+          else sd[bg.cand].in_off = bg.in_off;
+        }
+        pl->big = keep;
+      }
       if (!pl->big.empty())
         HIP_TRY(hipMemcpyAsync(pl->sizing_descs.p, sd.data(), (size_t)K * sizeof(MemberDesc), hipMemcpyHostToDevice, st));
     }
