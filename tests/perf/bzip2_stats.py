@@ -1,6 +1,6 @@
-"""Dev tool: bzip2 decode throughput (config 5: N x 900k blocks of wiki-like text) through the host-pointer API."""
+"""Measurement harness (lives under tests/ because it times the CPU oracle beside the GPU path): bzip2 decode throughput (config 5: N x 900k blocks of wiki-like text) through the host-pointer API."""
 import bz2, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import archive_amd
 from archive_amd import _native as N

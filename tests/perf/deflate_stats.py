@@ -1,6 +1,6 @@
-"""Dev tool: compressed size of the HIP Deflate vs the reference oracle / zlib, and device throughput."""
+"""Measurement harness (lives under tests/ because it times the CPU oracle beside the GPU path): compressed size of the HIP Deflate vs the reference oracle / zlib, and device throughput."""
 import ctypes, os, sys, time, zlib
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import archive_amd
 from archive_amd import _native as N

@@ -69,9 +69,9 @@ def side_profile(rnd, tag, title, cmd):
 def main():
     rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
     os.makedirs(PROF, exist_ok=True)
-    side_profile(rnd, "df", "Deflate level 6, 1 GiB log text (config 3)", "python tools/deflate_stats.py 1024")
+    side_profile(rnd, "df", "Deflate level 6, 1 GiB log text (config 3)", "python tests/perf/deflate_stats.py 1024")
     side_profile(rnd, "sm", "Inflate of ONE 256 MiB gzip member of wiki-like text (config 2a)", "python tools/sm_check.py 256 wiki")
-    side_profile(rnd, "bz", "BZip2 decode, 384 MiB of wiki-like text in 900k blocks (config 5)", "python tools/bzip2_stats.py 384")
+    side_profile(rnd, "bz", "BZip2 decode, 384 MiB of wiki-like text in 900k blocks (config 5)", "python tests/perf/bzip2_stats.py 384")
 
     # ---- kernel-trace stats
     stats_csv = one("prof_%s/**/*kernel_stats.csv" % rnd)

@@ -15,8 +15,8 @@ timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/
 timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python /root/repo/bench.py --steps 3 --warmup 1 --cpu-seconds 0 > $O/pmc_write.log 2>&1
 timeout 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/cal_fetch -o f -- python /root/repo/tools/pmc_calib.py > $O/cal_fetch.log 2>&1
 timeout 120 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/cal_write -o w -- python /root/repo/tools/pmc_calib.py > $O/cal_write.log 2>&1
-timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_df -o df -- python /root/repo/tools/deflate_stats.py 1024 > $O/prof_df.log 2>&1
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_df -o df -- python /root/repo/tests/perf/deflate_stats.py 1024 > $O/prof_df.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_sm -o sm -- python /root/repo/tools/sm_check.py 256 wiki > $O/prof_sm.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bz -o bz -- python /root/repo/tools/bzip2_stats.py 384 > $O/prof_bz.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bz -o bz -- python /root/repo/tests/perf/bzip2_stats.py 384 > $O/prof_bz.log 2>&1
 timeout 120 python /root/repo/tools/checksum_stats.py 1024 > $O/checksum_stats.log 2>&1; tail -2 $O/checksum_stats.log
 find $O/prof_$R $O/pmc_fetch $O/pmc_write $O/cal_fetch $O/cal_write -type f | head -30
