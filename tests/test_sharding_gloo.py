@@ -76,3 +76,21 @@ def test_two_rank_offsets_and_concatenation():
         buf[off:off + len(out)] = out
     assert bytes(buf) == whole
     assert res[0][1] == 0 and res[1][1] == res[0][3][0]
+
+
+def test_partition_properties_random():
+    """Contiguous, covering, and no rank is more than one member over its fair share of compressed bytes."""
+    import random
+    from archive_amd.sharding import partition_members
+    rnd = random.Random(12)
+    for _ in range(300):
+        n = rnd.randrange(0, 200)
+        sizes = [rnd.choice((1, 20, 300, 65536, rnd.randrange(1, 100000))) for _ in range(n)]
+        w = rnd.randrange(1, 17)
+        r = partition_members(sizes, w)
+        assert len(r) == w and r[0][0] == 0 and r[-1][1] == n
+        assert all(lo <= hi for lo, hi in r) and all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+        if n:
+            fair, biggest = sum(sizes) / w, max(sizes)
+            for lo, hi in r:
+                assert sum(sizes[lo:hi]) <= fair + biggest + 1e-9, (sizes, w, r)
