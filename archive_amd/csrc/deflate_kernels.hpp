@@ -76,16 +76,16 @@ AHIP_DEVINL u64 df_rd8(const u32 *ring, u32 r) {
   const u32 a = ring[i], b = ring[i + 1], c = ring[i + 2];
   return (u64)__builtin_amdgcn_alignbyte(b, a, r & 3) | ((u64)__builtin_amdgcn_alignbyte(c, b, r & 3) << 32);
 }
-// Lengths of up to NW candidate matches at once.  rc[k] = ring offset of candidate k (alive[k] says it shares
-// the first 4 bytes with the string at rp).  The candidates advance together, 8 bytes per round, so one
+// Lengths of up to NW candidate matches at once.  rc[k] = ring offset of candidate k (alive[k]: there is one;
+// a bucket-mate that does not even share 4 bytes ends with len < 4).  The candidates advance together, 8 bytes per round, so one
 // round costs ONE LDS round trip for all of them -- the kernel is bound by dependent LDS latency (two waves
 // per SIMD), not by LDS bandwidth.
 template <int NW>
 AHIP_DEVINL void df_match_lens(const u32 *ring, const u32 (&rc)[NW], u32 rp, u32 maxl, bool (&alive)[NW], u32 (&len)[NW]) {
   bool any = false;
 #pragma unroll
-  for (int k = 0; k < NW; ++k) { len[k] = alive[k] ? (maxl < 4 ? maxl : 4u) : 0u; alive[k] = alive[k] && maxl > 4; any |= alive[k]; }
-  for (u32 l = 4; any; l += 8) {
+  for (int k = 0; k < NW; ++k) { len[k] = 0; any |= alive[k]; }  // (maxl >= 4: the position has four bytes to hash)
+  for (u32 l = 0; any; l += 8) {  // the first round doubles as the check that the bucket-mate really shares 4 bytes
     const u64 pw = df_rd8(ring, rp + l);
     u64 cw[NW];
 #pragma unroll
@@ -199,8 +199,6 @@ __global__ __launch_bounds__(256) void deflate_match_kernel(const u8 *__restrict
         alive[k] = k < DF_WAYS ? (c != DF_EMPTY && dist[k] <= 32768) : (c < p && c >= base);
         rc[k] = alive[k] ? df_rc(c) : rp;
       }
-#pragma unroll
-      for (u32 k = 0; k <= DF_WAYS; ++k) alive[k] = alive[k] && df_rd4(ring, rc[k]) == w;  // (dead ones read rp: one address, a broadcast)
       AHIP_TICK(t3);
       AHIP_ACC(pc[2], t2, t3);
       df_match_lens<DF_WAYS + 1>(ring, rc, rp, maxl, alive, len);
