@@ -34,6 +34,13 @@ using namespace ahip;
 //                            member's token stream in device scratch
 //   inflate_resolve_kernel   LZ77 side: token queue + output window in LDS (9.6 KiB/wave) -> bytes
 constexpr int WAVES_PER_BLOCK = 1;
+// minimum waves per SIMD the register allocation must admit (tuning knobs; 1 = no constraint)
+#ifndef AHIP_RES_MIN_WAVES
+#define AHIP_RES_MIN_WAVES 1
+#endif
+#ifndef AHIP_TOK_MIN_WAVES
+#define AHIP_TOK_MIN_WAVES 1
+#endif
 
 struct TokKernelLds {
   WaveLds w;
@@ -43,7 +50,7 @@ struct TokKernelLds {
 // Persistent workgroups: the grid is sized to what is resident at once and strides over the
 // members, so the per-workgroup slab (scratch, SLAB_WORDS u32) stays L2-resident.
 //  tokens == nullptr: sizing run (end position, size and verdict only).
-__global__ __launch_bounds__(64) void inflate_tokenize_kernel(const u8 *__restrict__ in, u64 in_len,
+__global__ __launch_bounds__(64, AHIP_TOK_MIN_WAVES) void inflate_tokenize_kernel(const u8 *__restrict__ in, u64 in_len,
                                                              const MemberDesc *__restrict__ members, u32 first_member,
                                                              u32 n_members, u32 *__restrict__ tokens, u64 group_out0,
                                                              MemberResult *__restrict__ results,
@@ -66,7 +73,7 @@ __global__ __launch_bounds__(64) void inflate_tokenize_kernel(const u8 *__restri
   }
 }
 
-__global__ __launch_bounds__(64) void inflate_resolve_kernel(const u8 *__restrict__ in,
+__global__ __launch_bounds__(64, AHIP_RES_MIN_WAVES) void inflate_resolve_kernel(const u8 *__restrict__ in,
                                                             const MemberDesc *__restrict__ members, u32 first_member,
                                                             u32 n_members, u8 *out, const u32 *__restrict__ tokens,
                                                             u64 group_out0, MemberResult *__restrict__ results) {

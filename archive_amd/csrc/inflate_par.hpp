@@ -37,6 +37,18 @@ namespace ahip {
 #ifndef AHIP_SUB_BITS
 #define AHIP_SUB_BITS 512
 #endif
+#ifndef AHIP_RING_DW
+#define AHIP_RING_DW 2048
+#endif
+#ifndef AHIP_SPEC_BITS
+#define AHIP_SPEC_BITS 256
+#endif
+#ifndef AHIP_STEPS
+#define AHIP_STEPS 8
+#endif
+#ifndef AHIP_EMIT_MIN
+#define AHIP_EMIT_MIN 32
+#endif
 #ifndef AHIP_TOK_CAP
 #define AHIP_TOK_CAP 1024
 #endif
@@ -44,24 +56,41 @@ namespace ahip {
 #define AHIP_OB_CAP 4608
 #endif
 #ifndef AHIP_SLAB_ROWS
-#define AHIP_SLAB_ROWS 192
+#define AHIP_SLAB_ROWS 512
 #endif
-constexpr int SUB_BITS = AHIP_SUB_BITS;          // bits per lane subsequence
-constexpr int WIN_BITS = 64 * SUB_BITS;          // compressed bits per window (2 KiB at 256)
-constexpr int IN_DWORDS = WIN_BITS / 32 + 8;     // + slack: a token may run 48 bits past the window (multiple of 4)
+constexpr int SUB_BITS = AHIP_SUB_BITS;          // bits per work item ("subsequence") of the tokenizer
+constexpr int SUB_DW = SUB_BITS / 32;
+constexpr int RING_DW = AHIP_RING_DW;            // staged bitstream: a ring of dwords in LDS
+constexpr u32 RING_MASK = RING_DW - 1;
+constexpr int ITEMS = RING_DW / SUB_DW;          // items the ring holds
+constexpr u32 ITEM_MASK = ITEMS - 1;
+constexpr u32 SPEC_BITS = AHIP_SPEC_BITS;        // a speculative run covers the last SPEC_BITS of its item
+constexpr int STEPS = AHIP_STEPS;                // decode steps between two scheduling points
+constexpr u32 EMIT_MIN = AHIP_EMIT_MIN;          // items retired per emit (<= 64)
+constexpr u32 EPOCH_ITEMS = (1u << 27) / SUB_BITS;  // positions inside an epoch stay below 2^27 + slack
 constexpr int TOK_CAP = AHIP_TOK_CAP;            // token queue entries per resolve batch
 constexpr int OB_CAP = AHIP_OB_CAP;              // output bytes assembled in LDS per resolve batch
-constexpr int SLAB_ROWS = AHIP_SLAB_ROWS;        // tokens one lane may record per window
-constexpr int SLAB_WORDS = SLAB_ROWS * 64;       // per-workgroup token slab in device scratch (L2-resident)
+constexpr int SLAB_ROWS = AHIP_SLAB_ROWS;        // decode steps whose tokens the slab ring keeps
+constexpr u32 ROW_MASK = SLAB_ROWS - 1;
+constexpr int SLAB_WORDS = SLAB_ROWS * 64;       // per-workgroup token slab in device scratch
+static_assert((RING_DW & (RING_DW - 1)) == 0 && (SLAB_ROWS & (SLAB_ROWS - 1)) == 0 && (ITEMS & (ITEMS - 1)) == 0, "rings are powers of two");
+static_assert(SUB_BITS % 128 == 0 && SPEC_BITS <= (u32)SUB_BITS && SUB_BITS + 64 < 4096, "item geometry");
+static_assert(EMIT_MIN >= 1 && EMIT_MIN <= 64 && (u32)ITEMS >= 2 * EMIT_MIN && ITEMS >= 32, "scheduler geometry");
 
 constexpr u32 TK_LIT = 0x80000000u;  // | byte
 constexpr u32 TK_EOB = 0x40000000u;
 constexpr u32 TK_ERR = 0x20000000u;
 // match: len << 16 | dist   (len <= 258, dist <= 32768)
 
-// LDS of the tokenizer (next to WaveLds): the staged bitstream window
+// LDS of the tokenizer (next to WaveLds): the staged bitstream ring and the per-item scoreboard
 struct TokLds {
-  u32 inbuf[IN_DWORDS] __attribute__((aligned(16)));
+  u32 inbuf[RING_DW] __attribute__((aligned(16)));
+  u32 fa[ITEMS];    // decode run of item s: state<<30 | flags<<28 | lane<<22 | (start - s*SUB)<<12 | (end - s*SUB)
+  u32 fb[ITEMS];    //   slab row of its first token (16 bits) | need<<16: max over its matches of (distance - bytes
+                    //   of the item in front of the match), for the "source before the start of the output" check
+  u32 fc[ITEMS];    //   bytes | tokens<<20
+  u16 spec[ITEMS];  // speculative run of item s: 0x8000 done | 0x4000 usable | (end - (s+1)*SUB)
+  u32 q[64];        // repair queue of one scheduling point: the starts to decode from
 };
 // LDS of the resolver: token queue, output window, start-slot rows
 // E = u8: bytes.  E = u16: symbols of the chunked single-stream decode -- a byte value, or 0x8000 + j for "byte j
@@ -98,23 +127,26 @@ struct ParStats { u32 windows, rounds, fallbacks, partial; u32 cyc[8]; u32 dbg; 
 // Per-lane LSB-first bit reader over the LDS window.  The stream continues at bit `sh` of the
 // 64-bit pair (hi:lo); `nextw` is the dword after `hi`, always already requested from LDS, so a
 // refill never waits on the critical path.  v_alignbit_b32 extracts 32 stream bits in one op.
+// MASK: the staged bitstream is a ring of MASK + 1 dwords (ptr keeps counting; ~0u = a plain buffer).
 struct LaneBits { u32 lo, hi, nextw, sh, ptr; };
+template <u32 MASK>
 AHIP_DEVINL void lb_init(LaneBits &d, const u32 *inbuf, u32 p) {
   u32 w = p >> 5;
-  d.lo = inbuf[w];
-  d.hi = inbuf[w + 1];
-  d.nextw = inbuf[w + 2];
+  d.lo = inbuf[w & MASK];
+  d.hi = inbuf[(w + 1) & MASK];
+  d.nextw = inbuf[(w + 2) & MASK];
   d.ptr = w + 2;
   d.sh = p & 31;
 }
 // bring sh below 32 (branch-free) and re-request the look-ahead dword
+template <u32 MASK>
 AHIP_DEVINL void lb_normalize(LaneBits &d, const u32 *inbuf) {
   const bool adv = d.sh >= 32;
   d.lo = adv ? d.hi : d.lo;
   d.hi = adv ? d.nextw : d.hi;
   d.ptr += adv ? 1u : 0u;
   d.sh &= 31;
-  d.nextw = inbuf[d.ptr];
+  d.nextw = inbuf[d.ptr & MASK];
 }
 AHIP_DEVINL u32 lb_peek32(const LaneBits &d) { return __builtin_amdgcn_alignbit(d.hi, d.lo, d.sh); }
 AHIP_DEVINL u32 lb_pos(const LaneBits &d) { return (d.ptr - 2) * 32 + d.sh; }
@@ -161,8 +193,9 @@ struct BlockMeta {
 // One token at the lane's cursor, straight-line: every lane runs the litlen AND the distance
 // half (a 64-lane step almost always contains a match anyway); selects pick the result.  The
 // only branches skip the long-code resolution when no lane needs it.
+template <u32 MASK>
 AHIP_DEVINL u32 decode_token(LaneBits &d, const WaveLds &L, const BlockMeta &M, const u32 *inbuf) {
-  lb_normalize(d, inbuf);
+  lb_normalize<MASK>(d, inbuf);
   const u32 w = lb_peek32(d);  // 32 valid bits; litlen code + extra <= 20
   u32 e = L.ll[w & ((1u << LL_ROOT) - 1)];
   if (__any(e & E_LONG)) {
@@ -177,7 +210,7 @@ AHIP_DEVINL u32 decode_token(LaneBits &d, const WaveLds &L, const BlockMeta &M, 
   const bool is_special = e & (E_EOB | E_BAD | E_HOLE);
   const bool is_match = !is_lit && !is_special;
   d.sh += cl + (is_match ? xb : 0u);
-  lb_normalize(d, inbuf);
+  lb_normalize<MASK>(d, inbuf);
   const u32 w2 = lb_peek32(d);  // distance code + extra <= 28
   u32 t = L.dt[w2 & ((1u << D_ROOT) - 1)];
   if (__any(is_match && (t & E_LONG))) {
@@ -196,43 +229,7 @@ AHIP_DEVINL u32 decode_token(LaneBits &d, const WaveLds &L, const BlockMeta &M, 
   return tok;
 }
 
-constexpr u32 LR_EOB = 1, LR_ERR = 2, LR_OVF = 4;
-struct LaneRun { u32 end, flags, ntok, nbytes; i32 need; };  // need = max over matches of (dist - bytes before it in this lane)
-
-// Decode from `start` until the cursor reaches `boundary` (or EOB / error).
-//  RECORD: token j of this lane goes to slab[j * 64 + lane] -- every active lane is at the same
-//          j, so each step is one coalesced 256-byte row store into the L2-resident slab.
-template <bool RECORD>
-AHIP_DEVINL LaneRun run_lane(bool active, bool rec, u32 start, u32 boundary, const WaveLds &L, const BlockMeta &M,
-                             const u32 *inbuf, u32 *slab, int lane) {
-  LaneRun r{start, 0, 0, 0, 0};
-  LaneBits d{0, 0, 0, 0, 2};
-  if (active) lb_init(d, inbuf, start);
-  u32 lguard = 0;
-  for (;;) {
-    bool go = active && r.end < boundary && r.flags == 0;
-    if (!__any(go)) break;
-    if (++lguard > 2048) { r.flags = LR_ERR; break; }
-    if (go) {
-      u32 t = decode_token(d, L, M, inbuf);
-      if (t & (TK_EOB | TK_ERR)) {
-        r.flags = (t & TK_EOB) ? LR_EOB : LR_ERR;
-        r.end = lb_pos(d);
-      } else if (RECORD && r.ntok >= (u32)SLAB_ROWS) {
-        r.flags = LR_OVF;
-      } else {
-        if (RECORD && rec) slab[r.ntok * 64 + lane] = t;
-        const bool lit = t >> 31;
-        const i32 req = lit ? 0 : (i32)(t & 0xffff) - (i32)r.nbytes;
-        r.need = req > r.need ? req : r.need;
-        r.ntok += 1;
-        r.nbytes += lit ? 1u : (t >> 16);
-        r.end = lb_pos(d);
-      }
-    }
-  }
-  return r;
-}
+constexpr u32 LR_EOB = 1, LR_ERR = 2;  // how a run ended before its boundary
 
 // Execute `ntok` queued tokens (nbytes of output) in stream order into the LDS output window.
 //  hist: global address of the window's first output byte (earlier output lies below it).
@@ -434,118 +431,303 @@ AHIP_DEVINL u32 stored_block_emit(BitCursor &b, OutCursor &o, TokSink &sink, int
 
 // Decode one Huffman block (tables already built in L) starting at b.pos into tokens.
 // Returns MS_* exactly like huffman_block().
+//
+// Continuous-flow decode.  The block's bitstream is cut into ITEMS of SUB_BITS; the 64 lanes are independent
+// workers that pick up work units at scheduling points (every STEPS decode steps) and never wait for each other
+// inside an item:
+//   SPEC(s)  blind run over the last SPEC_BITS of item s (Huffman streams self-synchronise): its end is the
+//            PREDICTED start of item s+1.  Nothing is recorded.
+//   RUN(s)   decode from a start (predicted, or true) to the end of item s, recording tokens into the slab: row =
+//            global step number, column = lane, so every step is one coalesced 256-byte row store.
+// A scoreboard in LDS (TokLds::fa/fb/fc/need/spec, indexed by item mod ITEMS) holds what the runs found.  At every
+// scheduling point the wave
+//   publishes  the runs that ended,
+//   validates  in order: item V is final when its run started exactly where item V-1's final run ended (64 items
+//              per step: one LDS read per lane, a DPP shift, a ballot).  A mispredicted item is simply put back
+//              with its true start; only items that used its (wrong) end repeat,
+//   retires    final items EMIT_MIN at a time: wave prefix sums give stream order, the slab columns are gathered,
+//              transposed through the ring slots the retired items no longer need and leave as coalesced stores
+//              into the member's token stream; the freed ring slots are refilled with the next compressed bytes,
+//   assigns    idle lanes: the true-start run of item V first, then runs whose predicted start is known, then
+//              speculation ahead (not beyond `hint_end_bits`, the end of the member when the index knows it).
+// Lanes therefore stay busy across what used to be window boundaries: a token is decoded about 1.6 times
+// (speculation over half an item + the run + a few repeats) at near-full lane occupancy.
+// Anything irregular on the true path -- bad symbol, back-reference before the start of the output, output
+// window exhausted, slab ring overrun, input too close to its end -- stops the flow at the last retired item and
+// hands the rest of the block to the serial decoder, which restates the reference symbol by symbol.
 AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, u32 *slab, BitCursor &b, OutCursor &o, TokSink &sink,
-                                       int lane, ParStats &st) {
+                                       int lane, ParStats &st, u64 hint_end_bits) {
   BlockMeta M;
   load_long_meta(M.ll, L.lld, LL_ROOT);
   load_long_meta(M.d, L.dd, D_ROOT);
   const bool emit = sink.base != nullptr;
-  u32 wguard = 0;
-  for (;;) {
-    if (++wguard > (1u << 20)) { st.dbg |= 1; break; }
+  constexpr u32 SLACK_DW = 4;  // a token may run 48 bits past its item and the reader looks two dwords ahead
+  constexpr u32 SUB = SUB_BITS;
+  const u64 lt_mask = (1ull << lane) - 1;
+  u32 eguard = 0;
+  for (;;) {  // epochs: positions are 32-bit offsets from the epoch origin
+    if (++eguard > (1u << 16)) { st.dbg |= 1; break; }
     const u64 gbyte = (b.pos >> 3) & ~3ull;
-    if (gbyte + (u64)IN_DWORDS * 4 > b.in_len) break;  // too close to the end: checked serial path
-    // ---- stage the window ----
-    AHIP_TICK(t_a);
-    {
-      const u8 *g = b.in + gbyte;
-      for (int k = lane * 4; k < IN_DWORDS; k += 256) {
-        const uint4 v = load_u128_unaligned(g + 4 * k);  // IN_DWORDS is a multiple of 4
-        *(uint4 *)(P.inbuf + k) = v;
-      }
+    if (gbyte + (u64)(2 * SUB_DW + SLACK_DW) * 4 > b.in_len) break;  // too close to the end: checked serial path
+    const u64 avail_dw = (b.in_len - gbyte) >> 2;
+    const u64 ni64 = (avail_dw - SLACK_DW) / SUB_DW;
+    const u32 n_items = ni64 > EPOCH_ITEMS ? EPOCH_ITEMS : (u32)ni64;  // items this epoch may decode (>= 2)
+    u32 n_spec = n_items;                                               // items the member is expected to reach into
+    if (hint_end_bits > gbyte * 8) {
+      const u64 h = (hint_end_bits - gbyte * 8 + SUB - 1) / SUB;
+      if (h < n_spec) n_spec = (u32)h;
     }
+    const u32 spec_cap = (n_spec ? n_spec - 1 : 0u) < n_items - 1 ? (n_spec ? n_spec - 1 : 0u) : n_items - 1;  // SPEC(s) serves item s+1
+    AHIP_TICK(t_a);
+    for (u32 i = lane; i < (u32)ITEMS; i += 64) { P.fa[i] = 0; P.spec[i] = 0; }
+    const u32 total_dw = n_items * SUB_DW + SLACK_DW;
+    u32 stage_hi = 0;  // dwords staged so far (multiple of 4)
+    auto stage_to = [&](u32 target) {
+      for (u32 w = stage_hi + (u32)lane * 4; w < target; w += 256)
+        *(uint4 *)(P.inbuf + (w & RING_MASK)) = load_u128_unaligned(b.in + gbyte + 4 * (u64)w);
+      stage_hi = target;
+    };
+    stage_to(total_dw < (u32)RING_DW ? total_dw : (u32)RING_DW);
     wave_sync();
     AHIP_TICK(t_b);
     AHIP_ACC(st.cyc[1], t_a, t_b);
     st.windows++;
-    const u32 s0 = (u32)(b.pos - gbyte * 8);
-    const u32 boundary = (u32)(lane + 1) * SUB_BITS;
-    // ---- pass A: lane 0 from the true boundary (recording), the others blind.  The SAME loop body as
-    //      the pass-B rounds on purpose: a separate "ends only" variant was measured 8 % slower
-    //      (code size / instruction cache) ----
-    LaneRun R = run_lane<true>(true, emit && lane == 0, lane == 0 ? s0 : (u32)lane * SUB_BITS, boundary, L, M, P.inbuf,
-                               slab, lane);
-    AHIP_TICK(t_c);
-    AHIP_ACC(st.cyc[2], t_b, t_c);
-    // ---- pass B rounds: restart from the predecessor's end until the chain is consistent ----
-    // A lane decodes again only when the start it was given last time is no longer its predecessor's end, so
-    // after the first round (every lane once, recording) a round usually keeps one or two lanes busy and the
-    // lock-step loop is as long as THEIR token count, not the longest of 64.  At the fixpoint every lane
-    // started where its predecessor ended and lane 0 started at the true boundary: the chain is the true path
-    // up to the first flagged lane.
-    u32 used_start = lane == 0 ? s0 : ~0u;
-    u32 rguard = 0;
+    const u32 t0 = (u32)(b.pos - gbyte * 8);  // true start of item 0
+    // wave-uniform scheduler state
+    u32 next_spec = 0, next_fix = 1, V = 0, tV = t0, retired = 0, t_ret = t0, g = 0;
+    bool block_done = false, stop_serial = false;
+    // lane state: ms = mode<<28 | item (mode 0 idle, 1 SPEC, 2 RUN)
+    u32 ms = 0, bound = 0, start = 0, endp = 0, fl = 0, ntok = 0, nbytes = 0, row0 = 0;
+    u32 rowctr = 0;  // tokens this lane has recorded: its column of the slab is a ring of SLAB_ROWS
+    i32 need = 0;
+    LaneBits d{0, 0, 0, 0, 2};
+    u32 *const col = slab + (u32)lane * SLAB_ROWS;
+    u32 guard = 0;
     for (;;) {
-      if (++rguard > 80) { st.dbg |= 2; break; }
-      // DPP reads need the SOURCE lane active: take lane-1's values with every lane enabled
-      const u32 prev_end = lane_prev(R.end), prev_flags = lane_prev(R.flags);
-      const bool act = lane > 0 && prev_flags == 0 && prev_end != used_start;
-      if (!__any(act)) break;
-      LaneRun R2 = run_lane<true>(act, emit, prev_end, boundary, L, M, P.inbuf, slab, lane);
-      if (act) { R = R2; used_start = prev_end; }
-      st.rounds++;
-    }
-    const int final_upto = 63;
-    AHIP_TICK(t_d);
-    AHIP_ACC(st.cyc[3], t_c, t_d);
-    // ---- who is on the true path ----
-    u64 final_mask = (final_upto >= 63) ? ~0ull : ((2ull << final_upto) - 1);
-    u64 flagged = __ballot(R.flags != 0) & final_mask;
-    int kstop = flagged ? (__ffsll((long long)flagged) - 1) : 64;
-    u32 stop_flags = flagged ? lane_bcast(R.flags, kstop) : 0u;
-    if (stop_flags & (LR_ERR | LR_OVF)) { st.fallbacks++; break; }  // the serial decoder decides
-    const int nlanes = kstop < 64 ? kstop + 1 : 64;  // kstop's tokens before its EOB count too
-    const bool valid = lane < nlanes;
-    u32 tot_tok, tot_bytes;
-    const u32 T = wave_excl_sum(valid ? R.ntok : 0u, tot_tok);
-    const u32 B = wave_excl_sum(valid ? R.nbytes : 0u, tot_bytes);
-    if ((u64)tot_bytes > o.limit - o.pos) { st.fallbacks++; break; }  // output window exhausted: serial path reports it
-    // a back-reference reaching before the member start: dist > bytes before the token
-    if (__any(valid && (i64)R.need > (i64)(o.pos + B))) { st.fallbacks++; break; }
-    const u32 next_pos = lane_bcast(R.end, kstop < 64 ? kstop : 63);  // past the EOB code, or lane 63's end
-    // ---- slab (lane-major rows) -> the member's token stream (stream order) ----
-    AHIP_TICK(t_e0);
-    if (emit) {
-      // Transposed through LDS (the idle bitstream window) so that the stream is written with
-      // coalesced stores: per-lane 4-byte stores to 64 different lines ran at one line per cycle in
-      // the address coalescer and cost more than either decode pass.
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      constexpr u32 QCAP = 1024;
-      static_assert(IN_DWORDS >= (int)QCAP, "token transpose buffer lives in the window buffer");
-      const u32 cnt = valid ? R.ntok : 0u;
-      u32 *q = sink.base + sink.w;
-      for (u32 lo = 0; lo < tot_tok; lo += QCAP) {
-        // rows of this lane whose stream index T + r falls into [lo, lo + QCAP)
-        const u32 rb = lo > T ? lo - T : 0u;
-        const u32 re = lo + QCAP > T ? (cnt < lo + QCAP - T ? cnt : lo + QCAP - T) : 0u;
-        const bool any_rows = rb < re;
-        const u32 rmin = ~wave_umax(any_rows ? ~rb : 0u), rmax = wave_umax(any_rows ? re : 0u);
-        const u32 tb = T - lo;  // wraps for lanes that start before the batch; only used when in range
-        for (u32 r = rmin; r < rmax; r += 16) {  // 16 row loads in flight: this loop is latency-bound
-          u32 t[16];
-#pragma unroll
-          for (int u = 0; u < 16; ++u) t[u] = (r + u >= rb && r + u < re) ? slab[(r + u) * 64 + lane] : 0u;
-#pragma unroll
-          for (int u = 0; u < 16; ++u)
-            if (r + u >= rb && r + u < re) P.inbuf[tb + r + u] = t[u];
+      if (++guard > 4 * n_items + 4096) {  // never spin: the serial decoder takes over at the last retired item
+        st.dbg |= 2;
+#ifdef AHIP_FLOW_DEBUG
+        st.cyc[0] = V; st.cyc[1] = retired; st.cyc[2] = next_fix; st.cyc[3] = next_spec; st.cyc[4] = g; st.cyc[5] = n_items;
+        st.cyc[6] = uniform(P.fa[V & ITEM_MASK]); st.cyc[7] = (block_done ? 1u : 0u) | (u32)__popcll(__ballot((ms >> 28) != 0)) << 8 | stage_hi << 16;
+#endif
+        stop_serial = true;
+        break;
+      }
+      AHIP_TICK(t_s0);
+      // ===== scan the window [V, V + 64): validate in order, find the runs that have to be repeated =====
+      // pend = where this item's run has to start: the end of its predecessor's finished run (tV, the truth, for
+      // item V).  An item is final when its run started there and its predecessor is final.  A run that started
+      // somewhere else -- or an item that lost its run -- is decoded again from pend as soon as pend is known,
+      // not only when validation gets there.
+      u64 rm = 0;     // lanes whose item needs a (new) run
+      u32 pend = 0;   //   and where it starts
+      if (!block_done && !stop_serial) {
+        const u32 wi = V + (u32)lane;
+        const bool win = wi < n_items && wi < retired + (u32)ITEMS;
+        const u32 wa = win ? P.fa[wi & ITEM_MASK] : (1u << 30);
+        const u32 wstate = wa >> 30, wfl = (wa >> 28) & 3u;
+        const u32 wend = wi * SUB + (wa & 0xfffu), wstart = wi * SUB + ((wa >> 12) & 0x3ffu);
+        const u32 wkey = (wstate == 2 && wfl == 0) ? wend : ~0u;  // usable end of a finished run
+        pend = lane_prev(wkey);  // DPP: every lane enabled here
+        pend = lane == 0 ? tV : pend;
+        const bool ok = wstate == 2 && wstart == pend;
+        const u64 okm = __ballot(ok);
+        u32 n = okm == ~0ull ? 64u : (u32)__builtin_ctzll(~okm);
+        const u64 flm = __ballot(ok && wfl != 0) & (n == 64 ? ~0ull : ((1ull << n) - 1));
+        u32 stop_flags = 0;
+        if (flm) {
+          const int j = __builtin_ctzll(flm);
+          stop_flags = lane_bcast(wfl, j);
+          n = (stop_flags & LR_EOB) ? (u32)j + 1 : (u32)j;  // an item that ends in a bad symbol is left to the serial decoder
         }
+        if (n) { tV = lane_bcast(wend, (int)n - 1); V += n; }
+        if (stop_flags & LR_EOB) block_done = true;
+        else if (stop_flags) stop_serial = true;
+        if ((ms >> 28) == 1 && (ms & 0x0fffffffu) < V) ms = 0;  // speculation nobody needs any more
+        if (next_fix <= V) next_fix = V + 1;
+        const bool rerun = win && (u32)lane >= n && pend != ~0u && wi < next_fix && (wstate == 0 || (wstate == 2 && wstart != pend));
+        rm = (block_done || stop_serial) ? 0ull : __ballot(rerun);
+      }
+      AHIP_TICK(t_s1);
+      AHIP_ACC(st.cyc[3], t_s0, t_s1);
+      // ===== retire: the tokens of final items go to the member's token stream, the ring is refilled =====
+      bool finishing = block_done || stop_serial || V >= n_items;
+      while (V - retired >= (finishing ? 1u : EMIT_MIN)) {
+        const u32 nb = V - retired < 64 ? V - retired : 64u;
+        const bool mine = (u32)lane < nb;
+        const u32 s = retired + (u32)lane;
+        const u32 a = mine ? P.fa[s & ITEM_MASK] : 0u;
+        const u32 fbv = mine ? P.fb[s & ITEM_MASK] : 0u;
+        const u32 c = mine ? P.fc[s & ITEM_MASK] : 0u;
+        const u32 r0 = fbv & 0xffffu, nd = fbv >> 16;
+        const u32 cnt = c >> 20, nby = c & 0xfffffu, cl = (a >> 22) & 63u;
+        // an item whose slab rows have been overwritten since (it waited too long for its predecessors) is decoded
+        // again from its true start; what is in front of it still retires
+        const u32 col_now = lane_gather(rowctr, cl);
+        const u64 lost = __ballot(mine && emit && cnt && ((col_now - r0) & 0xffffu) > (u32)SLAB_ROWS);
+        if (lost) {
+          const u32 j = (u32)__builtin_ctzll(lost);
+          st.partial++;
+          if ((u32)lane == j) P.fa[s & ITEM_MASK] = 0;
+          wave_sync();
+          V = retired + j;  // the batch shrinks to the items in front of it; the scan finds the rest again
+          tV = j ? lane_bcast(s * SUB + (a & 0xfffu), (int)j - 1) : t_ret;
+          block_done = false;
+          finishing = stop_serial;
+          rm = 0;
+          if (j == 0) break;
+          continue;
+        }
+        u32 tot_tok, tot_bytes;
+        const u32 T = wave_excl_sum(cnt, tot_tok);
+        const u32 B = wave_excl_sum(nby, tot_bytes);
+        const bool bad_cap = (u64)tot_bytes > o.limit - o.pos;         // output window exhausted
+        const bool bad_far = __any(mine && (u64)nd > o.pos + B) != 0;  // back-reference before the start of the output
+        if (bad_cap || bad_far) {
+          st.fallbacks++;
+          st.dbg |= bad_cap ? 4u : 0u; st.dbg |= bad_far ? 8u : 0u;
+          stop_serial = true;
+          break;
+        }
+        if (emit) {
+          // every retiring item is one contiguous run in the slab column of the lane that decoded it: lane i copies
+          // item i's run to its place in the stream (per-lane sequential reads and writes, 16 in flight)
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          u32 *q = sink.base + sink.w + T;
+          const u32 *src = slab + cl * SLAB_ROWS;
+          const u32 maxcnt = wave_umax(cnt);
+          for (u32 u0 = 0; u0 < maxcnt; u0 += 16) {
+            u32 t[16];
+#pragma unroll
+            for (u32 u = 0; u < 16; ++u) t[u] = (u0 + u < cnt) ? src[(r0 + u0 + u) & ROW_MASK] : 0u;
+#pragma unroll
+            for (u32 u = 0; u < 16; ++u)
+              if (u0 + u < cnt) q[u0 + u] = t[u];
+          }
+        }
+        sink.w += tot_tok;
+        o.pos += tot_bytes;
+        t_ret = lane_bcast(s * SUB + (a & 0xfffu), (int)nb - 1);
+        if (mine) { P.fa[s & ITEM_MASK] = 0; P.spec[s & ITEM_MASK] = 0; }
+        retired += nb;
+        const u32 room = retired * SUB_DW + (u32)RING_DW;
         wave_sync();
-        const u32 nq = tot_tok - lo < QCAP ? tot_tok - lo : QCAP;
-        for (u32 k = lane; k < nq; k += 64) q[lo + k] = P.inbuf[k];
+        stage_to(total_dw < room ? total_dw : room);
         wave_sync();
       }
+      AHIP_TICK(t_s2);
+      AHIP_ACC(st.cyc[4], t_s1, t_s2);
+      if (stop_serial || (finishing && retired == V)) break;
+      // ===== assign work to idle lanes: repairs first, then runs with a predicted start, then speculation =====
+      {
+        const bool idle = (ms >> 28) == 0;
+        const u64 im = __ballot(idle);
+        if (im) {
+          const u32 nidle = (u32)__popcll(im);
+          const u32 rank = (u32)__popcll(im & lt_mask);
+          const u32 stage_items = (stage_hi - SLACK_DW) / SUB_DW;  // items whose bits (+ slack) are in the ring
+          const u32 lim = n_items < stage_items ? n_items : stage_items;
+          // (a) repairs (ordered: the one validation waits for comes first)
+          const bool rr = ((rm >> lane) & 1) && pend / SUB < lim;
+          const u64 rm2 = __ballot(rr);
+          const u32 nrr = (u32)__popcll(rm2);
+          const u32 na = nrr < nidle ? nrr : nidle;
+          const u32 rr_rank = (u32)__popcll(rm2 & lt_mask);
+          if (rr && rr_rank < na) { P.q[rr_rank] = pend; P.fa[(pend / SUB) & ITEM_MASK] = 1u << 30; }
+          st.rounds += na;
+          // (b) runs whose predicted start is known: consecutive items from next_fix
+          const u32 sb = next_fix + (u32)lane;
+          const bool okb = sb < lim && (P.spec[(sb - 1) & ITEM_MASK] & 0xc000u) == 0xc000u;
+          const u64 okm = __ballot(okb);
+          const u32 nready = okm == ~0ull ? 64u : (u32)__builtin_ctzll(~okm);
+          // (c) speculation ahead
+          if (next_spec < V) next_spec = V;
+          const u32 slim = spec_cap < lim ? spec_cap : lim;
+          const u32 nsp = slim > next_spec ? slim - next_spec : 0u;
+          const u32 nb_ = nready < nidle - na ? nready : nidle - na;
+          const u32 nc_ = nsp < nidle - na - nb_ ? nsp : nidle - na - nb_;
+          const u32 u2 = rank - na;  // wraps for the lanes that take (a); unused there
+          const bool take_a = idle && rank < na;
+          const bool take_b = idle && rank >= na && u2 < nb_;
+          const bool take_c = idle && rank >= na && !take_b && u2 - nb_ < nc_;
+          wave_sync();  // P.q
+          if (take_a || take_b || take_c) {
+            u32 s_new, st_new;
+            if (take_a) { st_new = P.q[rank]; s_new = st_new / SUB; }
+            else if (take_b) { s_new = next_fix + u2; st_new = s_new * SUB + (P.spec[(s_new - 1) & ITEM_MASK] & 0xfffu); }
+            else {
+              s_new = next_spec + (u2 - nb_);
+              st_new = (s_new + 1) * SUB - SPEC_BITS;
+              if (st_new < t0) st_new = t0;  // item 0 of the epoch: nothing in front of the true start belongs to this block
+            }
+            ms = (take_c ? 1u << 28 : 2u << 28) | s_new;
+            bound = (s_new + 1) * SUB;
+            start = st_new; endp = st_new; fl = 0; ntok = 0; nbytes = 0; need = 0; row0 = rowctr;
+            lb_init<RING_MASK>(d, P.inbuf, st_new);
+            if (take_b) P.fa[s_new & ITEM_MASK] = 1u << 30;  // in flight
+          }
+          next_fix += nb_;
+          next_spec += nc_;
+          wave_sync();
+        }
+      }
+      AHIP_TICK(t_s3);
+      AHIP_ACC(st.cyc[3], t_s2, t_s3);
+      // ===== decode steps =====
+      for (int k = 0; k < STEPS; ++k) {
+        const bool go = (ms >> 28) != 0 && fl == 0 && endp < bound;
+        if (!__any(go)) break;
+        if (go) {
+          const u32 t = decode_token<RING_MASK>(d, L, M, P.inbuf);
+          if (t & (TK_EOB | TK_ERR)) {
+            fl = (t & TK_EOB) ? LR_EOB : LR_ERR;
+            endp = lb_pos(d);
+          } else {
+            if (emit && (ms >> 29)) { col[rowctr & ROW_MASK] = t; rowctr += 1; }
+            const bool lit = t >> 31;
+            const i32 req = lit ? 0 : (i32)(t & 0xffff) - (i32)nbytes;
+            need = req > need ? req : need;
+            ntok += 1;
+            nbytes += lit ? 1u : (t >> 16);
+            endp = lb_pos(d);
+          }
+        }
+        ++g;
+      }
+      AHIP_TICK(t_s4);
+      AHIP_ACC(st.cyc[2], t_s3, t_s4);
+      // ===== publish the runs that ended =====
+      {
+        const u32 mode = ms >> 28, s = ms & 0x0fffffffu;
+        const bool fin = mode != 0 && !(fl == 0 && endp < bound);
+        if (__any(fin)) {
+          if (fin) {
+            if (mode == 1) {
+              const bool usable = fl == 0 && endp - bound < 64;
+              P.spec[s & ITEM_MASK] = (u16)(0x8000u | (usable ? 0x4000u : 0u) | ((endp - bound) & 0xfffu));
+            } else {
+              P.fb[s & ITEM_MASK] = (row0 & 0xffffu) | ((u32)need << 16);
+              P.fc[s & ITEM_MASK] = nbytes | (ntok << 20);
+              P.fa[s & ITEM_MASK] = (2u << 30) | (fl << 28) | ((u32)lane << 22) | ((start - s * SUB) << 12) | (endp - s * SUB);
+            }
+            ms = 0;
+          }
+          wave_sync();
+        }
+      }
     }
-    AHIP_TICK(t_f);
-    AHIP_ACC(st.cyc[4], t_e0, t_f);
-    sink.w += tot_tok;
-    o.pos += tot_bytes;
-    b.pos = gbyte * 8 + next_pos;
-    if (kstop < 64) return MS_OK;
+    b.pos = gbyte * 8 + t_ret;
+#ifdef AHIP_PROFILE
+    st.partial += g;  // decode steps of the wave
+#endif
+    if (stop_serial) { if (!(st.dbg & 2)) { /* counted at the site */ } break; }
+    if (block_done) return MS_OK;
+    // the epoch is used up (V == n_items): go on from the new origin
   }
-  AHIP_TICK(t_s0);
+  AHIP_TICK(t_x0);
   u32 rs = huffman_block_emit(L, b, o, sink, lane);
-  AHIP_TICK(t_s1);
-  AHIP_ACC(st.cyc[7], t_s0, t_s1);
+  AHIP_TICK(t_x1);
+  AHIP_ACC(st.cyc[7], t_x0, t_x1);
   return rs;
 }
 
@@ -564,6 +746,8 @@ AHIP_DEVINL void inflate_member(WaveLds &L, HeaderLds &H, TokLds *P, u32 *slab, 
   const u64 hist = CHUNK ? cx->hist : 0u;
   OutCursor o{out + m.out_off, hist, m.out_limit + hist};
   TokSink sink{tokens, 0};
+  // where the index expects the deflate data to end (a hint for speculation only: the decode itself never trusts it)
+  const u64 hint_end_bits = (!CHUNK && m.expect_end != ~0ull) ? m.expect_end * 8 : 0ull;
   u32 status = MS_EOS, blocks = 0;
   for (;;) {
     if (((b.pos + 7) >> 3) >= in_len) { status = MS_EOS; break; }
@@ -606,7 +790,7 @@ AHIP_DEVINL void inflate_member(WaveLds &L, HeaderLds &H, TokLds *P, u32 *slab, 
         AHIP_TICK(t_h1);
         AHIP_ACC(st.cyc[0], t_h0, t_h1);
         if (!ok) r = MS_OVERSUB;
-        else if (PAR) r = huffman_block_tokenize(L, *P, slab, b, o, sink, lane, st);
+        else if (PAR) r = huffman_block_tokenize(L, *P, slab, b, o, sink, lane, st, hint_end_bits);
         else r = huffman_block<WRITE>(L, b, o, lane);
       }
     }
@@ -630,7 +814,11 @@ AHIP_DEVINL void inflate_member(WaveLds &L, HeaderLds &H, TokLds *P, u32 *slab, 
     res.fallbacks = st.fallbacks;
     res.partial = st.partial;
     for (int k = 0; k < 8; ++k) res.cyc[k] = st.cyc[k];
+#ifndef AHIP_FLOW_DEBUG
     if (st.dbg) res.cyc[7] = 0xdead0000u | st.dbg;
+#else
+    if (st.dbg) res.blocks |= st.dbg << 16;
+#endif
     res.tok_words = sink.w;
   }
 }

@@ -34,8 +34,14 @@ constexpr u32 E_BAD = 0x400;   // litlen 286/287, distance 30/31: reference retu
 constexpr u32 E_LONG = 0x800;  // code longer than the primary table: canonical search
 constexpr u32 E_HOLE = 0x1000; // unfilled litlen entry (symbol 0, length 0): literal-0 forever
 
-constexpr int LL_ROOT = 10;
-constexpr int D_ROOT = 8;
+#ifndef AHIP_LL_ROOT
+#define AHIP_LL_ROOT 10
+#endif
+#ifndef AHIP_D_ROOT
+#define AHIP_D_ROOT 8
+#endif
+constexpr int LL_ROOT = AHIP_LL_ROOT;  // primary table bits: litlen / distance
+constexpr int D_ROOT = AHIP_D_ROOT;
 
 AHIP_DEVINL u32 litlen_entry(u32 sym, u32 len) {
   if (sym < 256) return (sym << 16) | E_LIT | len;
