@@ -47,47 +47,80 @@ struct TokKernelLds {
   TokLds p;
 };
 
-// Persistent workgroups: the grid is sized to what is resident at once and strides over the
-// members, so the per-workgroup slab (scratch, SLAB_WORDS u32) stays L2-resident.
+// Persistent workgroups: the grid is sized to what is resident at once and strides over the members.
 //  tokens == nullptr: sizing run (end position, size and verdict only).
+//  tokens / dir: the launch group's token areas and run directories (TokSink, tok_layout).
+AHIP_DEVINL TokSink member_sink(u32 *tokens, uint2 *dir, u64 out_rel, u64 out_limit, u32 k) {
+  TokSink sk{nullptr, 0, nullptr, 0, 0, ~0u, 0, 0, false};
+  if (tokens) {
+    u64 toff, doff;
+    tok_layout(out_rel, out_limit, k, toff, sk.col_cap, doff, sk.dir_cap);
+    sk.area = tokens + toff;
+    sk.dir = dir + doff;
+  }
+  return sk;
+}
 __global__ __launch_bounds__(64, AHIP_TOK_MIN_WAVES) void inflate_tokenize_kernel(const u8 *__restrict__ in, u64 in_len,
                                                              const MemberDesc *__restrict__ members, u32 first_member,
-                                                             u32 n_members, u32 *__restrict__ tokens, u64 group_out0,
-                                                             MemberResult *__restrict__ results,
-                                                             u32 *__restrict__ scratch) {
+                                                             u32 n_members, u32 *__restrict__ tokens, uint2 *__restrict__ dir,
+                                                             u64 group_out0, MemberResult *__restrict__ results) {
   __shared__ TokKernelLds lds;
   const int lane = threadIdx.x;
-  u32 *slab = scratch + (size_t)blockIdx.x * SLAB_WORDS;
   for (u32 k = blockIdx.x; k < n_members; k += gridDim.x) {
     const u32 m = first_member + k;
     MemberDesc d = members[m];
     d.in_off = uniform64(d.in_off);
     d.out_off = uniform64(d.out_off);
     d.out_limit = uniform64(d.out_limit);
-    u32 *tk = tokens ? tokens + (d.out_off - group_out0) : nullptr;
-    // header scratch lives in the upper part of the window buffer (the staged header bytes use the first 640)
+    // header scratch lives in the upper part of the ring buffer (the staged header bytes use the first 640)
     static_assert(sizeof(HeaderLds) + 1024 <= sizeof(TokLds), "header scratch must fit behind the staged header");
     HeaderLds &hdr = *(HeaderLds *)((u8 *)lds.p.inbuf + 1024);
     const u64 lim = uniform64(d.in_end) ? uniform64(d.in_end) : in_len;
-    inflate_member<false, true>(lds.w, hdr, &lds.p, slab, in, lim, d, (u8 *)nullptr, tk, results[m], lane);
+    inflate_member<false, true>(lds.w, hdr, &lds.p, in, lim, d, (u8 *)nullptr,
+                                member_sink(tokens, dir, d.out_off - group_out0, d.out_limit, k), results[m], lane);
   }
 }
 
 __global__ __launch_bounds__(64, AHIP_RES_MIN_WAVES) void inflate_resolve_kernel(const u8 *__restrict__ in,
                                                             const MemberDesc *__restrict__ members, u32 first_member,
                                                             u32 n_members, u8 *out, const u32 *__restrict__ tokens,
-                                                            u64 group_out0, MemberResult *__restrict__ results) {
+                                                            const uint2 *__restrict__ dir, u64 group_out0,
+                                                            MemberResult *__restrict__ results) {
   __shared__ ParLds lds;
   const int lane = threadIdx.x;
   for (u32 k = blockIdx.x; k < n_members; k += gridDim.x) {
     const u32 m = first_member + k;
-    const u64 out_off = uniform64(members[m].out_off);
-    const u64 nwords = uniform64(results[m].tok_words);
+    const u64 out_off = uniform64(members[m].out_off), out_limit = uniform64(members[m].out_limit);
+    if (uniform(results[m].status) == MS_TOKFULL) continue;  // inflate_redo_kernel decodes it
+    const u32 ndir = (u32)uniform64(results[m].tok_words);
+    u64 toff, doff;
+    u32 cc, dc;
+    tok_layout(out_off - group_out0, out_limit, k, toff, cc, doff, dc);
     u32 cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    resolve_member(lds, in, tokens + (out_off - group_out0), nwords, out + out_off, cyc, lane);
-#ifdef AHIP_PROFILE
+    resolve_member(lds, in, tokens + toff, dir + doff, ndir, out + out_off, cyc, lane);
+#if defined(AHIP_PROFILE) && !defined(AHIP_PROFILE_TOK_ONLY)
     if (lane == 0) { results[m].cyc[4] += cyc[4]; results[m].cyc[5] += cyc[5]; results[m].cyc[6] += cyc[6]; }
 #endif
+  }
+}
+
+// Members whose token area or run directory overflowed (MS_TOKFULL: pathological streams) are decoded here by the
+// serial byte-writing decoder, one wave each, after everything else.
+__global__ __launch_bounds__(64) void inflate_redo_kernel(const u8 *__restrict__ in, u64 in_len,
+                                                         const MemberDesc *__restrict__ members, u32 first_member,
+                                                         u32 n_members, u8 *out, MemberResult *__restrict__ results) {
+  __shared__ WaveLds lds;
+  __shared__ HeaderLds hdr;
+  const int lane = threadIdx.x;
+  for (u32 k = blockIdx.x; k < n_members; k += gridDim.x) {
+    const u32 m = first_member + k;
+    if (uniform(results[m].status) != MS_TOKFULL) continue;
+    MemberDesc d = members[m];
+    d.in_off = uniform64(d.in_off);
+    d.out_off = uniform64(d.out_off);
+    d.out_limit = uniform64(d.out_limit);
+    const u64 lim = uniform64(d.in_end) ? uniform64(d.in_end) : in_len;
+    inflate_member<true, false>(lds, hdr, nullptr, in, lim, d, out, TokSink{nullptr, 0, nullptr, 0, 0, ~0u, 0, 0, false}, results[m], lane);
   }
 }
 
@@ -108,7 +141,7 @@ __global__ __launch_bounds__(64) void inflate_members_serial_kernel(const u8 *__
   d.out_off = uniform64(d.out_off);
   d.out_limit = uniform64(d.out_limit);
   const u64 lim = uniform64(d.in_end) ? uniform64(d.in_end) : in_len;
-  inflate_member<WRITE, false>(lds, hdr, nullptr, nullptr, in, lim, d, out, nullptr, results[m], lane);
+  inflate_member<WRITE, false>(lds, hdr, nullptr, in, lim, d, out, TokSink{nullptr, 0, nullptr, 0, 0, ~0u, 0, 0, false}, results[m], lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -228,20 +261,25 @@ hipError_t launch_inflate_group(const u8 *in, u64 n, const MemberDesc *members, 
     res_resident = cus * (b > 0 ? b : 1);
   }
   const u32 grid1 = count < (u32)tok_resident ? count : (u32)tok_resident;
-  void *sp = nullptr, *tp = nullptr;
-  hipError_t e = scratch_reserve((size_t)grid1 * SLAB_WORDS * 4, &sp);
-  if (e != hipSuccess) return e;
+  void *tp = nullptr, *dp = nullptr;
+  hipError_t e = hipSuccess;
   if (WRITE) {
-    e = tokens_reserve((size_t)(out1 - out0) * 4 + 64, &tp);
+    // 1.5 token words + 1/16 directory entry per output byte, plus a fixed allowance per member (tok_layout)
+    const u64 span = out1 - out0;
+    if (span > (1ull << 40)) return hipErrorInvalidValue;
+    e = tokens_reserve(((size_t)(span * 3 / 2) + (size_t)count * 1024 + 64) * 4, &tp);
+    if (e != hipSuccess) return e;
+    e = scratch_reserve(((size_t)(span / 16) + (size_t)count * 64 + 64) * 8, &dp);
     if (e != hipSuccess) return e;
   }
   if (getenv("AHIP_DEBUG")) fprintf(stderr, "[ahip] inflate group first=%u count=%u grid=%u/%d out=%llu write=%d\n", first, count, grid1, res_resident, (unsigned long long)(out1 - out0), (int)WRITE);
-  hipLaunchKernelGGL(inflate_tokenize_kernel, dim3(grid1), dim3(64), 0, st, in, n, members, first, count, (u32 *)tp, out0,
-                     res, (u32 *)sp);
+  hipLaunchKernelGGL(inflate_tokenize_kernel, dim3(grid1), dim3(64), 0, st, in, n, members, first, count, (u32 *)tp, (uint2 *)dp,
+                     out0, res);
   if (WRITE) {
     const u32 grid2 = count < (u32)res_resident ? count : (u32)res_resident;
     hipLaunchKernelGGL(inflate_resolve_kernel, dim3(grid2), dim3(64), 0, st, in, members, first, count, out,
-                       (const u32 *)tp, out0, res);
+                       (const u32 *)tp, (const uint2 *)dp, out0, res);
+    hipLaunchKernelGGL(inflate_redo_kernel, dim3(grid2 < 1024 ? grid2 : 1024), dim3(64), 0, st, in, n, members, first, count, out, res);
   }
   return hipGetLastError();
 }
@@ -631,10 +669,8 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
     HIP_TRY(hipMemcpyAsync(dcand.p, cand.data(), (size_t)nc * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dchunks.p, cd.data(), (size_t)nc * sizeof(ChunkDesc), hipMemcpyHostToDevice, st));
     const u32 grid = nc < (u32)sm_resident_waves() ? nc : (u32)sm_resident_waves();
-    void *sp = nullptr;
-    HIP_TRY(scratch_reserve((size_t)grid * SLAB_WORDS * 4, &sp));
     hipLaunchKernelGGL(sm_tokenize_kernel, dim3(grid), dim3(64), 0, st, d_in, n, dchunks.as<ChunkDesc>(), nc, dcand.as<u64>(), nc,
-                       (u32 *)nullptr, dres.as<MemberResult>(), (u32 *)sp);
+                       (u32 *)nullptr, (uint2 *)nullptr, dres.as<MemberResult>());
     std::vector<MemberResult> rs(nc);
     HIP_TRY(hipMemcpyAsync(rs.data(), dres.p, (size_t)nc * sizeof(MemberResult), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -672,7 +708,8 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
   const u32 nch = (u32)g_sm.chain.size(), nc = (u32)g_sm.cand.size();
   const u64 total = g_sm.total_out;
   void *tp = nullptr, *sp = nullptr;
-  HIP_TRY(tokens_reserve((size_t)total * 4 + 64, &tp));
+  HIP_TRY(tokens_reserve(((size_t)(total * 3 / 2) + (size_t)nch * 1024 + 64) * 4, &tp));
+  HIP_TRY(scratch_reserve(((size_t)(total / 16) + (size_t)nch * 64 + 64) * 8, &sp));
   HIP_TRY(dsym.reserve((size_t)total * 2 + 64));
   HIP_TRY(dwin.reserve((size_t)nch * SM_WINDOW));
   HIP_TRY(dcand.reserve((size_t)nc * 8));
@@ -681,9 +718,8 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
   HIP_TRY(hipMemcpyAsync(dcand.p, g_sm.cand.data(), (size_t)nc * 8, hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(dchunks.p, g_sm.chain.data(), (size_t)nch * sizeof(ChunkDesc), hipMemcpyHostToDevice, st));
   const u32 grid = nch < (u32)sm_resident_waves() ? nch : (u32)sm_resident_waves();
-  HIP_TRY(scratch_reserve((size_t)grid * SLAB_WORDS * 4, &sp));
   hipLaunchKernelGGL(sm_tokenize_kernel, dim3(grid), dim3(64), 0, st, d_in, n, dchunks.as<ChunkDesc>(), nch, dcand.as<u64>(), nc,
-                     (u32 *)tp, dres.as<MemberResult>(), (u32 *)sp);
+                     (u32 *)tp, (uint2 *)sp, dres.as<MemberResult>());
   std::vector<MemberResult> rs(nch);
   HIP_TRY(hipMemcpyAsync(rs.data(), dres.p, (size_t)nch * sizeof(MemberResult), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
@@ -696,7 +732,7 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
       return AHIP_OK;
     }
   hipLaunchKernelGGL(sm_resolve_kernel, dim3(grid), dim3(64), 0, st, d_in, dchunks.as<ChunkDesc>(), nch, dsym.as<u16>(), (const u32 *)tp,
-                     dres.as<MemberResult>());
+                     (const uint2 *)sp, dres.as<MemberResult>());
   {
     static DevBuf dwsym, dgwin;
     u32 gs = 1;

@@ -26,6 +26,7 @@ enum : u32 {
   MS_FARREF = 17,   // back-reference reaches before this member's first byte
   MS_OVERSUB = 18,  // over-subscribed Huffman code lengths (not reproduced)
   MS_CHUNK_END = 19, // chunked single-stream decode: stopped at the next chunk's first block (end_pos is a BIT position)
+  MS_TOKFULL = 20,  // internal: the member's token area / run directory overflowed; the byte-writing serial kernel redoes it
 };
 
 struct MemberDesc {
@@ -64,7 +65,7 @@ struct MemberResult {
   u32 partial;  // windows cut short by the token/byte caps (diagnostics)
   u32 cyc[8];   // -DAHIP_PROFILE builds: shader-clock cycles / 16 per phase
                 //  0 header+tables 1 stage 2 pass A 3 pass B 4 emit 5 resolve 6 flush 7 serial decode
-  u64 tok_words; // words the tokenizer wrote for this member
+  u64 tok_words; // runs the tokenizer entered into this member's directory
 };
 
 #define AHIP_DEVINL __device__ __forceinline__

@@ -55,9 +55,6 @@ namespace ahip {
 #ifndef AHIP_OB_CAP
 #define AHIP_OB_CAP 4608
 #endif
-#ifndef AHIP_SLAB_ROWS
-#define AHIP_SLAB_ROWS 512
-#endif
 constexpr int SUB_BITS = AHIP_SUB_BITS;          // bits per work item ("subsequence") of the tokenizer
 constexpr int SUB_DW = SUB_BITS / 32;
 constexpr int RING_DW = AHIP_RING_DW;            // staged bitstream: a ring of dwords in LDS
@@ -70,14 +67,11 @@ constexpr u32 EMIT_MIN = AHIP_EMIT_MIN;          // items retired per emit (<= 6
 constexpr u32 EPOCH_ITEMS = (1u << 27) / SUB_BITS;  // positions inside an epoch stay below 2^27 + slack
 constexpr int TOK_CAP = AHIP_TOK_CAP;            // token queue entries per resolve batch
 constexpr int OB_CAP = AHIP_OB_CAP;              // output bytes assembled in LDS per resolve batch
-constexpr int SLAB_ROWS = AHIP_SLAB_ROWS;        // decode steps whose tokens the slab ring keeps
-constexpr u32 ROW_MASK = SLAB_ROWS - 1;
-constexpr int SLAB_WORDS = SLAB_ROWS * 64;       // per-workgroup token slab in device scratch
-static_assert((RING_DW & (RING_DW - 1)) == 0 && (SLAB_ROWS & (SLAB_ROWS - 1)) == 0 && (ITEMS & (ITEMS - 1)) == 0, "rings are powers of two");
+static_assert((RING_DW & (RING_DW - 1)) == 0 && (ITEMS & (ITEMS - 1)) == 0, "rings are powers of two");
 static_assert(SUB_BITS % 128 == 0 && SPEC_BITS <= (u32)SUB_BITS && SUB_BITS + 64 < 4096, "item geometry");
 static_assert(EMIT_MIN >= 1 && EMIT_MIN <= 64 && (u32)ITEMS >= 2 * EMIT_MIN && ITEMS >= 32, "scheduler geometry");
 
-constexpr u32 TK_LIT = 0x80000000u;  // | byte
+constexpr u32 TK_LIT = 0x80000000u;  // | byte << 16
 constexpr u32 TK_EOB = 0x40000000u;
 constexpr u32 TK_ERR = 0x20000000u;
 // match: len << 16 | dist   (len <= 258, dist <= 32768)
@@ -86,11 +80,13 @@ constexpr u32 TK_ERR = 0x20000000u;
 struct TokLds {
   u32 inbuf[RING_DW] __attribute__((aligned(16)));
   u32 fa[ITEMS];    // decode run of item s: state<<30 | flags<<28 | lane<<22 | (start - s*SUB)<<12 | (end - s*SUB)
-  u32 fb[ITEMS];    //   slab row of its first token (16 bits) | need<<16: max over its matches of (distance - bytes
-                    //   of the item in front of the match), for the "source before the start of the output" check
+  u32 fb[ITEMS];    //   where its first token sits in the recording lane's column (words)
   u32 fc[ITEMS];    //   bytes | tokens<<20
+  u16 need[ITEMS];  //   max over its matches of (distance - bytes of the item in front of the match): the "source
+                    //   before the start of the output" check
   u16 spec[ITEMS];  // speculative run of item s: 0x8000 done | 0x4000 usable | (end - (s+1)*SUB)
   u32 q[64];        // repair queue of one scheduling point: the starts to decode from
+  u32 colpos[64];   // words used in every column of the member's token area (kept here between blocks)
 };
 // LDS of the resolver: token queue, output window, start-slot rows
 // E = u8: bytes.  E = u16: symbols of the chunked single-stream decode -- a byte value, or 0x8000 + j for "byte j
@@ -114,13 +110,30 @@ AHIP_DEVINL u32 hist_get(const E *hist, i32 si, u64 opos) {
 
 constexpr u32 TK_STORED = 0x60000000u;  // | len (3..65535), followed by two words: absolute input byte offset lo, hi
 
-// Append-only token stream of one member in device memory (tokenizer -> resolver hand-off).
-// A member never needs more words than it has output bytes: every literal/match token covers
-// >= 1 byte and a stored run of >= 3 bytes takes 3 words (shorter runs are emitted as literals).
+// Token store of one member in device memory (tokenizer -> resolver hand-off).
+//   area  64 columns of col_cap words.  Lane l of the flow decoder records the tokens of its runs into column l, one
+//         behind the other, and they stay there: nothing is transposed or copied.  The serial decoder (irregular
+//         blocks, stored blocks) fills whatever the columns have left, column after column.
+//   dir   the run directory, in stream order: {word offset in area, tokens}.  The resolver walks it and gathers the
+//         runs into its LDS queue, a whole wave on one run at a time (coalesced).
+// Sizes (tok_layout): 1.5 words of area and 1/16 directory entry per output byte -- a token covers >= 1 byte, a
+// stored run of >= 3 bytes takes 3 words, repeated runs waste some; a member that still runs out (MS_TOKFULL) is
+// decoded by the byte-writing serial kernel afterwards.
 struct TokSink {
-  u32 *base;  // nullptr: sizing run, nothing is stored
-  u64 w;      // words written
+  u32 *area;   // nullptr: sizing run, nothing is stored
+  u32 col_cap;
+  uint2 *dir;
+  u32 dir_cap, ndir;
+  u32 scol, spos, srun;  // serial writer: its column (~0u: none yet), next word, first word of the open run
+  bool full;
 };
+// member k of a launch group whose output starts out_rel bytes into the group's output
+AHIP_DEVINL void tok_layout(u64 out_rel, u64 out_limit, u32 k, u64 &tok_off, u32 &col_cap, u64 &dir_off, u32 &dir_cap) {
+  tok_off = (out_rel * 3) / 2 + (u64)k * 1024;
+  col_cap = (u32)(((out_limit * 3) / 2 + 1023) / 64);
+  dir_off = out_rel / 16 + (u64)k * 64;
+  dir_cap = (u32)(out_limit / 16 + 63);
+}
 
 struct ParStats { u32 windows, rounds, fallbacks, partial; u32 cyc[8]; u32 dbg; };
 
@@ -190,26 +203,26 @@ struct BlockMeta {
   LongMeta<D_LONG_N> d;
 };
 
-// One token at the lane's cursor, straight-line: every lane runs the litlen AND the distance
-// half (a 64-lane step almost always contains a match anyway); selects pick the result.  The
-// only branches skip the long-code resolution when no lane needs it.
+// One token at the lane's cursor, straight-line: every lane runs the litlen AND the distance half (a 64-lane step
+// almost always contains a match anyway); selects pick the result.  The only branches skip the long-code
+// resolution when no lane needs it.  Returns the token -- literal (0x8000 | byte) << 16, match len << 16 | dist --
+// or, for anything else (end of block, bad litlen / distance symbol, unfilled entry), a word that is not negative
+// and has a zero distance field; `e` then says which.
 template <u32 MASK>
-AHIP_DEVINL u32 decode_token(LaneBits &d, const WaveLds &L, const BlockMeta &M, const u32 *inbuf) {
+AHIP_DEVINL u32 decode_token(LaneBits &d, const WaveLds &L, const BlockMeta &M, const u32 *inbuf, u32 &e) {
   lb_normalize<MASK>(d, inbuf);
   const u32 w = lb_peek32(d);  // 32 valid bits; litlen code + extra <= 20
-  u32 e = L.ll[w & ((1u << LL_ROOT) - 1)];
+  e = L.ll[w & ((1u << LL_ROOT) - 1)];
   if (__any(e & E_LONG)) {
     asm volatile("; long litlen code" ::: "memory");  // keep this a real branch: if-converted, its LDS read would sit on every step's critical path
     const u32 e2 = long_resolve<false>(M.ll, L.ll_sorted, w, LL_ROOT);
     e = (e & E_LONG) ? e2 : e;
   }
   const u32 cl = e & 15;
-  const u32 xb = (e >> 4) & 15;
-  const u32 lenv = (e >> 16) + ((w >> cl) & ((1u << xb) - 1));
-  const bool is_lit = e & E_LIT;
-  const bool is_special = e & (E_EOB | E_BAD | E_HOLE);
-  const bool is_match = !is_lit && !is_special;
-  d.sh += cl + (is_match ? xb : 0u);
+  const u32 xb = (e >> 4) & 15;  // 0 unless a length symbol
+  const u32 lenv = (e >> 16) + __builtin_amdgcn_ubfe(w, cl, xb);
+  const bool is_match = (e & (E_LIT | E_EOB | E_BAD | E_HOLE)) == 0;
+  d.sh += cl + xb;
   lb_normalize<MASK>(d, inbuf);
   const u32 w2 = lb_peek32(d);  // distance code + extra <= 28
   u32 t = L.dt[w2 & ((1u << D_ROOT) - 1)];
@@ -220,13 +233,9 @@ AHIP_DEVINL u32 decode_token(LaneBits &d, const WaveLds &L, const BlockMeta &M, 
   }
   const u32 dl = t & 15;
   const u32 dxb = (t >> 4) & 15;
-  const u32 dist = (t >> 16) + ((w2 >> dl) & ((1u << dxb) - 1));
+  const u32 dist = (t >> 16) + __builtin_amdgcn_ubfe(w2, dl, dxb);  // 0 for the symbols 30 / 31
   d.sh += is_match ? dl + dxb : 0u;
-  u32 tok = (lenv << 16) | dist;
-  tok = (is_match && (t & E_BAD)) ? TK_ERR : tok;
-  tok = is_special ? ((e & E_EOB) ? TK_EOB : TK_ERR) : tok;
-  tok = is_lit ? (TK_LIT | (e >> 16)) : tok;
-  return tok;
+  return (lenv << 16) | (is_match ? dist : 0u);
 }
 
 constexpr u32 LR_EOB = 1, LR_ERR = 2;  // how a run ended before its boundary
@@ -343,10 +352,43 @@ AHIP_DEVINL void flush_window(const ParLds &P, u8 *g, u32 A, u32 nbytes, int lan
 // Tokenizer side
 // ------------------------------------------------------------------------------------------
 
+// ---- the serial writer: one lane-uniform token at a time into the free space of the columns ----
+AHIP_DEVINL void sink_close(TokSink &k, u32 *colpos, int lane) {  // close the open run, note how far its column is used
+  if (!k.area || k.scol >= 64) return;
+  if (k.spos > k.srun) {
+    if (k.ndir < k.dir_cap) { if (lane == 0) k.dir[k.ndir] = make_uint2(k.srun, k.spos - k.srun); k.ndir++; }
+    else k.full = true;
+  }
+  if (lane == 0) colpos[k.scol] = k.spos - k.scol * k.col_cap;
+  wave_sync();
+  k.srun = k.spos;
+}
+AHIP_DEVINL void sink_open(TokSink &k, const u32 *colpos) {  // (re)start: the flow decoder may have used this column meanwhile
+  if (!k.area || k.scol >= 64) return;
+  k.spos = k.scol * k.col_cap + uniform(colpos[k.scol]);
+  k.srun = k.spos;
+}
+AHIP_DEVINL bool sink_room(TokSink &k, u32 *colpos, u32 words, int lane) {  // `words` contiguous words
+  for (;;) {
+    if (k.scol < 64 && k.spos + words <= (k.scol + 1) * k.col_cap) return true;
+    sink_close(k, colpos, lane);
+    k.scol += 1;  // ~0u -> 0
+    if (k.scol >= 64) { k.scol = 64; k.full = true; return false; }
+    k.spos = k.scol * k.col_cap + uniform(colpos[k.scol]);
+    k.srun = k.spos;
+  }
+}
+AHIP_DEVINL void sink_put(TokSink &k, u32 *colpos, u32 tok, int lane) {
+  if (!k.area || k.full) return;
+  if (!sink_room(k, colpos, 1, lane)) return;
+  if (lane == 0) k.area[k.spos] = tok;
+  k.spos += 1;
+}
+
 // Serial decode of one Huffman block that EMITS tokens instead of writing bytes: the checked path
 // for everything irregular (same decisions, in the same order, as huffman_token<WRITE, CAREFUL>).
 template <bool CAREFUL>
-AHIP_DEVINL u32 huffman_token_emit(WaveLds &L, BitCursor &b, OutCursor &o, TokSink &sink, u32 ll_max, u32 d_max, int lane) {
+AHIP_DEVINL u32 huffman_token_emit(WaveLds &L, BitCursor &b, OutCursor &o, TokSink &sink, u32 *colpos, u32 ll_max, u32 d_max, int lane) {
   if (CAREFUL && b.pos + ll_max > b.total_bits) return 100 + MS_FALSE_EOS;
   u64 w = peek_bits(b);
   u32 e = uniform(L.ll[(u32)w & ((1u << LL_ROOT) - 1)]);
@@ -355,8 +397,7 @@ AHIP_DEVINL u32 huffman_token_emit(WaveLds &L, BitCursor &b, OutCursor &o, TokSi
   if (e & (E_LIT | E_EOB | E_BAD | E_HOLE)) {
     if (e & E_LIT) {
       if (o.pos >= o.limit) return 100 + MS_CAP;
-      if (sink.base && lane == 0) sink.base[sink.w] = TK_LIT | (e >> 16);
-      sink.w += 1;
+      sink_put(sink, colpos, e & 0xffff0000u, lane);  // (0x8000 | byte) << 16
       o.pos += 1;
       b.pos += cl;
       return 0;
@@ -385,24 +426,27 @@ AHIP_DEVINL u32 huffman_token_emit(WaveLds &L, BitCursor &b, OutCursor &o, TokSi
   b.pos += used;
   if ((u64)dist > o.pos) return 100 + MS_FARREF;
   if (o.pos + (u64)len > o.limit) return 100 + MS_CAP;
-  if (sink.base && lane == 0) sink.base[sink.w] = ((u32)len << 16) | (u32)dist;
-  sink.w += 1;
+  sink_put(sink, colpos, ((u32)len << 16) | (u32)dist, lane);
   o.pos += (u64)len;
   return 0;
 }
-AHIP_DEVINL u32 huffman_block_emit(WaveLds &L, BitCursor &b, OutCursor &o, TokSink &sink, int lane) {
+AHIP_DEVINL u32 huffman_block_emit(WaveLds &L, BitCursor &b, OutCursor &o, TokSink &sink, u32 *colpos, int lane) {
   const u32 ll_max = L.lld.maxlen, d_max = L.dd.maxlen;
+  sink_open(sink, colpos);
+  u32 rs;
   for (;;) {
     u32 r;
-    if ((b.pos >> 3) + 16 <= b.in_len) r = huffman_token_emit<false>(L, b, o, sink, ll_max, d_max, lane);
-    else r = huffman_token_emit<true>(L, b, o, sink, ll_max, d_max, lane);
+    if ((b.pos >> 3) + 16 <= b.in_len) r = huffman_token_emit<false>(L, b, o, sink, colpos, ll_max, d_max, lane);
+    else r = huffman_token_emit<true>(L, b, o, sink, colpos, ll_max, d_max, lane);
     if (r == 0) continue;
-    if (r == 1) return MS_OK;
-    return r - 100;
+    rs = r == 1 ? (u32)MS_OK : r - 100;
+    break;
   }
+  sink_close(sink, colpos, lane);
+  return rs;
 }
-// _parseUncompressedBlock as tokens: runs of >= 3 bytes become one TK_STORED record (3 words)
-AHIP_DEVINL u32 stored_block_emit(BitCursor &b, OutCursor &o, TokSink &sink, int lane) {
+// _parseUncompressedBlock as tokens: runs of >= 3 bytes become one TK_STORED record (3 words, never split)
+AHIP_DEVINL u32 stored_block_emit(BitCursor &b, OutCursor &o, TokSink &sink, u32 *colpos, int lane) {
   b.pos = (b.pos + 7) & ~7ull;
   int len = read_bits(b, 16);
   int nlen_raw = read_bits(b, 16);
@@ -411,19 +455,20 @@ AHIP_DEVINL u32 stored_block_emit(BitCursor &b, OutCursor &o, TokSink &sink, int
   u64 byte = b.pos >> 3;
   if ((u64)len > b.in_len - byte) return MS_FALSE;
   if (o.pos + (u64)len > o.limit) return MS_CAP;
+  sink_open(sink, colpos);
   if (len >= 3) {
-    if (sink.base && lane == 0) {
-      sink.base[sink.w] = TK_STORED | (u32)len;
-      sink.base[sink.w + 1] = (u32)byte;
-      sink.base[sink.w + 2] = (u32)(byte >> 32);
+    if (sink.area && !sink.full && sink_room(sink, colpos, 3, lane)) {
+      if (lane == 0) {
+        sink.area[sink.spos] = TK_STORED | (u32)len;
+        sink.area[sink.spos + 1] = (u32)byte;
+        sink.area[sink.spos + 2] = (u32)(byte >> 32);
+      }
+      sink.spos += 3;
     }
-    sink.w += 3;
   } else {
-    for (int i = 0; i < len; ++i) {
-      if (sink.base && lane == 0) sink.base[sink.w] = TK_LIT | b.in[byte + i];
-      sink.w += 1;
-    }
+    for (int i = 0; i < len; ++i) sink_put(sink, colpos, TK_LIT | ((u32)b.in[byte + i] << 16), lane);
   }
+  sink_close(sink, colpos, lane);
   o.pos += (u64)len;
   b.pos += 8ull * (u64)len;
   return MS_OK;
@@ -437,30 +482,29 @@ AHIP_DEVINL u32 stored_block_emit(BitCursor &b, OutCursor &o, TokSink &sink, int
 // inside an item:
 //   SPEC(s)  blind run over the last SPEC_BITS of item s (Huffman streams self-synchronise): its end is the
 //            PREDICTED start of item s+1.  Nothing is recorded.
-//   RUN(s)   decode from a start (predicted, or true) to the end of item s, recording tokens into the slab: row =
-//            global step number, column = lane, so every step is one coalesced 256-byte row store.
+//   RUN(s)   decode from a start (predicted, or true) to the end of item s, recording tokens into the lane's column of
+//            the member's token area (TokSink), where they stay.
 // A scoreboard in LDS (TokLds::fa/fb/fc/need/spec, indexed by item mod ITEMS) holds what the runs found.  At every
 // scheduling point the wave
 //   publishes  the runs that ended,
 //   validates  in order: item V is final when its run started exactly where item V-1's final run ended (64 items
 //              per step: one LDS read per lane, a DPP shift, a ballot).  A mispredicted item is simply put back
 //              with its true start; only items that used its (wrong) end repeat,
-//   retires    final items EMIT_MIN at a time: wave prefix sums give stream order, the slab columns are gathered,
-//              transposed through the ring slots the retired items no longer need and leave as coalesced stores
-//              into the member's token stream; the freed ring slots are refilled with the next compressed bytes,
+//   retires    final items EMIT_MIN at a time: their runs are entered into the member's run directory (stream order);
+//              the freed ring slots are refilled with the next compressed bytes,
 //   assigns    idle lanes: the true-start run of item V first, then runs whose predicted start is known, then
 //              speculation ahead (not beyond `hint_end_bits`, the end of the member when the index knows it).
 // Lanes therefore stay busy across what used to be window boundaries: a token is decoded about 1.6 times
 // (speculation over half an item + the run + a few repeats) at near-full lane occupancy.
 // Anything irregular on the true path -- bad symbol, back-reference before the start of the output, output
-// window exhausted, slab ring overrun, input too close to its end -- stops the flow at the last retired item and
+// window exhausted, a full column, input too close to its end -- stops the flow at the last retired item and
 // hands the rest of the block to the serial decoder, which restates the reference symbol by symbol.
-AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, u32 *slab, BitCursor &b, OutCursor &o, TokSink &sink,
-                                       int lane, ParStats &st, u64 hint_end_bits) {
+AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutCursor &o, TokSink &sink, int lane,
+                                       ParStats &st, u64 hint_end_bits) {
   BlockMeta M;
   load_long_meta(M.ll, L.lld, LL_ROOT);
   load_long_meta(M.d, L.dd, D_ROOT);
-  const bool emit = sink.base != nullptr;
+  const bool emit = sink.area != nullptr;
   constexpr u32 SLACK_DW = 4;  // a token may run 48 bits past its item and the reader looks two dwords ahead
   constexpr u32 SUB = SUB_BITS;
   const u64 lt_mask = (1ull << lane) - 1;
@@ -497,11 +541,12 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, u32 *slab, BitCurs
     u32 next_spec = 0, next_fix = 1, V = 0, tV = t0, retired = 0, t_ret = t0, g = 0;
     bool block_done = false, stop_serial = false;
     // lane state: ms = mode<<28 | item (mode 0 idle, 1 SPEC, 2 RUN)
-    u32 ms = 0, bound = 0, start = 0, endp = 0, fl = 0, ntok = 0, nbytes = 0, row0 = 0;
-    u32 rowctr = 0;  // tokens this lane has recorded: its column of the slab is a ring of SLAB_ROWS
+    u32 ms = 0, bound = 0, start = 0, endp = 0, fl = 0, nbytes = 0, row0 = 0;
+    u32 rowctr = P.colpos[lane];  // words this lane has recorded into its column of the token area
     i32 need = 0;
     LaneBits d{0, 0, 0, 0, 2};
-    u32 *const col = slab + (u32)lane * SLAB_ROWS;
+    u32 *const col = sink.area + (u32)lane * sink.col_cap;
+    u32 rot = 0;  // rotates which idle lanes take the recording runs, so that the columns fill evenly
     u32 guard = 0;
     for (;;) {
       if (++guard > 4 * n_items + 4096) {  // never spin: the serial decoder takes over at the last retired item
@@ -543,69 +588,42 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, u32 *slab, BitCurs
         if (n) { tV = lane_bcast(wend, (int)n - 1); V += n; }
         if (stop_flags & LR_EOB) block_done = true;
         else if (stop_flags) stop_serial = true;
-        if ((ms >> 28) == 1 && (ms & 0x0fffffffu) < V) ms = 0;  // speculation nobody needs any more
+        if ((ms >> 28) == 1 && (ms & 0x0fffffffu) < V) { ms = 0; bound = 0; endp = 0; }  // speculation nobody needs any more
         if (next_fix <= V) next_fix = V + 1;
         const bool rerun = win && (u32)lane >= n && pend != ~0u && wi < next_fix && (wstate == 0 || (wstate == 2 && wstart != pend));
         rm = (block_done || stop_serial) ? 0ull : __ballot(rerun);
       }
       AHIP_TICK(t_s1);
       AHIP_ACC(st.cyc[3], t_s0, t_s1);
-      // ===== retire: the tokens of final items go to the member's token stream, the ring is refilled =====
-      bool finishing = block_done || stop_serial || V >= n_items;
+      // ===== retire: the runs of final items are entered into the run directory, the ring is refilled =====
+      const bool finishing = block_done || stop_serial || V >= n_items;
       while (V - retired >= (finishing ? 1u : EMIT_MIN)) {
         const u32 nb = V - retired < 64 ? V - retired : 64u;
         const bool mine = (u32)lane < nb;
         const u32 s = retired + (u32)lane;
         const u32 a = mine ? P.fa[s & ITEM_MASK] : 0u;
-        const u32 fbv = mine ? P.fb[s & ITEM_MASK] : 0u;
+        const u32 r0 = mine ? P.fb[s & ITEM_MASK] : 0u;
         const u32 c = mine ? P.fc[s & ITEM_MASK] : 0u;
-        const u32 r0 = fbv & 0xffffu, nd = fbv >> 16;
+        const u32 nd = mine ? (u32)P.need[s & ITEM_MASK] : 0u;
         const u32 cnt = c >> 20, nby = c & 0xfffffu, cl = (a >> 22) & 63u;
-        // an item whose slab rows have been overwritten since (it waited too long for its predecessors) is decoded
-        // again from its true start; what is in front of it still retires
-        const u32 col_now = lane_gather(rowctr, cl);
-        const u64 lost = __ballot(mine && emit && cnt && ((col_now - r0) & 0xffffu) > (u32)SLAB_ROWS);
-        if (lost) {
-          const u32 j = (u32)__builtin_ctzll(lost);
-          st.partial++;
-          if ((u32)lane == j) P.fa[s & ITEM_MASK] = 0;
-          wave_sync();
-          V = retired + j;  // the batch shrinks to the items in front of it; the scan finds the rest again
-          tV = j ? lane_bcast(s * SUB + (a & 0xfffu), (int)j - 1) : t_ret;
-          block_done = false;
-          finishing = stop_serial;
-          rm = 0;
-          if (j == 0) break;
-          continue;
-        }
-        u32 tot_tok, tot_bytes;
-        const u32 T = wave_excl_sum(cnt, tot_tok);
+        u32 tot_bytes;
         const u32 B = wave_excl_sum(nby, tot_bytes);
+        const u64 hm = __ballot(mine && cnt != 0);
+        const u32 nh = (u32)__popcll(hm);
         const bool bad_cap = (u64)tot_bytes > o.limit - o.pos;         // output window exhausted
         const bool bad_far = __any(mine && (u64)nd > o.pos + B) != 0;  // back-reference before the start of the output
-        if (bad_cap || bad_far) {
+        const bool bad_dir = emit && sink.ndir + nh > sink.dir_cap;    // directory full
+        if (bad_cap || bad_far || bad_dir) {
           st.fallbacks++;
-          st.dbg |= bad_cap ? 4u : 0u; st.dbg |= bad_far ? 8u : 0u;
+          st.dbg |= bad_cap ? 4u : 0u; st.dbg |= bad_far ? 8u : 0u; st.dbg |= bad_dir ? 16u : 0u;
+          if (bad_dir) sink.full = true;
           stop_serial = true;
           break;
         }
         if (emit) {
-          // every retiring item is one contiguous run in the slab column of the lane that decoded it: lane i copies
-          // item i's run to its place in the stream (per-lane sequential reads and writes, 16 in flight)
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-          u32 *q = sink.base + sink.w + T;
-          const u32 *src = slab + cl * SLAB_ROWS;
-          const u32 maxcnt = wave_umax(cnt);
-          for (u32 u0 = 0; u0 < maxcnt; u0 += 16) {
-            u32 t[16];
-#pragma unroll
-            for (u32 u = 0; u < 16; ++u) t[u] = (u0 + u < cnt) ? src[(r0 + u0 + u) & ROW_MASK] : 0u;
-#pragma unroll
-            for (u32 u = 0; u < 16; ++u)
-              if (u0 + u < cnt) q[u0 + u] = t[u];
-          }
+          if (mine && cnt != 0) sink.dir[sink.ndir + (u32)__popcll(hm & lt_mask)] = make_uint2(cl * sink.col_cap + r0, cnt);
+          sink.ndir += nh;
         }
-        sink.w += tot_tok;
         o.pos += tot_bytes;
         t_ret = lane_bcast(s * SUB + (a & 0xfffu), (int)nb - 1);
         if (mine) { P.fa[s & ITEM_MASK] = 0; P.spec[s & ITEM_MASK] = 0; }
@@ -615,6 +633,8 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, u32 *slab, BitCurs
         stage_to(total_dw < room ? total_dw : room);
         wave_sync();
       }
+      // a recording lane must not run out of column: the serial decoder takes over with what all columns have left
+      if (emit && !stop_serial && __any(rowctr + (u32)STEPS > sink.col_cap)) { st.fallbacks++; st.dbg |= 32; stop_serial = true; }
       AHIP_TICK(t_s2);
       AHIP_ACC(st.cyc[4], t_s1, t_s2);
       if (stop_serial || (finishing && retired == V)) break;
@@ -624,7 +644,10 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, u32 *slab, BitCurs
         const u64 im = __ballot(idle);
         if (im) {
           const u32 nidle = (u32)__popcll(im);
-          const u32 rank = (u32)__popcll(im & lt_mask);
+          if (rot >= nidle) rot = 0;
+          u32 rank = (u32)__popcll(im & lt_mask) + rot;
+          rank = rank >= nidle ? rank - nidle : rank;
+          rot += 7;
           const u32 stage_items = (stage_hi - SLACK_DW) / SUB_DW;  // items whose bits (+ slack) are in the ring
           const u32 lim = n_items < stage_items ? n_items : stage_items;
           // (a) repairs (ordered: the one validation waits for comes first)
@@ -662,7 +685,7 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, u32 *slab, BitCurs
             }
             ms = (take_c ? 1u << 28 : 2u << 28) | s_new;
             bound = (s_new + 1) * SUB;
-            start = st_new; endp = st_new; fl = 0; ntok = 0; nbytes = 0; need = 0; row0 = rowctr;
+            start = st_new; endp = st_new; fl = 0; nbytes = 0; need = 0; row0 = rowctr;
             lb_init<RING_MASK>(d, P.inbuf, st_new);
             if (take_b) P.fa[s_new & ITEM_MASK] = 1u << 30;  // in flight
           }
@@ -673,23 +696,25 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, u32 *slab, BitCurs
       }
       AHIP_TICK(t_s3);
       AHIP_ACC(st.cyc[3], t_s2, t_s3);
-      // ===== decode steps =====
+      // ===== decode steps =====  (idle and finished lanes have bound == 0)
       for (int k = 0; k < STEPS; ++k) {
-        const bool go = (ms >> 28) != 0 && fl == 0 && endp < bound;
+        const bool go = endp < bound;
         if (!__any(go)) break;
         if (go) {
-          const u32 t = decode_token<RING_MASK>(d, L, M, P.inbuf);
-          if (t & (TK_EOB | TK_ERR)) {
-            fl = (t & TK_EOB) ? LR_EOB : LR_ERR;
-            endp = lb_pos(d);
-          } else {
-            if (emit && (ms >> 29)) { col[rowctr & ROW_MASK] = t; rowctr += 1; }
-            const bool lit = t >> 31;
+          u32 e;
+          const u32 t = decode_token<RING_MASK>(d, L, M, P.inbuf, e);
+          endp = lb_pos(d);
+          const bool spc = (i32)t >= 0 && (t & 0xffffu) == 0;
+          if (__any(spc)) {
+            asm volatile("; special symbol" ::: "memory");
+            if (spc) { fl = (e & E_EOB) ? LR_EOB : LR_ERR; bound = 0; }
+          }
+          if (!spc) {
+            if (ms >> 29) { if (emit) col[rowctr] = t; rowctr += 1; }
+            const bool lit = (i32)t < 0;
             const i32 req = lit ? 0 : (i32)(t & 0xffff) - (i32)nbytes;
             need = req > need ? req : need;
-            ntok += 1;
             nbytes += lit ? 1u : (t >> 16);
-            endp = lb_pos(d);
           }
         }
         ++g;
@@ -699,23 +724,27 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, u32 *slab, BitCurs
       // ===== publish the runs that ended =====
       {
         const u32 mode = ms >> 28, s = ms & 0x0fffffffu;
-        const bool fin = mode != 0 && !(fl == 0 && endp < bound);
+        const bool fin = mode != 0 && !(endp < bound);
         if (__any(fin)) {
           if (fin) {
+            const u32 bnd = (s + 1) * SUB;
             if (mode == 1) {
-              const bool usable = fl == 0 && endp - bound < 64;
-              P.spec[s & ITEM_MASK] = (u16)(0x8000u | (usable ? 0x4000u : 0u) | ((endp - bound) & 0xfffu));
+              const bool usable = fl == 0 && endp - bnd < 64;
+              P.spec[s & ITEM_MASK] = (u16)(0x8000u | (usable ? 0x4000u : 0u) | ((endp - bnd) & 0xfffu));
             } else {
-              P.fb[s & ITEM_MASK] = (row0 & 0xffffu) | ((u32)need << 16);
-              P.fc[s & ITEM_MASK] = nbytes | (ntok << 20);
+              P.fb[s & ITEM_MASK] = row0;
+              P.fc[s & ITEM_MASK] = nbytes | (((rowctr - row0) & 0xfffu) << 20);
+              P.need[s & ITEM_MASK] = (u16)need;
               P.fa[s & ITEM_MASK] = (2u << 30) | (fl << 28) | ((u32)lane << 22) | ((start - s * SUB) << 12) | (endp - s * SUB);
             }
-            ms = 0;
+            ms = 0; bound = 0; endp = 0;
           }
           wave_sync();
         }
       }
     }
+    P.colpos[lane] = rowctr;
+    wave_sync();
     b.pos = gbyte * 8 + t_ret;
 #ifdef AHIP_PROFILE
     st.partial += g;  // decode steps of the wave
@@ -725,7 +754,7 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, u32 *slab, BitCurs
     // the epoch is used up (V == n_items): go on from the new origin
   }
   AHIP_TICK(t_x0);
-  u32 rs = huffman_block_emit(L, b, o, sink, lane);
+  u32 rs = huffman_block_emit(L, b, o, sink, P.colpos, lane);
   AHIP_TICK(t_x1);
   AHIP_ACC(st.cyc[7], t_x0, t_x1);
   return rs;
@@ -733,19 +762,18 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, u32 *slab, BitCurs
 
 // Inflate one stream.  Mirrors Inflate._inflate(): loop blocks until BFINAL, an error, or EOS.
 //  PAR = false: the serial byte-writing decoder (A/B baseline, single kernel).
-//  PAR = true : tokenizer -- no bytes are written; tokens go to `tokens` (nullptr = sizing run).
+//  PAR = true : tokenizer -- no bytes are written; tokens go to `sink` (sink.area == nullptr = sizing run).
 //  CHUNK = true: one chunk of a long stream (ChunkCtx): bit-granular start, `hist` bytes of earlier output count
 //  as already produced (so the back-reference range check holds across the chunk boundary), and the loop stops
 //  in front of a block header that sits on a candidate position; end_pos is then reported in BITS.
 template <bool WRITE, bool PAR, bool CHUNK = false>
-AHIP_DEVINL void inflate_member(WaveLds &L, HeaderLds &H, TokLds *P, u32 *slab, const u8 *in, u64 in_len,
-                                const MemberDesc &m, u8 *out, u32 *tokens, MemberResult &res, int lane,
-                                const ChunkCtx *cx = nullptr) {
+AHIP_DEVINL void inflate_member(WaveLds &L, HeaderLds &H, TokLds *P, const u8 *in, u64 in_len, const MemberDesc &m, u8 *out,
+                                TokSink sink, MemberResult &res, int lane, const ChunkCtx *cx = nullptr) {
   ParStats st{};
   BitCursor b{in, in_len, in_len * 8, m.in_off * 8 + (CHUNK ? cx->start_bit : 0u), nullptr, 0, 0};
   const u64 hist = CHUNK ? cx->hist : 0u;
   OutCursor o{out + m.out_off, hist, m.out_limit + hist};
-  TokSink sink{tokens, 0};
+  if (PAR) { P->colpos[lane] = 0; wave_sync(); }
   // where the index expects the deflate data to end (a hint for speculation only: the decode itself never trusts it)
   const u64 hint_end_bits = (!CHUNK && m.expect_end != ~0ull) ? m.expect_end * 8 : 0ull;
   u32 status = MS_EOS, blocks = 0;
@@ -762,7 +790,7 @@ AHIP_DEVINL void inflate_member(WaveLds &L, HeaderLds &H, TokLds *P, u32 *slab, 
     const int btype = hdr >> 1;
     u32 r;
     if (btype == 0) {
-      r = PAR ? stored_block_emit(b, o, sink, lane) : stored_block<WRITE>(b, o, lane);
+      r = PAR ? stored_block_emit(b, o, sink, P->colpos, lane) : stored_block<WRITE>(b, o, lane);
     } else if (btype == 3) {
       r = MS_FALSE;
     } else {
@@ -790,7 +818,7 @@ AHIP_DEVINL void inflate_member(WaveLds &L, HeaderLds &H, TokLds *P, u32 *slab, 
         AHIP_TICK(t_h1);
         AHIP_ACC(st.cyc[0], t_h0, t_h1);
         if (!ok) r = MS_OVERSUB;
-        else if (PAR) r = huffman_block_tokenize(L, *P, slab, b, o, sink, lane, st, hint_end_bits);
+        else if (PAR) r = huffman_block_tokenize(L, *P, b, o, sink, lane, st, hint_end_bits);
         else r = huffman_block<WRITE>(L, b, o, lane);
       }
     }
@@ -807,7 +835,7 @@ AHIP_DEVINL void inflate_member(WaveLds &L, HeaderLds &H, TokLds *P, u32 *slab, 
     res.end_pos = end > in_len ? in_len : end;
     if (CHUNK && status == MS_CHUNK_END) res.end_pos = b.pos;
     res.out_len = o.pos - hist;
-    res.status = status;
+    res.status = (PAR && sink.full) ? (u32)MS_TOKFULL : status;
     res.blocks = blocks;
     res.windows = st.windows;
     res.rounds = st.rounds;
@@ -819,7 +847,7 @@ AHIP_DEVINL void inflate_member(WaveLds &L, HeaderLds &H, TokLds *P, u32 *slab, 
 #else
     if (st.dbg) res.blocks |= st.dbg << 16;
 #endif
-    res.tok_words = sink.w;
+    res.tok_words = sink.ndir;  // runs in the directory
   }
 }
 
@@ -827,25 +855,57 @@ AHIP_DEVINL void inflate_member(WaveLds &L, HeaderLds &H, TokLds *P, u32 *slab, 
 // Resolver side: replay one member's token stream into its output window
 // ------------------------------------------------------------------------------------------
 template <typename E>
-AHIP_DEVINL void resolve_member(ParLdsT<E> &P, const u8 *in, const u32 *tokens, u64 nwords, E *out_base, u32 *cyc, int lane) {
+AHIP_DEVINL void resolve_member(ParLdsT<E> &P, const u8 *in, const u32 *area, const uint2 *dir, u32 ndir, E *out_base, u32 *cyc,
+                                int lane) {
   constexpr bool MARK = sizeof(E) == 2;
-  u64 cur = 0, opos = 0;
+  u32 de = 0, df = 0;  // cursor into the token stream: directory entry, tokens of it already consumed
+  u64 opos = 0;
   if (lane == 0) P.misc[0] = 0xffffffffu;
   wave_sync();
-  while (cur < nwords) {
+  while (de < ndir) {
     AHIP_TICK(t_0);
-    // ---- fetch up to TOK_CAP words; a stored-run record ends the batch (it is handled at a batch head) ----
-    const u32 want = (nwords - cur) < (u64)TOK_CAP ? (u32)(nwords - cur) : (u32)TOK_CAP;
-    u32 first_stored = want;
-    for (u32 k = lane; k < want; k += 64) {
-      const u32 t = tokens[cur + k];
-      P.tok[k] = t;
-      if ((t & 0xe0000000u) == TK_STORED) atomicMin(&P.misc[0], k);  // lowest index wins
+    // ---- gather up to TOK_CAP tokens of the next runs into the queue, a whole wave on one run at a time
+    //      (coalesced); a stored-run record ends the batch (it is handled at a batch head) ----
+    const u32 ei = de + (u32)lane;
+    const uint2 dv = ei < ndir ? dir[ei] : make_uint2(0u, 0u);
+    const u32 rcnt = lane == 0 ? dv.y - df : dv.y, roff = lane == 0 ? dv.x + df : dv.x;
+    u32 rtot;
+    const u32 rT = wave_excl_sum(rcnt, rtot);
+    const u32 take = rT < (u32)TOK_CAP ? (rcnt < (u32)TOK_CAP - rT ? rcnt : (u32)TOK_CAP - rT) : 0u;
+    const u32 nrun = (u32)__popcll(__ballot(take != 0));
+    const u32 want = rtot < (u32)TOK_CAP ? rtot : (u32)TOK_CAP;
+    for (u32 j = 0; j < nrun; j += 4) {  // four runs' loads in flight
+      u32 v[4], qd[4];
+#pragma unroll
+      for (u32 q = 0; q < 4; ++q) {
+        const int jj = (int)(j + q < nrun ? j + q : nrun - 1);
+        const u32 o_ = lane_bcast(roff, jj), c_ = j + q < nrun ? lane_bcast(take, jj) : 0u, t_ = lane_bcast(rT, jj);
+        qd[q] = (u32)lane < c_ ? t_ + (u32)lane : 0xffffffffu;
+        v[q] = (u32)lane < c_ ? area[o_ + (u32)lane] : 0u;
+        for (u32 u = 64 + (u32)lane; u < c_; u += 64) {  // a long run (the serial decoder's)
+          const u32 t = area[o_ + u];
+          P.tok[t_ + u] = t;
+          if ((t & 0xe0000000u) == TK_STORED) atomicMin(&P.misc[0], t_ + u);
+        }
+      }
+#pragma unroll
+      for (u32 q = 0; q < 4; ++q)
+        if (qd[q] != 0xffffffffu) {
+          P.tok[qd[q]] = v[q];
+          if ((v[q] & 0xe0000000u) == TK_STORED) atomicMin(&P.misc[0], qd[q]);  // lowest index wins
+        }
     }
     wave_sync();
-    first_stored = uniform(P.misc[0]) < want ? uniform(P.misc[0]) : want;
+    u32 first_stored = uniform(P.misc[0]) < want ? uniform(P.misc[0]) : want;
     // NOTE: the two words after a TK_STORED header are raw offsets and may alias the pattern; only the
     // FIRST hit is trusted, and the scan restarts after it.
+    // cursor += adv tokens
+    auto advance = [&](u32 adv) {
+      const u32 nfull = (u32)__popcll(__ballot(ei < ndir && rT + rcnt <= adv));  // runs used up (a prefix)
+      const u32 base = nfull < 64 ? lane_bcast(rT, (int)nfull) : rtot;
+      df = nfull ? adv - base : df + adv;
+      de += nfull;
+    };
     if (first_stored == 0) {
       // stored run at the head: input -> output copy
       const u32 len = P.tok[0] & 0xffff;
@@ -853,7 +913,7 @@ AHIP_DEVINL void resolve_member(ParLdsT<E> &P, const u8 *in, const u32 *tokens, 
       for (u32 i = lane; i < len; i += 64) out_base[opos + i] = (E)in[src + i];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       opos += len;
-      cur += 3;
+      advance(3);
       if (lane == 0) P.misc[0] = 0xffffffffu;
       wave_sync();
       continue;
@@ -879,7 +939,7 @@ AHIP_DEVINL void resolve_member(ParLdsT<E> &P, const u8 *in, const u32 *tokens, 
       q.len = inb ? (lit ? 1u : (t >> 16)) : 0u;
       q.off = run + wave_excl_sum(q.len, q.total);
       q.fits = inb && q.off + q.len <= (u32)OB_CAP;
-      q.key = (1u << 30) | (q.off << 17) | (lit ? (0x10000u | (t & 0xff)) : ((t & 0xffff) - 1));
+      q.key = (1u << 30) | (q.off << 17) | (lit ? (0x10000u | ((t >> 16) & 0xff)) : ((t & 0xffff) - 1));
       const i32 srel = (i32)q.off - (i32)(t & 0xffff);  // source start relative to the window
       q.pre = !MARK && q.fits && !lit && q.len <= 16 && srel + 16 <= 0;  // (symbols take the per-element path)
       q.w0 = q.w1 = 0;
@@ -928,7 +988,7 @@ AHIP_DEVINL void resolve_member(ParLdsT<E> &P, const u8 *in, const u32 *tokens, 
     AHIP_TICK(t_3);
     AHIP_ACC(cyc[5], t_2, t_3);
     opos += nbytes;
-    cur += ntok;
+    advance(ntok);
   }
 }
 

@@ -28,23 +28,24 @@ namespace ahip {
 
 // ---- decode-table entry ----
 //  bits 0-3  code length, bits 4-7 extra-bit count, bits 8-12 flags, bits 16-31 value
-constexpr u32 E_LIT = 0x100;   // value = literal byte
+constexpr u32 E_LIT = 0x100;   // value = 0x8000 | literal byte
 constexpr u32 E_EOB = 0x200;   // end of block (symbol 256)
 constexpr u32 E_BAD = 0x400;   // litlen 286/287, distance 30/31: reference returns -1
 constexpr u32 E_LONG = 0x800;  // code longer than the primary table: canonical search
 constexpr u32 E_HOLE = 0x1000; // unfilled litlen entry (symbol 0, length 0): literal-0 forever
 
 #ifndef AHIP_LL_ROOT
-#define AHIP_LL_ROOT 10
+#define AHIP_LL_ROOT 9
 #endif
 #ifndef AHIP_D_ROOT
-#define AHIP_D_ROOT 8
+#define AHIP_D_ROOT 7
 #endif
 constexpr int LL_ROOT = AHIP_LL_ROOT;  // primary table bits: litlen / distance
 constexpr int D_ROOT = AHIP_D_ROOT;
 
+// A literal's value is 0x8000 | byte: shifted up by 16 it IS the literal token (TK_LIT | byte << 16).
 AHIP_DEVINL u32 litlen_entry(u32 sym, u32 len) {
-  if (sym < 256) return (sym << 16) | E_LIT | len;
+  if (sym < 256) return ((0x8000u | sym) << 16) | E_LIT | len;
   if (sym == 256) return E_EOB | len;
   if (sym > 285) return E_BAD | len;
   u32 i = sym - 257;

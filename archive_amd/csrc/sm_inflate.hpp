@@ -168,15 +168,15 @@ __global__ __launch_bounds__(64) void sm_find_kernel(const u8 *__restrict__ in, 
   if (lane == 0) cand[(u64)k * split + part] = found;
 }
 
-// the tokenizer on chunks (persistent grid like inflate_tokenize_kernel)
+// the tokenizer on chunks (persistent grid like inflate_tokenize_kernel); chunk k's token area / run directory follow
+// tok_layout(out_off, out_limit, k)
 __global__ __launch_bounds__(64) void sm_tokenize_kernel(const u8 *__restrict__ in, u64 in_len,
                                                         const ChunkDesc *__restrict__ chunks, u32 n_chunks,
                                                         const u64 *__restrict__ cand_bits, u32 n_cand,
-                                                        u32 *__restrict__ tokens, MemberResult *__restrict__ results,
-                                                        u32 *__restrict__ scratch) {
+                                                        u32 *__restrict__ tokens, uint2 *__restrict__ dir,
+                                                        MemberResult *__restrict__ results) {
   __shared__ SmLds lds;
   const int lane = threadIdx.x;
-  u32 *slab = scratch + (size_t)blockIdx.x * SLAB_WORDS;
   for (u32 k = blockIdx.x; k < n_chunks; k += gridDim.x) {
     const ChunkDesc c = chunks[k];
     MemberDesc d;
@@ -186,23 +186,32 @@ __global__ __launch_bounds__(64) void sm_tokenize_kernel(const u8 *__restrict__ 
     d.expect_end = POS_UNKNOWN;
     d.in_end = 0;
     ChunkCtx cx{cand_bits, n_cand, (u32)uniform64(c.start_bit) & 7, uniform(c.hist)};
-    u32 *tk = tokens ? tokens + d.out_off : nullptr;
+    TokSink sk{nullptr, 0, nullptr, 0, 0, ~0u, 0, 0, false};
+    if (tokens) {
+      u64 toff, doff;
+      tok_layout(d.out_off, d.out_limit, k, toff, sk.col_cap, doff, sk.dir_cap);
+      sk.area = tokens + toff;
+      sk.dir = dir + doff;
+    }
     HeaderLds &hdr = *(HeaderLds *)((u8 *)lds.p.inbuf + 1024);
-    inflate_member<false, true, true>(lds.w, hdr, &lds.p, slab, in, in_len, d, (u8 *)nullptr, tk, results[k], lane, &cx);
+    inflate_member<false, true, true>(lds.w, hdr, &lds.p, in, in_len, d, (u8 *)nullptr, sk, results[k], lane, &cx);
   }
 }
 
 // tokens -> symbols
 __global__ __launch_bounds__(64) void sm_resolve_kernel(const u8 *__restrict__ in, const ChunkDesc *__restrict__ chunks,
                                                        u32 n_chunks, u16 *sym, const u32 *__restrict__ tokens,
-                                                       const MemberResult *__restrict__ results) {
+                                                       const uint2 *__restrict__ dir, const MemberResult *__restrict__ results) {
   __shared__ ParLdsT<u16> lds;
   const int lane = threadIdx.x;
   for (u32 k = blockIdx.x; k < n_chunks; k += gridDim.x) {
-    const u64 out_off = uniform64(chunks[k].out_off);
-    const u64 nwords = uniform64(results[k].tok_words);
+    const u64 out_off = uniform64(chunks[k].out_off), out_limit = uniform64(chunks[k].out_limit);
+    const u32 ndir = (u32)uniform64(results[k].tok_words);
+    u64 toff, doff;
+    u32 cc, dc;
+    tok_layout(out_off, out_limit, k, toff, cc, doff, dc);
     u32 cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    resolve_member<u16>(lds, in, tokens + out_off, nwords, sym + out_off, cyc, lane);
+    resolve_member<u16>(lds, in, tokens + toff, dir + doff, ndir, sym + out_off, cyc, lane);
   }
 }
 
