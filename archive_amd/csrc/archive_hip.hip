@@ -50,6 +50,10 @@ struct TokKernelLds {
 // Persistent workgroups: the grid is sized to what is resident at once and strides over the members.
 //  tokens == nullptr: sizing run (end position, size and verdict only).
 //  tokens / dir: the launch group's token areas and run directories (TokSink, tok_layout).
+// members the fast kernels leave to inflate_late_kernel
+AHIP_DEVINL bool member_is_late(const MemberResult &r) {
+  return r.status == MS_TOKFULL || r.status == MS_OVERSUB || (r.blocks & MR_FAR);
+}
 AHIP_DEVINL TokSink member_sink(u32 *tokens, uint2 *dir, u64 out_rel, u64 out_limit, u32 k) {
   TokSink sk{nullptr, 0, nullptr, 0, 0, ~0u, 0, 0, false};
   if (tokens) {
@@ -63,7 +67,8 @@ AHIP_DEVINL TokSink member_sink(u32 *tokens, uint2 *dir, u64 out_rel, u64 out_li
 __global__ __launch_bounds__(64, AHIP_TOK_MIN_WAVES) void inflate_tokenize_kernel(const u8 *__restrict__ in, u64 in_len,
                                                              const MemberDesc *__restrict__ members, u32 first_member,
                                                              u32 n_members, u32 *__restrict__ tokens, uint2 *__restrict__ dir,
-                                                             u64 group_out0, MemberResult *__restrict__ results) {
+                                                             u64 group_out0, MemberResult *__restrict__ results,
+                                                             u32 *__restrict__ late) {
   __shared__ TokKernelLds lds;
   const int lane = threadIdx.x;
   for (u32 k = blockIdx.x; k < n_members; k += gridDim.x) {
@@ -78,6 +83,7 @@ __global__ __launch_bounds__(64, AHIP_TOK_MIN_WAVES) void inflate_tokenize_kerne
     const u64 lim = uniform64(d.in_end) ? uniform64(d.in_end) : in_len;
     inflate_member<false, true>(lds.w, hdr, &lds.p, in, lim, d, (u8 *)nullptr,
                                 member_sink(tokens, dir, d.out_off - group_out0, d.out_limit, k), results[m], lane);
+    if (lane == 0 && member_is_late(results[m])) atomicAdd(late, 1u);  // rare: inflate_late_kernel finishes these
   }
 }
 
@@ -91,7 +97,7 @@ __global__ __launch_bounds__(64, AHIP_RES_MIN_WAVES) void inflate_resolve_kernel
   for (u32 k = blockIdx.x; k < n_members; k += gridDim.x) {
     const u32 m = first_member + k;
     const u64 out_off = uniform64(members[m].out_off), out_limit = uniform64(members[m].out_limit);
-    if (uniform(results[m].status) == MS_TOKFULL) continue;  // inflate_redo_kernel decodes it
+    if (uniform(results[m].status) == MS_TOKFULL || uniform(results[m].status) == MS_OVERSUB || (uniform(results[m].blocks) & MR_FAR)) continue;  // inflate_late_kernel
     const u32 ndir = (u32)uniform64(results[m].tok_words);
     u64 toff, doff;
     u32 cc, dc;
@@ -104,23 +110,45 @@ __global__ __launch_bounds__(64, AHIP_RES_MIN_WAVES) void inflate_resolve_kernel
   }
 }
 
-// Members whose token area or run directory overflowed (MS_TOKFULL: pathological streams) are decoded here by the
-// serial byte-writing decoder, one wave each, after everything else.
-__global__ __launch_bounds__(64) void inflate_redo_kernel(const u8 *__restrict__ in, u64 in_len,
+// What the fast kernels leave behind -- in member order, one wave, after everything else (normally nothing: the
+// counter is zero and the kernel returns at once):
+//   MR_FAR      a back-reference reaches into the output of EARLIER members (the reference's gzip decoder appends all
+//               members to one OutputStream, so that is legal there, quirk q8): resolved now that those bytes exist;
+//   MS_OVERSUB  over-subscribed code lengths: decoded with the reference's own overwritten table (`exact`, scratch);
+//   MS_TOKFULL  token area / run directory overflow: decoded by the byte-writing serial decoder.
+template <bool WRITE>
+__global__ __launch_bounds__(64) void inflate_late_kernel(const u8 *__restrict__ in, u64 in_len,
                                                          const MemberDesc *__restrict__ members, u32 first_member,
-                                                         u32 n_members, u8 *out, MemberResult *__restrict__ results) {
+                                                         u32 n_members, u8 *out, const u32 *__restrict__ tokens,
+                                                         const uint2 *__restrict__ dir, u64 group_out0,
+                                                         MemberResult *__restrict__ results, const u32 *__restrict__ late,
+                                                         u32 *__restrict__ exact) {
+  if (*late == 0) return;
   __shared__ WaveLds lds;
   __shared__ HeaderLds hdr;
+  __shared__ ParLds par;
   const int lane = threadIdx.x;
-  for (u32 k = blockIdx.x; k < n_members; k += gridDim.x) {
+  for (u32 k = 0; k < n_members; ++k) {
     const u32 m = first_member + k;
-    if (uniform(results[m].status) != MS_TOKFULL) continue;
+    const u32 status = uniform(results[m].status), blocks = uniform(results[m].blocks);
+    if (status != MS_TOKFULL && status != MS_OVERSUB && !(blocks & MR_FAR)) continue;
     MemberDesc d = members[m];
     d.in_off = uniform64(d.in_off);
     d.out_off = uniform64(d.out_off);
     d.out_limit = uniform64(d.out_limit);
-    const u64 lim = uniform64(d.in_end) ? uniform64(d.in_end) : in_len;
-    inflate_member<true, false>(lds, hdr, nullptr, in, lim, d, out, TokSink{nullptr, 0, nullptr, 0, 0, ~0u, 0, 0, false}, results[m], lane);
+    d.hist = uniform(d.hist);
+    if (status == MS_TOKFULL || status == MS_OVERSUB) {
+      const u64 lim = uniform64(d.in_end) ? uniform64(d.in_end) : in_len;
+      inflate_member<WRITE, false>(lds, hdr, nullptr, in, lim, d, out, TokSink{nullptr, 0, nullptr, 0, 0, ~0u, 0, 0, false}, results[m], lane,
+                                   nullptr, exact);
+    } else if (WRITE) {
+      u64 toff, doff;
+      u32 cc, dc;
+      tok_layout(d.out_off - group_out0, d.out_limit, k, toff, cc, doff, dc);
+      u32 cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      resolve_member(par, in, tokens + toff, dir + doff, (u32)uniform64(results[m].tok_words), out + d.out_off, cyc, lane);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");  // the next late member may read these bytes
   }
 }
 
@@ -273,14 +301,23 @@ hipError_t launch_inflate_group(const u8 *in, u64 n, const MemberDesc *members, 
     if (e != hipSuccess) return e;
   }
   if (getenv("AHIP_DEBUG")) fprintf(stderr, "[ahip] inflate group first=%u count=%u grid=%u/%d out=%llu write=%d\n", first, count, grid1, res_resident, (unsigned long long)(out1 - out0), (int)WRITE);
+  // the late list: a counter + the scratch of the exact (over-subscribed) tables
+  static DevBuf dlate, dexact;
+  e = dlate.reserve(64);
+  if (e != hipSuccess) return e;
+  e = dexact.reserve(2 * 32768 * 4);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(dlate.p, 0, 4, st);
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL(inflate_tokenize_kernel, dim3(grid1), dim3(64), 0, st, in, n, members, first, count, (u32 *)tp, (uint2 *)dp,
-                     out0, res);
+                     out0, res, dlate.as<u32>());
   if (WRITE) {
     const u32 grid2 = count < (u32)res_resident ? count : (u32)res_resident;
     hipLaunchKernelGGL(inflate_resolve_kernel, dim3(grid2), dim3(64), 0, st, in, members, first, count, out,
                        (const u32 *)tp, (const uint2 *)dp, out0, res);
-    hipLaunchKernelGGL(inflate_redo_kernel, dim3(grid2 < 1024 ? grid2 : 1024), dim3(64), 0, st, in, n, members, first, count, out, res);
   }
+  hipLaunchKernelGGL(inflate_late_kernel<WRITE>, dim3(1), dim3(64), 0, st, in, n, members, first, count, out, (const u32 *)tp,
+                     (const uint2 *)dp, out0, res, dlate.as<u32>(), dexact.as<u32>());
   return hipGetLastError();
 }
 
@@ -521,14 +558,20 @@ int32_t plan_verdict(ahip_gzip_plan *pl, hipStream_t st, bool *needs_sizing) {
   HIP_TRY(hipMemcpyAsync(&rs, pl->drun.p, sizeof rs, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   if (rs.mismatches) {
+    if (getenv("AHIP_DEBUG") && rs.first_bad < pl->sum.members) {
+      MemberResult r{}; MemberDesc d{}; u32 ex = 0;
+      (void)hipMemcpy(&r, pl->results.as<MemberResult>() + rs.first_bad, sizeof r, hipMemcpyDeviceToHost);
+      (void)hipMemcpy(&d, pl->members.as<MemberDesc>() + rs.first_bad, sizeof d, hipMemcpyDeviceToHost);
+      (void)hipMemcpy(&ex, pl->expect_status.as<u32>() + rs.first_bad, 4, hipMemcpyDeviceToHost);
+      fprintf(stderr, "[ahip] verify: %u mismatches, first member %u: status %u (expected %u) out_len %llu (limit %llu) end %llu (expected %llu) blocks %x runs %llu hist %u sized=%d\n",
+              rs.mismatches, rs.first_bad, r.status, ex, (unsigned long long)r.out_len, (unsigned long long)d.out_limit,
+              (unsigned long long)r.end_pos, (unsigned long long)d.expect_end, r.blocks, (unsigned long long)r.tok_words, d.hist, (int)pl->sized);
+    }
     if (!pl->sized) { *needs_sizing = true; return AHIP_OK; }
     return fail(AHIP_E_DEVICE, "internal: decode disagrees with its own sizing run");
   }
-  if (rs.any_farref & 2u) return AHIP_RANGE;  // first member: source before the start of the stream
-  if (rs.any_range) return AHIP_RANGE;
+  if (rs.any_range) return AHIP_RANGE;  // incl. a back-reference to before the first byte of the whole output
   if (rs.any_hang) return AHIP_HANG;
-  if (rs.any_farref) return fail(AHIP_E_UNSUPPORTED, "back-reference reaches into a previous gzip member");
-  if (rs.any_oversub) return fail(AHIP_E_UNSUPPORTED, "over-subscribed Huffman code");
   return AHIP_OK;
 }
 
@@ -785,7 +828,6 @@ int32_t member_status_to_abi(u32 ms) {
     case MS_FALSE: return AHIP_FALSE;
     case MS_RANGE: case MS_FARREF: return AHIP_RANGE;  // single stream: source before index 0
     case MS_HANG: return AHIP_HANG;
-    case MS_OVERSUB: g_err = "over-subscribed Huffman code"; return AHIP_E_UNSUPPORTED;
     default: g_err = "internal: unexpected member status"; return AHIP_E_DEVICE;
   }
 }
@@ -820,7 +862,6 @@ int32_t zlib_stream_device(const u8 *host_in, const u8 *d_in, u64 n, u64 pos, bo
     if (rc != AHIP_OK) return rc;
     if (r.status == MS_RANGE || r.status == MS_FARREF) return AHIP_RANGE;
     if (r.status == MS_HANG) return AHIP_HANG;
-    if (r.status == MS_OVERSUB) return fail(AHIP_E_UNSUPPORTED, "over-subscribed Huffman code");
     if (r.out_len) {
       // grow keeping the committed prefix
       if (committed + r.out_len > outbuf.cap) {

@@ -23,8 +23,9 @@ enum : u32 {
   MS_EOS = 4,       // input ended between blocks before a final block: the reference just stops
   MS_FALSE_EOS = 5, // internal: MS_FALSE caused by running out of input (stream position = end)
   MS_CAP = 16,      // member wanted to write past its output window
-  MS_FARREF = 17,   // back-reference reaches before this member's first byte
-  MS_OVERSUB = 18,  // over-subscribed Huffman code lengths (not reproduced)
+  MS_FARREF = 17,   // back-reference reaches before the first byte of the OUTPUT STREAM (Dart RangeError)
+  MS_OVERSUB = 18,  // internal: over-subscribed Huffman code lengths met by the fast kernels; the late kernel decodes
+                    // the member with the reference's own overwritten single-level table
   MS_CHUNK_END = 19, // chunked single-stream decode: stopped at the next chunk's first block (end_pos is a BIT position)
   MS_TOKFULL = 20,  // internal: the member's token area / run directory overflowed; the byte-writing serial kernel redoes it
 };
@@ -35,7 +36,11 @@ struct MemberDesc {
   u64 out_limit;  // size of that window
   u64 expect_end; // expected reference stream position after the deflate data (~0 = unknown)
   u64 in_end;     // end of the bytes this stream may read (0 = the end of the whole input): a ZIP entry's slice
+  u32 hist;       // bytes of earlier output (in front of out_off) a back-reference may reach: gzip members share one
+                  // OutputStream in the reference (quirk q8); 0 for streams with an output of their own
+  u32 pad;
 };
+constexpr u32 MR_FAR = 0x80000000u;  // MemberResult::blocks: some back-reference reaches into earlier output (resolved late, in order)
 
 // Chunked decode of ONE long stream (sm_inflate): a chunk starts at a block header found by the block finder
 // (any bit offset), may refer to `hist` bytes of output before its own, and stops in front of the first block

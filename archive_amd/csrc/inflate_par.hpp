@@ -44,7 +44,7 @@ namespace ahip {
 #define AHIP_SPEC_BITS 256
 #endif
 #ifndef AHIP_STEPS
-#define AHIP_STEPS 8
+#define AHIP_STEPS 12
 #endif
 #ifndef AHIP_EMIT_MIN
 #define AHIP_EMIT_MIN 32
@@ -426,6 +426,7 @@ AHIP_DEVINL u32 huffman_token_emit(WaveLds &L, BitCursor &b, OutCursor &o, TokSi
   b.pos += used;
   if ((u64)dist > o.pos) return 100 + MS_FARREF;
   if (o.pos + (u64)len > o.limit) return 100 + MS_CAP;
+  if ((u64)dist > o.pos - o.hist) o.far = 1;
   sink_put(sink, colpos, ((u32)len << 16) | (u32)dist, lane);
   o.pos += (u64)len;
   return 0;
@@ -620,6 +621,7 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
           stop_serial = true;
           break;
         }
+        if (__any(mine && (u64)nd > o.pos - o.hist + B)) o.far = 1;  // reaches into earlier output (q8): resolved late
         if (emit) {
           if (mine && cnt != 0) sink.dir[sink.ndir + (u32)__popcll(hm & lt_mask)] = make_uint2(cl * sink.col_cap + r0, cnt);
           sink.ndir += nh;
@@ -634,7 +636,7 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
         wave_sync();
       }
       // a recording lane must not run out of column: the serial decoder takes over with what all columns have left
-      if (emit && !stop_serial && __any(rowctr + (u32)STEPS > sink.col_cap)) { st.fallbacks++; st.dbg |= 32; stop_serial = true; }
+      if (emit && !finishing && __any(rowctr + (u32)STEPS > sink.col_cap)) { st.fallbacks++; st.dbg |= 32; stop_serial = true; }
       AHIP_TICK(t_s2);
       AHIP_ACC(st.cyc[4], t_s1, t_s2);
       if (stop_serial || (finishing && retired == V)) break;
@@ -766,13 +768,15 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
 //  CHUNK = true: one chunk of a long stream (ChunkCtx): bit-granular start, `hist` bytes of earlier output count
 //  as already produced (so the back-reference range check holds across the chunk boundary), and the loop stops
 //  in front of a block header that sits on a candidate position; end_pos is then reported in BITS.
+//  exact != nullptr: over-subscribed code lengths are decoded with the reference's own table (serial decoder only)
 template <bool WRITE, bool PAR, bool CHUNK = false>
 AHIP_DEVINL void inflate_member(WaveLds &L, HeaderLds &H, TokLds *P, const u8 *in, u64 in_len, const MemberDesc &m, u8 *out,
-                                TokSink sink, MemberResult &res, int lane, const ChunkCtx *cx = nullptr) {
+                                TokSink sink, MemberResult &res, int lane, const ChunkCtx *cx = nullptr,
+                                u32 *exact = nullptr) {
   ParStats st{};
   BitCursor b{in, in_len, in_len * 8, m.in_off * 8 + (CHUNK ? cx->start_bit : 0u), nullptr, 0, 0};
-  const u64 hist = CHUNK ? cx->hist : 0u;
-  OutCursor o{out + m.out_off, hist, m.out_limit + hist};
+  const u64 hist = CHUNK ? cx->hist : m.hist;
+  OutCursor o{out + m.out_off - hist, hist, m.out_limit > ~0ull - hist ? ~0ull : m.out_limit + hist, CHUNK ? 0u : hist, 0};
   if (PAR) { P->colpos[lane] = 0; wave_sync(); }
   // where the index expects the deflate data to end (a hint for speculation only: the decode itself never trusts it)
   const u64 hint_end_bits = (!CHUNK && m.expect_end != ~0ull) ? m.expect_end * 8 : 0ull;
@@ -817,7 +821,16 @@ AHIP_DEVINL void inflate_member(WaveLds &L, HeaderLds &H, TokLds *P, const u8 *i
         ok &= build_decode_table<true>(H.lens + hlit, hdist, L.dt, D_ROOT, L.dd, L.d_sorted, lane);
         AHIP_TICK(t_h1);
         AHIP_ACC(st.cyc[0], t_h0, t_h1);
-        if (!ok) r = MS_OVERSUB;
+        if (!ok) {
+          if (!PAR && exact) {
+            ExactTabs X{exact, exact + 32768, 0, 0};
+            X.ll_max = build_exact_table(H.lens, hlit, X.ll, lane);
+            X.d_max = build_exact_table(H.lens + hlit, hdist, X.dt, lane);
+            r = huffman_block_exact<WRITE>(X, b, o, lane);
+          } else {
+            r = MS_OVERSUB;
+          }
+        }
         else if (PAR) r = huffman_block_tokenize(L, *P, b, o, sink, lane, st, hint_end_bits);
         else r = huffman_block<WRITE>(L, b, o, lane);
       }
@@ -836,7 +849,7 @@ AHIP_DEVINL void inflate_member(WaveLds &L, HeaderLds &H, TokLds *P, const u8 *i
     if (CHUNK && status == MS_CHUNK_END) res.end_pos = b.pos;
     res.out_len = o.pos - hist;
     res.status = (PAR && sink.full) ? (u32)MS_TOKFULL : status;
-    res.blocks = blocks;
+    res.blocks = blocks | (o.far ? MR_FAR : 0u);
     res.windows = st.windows;
     res.rounds = st.rounds;
     res.fallbacks = st.fallbacks;

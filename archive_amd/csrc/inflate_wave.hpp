@@ -221,9 +221,11 @@ AHIP_DEVINL void fixed_lengths(u8 *lens, int lane) {
 }
 
 struct OutCursor {
-  u8 *base;   // member's output window
-  u64 pos;    // bytes produced
-  u64 limit;  // window size
+  u8 *base;   // address of output position 0 (= the stream's own first byte minus `hist`)
+  u64 pos;    // bytes produced + hist
+  u64 limit;  // window size + hist
+  u64 hist;   // bytes of earlier output in front of this stream that a back-reference may reach (quirk q8)
+  u32 far;    // some back-reference did reach into them
 };
 
 // writeBackReference(distance, count): every lane copies bytes lane, lane+64, ...
@@ -292,6 +294,7 @@ AHIP_DEVINL u32 huffman_token(WaveLds &L, BitCursor &b, OutCursor &o, u32 ll_max
   b.pos += used;
   if ((u64)dist > o.pos) return 100 + MS_FARREF;
   if (o.pos + (u64)len > o.limit) return 100 + MS_CAP;
+  if ((u64)dist > o.pos - o.hist) o.far = 1;
   lz_copy<WRITE>(o, (u32)dist, (u32)len, lane);
   return 0;
 }
@@ -307,6 +310,85 @@ AHIP_DEVINL u32 huffman_block(WaveLds &L, BitCursor &b, OutCursor &o, int lane) 
     if (r == 0) continue;
     if (r == 1) return MS_OK;
     return r - 100;
+  }
+}
+
+// ---- over-subscribed code lengths: the reference's own table ----
+// HuffmanTable (_huffman_table.dart:9-46) never checks the Kraft sum: when there are more codes of a length than fit,
+// `code` runs past 2^length, its low bits wrap, and later fills overwrite earlier ones.  That cannot be described
+// canonically, so the rare member that needs it is decoded (by the late kernel, one wave) with the reference's
+// single-level 2^maxCodeLength table, built here in the reference's order -- symbol after symbol; only the strided
+// fill of one symbol is spread over the lanes -- in device scratch (up to 2 x 128 KiB).
+struct ExactTabs { u32 *ll, *dt; u32 ll_max, d_max; };
+AHIP_DEVINL u32 build_exact_table(const u8 *lens, int n, u32 *table, int lane) {
+  u32 maxlen = 0;
+  for (int i = 0; i < n; ++i) { const u32 l = lens[i]; maxlen = l > maxlen ? l : maxlen; }
+  maxlen = uniform(maxlen);
+  const u32 size = 1u << maxlen;
+  for (u32 j = lane; j < size; j += 64) table[j] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  u32 code = 0, skip = 2;
+  for (u32 bl = 1; bl <= maxlen; ++bl) {
+    for (int i = 0; i < n; ++i) {
+      if (uniform(lens[i]) != bl) continue;
+      const u32 rev = __brev(code) >> (32 - bl);  // the low `bl` bits of code, reversed (higher bits are dropped)
+      for (u32 j = rev + (u32)lane * skip; j < size; j += 64 * skip) table[j] = (bl << 16) | (u32)i;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // later symbols overwrite earlier ones: keep the order
+      ++code;
+    }
+    code <<= 1;
+    skip <<= 1;
+  }
+  return maxlen;
+}
+// table[bits & (size - 1)] as one of our entries (an unfilled slot is symbol 0 with length 0)
+template <bool IS_DIST>
+AHIP_DEVINL u32 exact_entry(const u32 *table, u32 maxlen, u32 bits) {
+  const u32 raw = uniform(table[bits & ((1u << maxlen) - 1)]);
+  if (raw == 0) return IS_DIST ? dist_entry(0, 0) : (u32)E_HOLE;
+  return IS_DIST ? dist_entry(raw & 0xffff, raw >> 16) : litlen_entry(raw & 0xffff, raw >> 16);
+}
+// _decodeHuffman with those tables: the careful form of huffman_token, symbol by symbol
+template <bool WRITE>
+AHIP_DEVINL u32 huffman_block_exact(const ExactTabs &X, BitCursor &b, OutCursor &o, int lane) {
+  for (;;) {
+    if (b.pos + X.ll_max > b.total_bits) return MS_FALSE_EOS;
+    u64 w = peek_bits(b);
+    const u32 e = exact_entry<false>(X.ll, X.ll_max, (u32)w);
+    const u32 cl = e & 15;
+    if (e & (E_LIT | E_EOB | E_BAD | E_HOLE)) {
+      if (e & E_LIT) {
+        if (o.pos >= o.limit) return MS_CAP;
+        if (WRITE && lane == 0) o.base[o.pos] = (u8)(e >> 16);
+        o.pos += 1;
+        b.pos += cl;
+        continue;
+      }
+      if (e & E_EOB) { b.pos += cl; return MS_OK; }
+      return (e & E_BAD) ? MS_FALSE : MS_HANG;
+    }
+    u32 used = cl;
+    w >>= cl;
+    const u32 xb = (e >> 4) & 15;
+    i32 len = (i32)(e >> 16);
+    if (xb && b.pos + used + xb > b.total_bits) len -= 1;
+    else { len += (i32)((u32)w & ((1u << xb) - 1)); w >>= xb; used += xb; }
+    if (b.pos + used + X.d_max > b.total_bits) return MS_FALSE_EOS;
+    const u32 d = exact_entry<true>(X.dt, X.d_max, (u32)w);
+    if (d & E_BAD) return MS_FALSE;
+    const u32 dl = d & 15;
+    w >>= dl;
+    used += dl;
+    const u32 dxb = (d >> 4) & 15;
+    i32 dist = (i32)(d >> 16);
+    if (dxb && b.pos + used + dxb > b.total_bits) dist -= 1;
+    else { dist += (i32)((u32)w & ((1u << dxb) - 1)); used += dxb; }
+    b.pos += used;
+    if ((u64)dist > o.pos) return MS_FARREF;
+    if (o.pos + (u64)len > o.limit) return MS_CAP;
+    if ((u64)dist > o.pos - o.hist) o.far = 1;
+    if (WRITE) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the copy reads what earlier symbols wrote
+    lz_copy<WRITE>(o, (u32)dist, (u32)len, lane);
   }
 }
 

@@ -122,3 +122,44 @@ def _fixed_far_distance():
     # (5 bits) + 1 extra bit -> distance 5/6 > 1 byte of history
     f = [(1, 1, False), (1, 2, False), (0x30 + 0x61, 8, True), (1, 7, True), (4, 5, True), (1, 1, False), (0, 7, True)]
     return _pack_bits(f)
+
+
+def oversubscribed_dynamic_block(data_bits=(0, 0, 1, 1, 1, 0)):
+    """One final dynamic block whose literal/length code is OVER-subscribed: 'a', 'b', 'c' all have length 1 and the
+    end-of-block code length 2.  The reference's HuffmanTable does not notice (lib/src/codecs/zlib/_huffman_table.dart:24-45):
+    the third one-bit code wraps around and overwrites the first, the two-bit code overwrites half of 'b'.  With the
+    default data bits the reference decodes b"ccbb"."""
+    f = [(1, 1, False), (2, 2, False), (0, 5, False), (0, 5, False), (14, 4, False)]  # BFINAL, dynamic, HLIT 257, HDIST 1, HCLEN 18
+    order = [16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15]
+    cl_len = {0: 1, 1: 2, 2: 3, 18: 3}
+    for sym in order[:18]:
+        f.append((cl_len.get(sym, 0), 3, False))
+    cl_code = {0: (0b0, 1), 1: (0b10, 2), 2: (0b110, 3), 18: (0b111, 3)}  # canonical, sent MSB first
+
+    def cl(sym):
+        c, n = cl_code[sym]
+        f.append((c, n, True))
+
+    cl(18); f.append((97 - 11, 7, False))     # symbols 0..96: zero
+    cl(1); cl(1); cl(1)                       # 'a', 'b', 'c': length 1 each  (over-subscribed)
+    cl(18); f.append((138 - 11, 7, False))    # 100..237
+    cl(18); f.append((18 - 11, 7, False))     # 238..255
+    cl(2)                                     # 256: length 2
+    cl(1)                                     # the one distance code: length 1
+    for b in data_bits:
+        f.append((b, 1, False))
+    return _pack_bits(f) + bytes(4)
+
+
+def raw_far_reference(lit=b"a", length=3, dist_code=4, dist_extra=1):
+    """A fixed-Huffman stream: the literals, then one match whose distance (code 4 + 1 extra bit: 5 or 6) reaches
+    further back than the stream's own output -- legal in the reference when earlier gzip members put bytes there (q8)."""
+    f = [(1, 1, False), (1, 2, False)]
+    for ch in lit:
+        f.append((0x30 + ch, 8, True) if ch < 144 else (0x190 + ch - 144, 9, True))
+    f += [(length - 2, 7, True), (dist_code, 5, True), (dist_extra, 1, False), (0, 7, True)]
+    return _pack_bits(f)
+
+
+def gz_wrap(raw, data_for_trailer=b""):
+    return bytes([0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 255]) + raw + struct.pack("<II", zlib.crc32(data_for_trailer), len(data_for_trailer))

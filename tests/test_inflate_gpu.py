@@ -234,3 +234,33 @@ def test_device_resident_plan_api(amd):
     assert N.lib().ahip_gzip_decode_device(d_in.data_ptr(), d_in.numel(), d_out.data_ptr(), d_out.numel(),
                                            ctypes.byref(olen), None) == 0
     assert hashlib.sha256(d_out.cpu().numpy().tobytes()).digest() == hashlib.sha256(bytes(plain)).digest()
+
+
+def test_back_reference_into_previous_gzip_member(amd, orc):
+    """Quirk q8: the reference's gzip decoder appends every member to ONE OutputStream (_gzip_decoder_web.dart:27-41), so
+    a distance may reach into what earlier members produced (util/output_memory_stream.dart:79-98)."""
+    first = streams.text(40000, 77)
+    far = streams.gz_wrap(streams.raw_far_reference())               # 'a' + copy 3 bytes from 6 back
+    far2 = streams.gz_wrap(streams.raw_far_reference(lit=b"xy", length=5, dist_extra=0))
+    cases = [streams.gz_member(first) + far,
+             streams.gz_member(first) + far + far2 + streams.gz_member(streams.text(3000, 78)),  # a chain of them
+             streams.bgzf_member(first[:5000]) + far + streams.bgzf_member(first[:700]) + far2,
+             streams.gz_member(b"12345") + far,                          # reaches exactly the first byte of the stream
+             streams.gz_member(b"1234") + far,                           # one byte too far: RangeError
+             far]                                                        # first member: RangeError
+    for i, c in enumerate(cases):
+        want = _noneify(orc.gzip_decode(c))
+        assert _gz(amd, c) == want, i
+    assert orc.gzip_decode(cases[0])[1].endswith(b"a" + first[-5:-2])
+
+
+def test_over_subscribed_code_lengths(amd, orc):
+    """HuffmanTable never checks the Kraft sum (_huffman_table.dart:24-45): later codes overwrite earlier ones."""
+    raw = streams.oversubscribed_dynamic_block()
+    assert orc.inflate_raw(raw)[:2] == (0, b"ccbb")
+    assert _raw(amd, raw) == orc.inflate_raw(raw)
+    for bits in [(1, 1, 0, 1, 0), (0, 1, 0), (1, 0), (0,) * 40 + (1, 0), (1,) * 9]:
+        r = streams.oversubscribed_dynamic_block(bits)
+        assert _raw(amd, r)[:2] == orc.inflate_raw(r)[:2], bits
+    g = streams.gz_member(streams.text(20000, 5)) + streams.gz_wrap(raw[:-4], b"ccbb") + streams.gz_member(streams.text(9000, 6))
+    assert _gz(amd, g) == _noneify(orc.gzip_decode(g))
