@@ -291,6 +291,12 @@ hipError_t launch_inflate_group(const u8 *in, u64 n, const MemberDesc *members, 
   const u32 grid1 = count < (u32)tok_resident ? count : (u32)tok_resident;
   void *tp = nullptr, *dp = nullptr;
   hipError_t e = hipSuccess;
+  // The token / directory scratch is shared by every launch of the process: a launch on another stream than the
+  // previous one first waits for that one to be done with it.
+  static hipEvent_t scratch_free = nullptr;
+  static hipStream_t scratch_user = nullptr;
+  if (!scratch_free) { e = hipEventCreateWithFlags(&scratch_free, hipEventDisableTiming); if (e != hipSuccess) return e; scratch_user = st; }
+  if (scratch_user != st) { e = hipStreamWaitEvent(st, scratch_free, 0); if (e != hipSuccess) return e; scratch_user = st; }
   if (WRITE) {
     // 1.5 token words + 1/16 directory entry per output byte, plus a fixed allowance per member (tok_layout)
     const u64 span = out1 - out0;
@@ -318,6 +324,8 @@ hipError_t launch_inflate_group(const u8 *in, u64 n, const MemberDesc *members, 
   }
   hipLaunchKernelGGL(inflate_late_kernel<WRITE>, dim3(1), dim3(64), 0, st, in, n, members, first, count, out, (const u32 *)tp,
                      (const uint2 *)dp, out0, res, dlate.as<u32>(), dexact.as<u32>());
+  e = hipEventRecord(scratch_free, st);
+  if (e != hipSuccess) return e;
   return hipGetLastError();
 }
 
@@ -369,6 +377,7 @@ struct ahip_gzip_plan {
   DevBuf tile_counts, tile_offsets, cand_pos, hdr, scratch_u32, members, expect_status, results, sizing_descs,
       sizing_results, dsum, drun;
   bool ran = false;
+  hipStream_t run_stream = nullptr;  // the stream the last ahip_gzip_plan_run was enqueued on
   std::vector<u64> host_out_off;  // M + 1 entries: output offset of every member, then the total
   struct Big { u32 cand, member; u64 in_off, out_off, out_len; };
   std::vector<Big> big;           // long members decoded by many waves each (sm_inflate), outside the member launch
@@ -426,10 +435,14 @@ int32_t plan_build(ahip_gzip_plan *pl, bool force_sizing, hipStream_t st) {
     HIP_TRY(pl->sizing_results.reserve((size_t)K * sizeof(MemberResult)));
     hipLaunchKernelGGL(gz_make_sizing_descs, dim3(cdiv(K, 256)), dim3(256), 0, st, pl->hdr.as<GzHeader>(), K,
                        pl->sizing_descs.as<MemberDesc>());
-    // Long members (a file that is ONE gzip member is the common case) are measured by many waves each; the
-    // member launch skips them (their descriptor is pointed at the end of the input).
+    // Long members (a file that is ONE gzip member is the common case) are measured by many waves each, in stream
+    // order, BEFORE the all-candidates launch: every `1f 8b 08` inside a measured member is a false candidate (about
+    // one per 16 MiB of compressed data) and is skipped together with the member itself (descriptor pointed at the
+    // end of the input).  A candidate looks long when the next candidate is >= sm_min_bytes away; once eight have
+    // been measured the all-members launch (one wave each, all at once) wins unless a member is really long.
     pl->big.clear();
-    if (K <= 256 && n >= sm_min_bytes() && !getenv("AHIP_NO_SM")) {
+    std::vector<std::pair<u32, MemberResult>> measured;
+    if (K <= (1u << 20) && n >= sm_min_bytes() && !getenv("AHIP_NO_SM")) {
       std::vector<GzHeader> hh(K);
       std::vector<u64> cp(K);
       std::vector<MemberDesc> sd(K);
@@ -437,41 +450,33 @@ int32_t plan_build(ahip_gzip_plan *pl, bool force_sizing, hipStream_t st) {
       HIP_TRY(hipMemcpyAsync(cp.data(), pl->cand_pos.p, (size_t)K * 8, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipMemcpyAsync(sd.data(), pl->sizing_descs.p, (size_t)K * sizeof(MemberDesc), hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
+      u64 covered_until = 0;
+      bool changed = false;
       for (u32 i = 0; i < K; ++i) {
+        if (cp[i] < covered_until) { sd[i].in_off = n; changed = true; continue; }  // inside a measured member
         const u64 lim = i + 1 < K ? cp[i + 1] : n;
-        if (!(hh[i].flags & HF_RANGE) && hh[i].payload_off < lim && lim - hh[i].payload_off >= sm_min_bytes()) {
-          pl->big.push_back({i, 0xffffffffu, hh[i].payload_off, 0, 0});
-          sd[i].in_off = n;  // nothing to read: the member launch is done with it at once
-        }
+        if ((hh[i].flags & HF_RANGE) || hh[i].payload_off >= lim) continue;
+        const u64 gap = lim - hh[i].payload_off;
+        if (gap < sm_min_bytes() || (measured.size() >= 8 && gap < (32ull << 20))) continue;
+        MemberResult r{};
+        bool handled = false;
+        int32_t rc = sm_inflate(in, n, hh[i].payload_off, nullptr, 0, false, &r, &handled, st);
+        if (rc != AHIP_OK) return rc;
+        if (!handled) { rc = inflate_one_wave(in, n, hh[i].payload_off, nullptr, ~0ull, false, &r, st); if (rc != AHIP_OK) return rc; }
+        measured.push_back({i, r});
+        pl->big.push_back({i, 0xffffffffu, hh[i].payload_off, 0, 0});
+        sd[i].in_off = n;  // nothing to read: the member launch is done with it at once
+        changed = true;
+        if (r.status == MS_OK) covered_until = r.end_pos;
       }
-      // Long members are taken one after another (each on the whole GPU): with many of them, the ordinary launch
-      // -- all members at once, one wave each -- wins unless a member is really long.
-      if (pl->big.size() > 8) {
-        std::vector<ahip_gzip_plan::Big> keep;
-        for (const auto &bg : pl->big) {
-          const u64 lim = bg.cand + 1 < K ? cp[bg.cand + 1] : n;
-          if (lim - bg.in_off >= (32ull << 20)) keep.push_back(bg);
-          else sd[bg.cand].in_off = bg.in_off;
-        }
-        pl->big = keep;
-      }
-      if (!pl->big.empty())
+      if (changed)
         HIP_TRY(hipMemcpyAsync(pl->sizing_descs.p, sd.data(), (size_t)K * sizeof(MemberDesc), hipMemcpyHostToDevice, st));
     }
     HIP_TRY(launch_inflate<false>(in, n, pl->sizing_descs.as<MemberDesc>(), K, (u8 *)nullptr,
                                   pl->sizing_results.as<MemberResult>(), st));
-    u64 covered_until = 0;  // candidates inside a member that has just been measured are false ones: skip them
-    for (auto &bg : pl->big) {
-      if (bg.in_off < covered_until) continue;
-      MemberResult r{};
-      bool handled = false;
-      int32_t rc = sm_inflate(in, n, bg.in_off, nullptr, 0, false, &r, &handled, st);
-      if (rc != AHIP_OK) return rc;
-      if (!handled) { rc = inflate_one_wave(in, n, bg.in_off, nullptr, ~0ull, false, &r, st); if (rc != AHIP_OK) return rc; }
-      HIP_TRY(hipMemcpyAsync(pl->sizing_results.as<MemberResult>() + bg.cand, &r, sizeof r, hipMemcpyHostToDevice, st));
-      HIP_TRY(hipStreamSynchronize(st));
-      if (r.status == MS_OK) covered_until = r.end_pos;
-    }
+    for (auto &mr : measured)
+      HIP_TRY(hipMemcpyAsync(pl->sizing_results.as<MemberResult>() + mr.first, &mr.second, sizeof(MemberResult), hipMemcpyHostToDevice, st));
+    if (!measured.empty()) HIP_TRY(hipStreamSynchronize(st));
     hipLaunchKernelGGL(gz_apply_sizing, dim3(cdiv(K, 256)), dim3(256), 0, st, pl->hdr.as<GzHeader>(), K,
                        pl->sizing_results.as<MemberResult>(), n);
     pl->sized = true;
@@ -529,6 +534,7 @@ int32_t plan_run(ahip_gzip_plan *pl, u8 *d_out, size_t out_cap, hipStream_t st) 
   init.first_bad = 0xffffffffu;
   HIP_TRY(hipMemcpyAsync(pl->drun.p, &init, sizeof init, hipMemcpyHostToDevice, st));
   pl->ran = true;
+  pl->run_stream = st;
   if (M == 0) return AHIP_OK;
   HIP_TRY(pl->results.reserve((size_t)M * sizeof(MemberResult)));
   const u64 whole[2] = {0, pl->sum.total_out};  // one group: only its total is needed
@@ -1354,7 +1360,7 @@ int32_t ahip_gzip_plan_status(ahip_gzip_plan *plan, size_t *out_len) {
   if (out_len) *out_len = plan->sum.total_out;
   if (!plan->ran) return fail(AHIP_E_ARG, "plan has not been run");
   bool needs = false;
-  int32_t rc = plan_verdict(plan, nullptr, &needs);
+  int32_t rc = plan_verdict(plan, plan->run_stream, &needs);  // waits for the run on the stream it was enqueued on
   if (rc != AHIP_OK) return rc;
   if (needs) return fail(AHIP_E_UNSUPPORTED, "member index (BC/ISIZE) disagrees with the data; use ahip_gzip_decode_device");
   if (plan->sum.range_error) return AHIP_RANGE;
@@ -1422,6 +1428,9 @@ static int32_t gzip_decode_impl(const u8 *host_in, const u8 *d_in, size_t in_len
     HIP_TRY(hipMemcpy(tail_host.data(), d_in + pl.sum.tail_pos, tail_host.size(), hipMemcpyDeviceToHost));
     h = tail_host.data() - pl.sum.tail_pos;
   }
+  // `1f 8b` and then the end of the input: _readHeader has matched the 16-bit signature and its next readByte()
+  // throws (_gzip_decoder_web.dart:99-107) -- the zlib decoder is never asked
+  if (in_len - pl.sum.tail_pos == 2 && h[pl.sum.tail_pos] == 0x1f && h[pl.sum.tail_pos + 1] == 0x8b) return AHIP_RANGE;
   // cheap pre-check of the first header so the common "trailing garbage" case needs no kernels
   if (!raw) {
     u64 p = pl.sum.tail_pos;
@@ -1543,7 +1552,13 @@ static int32_t inflate_batch_impl(const u8 *d_in, size_t in_len, u32 n, const ui
   auto skip_desc = [&](u64 ooff, u64 olim) { return MemberDesc{(u64)in_len, ooff, olim, POS_UNKNOWN, 0}; };
   std::vector<u64> size(n);
   if (size_hint) {
-    for (u32 i = 0; i < n; ++i) size[i] = size_hint[i];
+    // Directory sizes are untrusted: DEFLATE cannot expand a slice beyond 1032 x its length (258 bytes per 2 bits),
+    // so anything larger is clamped -- the entry then reports AHIP_E_CAP like any other too-small window -- and the
+    // sums below cannot wrap.
+    for (u32 i = 0; i < n; ++i) {
+      const u64 bound = in_size[i] > (~0ull >> 12) ? ~0ull >> 1 : in_size[i] * 1032 + 64;
+      size[i] = size_hint[i] < bound ? size_hint[i] : bound;
+    }
   } else {  // sizing run: every entry's true length
     for (u32 i = 0; i < n; ++i) md[i] = big(i) ? skip_desc(0, 0) : entry_desc(i, 0, ~0ull);
     HIP_TRY(hipMemcpyAsync(ddesc.p, md.data(), (size_t)n * sizeof(MemberDesc), hipMemcpyHostToDevice, st));
@@ -1557,7 +1572,11 @@ static int32_t inflate_batch_impl(const u8 *d_in, size_t in_len, u32 n, const ui
   }
   std::vector<u64> off(n + 1);
   u64 total = 0;
-  for (u32 i = 0; i < n; ++i) { off[i] = total; total += size[i]; }
+  for (u32 i = 0; i < n; ++i) {
+    off[i] = total;
+    if (size[i] > (1ull << 46) || total + size[i] > (1ull << 46)) return fail(AHIP_E_ARG, "entry sizes add up to more than any device holds");
+    total += size[i];
+  }
   off[n] = total;
   if (out_total) *out_total = total;
   if (total > out_cap) return fail(AHIP_E_CAP, "output buffer too small");

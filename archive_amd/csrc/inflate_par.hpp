@@ -449,6 +449,7 @@ AHIP_DEVINL u32 huffman_block_emit(WaveLds &L, BitCursor &b, OutCursor &o, TokSi
 // _parseUncompressedBlock as tokens: runs of >= 3 bytes become one TK_STORED record (3 words, never split)
 AHIP_DEVINL u32 stored_block_emit(BitCursor &b, OutCursor &o, TokSink &sink, u32 *colpos, int lane) {
   b.pos = (b.pos + 7) & ~7ull;
+  b.blen = 0;
   int len = read_bits(b, 16);
   int nlen_raw = read_bits(b, 16);
   int nlen = nlen_raw ^ 0xffff;
@@ -774,7 +775,7 @@ AHIP_DEVINL void inflate_member(WaveLds &L, HeaderLds &H, TokLds *P, const u8 *i
                                 TokSink sink, MemberResult &res, int lane, const ChunkCtx *cx = nullptr,
                                 u32 *exact = nullptr) {
   ParStats st{};
-  BitCursor b{in, in_len, in_len * 8, m.in_off * 8 + (CHUNK ? cx->start_bit : 0u), nullptr, 0, 0};
+  BitCursor b{in, in_len, in_len * 8, m.in_off * 8 + (CHUNK ? cx->start_bit : 0u), nullptr, 0, 0, 0};
   const u64 hist = CHUNK ? cx->hist : m.hist;
   OutCursor o{out + m.out_off - hist, hist, m.out_limit > ~0ull - hist ? ~0ull : m.out_limit + hist, CHUNK ? 0u : hist, 0};
   if (PAR) { P->colpos[lane] = 0; wave_sync(); }
@@ -788,6 +789,7 @@ AHIP_DEVINL void inflate_member(WaveLds &L, HeaderLds &H, TokLds *P, const u8 *i
       while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (cx->cand_bits[mid] < b.pos) lo = mid + 1; else hi = mid; }
       if (lo < cx->n_cand && cx->cand_bits[lo] == b.pos) { status = MS_CHUNK_END; break; }
     }
+    b.blen = (8 - ((u32)b.pos & 7)) & 7;  // what the accumulator holds between blocks: the rest of the current byte
     int hdr = read_bits(b, 3);
     ++blocks;
     const bool final_block = hdr & 1;
@@ -816,9 +818,13 @@ AHIP_DEVINL void inflate_member(WaveLds &L, HeaderLds &H, TokLds *P, const u8 *i
         r = dynamic_header(H, b, lane, hlit, hdist);
         b.stage = nullptr;
       }
+      const u64 data_pos = b.pos;
+      const u32 data_blen = b.blen;
+      bool replayable = false;
       if (r == MS_OK) {
         bool ok = build_decode_table<false>(H.lens, hlit, L.ll, LL_ROOT, L.lld, L.ll_sorted, lane);
         ok &= build_decode_table<true>(H.lens + hlit, hdist, L.dt, D_ROOT, L.dd, L.d_sorted, lane);
+        replayable = ok;
         AHIP_TICK(t_h1);
         AHIP_ACC(st.cyc[0], t_h0, t_h1);
         if (!ok) {
@@ -833,17 +839,21 @@ AHIP_DEVINL void inflate_member(WaveLds &L, HeaderLds &H, TokLds *P, const u8 *i
         }
         else if (PAR) r = huffman_block_tokenize(L, *P, b, o, sink, lane, st, hint_end_bits);
         else r = huffman_block<WRITE>(L, b, o, lane);
+        if (r == MS_FALSE && replayable) {  // a bad symbol: where exactly did the reference's reader stop?
+          b.pos = data_pos;
+          b.blen = data_blen;
+          replay_to_failure(L, b);
+        }
       }
     }
     if (r != MS_OK) { status = r; break; }
     if (final_block) { status = MS_OK; break; }
   }
   if (lane == 0) {
-    // Position the reference's InputStream is left at.  Exact after a complete block
-    // (whole bytes are un-read) and after an end-of-input failure; after a bad-symbol failure
-    // in the middle of the input the reference has over-read by up to two bytes -- see
-    // DESIGN.md "deviations".
+    // Position the reference's InputStream is left at: after a complete block whole bytes are un-read
+    // (inflate.dart:337-340); after a failure inside a block nothing is (the accumulator keeps what it pulled).
     u64 end = (b.pos + 7) >> 3;
+    if (status == MS_FALSE) end = (b.pos + b.blen) >> 3;
     if (status == MS_FALSE_EOS) { end = in_len; status = MS_FALSE; }  // every byte was pulled into the accumulator
     res.end_pos = end > in_len ? in_len : end;
     if (CHUNK && status == MS_CHUNK_END) res.end_pos = b.pos;

@@ -93,7 +93,13 @@ struct BitCursor {
   const u32 *stage;
   u64 stage_byte;
   u32 stage_len;
+  // The reference pulls whole bytes into its accumulator and leaves them there when a block fails half way
+  // (inflate.dart:159-211: no un-read on `return -1`), so its stream position after such a failure is
+  // (pos + blen) / 8 with blen = the bits its accumulator would still hold.  Tracked by the serial readers only
+  // (block headers; replay_to_failure() for a Huffman block).
+  u32 blen;
 };
+AHIP_DEVINL void acc_need(BitCursor &b, u32 n) { while (b.blen < n) b.blen += 8; }
 
 // >= 57 valid bits starting at the cursor; bytes past the end read as zero.
 AHIP_DEVINL u64 peek_bits(const BitCursor &b) {
@@ -122,6 +128,8 @@ AHIP_DEVINL int read_bits(BitCursor &b, u32 n) {
   if (n == 0) return 0;
   if (b.pos + n > b.total_bits) return -1;
   u32 v = (u32)peek_bits(b) & ((1u << n) - 1);
+  acc_need(b, n);
+  b.blen -= n;
   b.pos += n;
   return (int)v;
 }
@@ -313,6 +321,34 @@ AHIP_DEVINL u32 huffman_block(WaveLds &L, BitCursor &b, OutCursor &o, int lane) 
   }
 }
 
+// A Huffman block ended in a bad litlen / distance symbol (MS_FALSE, not at the end of the input).  Walk the block
+// again from its first code, symbol by symbol, keeping the reference's accumulator length: b.pos / b.blen end up
+// where the reference's `return -1` leaves them (inflate.dart:300-343).  Only ever runs on corrupt data.
+AHIP_DEVINL void replay_to_failure(const WaveLds &L, BitCursor &b) {
+  const u32 ll_max = L.lld.maxlen, d_max = L.dd.maxlen;
+  for (u32 guard = 0; guard < (1u << 28); ++guard) {
+    u64 w = peek_bits(b);
+    u32 e = uniform(L.ll[(u32)w & ((1u << LL_ROOT) - 1)]);
+    if (e & E_LONG) e = uniform(long_lookup<false>(L.lld, L.ll_sorted, (u32)w, LL_ROOT));
+    acc_need(b, ll_max);
+    const u32 cl = e & 15;
+    b.blen -= cl; b.pos += cl;
+    if (e & E_LIT) continue;
+    if (e & (E_EOB | E_BAD | E_HOLE)) return;
+    w >>= cl;
+    const u32 xb = (e >> 4) & 15;
+    if (xb) { acc_need(b, xb); b.blen -= xb; b.pos += xb; w >>= xb; }
+    u32 d = uniform(L.dt[(u32)w & ((1u << D_ROOT) - 1)]);
+    if (d & E_LONG) d = uniform(long_lookup<true>(L.dd, L.d_sorted, (u32)w, D_ROOT));
+    acc_need(b, d_max);
+    const u32 dl = d & 15;
+    b.blen -= dl; b.pos += dl;
+    if (d & E_BAD) return;
+    const u32 dxb = (d >> 4) & 15;
+    if (dxb) { acc_need(b, dxb); b.blen -= dxb; b.pos += dxb; }
+  }
+}
+
 // ---- over-subscribed code lengths: the reference's own table ----
 // HuffmanTable (_huffman_table.dart:9-46) never checks the Kraft sum: when there are more codes of a length than fit,
 // `code` runs past 2^length, its low bits wrap, and later fills overwrite earlier ones.  That cannot be described
@@ -356,33 +392,38 @@ AHIP_DEVINL u32 huffman_block_exact(const ExactTabs &X, BitCursor &b, OutCursor 
     u64 w = peek_bits(b);
     const u32 e = exact_entry<false>(X.ll, X.ll_max, (u32)w);
     const u32 cl = e & 15;
+    acc_need(b, X.ll_max);
     if (e & (E_LIT | E_EOB | E_BAD | E_HOLE)) {
       if (e & E_LIT) {
         if (o.pos >= o.limit) return MS_CAP;
         if (WRITE && lane == 0) o.base[o.pos] = (u8)(e >> 16);
         o.pos += 1;
-        b.pos += cl;
+        b.pos += cl; b.blen -= cl;
         continue;
       }
-      if (e & E_EOB) { b.pos += cl; return MS_OK; }
-      return (e & E_BAD) ? MS_FALSE : MS_HANG;
+      if (e & E_HOLE) return MS_HANG;
+      b.pos += cl; b.blen -= cl;
+      return (e & E_EOB) ? MS_OK : MS_FALSE;
     }
     u32 used = cl;
     w >>= cl;
     const u32 xb = (e >> 4) & 15;
     i32 len = (i32)(e >> 16);
+    b.blen -= cl;
     if (xb && b.pos + used + xb > b.total_bits) len -= 1;
-    else { len += (i32)((u32)w & ((1u << xb) - 1)); w >>= xb; used += xb; }
+    else { len += (i32)((u32)w & ((1u << xb) - 1)); w >>= xb; used += xb; if (xb) { acc_need(b, xb); b.blen -= xb; } }
     if (b.pos + used + X.d_max > b.total_bits) return MS_FALSE_EOS;
     const u32 d = exact_entry<true>(X.dt, X.d_max, (u32)w);
-    if (d & E_BAD) return MS_FALSE;
+    acc_need(b, X.d_max);
+    if (d & E_BAD) { b.pos += used + (d & 15); b.blen -= d & 15; return MS_FALSE; }
     const u32 dl = d & 15;
+    b.blen -= dl;
     w >>= dl;
     used += dl;
     const u32 dxb = (d >> 4) & 15;
     i32 dist = (i32)(d >> 16);
     if (dxb && b.pos + used + dxb > b.total_bits) dist -= 1;
-    else { dist += (i32)((u32)w & ((1u << dxb) - 1)); used += dxb; }
+    else { dist += (i32)((u32)w & ((1u << dxb) - 1)); used += dxb; if (dxb) { acc_need(b, dxb); b.blen -= dxb; } }
     b.pos += used;
     if ((u64)dist > o.pos) return MS_FARREF;
     if (o.pos + (u64)len > o.limit) return MS_CAP;
@@ -396,6 +437,7 @@ AHIP_DEVINL u32 huffman_block_exact(const ExactTabs &X, BitCursor &b, OutCursor 
 template <bool WRITE>
 AHIP_DEVINL u32 stored_block(BitCursor &b, OutCursor &o, int lane) {
   b.pos = (b.pos + 7) & ~7ull;  // the accumulator is dropped; it never holds a whole byte here
+  b.blen = 0;
   int len = read_bits(b, 16);
   int nlen_raw = read_bits(b, 16);
   int nlen = nlen_raw ^ 0xffff;
@@ -471,6 +513,8 @@ AHIP_DEVINL u32 dynamic_header(HeaderLds &L, BitCursor &b, int lane, int &hlit_o
   while (i < num) {
     if (b.pos + cl_max > b.total_bits) return MS_FALSE_EOS;
     u32 e = uniform(L.cl[(u32)peek_bits(b) & (cl_size - 1)]);
+    acc_need(b, cl_max);
+    b.blen -= e >> 16;
     b.pos += e >> 16;
     u32 code = e & 0xffff;
     int repeat;
