@@ -997,13 +997,22 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
   const u64 nblock_max = 100000ull * (u64)level;
   const u64 wstride = nblock_max / BZ_G + 2;
   static DevBuf dpre, dwalk, drank, dspans;
-  HIP_TRY(dtt.reserve((size_t)ncand * nblock_max * 4));
-  HIP_TRY(dsel.reserve((size_t)ncand * BZ_MAX_SELECTORS));
-  HIP_TRY(dpre.reserve((size_t)ncand * nblock_max));
-  HIP_TRY(dwalk.reserve((size_t)ncand * wstride * sizeof(BzWalk)));
-  HIP_TRY(drank.reserve((size_t)ncand * wstride * 4));
-  HIP_TRY(dspans.reserve((size_t)ncand * BZ_SPANS * sizeof(BzSpan)));
-  HIP_TRY(dres.reserve((size_t)ncand * sizeof(BzResult)));
+  // Candidates are taken in bounded batches in stream order (work memory O(batch x block size), about 5.4 MB per
+  // block at level 9), following the chain of blocks exactly like decodeStream between them: a block ends where
+  // the next magic starts.  A batch's blocks are placed and expanded before the next batch is decoded; nothing
+  // behind the point where the chain stops is ever touched.
+  const u64 per_block = nblock_max * 5 + wstride * (sizeof(BzWalk) + 4) + BZ_SPANS * sizeof(BzSpan) + BZ_MAX_SELECTORS + sizeof(BzResult) + 64;
+  u64 batch_mem = 6ull << 30;
+  if (const char *e = getenv("AHIP_BZ_BATCH_BYTES")) { if (atoll(e) > 0) batch_mem = (u64)atoll(e); }
+  u32 batch = (u32)std::min<u64>(ncand, std::max<u64>(4, batch_mem / per_block));
+  HIP_TRY(dtt.reserve((size_t)batch * nblock_max * 4));
+  HIP_TRY(dsel.reserve((size_t)batch * BZ_MAX_SELECTORS));
+  HIP_TRY(dpre.reserve((size_t)batch * nblock_max));
+  HIP_TRY(dwalk.reserve((size_t)batch * wstride * sizeof(BzWalk)));
+  HIP_TRY(drank.reserve((size_t)batch * wstride * 4));
+  HIP_TRY(dspans.reserve((size_t)batch * BZ_SPANS * sizeof(BzSpan)));
+  HIP_TRY(dres.reserve((size_t)batch * sizeof(BzResult)));
+  HIP_TRY(doff.reserve((size_t)batch * 8));
   {
     u32 table[256 + 64];
     for (u32 i = 0; i < 256; ++i) {
@@ -1022,103 +1031,100 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
     HIP_TRY(hipMemcpy(dcrc.p, table, sizeof(table), hipMemcpyHostToDevice));
   }
   const u32 wgrid = (u32)cdiv(wstride, 256);
-  hipLaunchKernelGGL(bz_decode_block, dim3(ncand), dim3(64), 0, st, d_in, (u64)in_len, dcand.as<BzCand>(), ncand,
-                     (u32)level, dtt.as<u32>(), dsel.as<u8>(), dres.as<BzResult>());
-  hipLaunchKernelGGL(bz_tinv_scatter, dim3(ncand), dim3(1024), 0, st, dtt.as<u32>(), (u32)level, dcand.as<BzCand>(),
-                     dres.as<BzResult>());
-  hipLaunchKernelGGL(bz_walk<false>, dim3(wgrid, ncand), dim3(256), 0, st, dtt.as<u32>(), (u32)level, dcand.as<BzCand>(),
-                     dres.as<BzResult>(), dwalk.as<BzWalk>(), drank.as<u32>(), dpre.as<u8>());
-  hipLaunchKernelGGL(bz_rank, dim3(ncand), dim3(256), 0, st, (u32)level, dcand.as<BzCand>(), dres.as<BzResult>(),
-                     dwalk.as<BzWalk>(), drank.as<u32>());
-  hipLaunchKernelGGL(bz_walk<true>, dim3(wgrid, ncand), dim3(256), 0, st, dtt.as<u32>(), (u32)level, dcand.as<BzCand>(),
-                     dres.as<BzResult>(), dwalk.as<BzWalk>(), drank.as<u32>(), dpre.as<u8>());
-  hipLaunchKernelGGL(bz_rle_scan, dim3(ncand), dim3(1024), 0, st, (u32)level, dcand.as<BzCand>(), dres.as<BzResult>(),
-                     dpre.as<u8>(), dspans.as<BzSpan>());
-  // blocks the parallel path handed back (BZ_ST_SERIAL): the reference loop, counting only (no slab)
-  hipLaunchKernelGGL(bz_unbwt, dim3(cdiv(ncand, 64)), dim3(64), 0, st, dtt.as<u32>(), (u32)level, ncand,
-                     dcand.as<BzCand>(), (u8 *)nullptr, (u64)0, dres.as<BzResult>(), dcrc.as<u32>(),
-                     (const u64 *)nullptr, (u8 *)nullptr);
-  std::vector<BzResult> res(ncand);
-  HIP_TRY(hipMemcpy(res.data(), dres.p, (size_t)ncand * sizeof(BzResult), hipMemcpyDeviceToHost));
-  HIP_TRY(hipGetLastError());
-  // follow the chain of blocks exactly like decodeStream: a block ends where the next magic starts.
-  // Sizes are known here; block CRCs only after the expansion, so the walk is done for placement first and
-  // the verdict (first CRC mismatch stops the stream, its bytes already written) afterwards.
-  struct Placed { u32 cand; u64 off, len; };
-  std::vector<Placed> placed;
-  u64 total = 0;
+  static DevBuf ddir;
+  // chain state (decodeStream's loop)
+  u64 total = 0;        // bytes placed so far
+  u64 keep = 0;         // bytes that count (a CRC mismatch stops the stream behind the block it was found in)
   int32_t verdict = AHIP_OK;
-  bool saw_eos = false;
-  u32 eos_stored = 0;
-  {
-    size_t i = 0;
-    for (;;) {
-      const BzResult &r = res[i];
+  bool saw_eos = false, stopped = false, crc_stop = false, over_cap = false;
+  u32 eos_stored = 0, combined = 0;
+  size_t next = 0;      // candidate the chain expects next
+  for (size_t c0 = 0; c0 < ncand && !stopped; c0 += batch) {
+    if (next >= c0 + batch) continue;  // the chain has already stepped over this whole batch (false magics inside data)
+    const u32 nb = (u32)std::min<size_t>(batch, ncand - c0);
+    const BzCand *dc = dcand.as<BzCand>() + c0;
+    hipLaunchKernelGGL(bz_decode_block, dim3(nb), dim3(64), 0, st, d_in, (u64)in_len, dc, nb, (u32)level, dtt.as<u32>(), dsel.as<u8>(),
+                       dres.as<BzResult>());
+    hipLaunchKernelGGL(bz_tinv_scatter, dim3(nb), dim3(1024), 0, st, dtt.as<u32>(), (u32)level, dc, dres.as<BzResult>());
+    hipLaunchKernelGGL(bz_walk<false>, dim3(wgrid, nb), dim3(256), 0, st, dtt.as<u32>(), (u32)level, dc, dres.as<BzResult>(),
+                       dwalk.as<BzWalk>(), drank.as<u32>(), dpre.as<u8>());
+    hipLaunchKernelGGL(bz_rank, dim3(nb), dim3(256), 0, st, (u32)level, dc, dres.as<BzResult>(), dwalk.as<BzWalk>(), drank.as<u32>());
+    hipLaunchKernelGGL(bz_walk<true>, dim3(wgrid, nb), dim3(256), 0, st, dtt.as<u32>(), (u32)level, dc, dres.as<BzResult>(),
+                       dwalk.as<BzWalk>(), drank.as<u32>(), dpre.as<u8>());
+    hipLaunchKernelGGL(bz_rle_scan, dim3(nb), dim3(1024), 0, st, (u32)level, dc, dres.as<BzResult>(), dpre.as<u8>(), dspans.as<BzSpan>());
+    // blocks the parallel path handed back (BZ_ST_SERIAL): the reference loop, counting only (no slab)
+    hipLaunchKernelGGL(bz_unbwt, dim3(cdiv(nb, 64)), dim3(64), 0, st, dtt.as<u32>(), (u32)level, nb, dc, (u8 *)nullptr, (u64)0,
+                       dres.as<BzResult>(), dcrc.as<u32>(), (const u64 *)nullptr, (u8 *)nullptr);
+    std::vector<BzResult> res(nb);
+    HIP_TRY(hipMemcpy(res.data(), dres.p, (size_t)nb * sizeof(BzResult), hipMemcpyDeviceToHost));
+    HIP_TRY(hipGetLastError());
+    // Sizes are known here; block CRCs only after the expansion, so the walk is done for placement first and the
+    // verdict (first CRC mismatch stops the stream, its bytes already written) afterwards.
+    struct Placed { u32 cand; u64 off, len; };
+    std::vector<Placed> placed;
+    while (next < c0 + nb) {
+      const size_t i = next;
+      const BzResult &r = res[i - c0];
       if (cands[i].kind == 2) {  // end of stream: combined CRC, then decodeStream returns true
-        if (r.status == BZ_ST_RANGE) { verdict = AHIP_RANGE; break; }
-        saw_eos = true; eos_stored = r.stored_crc;
+        if (r.status == BZ_ST_RANGE) verdict = AHIP_RANGE;
+        else { saw_eos = true; eos_stored = r.stored_crc; }
+        stopped = true;
         break;
       }
-      if (r.status == BZ_ST_RANGE) { verdict = AHIP_RANGE; break; }
+      if (r.status == BZ_ST_RANGE) { verdict = AHIP_RANGE; stopped = true; break; }
       if (r.status == BZ_ST_UNSUPPORTED) return fail(AHIP_E_UNSUPPORTED, "randomised bzip2 block");
-      if (r.status != BZ_ST_OK && r.status != BZ_ST_OVERFLOW) { verdict = AHIP_FALSE; break; }
-      placed.push_back({(u32)i, total, r.out_len});
+      if (r.status != BZ_ST_OK && r.status != BZ_ST_OVERFLOW) { verdict = AHIP_FALSE; stopped = true; break; }
+      placed.push_back({(u32)(i - c0), total, r.out_len});
       total += r.out_len;
       // next block type is read at r.end_bit
-      if ((r.end_bit + 7) / 8 >= in_len) break;  // while (!input.isEOS): clean end without an end-of-stream block
+      if ((r.end_bit + 7) / 8 >= in_len) { stopped = true; break; }  // while (!input.isEOS): clean end without an end-of-stream block
       size_t j = i + 1;
       while (j < ncand && cands[j].bit < r.end_bit) ++j;
       if (j >= ncand || cands[j].bit != r.end_bit) {
         // not a block magic there: _readBlockType returns -1 (or runs off the end)
         verdict = (r.end_bit + 48 > (u64)in_len * 8) ? AHIP_RANGE : AHIP_FALSE;
+        stopped = true;
         break;
       }
-      i = j;
+      next = j;
     }
-  }
-  if (verdict == AHIP_RANGE) { if (out_len) *out_len = total; return AHIP_RANGE; }
-  if (total > out_cap) { if (out_len) *out_len = total; return fail(AHIP_E_CAP, "output buffer too small"); }
-  if (!placed.empty()) {
-    std::vector<u64> par_off(ncand, ~0ull), ser_off(ncand, ~0ull);
-    bool any_serial = false;
-    for (const Placed &pl : placed) {
-      if (res[pl.cand].status == BZ_ST_OK) par_off[pl.cand] = pl.off;
-      else { ser_off[pl.cand] = pl.off; any_serial = true; }
-    }
-    HIP_TRY(doff.reserve((size_t)ncand * 8));
-    HIP_TRY(hipMemcpy(doff.p, par_off.data(), (size_t)ncand * 8, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(bz_rle_expand, dim3(BZ_SPANS / 256, ncand), dim3(256), 0, st, (u32)level, dcand.as<BzCand>(),
-                       dres.as<BzResult>(), dpre.as<u8>(), dspans.as<BzSpan>(), doff.as<u64>(), d_out,
-                       dcrc.as<u32>());
-    if (any_serial) {
-      static DevBuf ddir;
-      HIP_TRY(ddir.reserve((size_t)ncand * 8));
-      HIP_TRY(hipMemcpy(ddir.p, ser_off.data(), (size_t)ncand * 8, hipMemcpyHostToDevice));
-      hipLaunchKernelGGL(bz_unbwt, dim3(cdiv(ncand, 64)), dim3(64), 0, st, dtt.as<u32>(), (u32)level, ncand,
-                         dcand.as<BzCand>(), (u8 *)nullptr, (u64)0, dres.as<BzResult>(), dcrc.as<u32>(),
-                         ddir.as<u64>(), d_out);
-    }
-    std::vector<BzResult> res2(ncand);
-    HIP_TRY(hipMemcpy(res2.data(), dres.p, (size_t)ncand * sizeof(BzResult), hipMemcpyDeviceToHost));
-    HIP_TRY(hipGetLastError());
-    // verdict: block CRCs in stream order, then the combined CRC
-    u32 combined = 0;
-    u64 keep = total;
-    for (const Placed &pl : placed) {
-      const u32 crc = res[pl.cand].status == BZ_ST_OK ? (res2[pl.cand].crc ^ 0xffffffffu) : res[pl.cand].crc;
-      if (verify && crc != res[pl.cand].stored_crc) {  // the block's bytes were already written
-        verdict = AHIP_FALSE; keep = pl.off + pl.len; saw_eos = false;
-        break;
+    if (verdict == AHIP_RANGE) { if (out_len) *out_len = total; return AHIP_RANGE; }
+    if (total > out_cap) over_cap = true;  // keep walking: the caller is told the full size
+    if (!placed.empty() && !crc_stop && !over_cap) {
+      std::vector<u64> par_off(nb, ~0ull), ser_off(nb, ~0ull);
+      bool any_serial = false;
+      for (const Placed &pl : placed) {
+        if (res[pl.cand].status == BZ_ST_OK) par_off[pl.cand] = pl.off;
+        else { ser_off[pl.cand] = pl.off; any_serial = true; }
       }
-      combined = ((combined << 1) | (combined >> 31)) ^ crc;
+      HIP_TRY(hipMemcpy(doff.p, par_off.data(), (size_t)nb * 8, hipMemcpyHostToDevice));
+      hipLaunchKernelGGL(bz_rle_expand, dim3(BZ_SPANS / 256, nb), dim3(256), 0, st, (u32)level, dc, dres.as<BzResult>(), dpre.as<u8>(),
+                         dspans.as<BzSpan>(), doff.as<u64>(), d_out, dcrc.as<u32>());
+      if (any_serial) {
+        HIP_TRY(ddir.reserve((size_t)nb * 8));
+        HIP_TRY(hipMemcpy(ddir.p, ser_off.data(), (size_t)nb * 8, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(bz_unbwt, dim3(cdiv(nb, 64)), dim3(64), 0, st, dtt.as<u32>(), (u32)level, nb, dc, (u8 *)nullptr, (u64)0,
+                           dres.as<BzResult>(), dcrc.as<u32>(), ddir.as<u64>(), d_out);
+      }
+      std::vector<BzResult> res2(nb);
+      HIP_TRY(hipMemcpy(res2.data(), dres.p, (size_t)nb * sizeof(BzResult), hipMemcpyDeviceToHost));
+      HIP_TRY(hipGetLastError());
+      // verdict: block CRCs in stream order, then (at the end) the combined CRC
+      for (const Placed &pl : placed) {
+        const u32 crc = res[pl.cand].status == BZ_ST_OK ? (res2[pl.cand].crc ^ 0xffffffffu) : res[pl.cand].crc;
+        if (verify && crc != res[pl.cand].stored_crc) {  // the block's bytes were already written
+          verdict = AHIP_FALSE; keep = pl.off + pl.len; saw_eos = false; crc_stop = true; stopped = true;
+          break;
+        }
+        combined = ((combined << 1) | (combined >> 31)) ^ crc;
+        keep = pl.off + pl.len;
+      }
     }
-    if (saw_eos && verify && eos_stored != combined && verdict == AHIP_OK) verdict = AHIP_FALSE;
-    total = keep;
-    HIP_TRY(hipStreamSynchronize(st));
-  } else if (saw_eos && verify && eos_stored != 0) {
-    verdict = AHIP_FALSE;
   }
-  if (out_len) *out_len = total;
+  HIP_TRY(hipStreamSynchronize(st));
+  if (over_cap) { if (out_len) *out_len = total; return fail(AHIP_E_CAP, "output buffer too small"); }
+  if (saw_eos && verify && eos_stored != combined && verdict == AHIP_OK) verdict = AHIP_FALSE;
+  if (out_len) *out_len = crc_stop ? keep : total;
   return verdict;
 }
 

@@ -35,7 +35,11 @@ def _malformed():
         pos = 40 + (k * 7919) % (len(small) - 60)
         b[pos] ^= 1 << (k % 8)
         flips["flip%d" % k] = bytes(b)
-    return {**flips, "truncated_tail": c[:-3], "truncated_mid": c[:50], "no_magic": b"BZh9" + bytes(20), "not_bz": b"hello",
+    # a block magic (byte-aligned) dropped into the middle of a block's payload, and one behind the end of the stream
+    two = bytearray(bz2.compress(streams.text(150000, 3), 1))
+    two[len(two) // 3:len(two) // 3 + 6] = bytes.fromhex("314159265359")
+    return {**flips, "magic_inside_block": bytes(two), "magic_after_end": c + bytes.fromhex("314159265359") + bytes(40),
+            "truncated_tail": c[:-3], "truncated_mid": c[:50], "no_magic": b"BZh9" + bytes(20), "not_bz": b"hello",
             "short": b"BZ", "header_only": b"BZh9", "bad_level": b"BZhx" + c[4:], "two_streams": c + c,
             "corrupt_block": bytes(bad_block)}
 
@@ -106,3 +110,31 @@ def test_gpu_device_resident_api(native_built):
     assert N.lib().ahip_bzip2_decode_device(d_in.data_ptr(), d_in.numel(), 1, d_out.data_ptr(), d_out.numel(),
                                             ctypes.byref(olen), None) == 0
     assert olen.value == len(data) and bytes(d_out.cpu().numpy()) == data
+
+
+@pytest.mark.gpu
+def test_gpu_many_blocks_in_small_batches(native_built, monkeypatch):
+    """64 blocks of 900 k (block boundaries fall on arbitrary bit offsets), work memory limited so that the candidates
+    are taken in several batches along the chain; size query with a too-small buffer reports the whole size."""
+    import ctypes
+    import zlib
+
+    import torch
+    from archive_amd import _native as N
+    from tools import corpus
+    assert N.lib().ahip_init(0) == 0
+    monkeypatch.setenv("AHIP_BZ_BATCH_BYTES", str(64 << 20))  # about 11 blocks per batch
+    data = bytes(corpus.text(corpus.WIKI, 8, 0, 64 * 900000 - 12345))
+    comp = bz2.compress(data, 9)
+    d_in = torch.frombuffer(bytearray(comp), dtype=torch.uint8).cuda()
+    olen = ctypes.c_size_t()
+    small = torch.empty(5000000, dtype=torch.uint8, device="cuda")
+    assert N.lib().ahip_bzip2_decode_device(d_in.data_ptr(), d_in.numel(), 1, small.data_ptr(), small.numel(), ctypes.byref(olen), None) == -1
+    assert olen.value == len(data)
+    d_out = torch.empty(len(data), dtype=torch.uint8, device="cuda")
+    assert N.lib().ahip_bzip2_decode_device(d_in.data_ptr(), d_in.numel(), 1, d_out.data_ptr(), d_out.numel(), ctypes.byref(olen), None) == 0
+    assert olen.value == len(data)
+    crc = ctypes.c_uint32()
+    assert N.lib().ahip_crc32_device(d_out.data_ptr(), len(data), 0, ctypes.byref(crc), None) == 0
+    assert crc.value == zlib.crc32(data)
+    assert bytes(d_out[:100000].cpu().numpy()) == data[:100000] and bytes(d_out[-100000:].cpu().numpy()) == data[-100000:]
