@@ -174,7 +174,8 @@ class Deflate:
         return b
 
     def finish(self):
-        pass
+        """Deflate.finish() flushes the pending buffer (deflate.dart:69): everything is already in get_bytes() here."""
+        return None
 
     getBytes = get_bytes
     takeBytes = take_bytes
@@ -198,7 +199,7 @@ class ZLibEncoder:
         level = 6 if level is None else level
         if raw:
             return Deflate(data, level=level, window_bits=15 if window_bits is None else window_bits).get_bytes()
-        return _encode(N.lib().ahip_zlib_encode, data, (level,))
+        return _encode(N.lib().ahip_zlib_encode, data, (level, 15 if window_bits is None else window_bits))
 
     encodeBytes = encode_bytes
 
@@ -212,7 +213,7 @@ class GZipEncoder:
         level = 6 if level is None else level
         if raw:
             return Deflate(data, level=level, window_bits=15 if window_bits is None else window_bits).get_bytes()
-        return _encode(N.lib().ahip_gzip_encode, data, (level, int(time.time()) if mtime is None else mtime))
+        return _encode(N.lib().ahip_gzip_encode, data, (level, 15 if window_bits is None else window_bits, int(time.time()) if mtime is None else mtime))
 
     encodeBytes = encode_bytes
 

@@ -912,7 +912,7 @@ int32_t zlib_stream_device(const u8 *host_in, const u8 *d_in, u64 n, u64 pos, bo
 // ------------------------------------------------------------------------------------------
 extern "C" {
 
-uint32_t ahip_abi_version(void) { return (1u << 16) | 0u; }
+uint32_t ahip_abi_version(void) { return (2u << 16) | 0u; }
 
 const char *ahip_last_error(void) { return g_err.c_str(); }
 
@@ -1162,17 +1162,42 @@ int32_t ahip_bzip2_decode(const uint8_t *in, size_t in_len, int32_t verify, uint
   return rc;
 }
 
+size_t ahip_decode_bound(const uint8_t *in, size_t in_len) {
+  // walk the members through their BC subfields (FEXTRA {'B','C',2,0,BSIZE-1}); anything else: unknown
+  size_t pos = 0, total = 0, members = 0;
+  while (pos < in_len) {
+    if (in_len - pos < 18 || in[pos] != 0x1f || in[pos + 1] != 0x8b || in[pos + 2] != 8) break;
+    size_t next = 0;
+    if ((in[pos + 3] & 4) && pos + 12 <= in_len) {
+      const size_t xlen = in[pos + 10] | ((size_t)in[pos + 11] << 8);
+      for (size_t q = pos + 12; q + 4 <= pos + 12 + xlen && q + 4 <= in_len;) {
+        const size_t slen = in[q + 2] | ((size_t)in[q + 3] << 8);
+        if (in[q] == 'B' && in[q + 1] == 'C' && slen == 2 && q + 6 <= in_len) { next = pos + (in[q + 4] | ((size_t)in[q + 5] << 8)) + 1; break; }
+        q += 4 + slen;
+      }
+    }
+    if (!next) {  // no BC: fine only if this is the one and only member and small enough for ISIZE to be the size
+      if (members == 0 && in_len < (1ull << 30)) { next = in_len; } else return 0;
+    }
+    if (next > in_len || next < pos + 18) return 0;
+    total += (size_t)in[next - 4] | ((size_t)in[next - 3] << 8) | ((size_t)in[next - 2] << 16) | ((size_t)in[next - 1] << 24);
+    ++members;
+    pos = next;
+  }
+  return pos == in_len ? total : 0;
+}
+
 size_t ahip_deflate_bound(size_t in_len) {
   const size_t chunks = (in_len + DF_CHUNK - 1) / DF_CHUNK;
   return in_len + chunks * 16 + 64;
 }
 
 // Deflate on device memory.  Returns the compressed size through *out_len.
-static int32_t deflate_device_impl(const u8 *d_in, size_t n, int level, u8 *d_out, size_t cap, size_t *out_len,
+static int32_t deflate_device_impl(const u8 *d_in, size_t n, int level, int window_bits, u8 *d_out, size_t cap, size_t *out_len,
                                    hipStream_t st) {
   static DevBuf b_match, b_tok, b_ntok, b_slabs, b_csize, b_coff;
   if (out_len) *out_len = 0;
-  if (level < 0 || level > 9) return AHIP_OK;  // the reference's _init fails silently: no output
+  if (level < 0 || level > 9 || window_bits < 9 || window_bits > 15) return AHIP_OK;  // the reference's _init fails silently: no output (deflate.dart:105-115)
   if (n == 0) {  // reference: one fixed-Huffman block holding only the end-of-block code (level >= 1), or an empty stored block
     const u8 fixed_empty[2] = {0x03, 0x00}, stored_empty[5] = {0x01, 0x00, 0x00, 0xff, 0xff};
     const u8 *src = level == 0 ? stored_empty : fixed_empty;
@@ -1189,6 +1214,7 @@ static int32_t deflate_device_impl(const u8 *d_in, size_t n, int level, u8 *d_ou
   P.lazy = level >= 4 ? 1u : 0u;
   P.store = level == 0 ? 1u : 0u;
   P.max_cmp = 258;
+  P.max_dist = (1u << window_bits) - 262;
   HIP_TRY(b_match.reserve(n * 4 + 64 + (size_t)P.chunks * 32 + 64));
   HIP_TRY(b_tok.reserve(n * 4 + 64));
   HIP_TRY(b_ntok.reserve((size_t)P.chunks * 4));
@@ -1244,12 +1270,12 @@ static int32_t deflate_device_impl(const u8 *d_in, size_t n, int level, u8 *d_ou
   return AHIP_OK;
 }
 
-int32_t ahip_deflate_raw_device(const void *d_in, size_t in_len, int32_t level, void *d_out, size_t out_cap,
+int32_t ahip_deflate_raw_device(const void *d_in, size_t in_len, int32_t level, int32_t window_bits, void *d_out, size_t out_cap,
                                 size_t *out_len, void *stream) {
   std::lock_guard<std::recursive_mutex> lk(g_mu);
   int32_t rc = ensure_init();
   if (rc != AHIP_OK) return rc;
-  return deflate_device_impl((const u8 *)d_in, in_len, level, (u8 *)d_out, out_cap, out_len, (hipStream_t)stream);
+  return deflate_device_impl((const u8 *)d_in, in_len, level, window_bits, (u8 *)d_out, out_cap, out_len, (hipStream_t)stream);
 }
 
 // host-pointer Deflate; the checksums of the input are taken from its device copy
@@ -1260,7 +1286,6 @@ static int32_t deflate_host_impl(const uint8_t *in, size_t in_len, int32_t level
   if (crc32) *crc32 = 0;
   if (adler32) *adler32 = 1;
   if (window_bits < 9 || window_bits > 15 || level < 0 || level > 9) return AHIP_OK;  // reference: silent no-op
-  if (window_bits != 15) return fail(AHIP_E_UNSUPPORTED, "only windowBits 15 is implemented");
   int32_t rc = ensure_init();
   if (rc != AHIP_OK) return rc;
   static DevBuf din, dout;
@@ -1269,7 +1294,7 @@ static int32_t deflate_host_impl(const uint8_t *in, size_t in_len, int32_t level
   HIP_TRY(dout.reserve(bound));
   if (in_len) HIP_TRY(hipMemcpy(din.p, in, in_len, hipMemcpyHostToDevice));
   size_t produced = 0;
-  rc = deflate_device_impl(din.as<u8>(), in_len, level, dout.as<u8>(), bound, &produced, nullptr);
+  rc = deflate_device_impl(din.as<u8>(), in_len, level, window_bits, dout.as<u8>(), bound, &produced, nullptr);
   if (rc != AHIP_OK) return rc;
   if (out_len) *out_len = produced;
   if (crc32) { rc = crc32_device_impl(din.as<u8>(), in_len, 0, crc32, nullptr); if (rc != AHIP_OK) return rc; }
@@ -1300,13 +1325,13 @@ int32_t ahip_adler32_device(const void *d_data, size_t len, uint32_t adler, uint
   return adler32_device_impl((const u8 *)d_data, len, adler, out, (hipStream_t)stream);
 }
 
-int32_t ahip_gzip_encode(const uint8_t *in, size_t in_len, int32_t level, uint32_t mtime, uint8_t *out, size_t out_cap,
-                         size_t *out_len) {
+int32_t ahip_gzip_encode(const uint8_t *in, size_t in_len, int32_t level, int32_t window_bits, uint32_t mtime, uint8_t *out,
+                         size_t out_cap, size_t *out_len) {
   if (out_len) *out_len = 0;
   if (out_cap < 18) { if (out_len) *out_len = ahip_deflate_bound(in_len) + 18; return fail(AHIP_E_CAP, "output buffer too small"); }
   size_t clen = 0;
   uint32_t crc = 0;
-  int32_t rc = deflate_host_impl(in, in_len, level, 15, out + 10, out_cap - 18, &clen, &crc, nullptr);
+  int32_t rc = deflate_host_impl(in, in_len, level, window_bits, out + 10, out_cap - 18, &clen, &crc, nullptr);
   if (out_len) *out_len = clen + 18;
   if (rc != AHIP_OK) return rc;
   const uint8_t h[10] = {0x1f, 0x8b, 8, 0, (uint8_t)mtime, (uint8_t)(mtime >> 8), (uint8_t)(mtime >> 16), (uint8_t)(mtime >> 24), 0, 0xff};
@@ -1316,15 +1341,22 @@ int32_t ahip_gzip_encode(const uint8_t *in, size_t in_len, int32_t level, uint32
   return AHIP_OK;
 }
 
-int32_t ahip_zlib_encode(const uint8_t *in, size_t in_len, int32_t level, uint8_t *out, size_t out_cap, size_t *out_len) {
+int32_t ahip_zlib_encode(const uint8_t *in, size_t in_len, int32_t level, int32_t window_bits, uint8_t *out, size_t out_cap,
+                         size_t *out_len) {
   if (out_len) *out_len = 0;
   if (out_cap < 6) { if (out_len) *out_len = ahip_deflate_bound(in_len) + 6; return fail(AHIP_E_CAP, "output buffer too small"); }
   size_t clen = 0;
   uint32_t a = 1;
-  int32_t rc = deflate_host_impl(in, in_len, level, 15, out + 2, out_cap - 6, &clen, nullptr, &a);
+  int32_t rc = deflate_host_impl(in, in_len, level, window_bits, out + 2, out_cap - 6, &clen, nullptr, &a);
   if (out_len) *out_len = clen + 6;
   if (rc != AHIP_OK) return rc;
-  out[0] = 0x78; out[1] = 0x01;
+  // CMF / FLG exactly as the reference builds them (_zlib_encoder_web.dart:42-63): CINFO = windowBits - 8,
+  // FLEVEL = FDICT = 0, FCHECK the smallest value that makes the pair a multiple of 31 (`78 01` for 15)
+  const int wb = window_bits < 0 ? 0 : (window_bits > 15 ? 15 : window_bits);
+  const uint32_t cmf = (uint32_t)(((wb - 8) << 4) | 8) & 0xff;
+  uint32_t flg = 0;
+  while ((cmf * 256 + flg) % 31 != 0) ++flg;
+  out[0] = (uint8_t)cmf; out[1] = (uint8_t)flg;
   uint8_t *t = out + 2 + clen;
   t[0] = (uint8_t)(a >> 24); t[1] = (uint8_t)(a >> 16); t[2] = (uint8_t)(a >> 8); t[3] = (uint8_t)a;
   return AHIP_OK;

@@ -53,6 +53,7 @@ struct DeflateParams {
   u32 lazy;     // 1 = one-step lazy evaluation (levels 4..9), 0 = greedy (levels 1..3)
   u32 store;    // 1 = level 0: stored blocks only
   u32 max_cmp;  // longest match searched (258)
+  u32 max_dist; // farthest match: 2^windowBits - 262 (deflate.dart:1120-1131, MAX_DIST)
 };
 
 template <u32 HB> AHIP_DEVINL u32 df_hash4(u32 w) { return (w * 2654435761u) >> (32 - HB); }
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256) void deflate_match_kernel(const u8 *__restrict
       for (u32 k = 0; k <= DF_WAYS; ++k) {
         const u32 c = cand[k];
         dist[k] = p - c;
-        alive[k] = k < DF_WAYS ? (c != DF_EMPTY && dist[k] <= 32768) : (c < p && c >= base);
+        alive[k] = k < DF_WAYS ? (c != DF_EMPTY && dist[k] <= P.max_dist) : (c < p && c >= base && dist[k] <= P.max_dist);
         rc[k] = alive[k] ? df_rc(c) : rp;
       }
       AHIP_TICK(t3);

@@ -1,8 +1,9 @@
-// dart/archive_hip_ffi.dart -- dart:ffi binding of libarchive_hip.so (include/archive_hip.h).
+// dart/archive_hip_ffi.dart -- dart:ffi binding of libarchive_hip.so (include/archive_hip.h, ABI 2.x).
 //
-// UNTESTED IN THIS REPOSITORY'S CI: the build image has no Dart SDK.  It is the binding a
-// maintainer of brendan-duncan/archive drops next to lib/src/codecs/zlib/ (see INTEGRATION.md);
-// the same entry points are exercised from Python (archive_amd/_native.py) by the test suite.
+// UNTESTED IN THIS REPOSITORY'S CI: the build image has no Dart SDK.  It is the binding a maintainer of
+// brendan-duncan/archive drops next to lib/src/codecs/zlib/ (see INTEGRATION.md); the same entry points are
+// exercised from Python (archive_amd/_native.py) by the test suite, and tests/test_abi.py checks that every symbol
+// looked up here exists in the header with the same number of arguments.
 import 'dart:ffi';
 import 'dart:typed_data';
 
@@ -16,6 +17,8 @@ typedef _InflateNative = Int32 Function(Pointer<Uint8> input, IntPtr inLen, Poin
     Pointer<IntPtr> outLen, Pointer<IntPtr> consumed);
 typedef _InflateDart = int Function(
     Pointer<Uint8> input, int inLen, Pointer<Uint8> out, int outCap, Pointer<IntPtr> outLen, Pointer<IntPtr> consumed);
+typedef _BoundNative = IntPtr Function(Pointer<Uint8> input, IntPtr inLen);
+typedef _BoundDart = int Function(Pointer<Uint8> input, int inLen);
 
 typedef _BatchNative = Int32 Function(
     Pointer<Uint8> input,
@@ -43,24 +46,50 @@ typedef _BatchDart = int Function(
     Pointer<Uint64> outLen,
     Pointer<Int32> status,
     Pointer<IntPtr> outTotal);
-typedef _EncodeNative = Int32 Function(
-    Pointer<Uint8> input, IntPtr inLen, Int32 level, Pointer<Uint8> out, IntPtr outCap, Pointer<IntPtr> outLen);
-typedef _EncodeDart = int Function(
-    Pointer<Uint8> input, int inLen, int level, Pointer<Uint8> out, int outCap, Pointer<IntPtr> outLen);
+typedef _DeflateNative = Int32 Function(Pointer<Uint8> input, IntPtr inLen, Int32 level, Int32 windowBits,
+    Pointer<Uint8> out, IntPtr outCap, Pointer<IntPtr> outLen, Pointer<Uint32> crc32);
+typedef _DeflateDart = int Function(Pointer<Uint8> input, int inLen, int level, int windowBits, Pointer<Uint8> out,
+    int outCap, Pointer<IntPtr> outLen, Pointer<Uint32> crc32);
+typedef _GzEncodeNative = Int32 Function(Pointer<Uint8> input, IntPtr inLen, Int32 level, Int32 windowBits,
+    Uint32 mtime, Pointer<Uint8> out, IntPtr outCap, Pointer<IntPtr> outLen);
+typedef _GzEncodeDart = int Function(Pointer<Uint8> input, int inLen, int level, int windowBits, int mtime,
+    Pointer<Uint8> out, int outCap, Pointer<IntPtr> outLen);
+typedef _ZlEncodeNative = Int32 Function(Pointer<Uint8> input, IntPtr inLen, Int32 level, Int32 windowBits,
+    Pointer<Uint8> out, IntPtr outCap, Pointer<IntPtr> outLen);
+typedef _ZlEncodeDart = int Function(
+    Pointer<Uint8> input, int inLen, int level, int windowBits, Pointer<Uint8> out, int outCap, Pointer<IntPtr> outLen);
+typedef _BoundSizeNative = IntPtr Function(IntPtr inLen);
+typedef _BoundSizeDart = int Function(int inLen);
 typedef _BzNative = Int32 Function(
     Pointer<Uint8> input, IntPtr inLen, Int32 verify, Pointer<Uint8> out, IntPtr outCap, Pointer<IntPtr> outLen);
 typedef _BzDart = int Function(
     Pointer<Uint8> input, int inLen, int verify, Pointer<Uint8> out, int outCap, Pointer<IntPtr> outLen);
 
+/// What `Deflate(bytes, ...)` produced: the stream, the CRC-32 of the input, the input length.
+class DeflateResult {
+  final Uint8List bytes;
+  final int crc32;
+  final int total;
+  DeflateResult(this.bytes, this.crc32, this.total);
+}
+
 class ArchiveHip {
   static const ok = 0, stoppedEarly = 1, rangeError = 2, wouldHang = 3, eCap = -1;
+
+  /// One library per isolate group; every class of the seam shares it.
+  static final ArchiveHip instance = ArchiveHip();
 
   final DynamicLibrary _lib;
   late final _DecodeDart _gzip = _lib.lookupFunction<_DecodeNative, _DecodeDart>('ahip_gzip_decode');
   late final _DecodeDart _zlib = _lib.lookupFunction<_DecodeNative, _DecodeDart>('ahip_zlib_decode');
   late final _InflateDart _inflate = _lib.lookupFunction<_InflateNative, _InflateDart>('ahip_inflate_raw');
+  late final _BoundDart _decodeBound = _lib.lookupFunction<_BoundNative, _BoundDart>('ahip_decode_bound');
   late final _BatchDart _batch = _lib.lookupFunction<_BatchNative, _BatchDart>('ahip_inflate_batch');
-  late final _EncodeDart _zlibEncode = _lib.lookupFunction<_EncodeNative, _EncodeDart>('ahip_zlib_encode');
+  late final _DeflateDart _deflate = _lib.lookupFunction<_DeflateNative, _DeflateDart>('ahip_deflate_raw');
+  late final _GzEncodeDart _gzipEncode = _lib.lookupFunction<_GzEncodeNative, _GzEncodeDart>('ahip_gzip_encode');
+  late final _ZlEncodeDart _zlibEncode = _lib.lookupFunction<_ZlEncodeNative, _ZlEncodeDart>('ahip_zlib_encode');
+  late final _BoundSizeDart _deflateBound =
+      _lib.lookupFunction<_BoundSizeNative, _BoundSizeDart>('ahip_deflate_bound');
   late final _BzDart _bzip2 = _lib.lookupFunction<_BzNative, _BzDart>('ahip_bzip2_decode');
   late final int Function(int) _init =
       _lib.lookupFunction<Int32 Function(Int32), int Function(int)>('ahip_init');
@@ -72,18 +101,22 @@ class ArchiveHip {
     if (rc != ok) throw StateError('ahip_init: ${_lastError().toDartString()}');
   }
 
-  /// Runs [call] with a growing output buffer; maps status codes to the reference's behaviour:
-  /// 0/1 -> bytes (the reference is silent about early stops), 2 -> RangeError.
+  /// Runs [call] on [data]; the output buffer is sized by [sizeHint], by `ahip_decode_bound` (the ISIZE trailers
+  /// of a gzip stream) or by a guess, and grown once if the library reports the real size (AHIP_E_CAP).  Status
+  /// codes are mapped to the reference's behaviour: 0/1 -> bytes (the reference is silent about early stops),
+  /// 2 -> RangeError.
   Uint8List _run(List<int> data, int Function(Pointer<Uint8>, int, Pointer<Uint8>, int, Pointer<IntPtr>) call,
-      {int? sizeHint}) {
+      {int? sizeHint, bool askBound = false}) {
     final n = data.length;
     final inp = malloc<Uint8>(n == 0 ? 1 : n);
     inp.asTypedList(n).setAll(0, data);
     final outLen = malloc<IntPtr>();
-    var cap = sizeHint ?? (4 * n + 64);
+    var cap = sizeHint ?? 0;
+    if (cap == 0 && askBound) cap = _decodeBound(inp, n);
+    if (cap == 0) cap = 4 * n + 64;
     try {
       for (var attempt = 0; attempt < 3; ++attempt) {
-        final out = malloc<Uint8>(cap);
+        final out = malloc<Uint8>(cap == 0 ? 1 : cap);
         try {
           final rc = call(inp, n, out, cap, outLen);
           if (rc == eCap) {
@@ -107,8 +140,11 @@ class ArchiveHip {
 
   int lastStatus = 0;
 
+  /// Bytes of the input the last [inflateRaw] consumed (the reference InputStream's position afterwards).
+  int lastConsumed = 0;
+
   Uint8List gzipDecode(List<int> data, {bool verify = false, bool raw = false}) =>
-      _run(data, (i, n, o, c, l) => _gzip(i, n, verify ? 1 : 0, raw ? 1 : 0, o, c, l));
+      _run(data, (i, n, o, c, l) => _gzip(i, n, verify ? 1 : 0, raw ? 1 : 0, o, c, l), askBound: true);
 
   Uint8List zlibDecode(List<int> data, {bool verify = false, bool raw = false}) =>
       _run(data, (i, n, o, c, l) => _zlib(i, n, verify ? 1 : 0, raw ? 1 : 0, o, c, l));
@@ -116,15 +152,40 @@ class ArchiveHip {
   Uint8List inflateRaw(List<int> data, {int? uncompressedSize}) {
     final consumed = malloc<IntPtr>();
     try {
-      return _run(data, (i, n, o, c, l) => _inflate(i, n, o, c, l, consumed), sizeHint: uncompressedSize);
+      final out =
+          _run(data, (i, n, o, c, l) => _inflate(i, n, o, c, l, consumed), sizeHint: uncompressedSize);
+      lastConsumed = consumed.value;
+      return out;
     } finally {
       malloc.free(consumed);
     }
   }
 
-  /// ZLibEncoder().encodeBytes(data, level: level)  (zlib/_zlib_encoder_web.dart:27-73)
-  Uint8List zlibEncode(List<int> data, {int level = 6}) =>
-      _run(data, (i, n, o, c, l) => _zlibEncode(i, n, level, o, c, l), sizeHint: data.length + data.length ~/ 512 + 128);
+  /// Deflate(bytes, level: level, windowBits: windowBits)  (zlib/deflate.dart:39-48): an invalid level or window
+  /// yields no output, like the reference's silent _init.
+  DeflateResult deflateRaw(List<int> data, {int level = 6, int windowBits = 15}) {
+    final crc = malloc<Uint32>();
+    try {
+      final out = _run(data, (i, n, o, c, l) => _deflate(i, n, level, windowBits, o, c, l, crc),
+          sizeHint: _deflateBound(data.length));
+      return DeflateResult(out, crc.value, data.length);
+    } finally {
+      malloc.free(crc);
+    }
+  }
+
+  /// ZLibEncoder().encodeBytes(data, level: level, windowBits: windowBits)  (zlib/_zlib_encoder_web.dart:27-73)
+  Uint8List zlibEncode(List<int> data, {int level = 6, int windowBits = 15}) =>
+      _run(data, (i, n, o, c, l) => _zlibEncode(i, n, level, windowBits, o, c, l),
+          sizeHint: _deflateBound(data.length) + 6);
+
+  /// GZipEncoder().encodeBytes(data, level: level)  (zlib/_gzip_encoder_web.dart:27-100); [mtime] defaults to now,
+  /// like the reference's DateTime.now().
+  Uint8List gzipEncode(List<int> data, {int level = 6, int windowBits = 15, int? mtime}) {
+    final t = mtime ?? DateTime.now().millisecondsSinceEpoch ~/ 1000;
+    return _run(data, (i, n, o, c, l) => _gzipEncode(i, n, level, windowBits, t, o, c, l),
+        sizeHint: _deflateBound(data.length) + 18);
+  }
 
   /// BZip2Decoder().decodeBytes(data, verify: verify)  (bzip2_decoder.dart:13-88)
   Uint8List bzip2Decode(List<int> data, {bool verify = false}) =>

@@ -16,8 +16,8 @@
  *    3  AHIP_HANG    the reference would not terminate (zero-length litlen table entry)
  *   -1  AHIP_E_CAP   `out` is too small; *out_len holds the required size
  *   -2  AHIP_E_DEVICE no usable GPU / HIP runtime error (ahip_last_error() has the text)
- *   -3  AHIP_E_UNSUPPORTED input uses a malformed construct this build does not reproduce
- *                    (over-subscribed Huffman code, cross-member back-reference)
+ *   -3  AHIP_E_UNSUPPORTED input uses a construct this build does not reproduce (only bzip2's obsolete
+ *                    randomised blocks)
  *   -4  AHIP_E_ARG   bad argument
  */
 #ifndef ARCHIVE_HIP_H
@@ -67,6 +67,13 @@ int32_t ahip_gzip_decode(const uint8_t *in, size_t in_len, int32_t verify, int32
 int32_t ahip_zlib_decode(const uint8_t *in, size_t in_len, int32_t verify, int32_t raw,
                          uint8_t *out, size_t out_cap, size_t *out_len);
 
+/* Size the decoded output is expected to have, so that a caller can allocate once: for a gzip stream whose members all
+ * carry a BGZF `BC` subfield (or that is one member) the sum of the ISIZE trailers; 0 = unknown (zlib / raw input, members
+ * without `BC`, ISIZE that cannot be trusted because the stream is > 4 GiB).  Host-only, reads a few bytes per member;
+ * the decode never relies on it (the reference ignores ISIZE, _gzip_decoder_web.dart:43-44): a too-small guess just
+ * comes back as AHIP_E_CAP with the real size. */
+size_t ahip_decode_bound(const uint8_t *in, size_t in_len);
+
 /* ---- Inflate: device-resident entry points (bench, multi-GPU sharding, zero-copy callers) ----
  * d_in / d_out are device pointers on the current HIP device; `stream` is a hipStream_t
  * (NULL = the default stream).  The call enqueues all work on `stream` and synchronises it
@@ -93,8 +100,9 @@ void ahip_gzip_plan_destroy(ahip_gzip_plan *plan);
 int32_t ahip_debug_plan_results(ahip_gzip_plan *plan, uint32_t *host_words, size_t max_members, size_t *n_members);
 
 /* ---- Deflate ----
- * ref: codecs/zlib/deflate.dart:39-48 `Deflate(bytes, level: L).getBytes()`; level 0..9 as in
- * DeflateLevel (deflate.dart:10-18), window_bits must be 15.  The stream is valid DEFLATE for any
+ * ref: codecs/zlib/deflate.dart:39-48 `Deflate(bytes, level: L, windowBits: W).getBytes()`; level 0..9 as in
+ * DeflateLevel (deflate.dart:10-18), window_bits 9..15 (matches reach at most 2^W - 262 bytes back, deflate.dart:105-124).
+ * The stream is valid DEFLATE for any
  * inflater (and round-trips through ahip_inflate_raw); its SIZE is within the tolerance DESIGN.md
  * states of the reference's, its bytes are not the reference's (no reference test pins them).
  * An invalid level or window writes nothing and returns AHIP_OK, like the reference's silent _init.
@@ -102,13 +110,13 @@ int32_t ahip_debug_plan_results(ahip_gzip_plan *plan, uint32_t *host_words, size
 int32_t ahip_deflate_raw(const uint8_t *in, size_t in_len, int32_t level, int32_t window_bits, uint8_t *out,
                          size_t out_cap, size_t *out_len, uint32_t *crc32);
 /* ref: codecs/zlib/_gzip_encoder_web.dart:27-100 (mtime supplied by the caller; the reference stamps "now") */
-int32_t ahip_gzip_encode(const uint8_t *in, size_t in_len, int32_t level, uint32_t mtime, uint8_t *out,
+int32_t ahip_gzip_encode(const uint8_t *in, size_t in_len, int32_t level, int32_t window_bits, uint32_t mtime, uint8_t *out,
                          size_t out_cap, size_t *out_len);
-/* ref: codecs/zlib/_zlib_encoder_web.dart:27-73 (`78 01`, Adler-32 big-endian) */
-int32_t ahip_zlib_encode(const uint8_t *in, size_t in_len, int32_t level, uint8_t *out, size_t out_cap,
+/* ref: codecs/zlib/_zlib_encoder_web.dart:27-73 (CMF from window_bits, FLEVEL 0: `78 01` for 15; Adler-32 big-endian) */
+int32_t ahip_zlib_encode(const uint8_t *in, size_t in_len, int32_t level, int32_t window_bits, uint8_t *out, size_t out_cap,
                          size_t *out_len);
 /* device-resident form: d_in/d_out on the current device; synchronises `stream` before returning */
-int32_t ahip_deflate_raw_device(const void *d_in, size_t in_len, int32_t level, void *d_out, size_t out_cap,
+int32_t ahip_deflate_raw_device(const void *d_in, size_t in_len, int32_t level, int32_t window_bits, void *d_out, size_t out_cap,
                                 size_t *out_len, void *stream);
 /* upper bound of the compressed size for in_len input bytes */
 size_t ahip_deflate_bound(size_t in_len);

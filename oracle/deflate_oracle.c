@@ -38,7 +38,7 @@
 uint32_t orc_crc32(const uint8_t *p, size_t n, uint32_t crc);
 uint32_t orc_adler32(const uint8_t *p, size_t n, uint32_t adler);
 
-enum { MIN_MATCH = 3, MAX_MATCH = 258, MIN_LOOKAHEAD = 262, W_SIZE = 32768, W_MASK = 32767, HASH_SIZE = 32768,
+enum { MIN_MATCH = 3, MAX_MATCH = 258, MIN_LOOKAHEAD = 262, W_SIZE_MAX = 32768, HASH_SIZE = 32768,
        HASH_MASK = 32767, HASH_SHIFT = 5, LIT_BUFSIZE = 16384, L_CODES = 286, D_CODES = 30, BL_CODES = 19,
        HEAP_SIZE = 573, MAX_BITS = 15, MAX_BL_BITS = 7, END_BLOCK = 256, LITERALS = 256, TOO_FAR = 4096 };
 enum { FN_STORED = 0, FN_FAST = 1, FN_SLOW = 2 };
@@ -114,8 +114,9 @@ typedef struct {
   const uint8_t *in; size_t in_len, in_pos;
   uint8_t *out; size_t out_len, out_cap; int overflow;
   int level, good_length, max_lazy, nice_length, max_chain, func, truncate;
-  uint8_t window[2 * W_SIZE];
-  uint16_t prev[W_SIZE], head[HASH_SIZE];
+  uint8_t window[2 * W_SIZE_MAX];
+  uint16_t prev[W_SIZE_MAX], head[HASH_SIZE];
+  int w_size, w_mask; /* 1 << windowBits (deflate.dart:110-124: windowBits 9..15) */
   int ins_h, strstart, block_start, lookahead, match_length, prev_length, match_available, match_start, prev_match;
   uint16_t dyn_ltree[HEAP_SIZE * 2], dyn_dtree[(2 * D_CODES + 1) * 2], bl_tree[(2 * BL_CODES + 1) * 2];
   tree_desc l_desc, d_desc, bl_desc;
@@ -408,16 +409,16 @@ static int read_buf(deflate_t *s, int start, int size) {
 }
 static void fill_window(deflate_t *s) {
   do {
-    int more = 2 * W_SIZE - s->lookahead - s->strstart;
-    if (more == 0 && s->strstart == 0 && s->lookahead == 0) more = W_SIZE;
-    else if (s->strstart >= W_SIZE + W_SIZE - MIN_LOOKAHEAD) {
-      memcpy(s->window, s->window + W_SIZE, W_SIZE);
-      s->match_start -= W_SIZE;
-      s->strstart -= W_SIZE;
-      s->block_start -= W_SIZE;
-      for (int p = 0; p < HASH_SIZE; p++) { unsigned m = s->head[p]; s->head[p] = (uint16_t)(m >= W_SIZE ? m - W_SIZE : 0); }
-      for (int p = 0; p < W_SIZE; p++) { unsigned m = s->prev[p]; s->prev[p] = (uint16_t)(m >= W_SIZE ? m - W_SIZE : 0); }
-      more += W_SIZE;
+    int more = 2 * s->w_size - s->lookahead - s->strstart;
+    if (more == 0 && s->strstart == 0 && s->lookahead == 0) more = s->w_size;
+    else if (s->strstart >= s->w_size + s->w_size - MIN_LOOKAHEAD) {
+      memcpy(s->window, s->window + s->w_size, s->w_size);
+      s->match_start -= s->w_size;
+      s->strstart -= s->w_size;
+      s->block_start -= s->w_size;
+      for (int p = 0; p < HASH_SIZE; p++) { unsigned m = s->head[p]; s->head[p] = (uint16_t)(m >= s->w_size ? m - s->w_size : 0); }
+      for (int p = 0; p < s->w_size; p++) { unsigned m = s->prev[p]; s->prev[p] = (uint16_t)(m >= s->w_size ? m - s->w_size : 0); }
+      more += s->w_size;
     }
     if (s->in_pos >= s->in_len) return;
     int n = read_buf(s, s->strstart + s->lookahead, more);
@@ -432,13 +433,13 @@ static void fill_window(deflate_t *s) {
   do {                                                                                           \
     (s)->ins_h = (((s)->ins_h << HASH_SHIFT) ^ (s)->window[(s)->strstart + (MIN_MATCH - 1)]) & HASH_MASK; \
     (hash_head) = (s)->head[(s)->ins_h];                                                         \
-    (s)->prev[(s)->strstart & W_MASK] = (s)->head[(s)->ins_h];                                   \
+    (s)->prev[(s)->strstart & s->w_mask] = (s)->head[(s)->ins_h];                                   \
     (s)->head[(s)->ins_h] = (uint16_t)(s)->strstart;                                             \
   } while (0)
 
 static int longest_match(deflate_t *s, int cur_match) {
   int chain_length = s->max_chain, scan = s->strstart, match, len, best_len = s->prev_length;
-  int limit = s->strstart > (W_SIZE - MIN_LOOKAHEAD) ? s->strstart - (W_SIZE - MIN_LOOKAHEAD) : 0;
+  int limit = s->strstart > (s->w_size - MIN_LOOKAHEAD) ? s->strstart - (s->w_size - MIN_LOOKAHEAD) : 0;
   int nice_match = s->nice_length;
   const uint8_t *w = s->window;
   int strend = s->strstart + MAX_MATCH;
@@ -465,7 +466,7 @@ static int longest_match(deflate_t *s, int cur_match) {
       scan_end1 = w[scan + best_len - 1];
       scan_end = w[scan + best_len];
     }
-  } while ((cur_match = s->prev[cur_match & W_MASK]) > limit && --chain_length != 0);
+  } while ((cur_match = s->prev[cur_match & s->w_mask]) > limit && --chain_length != 0);
   return best_len <= s->lookahead ? best_len : s->lookahead;
 }
 
@@ -485,7 +486,7 @@ static void deflate_stored(deflate_t *s) {
       s->strstart = max_start;
       flush_block_only(s, 0);
     }
-    if (s->strstart - s->block_start >= W_SIZE - MIN_LOOKAHEAD) flush_block_only(s, 0);
+    if (s->strstart - s->block_start >= s->w_size - MIN_LOOKAHEAD) flush_block_only(s, 0);
   }
   flush_block_only(s, 1);
 }
@@ -497,7 +498,7 @@ static void deflate_fast(deflate_t *s) {
       if (s->lookahead == 0) break;
     }
     if (s->lookahead >= MIN_MATCH) INSERT_STRING(s, hash_head);
-    if (hash_head != 0 && ((s->strstart - hash_head) & 0xffff) <= W_SIZE - MIN_LOOKAHEAD)
+    if (hash_head != 0 && ((s->strstart - hash_head) & 0xffff) <= s->w_size - MIN_LOOKAHEAD)
       s->match_length = longest_match(s, hash_head);
     if (s->match_length >= MIN_MATCH) {
       bflush = tr_tally(s, s->strstart - s->match_start, s->match_length - MIN_MATCH);
@@ -533,7 +534,7 @@ static void deflate_slow(deflate_t *s) {
     s->prev_match = s->match_start;
     s->match_length = MIN_MATCH - 1;
     if (hash_head != 0 && s->prev_length < s->max_lazy &&
-        ((s->strstart - hash_head) & 0xffff) <= W_SIZE - MIN_LOOKAHEAD) {
+        ((s->strstart - hash_head) & 0xffff) <= s->w_size - MIN_LOOKAHEAD) {
       s->match_length = longest_match(s, hash_head);
       if (s->match_length <= 5 && (s->match_length == MIN_MATCH && s->strstart - s->match_start > TOO_FAR))
         s->match_length = MIN_MATCH - 1;
@@ -573,7 +574,8 @@ static int df_init(deflate_t *s, int level, int window_bits) {
                                  {4, 6, 32, 32, FN_FAST},     {4, 4, 16, 16, FN_SLOW},      {8, 16, 32, 32, FN_SLOW},
                                  {8, 16, 128, 128, FN_SLOW},  {8, 32, 128, 256, FN_SLOW},   {32, 128, 258, 1024, FN_SLOW},
                                  {32, 258, 258, 4096, FN_SLOW}};
-  if (window_bits != 15) return 0; /* only the default window is restated (reference allows 9..15) */
+  if (window_bits < 9 || window_bits > 15) return 0; /* deflate.dart:110-111 */
+  s->w_size = 1 << window_bits; s->w_mask = s->w_size - 1;
   if (level < 0 || level > 9) return 0;
   static_init();
   s->level = level;
@@ -598,12 +600,19 @@ static int df_init(deflate_t *s, int level, int window_bits) {
 /* Deflate(bytes, level: L).getBytes().  truncate_heuristic: 1 = the reference's behaviour
  * (deflate.dart:549-562), 0 = stock zlib.  Returns 0, or -1 if `cap` is too small; with an
  * invalid level nothing is written (the reference's _init returns false, deflate.dart:108-121). */
+int orc_deflate_raw_wb(const uint8_t *in, size_t n, int level, int window_bits, int truncate_heuristic, uint8_t *out, size_t cap,
+                       size_t *out_len, uint32_t *crc_out);
 int orc_deflate_raw(const uint8_t *in, size_t n, int level, int truncate_heuristic, uint8_t *out, size_t cap,
                     size_t *out_len, uint32_t *crc_out) {
+  return orc_deflate_raw_wb(in, n, level, 15, truncate_heuristic, out, cap, out_len, crc_out);
+}
+/* Deflate(bytes, level: L, windowBits: W).getBytes()  (deflate.dart:39-48,102-124) */
+int orc_deflate_raw_wb(const uint8_t *in, size_t n, int level, int window_bits, int truncate_heuristic, uint8_t *out, size_t cap,
+                       size_t *out_len, uint32_t *crc_out) {
   deflate_t *s = (deflate_t *)calloc(1, sizeof(deflate_t));
   if (!s) return -1;
   s->in = in; s->in_len = n; s->out = out; s->out_cap = cap; s->truncate = truncate_heuristic;
-  if (df_init(s, level, 15)) {
+  if (df_init(s, level, window_bits)) {
     /* _deflate(finish): runs when there is input, lookahead, or a pending finish (always, on the first call) */
     switch (s->func) {
       case FN_STORED: deflate_stored(s); break;

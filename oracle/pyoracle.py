@@ -99,16 +99,20 @@ def adler32(data, adler=1):
     return lib().orc_adler32(ctypes.addressof(buf), n, adler)
 
 
-def deflate_raw(data, level=6, truncate_heuristic=True):
-    """Deflate(bytes, level: L).getBytes() -> (compressed bytes, crc32).  truncate_heuristic=False
+def deflate_raw(data, level=6, truncate_heuristic=True, window_bits=15):
+    """Deflate(bytes, level: L, windowBits: W).getBytes() -> (compressed bytes, crc32).  truncate_heuristic=False
     switches off the reference's block-truncation heuristic (= stock zlib behaviour)."""
     buf, n = _inbuf(data)
     cap = n + n // 8 + 1024
     out = ctypes.create_string_buffer(cap)
     olen = ctypes.c_size_t(0)
     crc = ctypes.c_uint32(0)
-    rc = lib().orc_deflate_raw(ctypes.addressof(buf), n, level, int(truncate_heuristic), ctypes.addressof(out), cap,
-                               ctypes.byref(olen), ctypes.byref(crc))
+    L = lib()
+    L.orc_deflate_raw_wb.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                     ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_uint32)]
+    L.orc_deflate_raw_wb.restype = ctypes.c_int
+    rc = L.orc_deflate_raw_wb(ctypes.addressof(buf), n, level, window_bits, int(truncate_heuristic), ctypes.addressof(out), cap,
+                              ctypes.byref(olen), ctypes.byref(crc))
     assert rc == 0
     return out.raw[:olen.value], crc.value
 

@@ -21,7 +21,7 @@ for c in range(n >> 20):
 d_in = torch.from_numpy(buf).cuda(); d_out = torch.empty(L.ahip_deflate_bound(n), dtype=torch.uint8, device="cuda"); olen = ctypes.c_size_t()
 for it in range(3):
     torch.cuda.synchronize(); t = time.perf_counter()
-    rc = L.ahip_deflate_raw_device(d_in.data_ptr(), n, 6, d_out.data_ptr(), d_out.numel(), ctypes.byref(olen), None)
+    rc = L.ahip_deflate_raw_device(d_in.data_ptr(), n, 6, 15, d_out.data_ptr(), d_out.numel(), ctypes.byref(olen), None)
     torch.cuda.synchronize(); dt = time.perf_counter() - t
     print("deflate L6 %d MiB: rc %d  %.1f ms  %.2f GB/s in  ratio %.3f" % (mb, rc, dt * 1e3, n / dt / 1e9, n / max(1, olen.value)))
 comp = d_out[:olen.value].cpu().numpy().tobytes()

@@ -10,12 +10,13 @@ pytestmark = pytest.mark.gpu
 
 from tests import streams  # noqa: E402
 
-# Stated size tolerance: at level 6 the HIP encoder's raw DEFLATE size may
-# exceed the reference's (oracle, same level) by at most 10 % on the benchmark corpora (config-3 log
-# text: measured +7.7 %, config-2 wiki-like text: +6.0 %), by at most 45 % on the degenerate
-# 12-word-vocabulary text (measured +38 %: zlib's 128-deep hash chains find much longer matches than
-# a 4-way bucket), and never exceeds stored size + 5 bytes per 32 KiB chunk.
-SIZE_TOLERANCE_L6 = {"log": 1.10, "wiki": 1.10, "text": 1.45}
+# Stated size tolerance, raw DEFLATE size against the reference's (oracle) at the same level:
+#   benchmark corpora (config-3 log text, config-2 wiki-like text): <= +8 % at levels 1, 6 and 9 (measured r01:
+#   +3.1 / +7.7 / +4.6 % on the log text, +6.0 % on the wiki text at level 6);
+#   degenerate 12-word-vocabulary text: <= +45 % at level 6, <= +55 % at level 9 (measured +38 / +48 %: zlib's
+#   128- / 4096-deep hash chains find much longer matches than a 4-way bucket; stated, not hidden);
+#   never more than stored size + 5 bytes per 32 KiB chunk.
+SIZE_TOLERANCE = {1: {"log": 1.08, "wiki": 1.08}, 6: {"log": 1.08, "wiki": 1.08, "text": 1.45}, 9: {"log": 1.08, "wiki": 1.08, "text": 1.55}}
 
 
 @pytest.fixture(scope="module")
@@ -59,20 +60,43 @@ def test_round_trip_through_reference_inflate(amd, orc, level):
         assert amd.Inflate(c + bytes(4)).get_bytes() == d  # and through the HIP inflate
 
 
-def test_size_within_tolerance_of_reference_level6(amd, orc):
+@pytest.mark.parametrize("level", [1, 6, 9])
+def test_size_within_tolerance_of_reference(amd, orc, level):
     for name in ("text", "log", "wiki", "zeros", "period3", "ramp", "random"):
         d = _corpora()[name]
-        ours = len(amd.Deflate(d, level=6).get_bytes())
-        ref = len(orc.deflate_raw(d, 6)[0])
+        ours = len(amd.Deflate(d, level=level).get_bytes())
+        ref = len(orc.deflate_raw(d, level)[0])
         chunks = (len(d) + 32767) // 32768
         assert ours <= len(d) + 5 * chunks + 16, name
-        if name in SIZE_TOLERANCE_L6:
-            assert ours <= ref * SIZE_TOLERANCE_L6[name], (name, ours, ref)
+        if name in SIZE_TOLERANCE[level]:
+            assert ours <= ref * SIZE_TOLERANCE[level][name], (name, level, ours, ref, ours / ref)
+
+
+@pytest.mark.parametrize("wbits", [9, 11, 14])
+def test_window_bits(amd, orc, wbits):
+    """Deflate(bytes, windowBits: 9..15) (deflate.dart:105-124): no match reaches further back than 2^W - 262, so the
+    stream inflates with a window of that size (zlib checks it); size within the same tolerance of the reference's at
+    the same window; the zlib header carries CINFO = W - 8 (_zlib_encoder_web.dart:42-63)."""
+    for name in ("log", "wiki", "text", "random", "period3", "chunk_plus1"):
+        d = _corpora()[name]
+        c = amd.Deflate(d, level=6, window_bits=wbits).get_bytes()
+        assert zlib.decompress(c, -wbits) == d, (name, wbits)          # zlib refuses distances beyond its window
+        assert orc.inflate_raw(c + bytes(4))[:2] == (0, d)
+        if name in ("log", "wiki"):
+            ref = len(orc.deflate_raw(d, 6, window_bits=wbits)[0])
+            assert len(c) <= ref * 1.08, (name, wbits, len(c), ref)
+    d = _corpora()["log"][:100000]
+    z = amd.ZLibEncoder().encode_bytes(d, window_bits=wbits)
+    cmf = ((wbits - 8) << 4) | 8
+    assert z[0] == cmf and (z[0] * 256 + z[1]) % 31 == 0 and z[1] < 31 and zlib.decompress(z) == d
+    g = amd.GZipEncoder().encode_bytes(d, window_bits=wbits, mtime=0)
+    assert orc.gzip_decode(g) == (0, d)
 
 
 def test_invalid_parameters_are_silent(amd):
     assert amd.Deflate(b"hello", level=12).get_bytes() == b""
     assert amd.Deflate(b"hello", level=6, window_bits=20).get_bytes() == b""
+    assert amd.Deflate(b"hello", level=6, window_bits=8).get_bytes() == b""
 
 
 def test_encoder_framing(amd, orc):

@@ -35,6 +35,20 @@ def test_byte_identical_to_zlib_without_the_truncation_heuristic(level):
         assert crc == zlib.crc32(d)
 
 
+@pytest.mark.parametrize("wbits", [9, 10, 12, 14])
+def test_window_bits_byte_identical_to_zlib(wbits):
+    """Deflate(bytes, windowBits: 9..14) (deflate.dart:105-124): the window shrinks, nothing else changes."""
+    for name, d in _corpora().items():
+        for level in (1, 6, 9):
+            z = zlib.compressobj(level, zlib.DEFLATED, -wbits, 8)
+            ref = z.compress(d) + z.flush()
+            got, _ = orc.deflate_raw(d, level, truncate_heuristic=False, window_bits=wbits)
+            assert got == ref, (name, level, wbits)
+            c, _ = orc.deflate_raw(d, level, window_bits=wbits)
+            assert zlib.decompress(c, -15) == d
+    assert orc.deflate_raw(b"hello", 6, window_bits=8)[0] == b"" and orc.deflate_raw(b"hello", 6, window_bits=16)[0] == b""
+
+
 @pytest.mark.parametrize("level", [0, 1, 6, 9])
 def test_reference_behaviour_round_trips(level):
     for name, d in _corpora().items():

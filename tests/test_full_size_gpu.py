@@ -55,7 +55,7 @@ def test_config3_1gib_deflate_roundtrip(native_built):
     d_in = torch.from_numpy(buf).cuda()
     d_out = torch.empty(L.ahip_deflate_bound(n), dtype=torch.uint8, device="cuda")
     olen = ctypes.c_size_t()
-    assert L.ahip_deflate_raw_device(d_in.data_ptr(), n, 6, d_out.data_ptr(), d_out.numel(), ctypes.byref(olen), None) == 0
+    assert L.ahip_deflate_raw_device(d_in.data_ptr(), n, 6, 15, d_out.data_ptr(), d_out.numel(), ctypes.byref(olen), None) == 0
     comp = d_out[:olen.value].cpu().numpy().tobytes()
     # inflates to the input (zlib on the host: streaming, CRC + length)
     z = zlib.decompressobj(-15)
@@ -77,12 +77,12 @@ def test_config3_1gib_deflate_roundtrip(native_built):
     sample = buf[:4 << 20].tobytes()
     ref = len(orc.deflate_raw(sample, 6)[0])
     so = ctypes.c_size_t()
-    assert L.ahip_deflate_raw_device(d_in.data_ptr(), len(sample), 6, d_out.data_ptr(), d_out.numel(), ctypes.byref(so), None) == 0
-    assert so.value <= ref * 1.10, (so.value, ref)  # <= +10 % at level 6 on the benchmark corpora
+    assert L.ahip_deflate_raw_device(d_in.data_ptr(), len(sample), 6, 15, d_out.data_ptr(), d_out.numel(), ctypes.byref(so), None) == 0
+    assert so.value <= ref * 1.08, (so.value, ref)  # <= +8 % at level 6 on the benchmark corpora
     # the first 64 MiB of the stream's source also survive the HIP inflate (one wave: a single member)
     piece = 64 << 20
     po = ctypes.c_size_t()
-    assert L.ahip_deflate_raw_device(d_in.data_ptr(), piece, 6, d_out.data_ptr(), d_out.numel(), ctypes.byref(po), None) == 0
+    assert L.ahip_deflate_raw_device(d_in.data_ptr(), piece, 6, 15, d_out.data_ptr(), d_out.numel(), ctypes.byref(po), None) == 0
     u64s = ctypes.c_uint64 * 1
     back = torch.empty(piece + 64, dtype=torch.uint8, device="cuda")
     out_off, out_len, status, tot = u64s(), u64s(), (ctypes.c_int32 * 1)(), ctypes.c_size_t()

@@ -12,6 +12,6 @@ d_in = torch.from_numpy(buf).cuda(); d_out = torch.empty(L.ahip_deflate_bound(n)
 for lvl in (1, 6, 9):
     for it in range(3):
         torch.cuda.synchronize(); t = time.perf_counter()
-        rc = L.ahip_deflate_raw_device(d_in.data_ptr(), n, lvl, d_out.data_ptr(), d_out.numel(), ctypes.byref(olen), None)
+        rc = L.ahip_deflate_raw_device(d_in.data_ptr(), n, lvl, 15, d_out.data_ptr(), d_out.numel(), ctypes.byref(olen), None)
         torch.cuda.synchronize(); dt = time.perf_counter() - t
     print(os.environ.get("AHIP_LIB"), "level %d, 256 MiB: %.2f ms  %.2f GB/s  ratio %.4f" % (lvl, dt * 1e3, n / dt / 1e9, n / olen.value))
