@@ -2,13 +2,22 @@
 """bench.py -- headline benchmark: Inflate GB/s (uncompressed out) on a multi-member gzip stream.
 
 One "step" = one complete decode of the rank's device-resident stream: member index build
-(candidate scan, header parse, chain), the inflate kernel, verification, and -- for N > 1 -- the
+(candidate scan, header parse, chain), the inflate kernels, verification, and -- for N > 1 -- the
 one collective the path has: an all-gather of per-rank output sizes (RCCL) whose exclusive scan
 is each shard's offset in the logical concatenated output.  Inputs and outputs stay in HBM.
 
 Workload (config.workload): BASELINE.json configs[3] -- 65 536 gzip members x 64 KiB of
 synthetic log text (4 GiB out, ~1.7 GiB in) PER GPU (weak scaling: rank r holds members
 [r*M, (r+1)*M) of a stream of N*M members).  --members shrinks it for quick runs.
+
+The JSON line also carries
+  check     CRC-32 of the decoded bytes taken on the device vs the CRC-32 the generator's gzip trailers imply
+            (per-member CRCs combined with the GF(2) shift x^(8 len)) -- the number carries its own proof;
+  strong    (N > 1) the same 4 GiB stream ONCE, partitioned over the ranks on compressed bytes; every rank indexes
+            and decodes only its slice, the shard CRCs combine to the whole stream's;
+  extras    (N = 1) the other BASELINE configs, device-resident unless said otherwise: 2a one 256 MiB member, 2b
+            4 096 members of wiki-like text, 3 Deflate level 6 on 1 GiB, 4 without the BGZF BC subfield, 5 bzip2,
+            and the host-pointer entry point end to end (PCIe included).
 """
 import argparse
 import ctypes
@@ -23,6 +32,78 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
+# ---- CRC-32 of a concatenation from the CRCs of its pieces (zlib's crc32_combine, vectorised over many pairs) ----
+def _gf2_times(mat, vec):
+    """mat: (32,) uint32 columns; vec: (k,) uint32 -> (k,) uint32"""
+    import numpy as np
+    out = np.zeros_like(vec)
+    for b in range(32):
+        out ^= np.where((vec >> np.uint32(b)) & np.uint32(1), mat[b], np.uint32(0)).astype(np.uint32)
+    return out
+
+
+def _gf2_square(mat):
+    return _gf2_times(mat, mat)
+
+
+def _shift_matrix(nbytes):
+    """operator that appends `nbytes` zero bytes to a CRC-32 register"""
+    import numpy as np
+    odd = np.zeros(32, dtype=np.uint32)
+    odd[0] = 0xEDB88320
+    for n in range(1, 32):
+        odd[n] = np.uint32(1) << np.uint32(n - 1)
+    even = _gf2_square(odd)  # two zero bits
+    odd = _gf2_square(even)  # four
+    ident = np.array([np.uint32(1) << np.uint32(b) for b in range(32)], dtype=np.uint32)
+    result, n, cur = ident, int(nbytes), None
+    # apply len2 zero BYTES: first squaring of `odd` is 8 bits = one byte
+    cur = _gf2_square(odd)
+    while n:
+        if n & 1:
+            result = _gf2_times(cur, result)
+        n >>= 1
+        if n:
+            cur = _gf2_square(cur)
+    return result
+
+
+def crc32_of_concat(crcs, lens):
+    """CRC-32 of piece_0 + piece_1 + ... from (crc_i, len_i); equal lengths are folded as a tree."""
+    import numpy as np
+    crcs = np.asarray(crcs, dtype=np.uint32)
+    lens = [int(v) for v in lens]
+    if len(set(lens)) == 1 and len(lens) & (len(lens) - 1) == 0 and len(lens) > 1:
+        step = lens[0]
+        while len(crcs) > 1:
+            m = _shift_matrix(step)
+            crcs = _gf2_times(m, crcs[0::2]) ^ crcs[1::2]
+            step *= 2
+        return int(crcs[0])
+    total = np.uint32(crcs[0])
+    for c, n in zip(crcs[1:], lens[1:]):
+        total = _gf2_times(_shift_matrix(n), np.array([total], dtype=np.uint32))[0] ^ np.uint32(c)
+    return int(total)
+
+
+def member_table(buf, count):
+    """(start offsets[count+1], crc32[count], isize[count]) of the first `count` members (BC subfields, else zlib)."""
+    import zlib
+    offs, crcs, sizes, p, n = [0], [], [], 0, len(buf)
+    while len(crcs) < count and p < n:
+        if buf[p + 3] & 4 and buf[p + 12] == 66 and buf[p + 13] == 67:
+            q = p + (int(buf[p + 16]) | (int(buf[p + 17]) << 8)) + 1
+        else:
+            d = zlib.decompressobj(31)
+            d.decompress(bytes(buf[p:p + 4 * 65536 + 4096]))
+            q = p + min(n - p, 4 * 65536 + 4096) - len(d.unused_data)
+        crcs.append(int.from_bytes(bytes(buf[q - 8:q - 4]), "little"))
+        sizes.append(int.from_bytes(bytes(buf[q - 4:q]), "little"))
+        offs.append(q)
+        p = q
+    return offs, crcs, sizes
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -33,7 +114,8 @@ def main():
     ap.add_argument("--kind", default="log", choices=["log", "wiki"])
     ap.add_argument("--no-bc", action="store_true", help="omit the BGZF BC subfield (forces sizing runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration (0 = skip)")
-    ap.add_argument("--check", action="store_true", help="verify the decoded bytes against the generator's plain text")
+    ap.add_argument("--check", action="store_true", help="also compare the decoded bytes with the generator's plain text")
+    ap.add_argument("--no-extras", action="store_true", help="skip the other configs (N = 1) / the strong-scaling leg (N > 1)")
     args = ap.parse_args()
 
     import numpy as np
@@ -75,58 +157,79 @@ def main():
     d_out = torch.empty(out_bytes + 64, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream()
     sh = ctypes.c_void_p(stream.cuda_stream)
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
-    def step(i=None):
-        plan = ctypes.c_void_p()
-        rc = L.ahip_gzip_plan_create(d_in.data_ptr(), d_in.numel(), sh, ctypes.byref(plan))
-        if rc != 0:
-            raise SystemExit("plan_create: %d %s" % (rc, N.last_error()))
-        if i is not None:
-            ev0[i].record(stream)
-        rc = L.ahip_gzip_plan_run(plan, d_out.data_ptr(), d_out.numel(), sh)
-        if i is not None:
-            ev1[i].record(stream)
-        if rc != 0:
-            raise SystemExit("plan_run: %d %s" % (rc, N.last_error()))
-        olen = ctypes.c_size_t()
-        rc = L.ahip_gzip_plan_status(plan, ctypes.byref(olen))
-        L.ahip_gzip_plan_destroy(plan)
-        if rc != 0 or olen.value != out_bytes:
-            raise SystemExit("decode verdict %d, %d bytes (expected %d): %s" % (rc, olen.value, out_bytes, N.last_error()))
-        if world > 1:  # the path's one exchange: output-size all-gather -> shard offsets (RCCL)
-            from archive_amd.sharding import exchange_output_offsets
-            exchange_output_offsets(olen.value, device=dev)
-        return olen.value
+    def decode_loop(d_src, d_dst, expect_bytes, steps, warmup, exchange):
+        """times `steps` whole decodes of d_src; returns (elapsed seconds, mean ms of the inflate stage)"""
+        ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
 
-    for _ in range(args.warmup):
-        step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        def step(i=None):
+            plan = ctypes.c_void_p()
+            rc = L.ahip_gzip_plan_create(d_src.data_ptr(), d_src.numel(), sh, ctypes.byref(plan))
+            if rc != 0:
+                raise SystemExit("plan_create: %d %s" % (rc, N.last_error()))
+            if i is not None:
+                ev0[i].record(stream)
+            rc = L.ahip_gzip_plan_run(plan, d_dst.data_ptr(), d_dst.numel(), sh)
+            if i is not None:
+                ev1[i].record(stream)
+            if rc != 0:
+                raise SystemExit("plan_run: %d %s" % (rc, N.last_error()))
+            olen = ctypes.c_size_t()
+            rc = L.ahip_gzip_plan_status(plan, ctypes.byref(olen))
+            L.ahip_gzip_plan_destroy(plan)
+            if rc != 0 or (expect_bytes is not None and olen.value != expect_bytes):
+                raise SystemExit("decode verdict %d, %d bytes (expected %s): %s" % (rc, olen.value, expect_bytes, N.last_error()))
+            if exchange and world > 1:  # the path's one exchange: output-size all-gather -> shard offsets (RCCL)
+                from archive_amd.sharding import exchange_output_offsets
+                exchange_output_offsets(olen.value, device=dev)
+            return olen.value
+
+        for _ in range(warmup):
+            step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            n_out = step(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        kern_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / steps
+        return float(el.item()), kern_ms, n_out
+
+    elapsed, kern_ms, _ = decode_loop(d_in, d_out, out_bytes, args.steps, args.warmup, True)
     tot = torch.tensor([float(out_bytes)], dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    elapsed = float(el.item())
     total_out = float(tot.item())
 
+    # ---- the proof: CRC-32 of what sits in d_out (device kernel) vs what the gzip trailers say it must be ----
+    offs, crcs, sizes = member_table(comp, args.members)
+    want_crc = crc32_of_concat(crcs, sizes)
+    got = ctypes.c_uint32()
+    if L.ahip_crc32_device(d_out.data_ptr(), out_bytes, 0, ctypes.byref(got), sh) != 0:
+        raise SystemExit("crc32_device: " + N.last_error())
+    crc_ok = got.value == want_crc and sum(sizes) == out_bytes
     if args.check:
-        got = d_out[:out_bytes].cpu().numpy()
-        if not np.array_equal(got, plain):
+        if not np.array_equal(d_out[:out_bytes].cpu().numpy(), plain):
             raise SystemExit("decoded bytes differ from the generator's plain text")
+    ok_all = torch.tensor([1.0 if crc_ok else 0.0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
+    if float(ok_all.item()) != 1.0:
+        raise SystemExit("rank %d: device CRC-32 %08x != %08x expected from the member trailers" % (rank, got.value, want_crc))
+
+    strong = None
+    if world > 1 and not args.no_extras:
+        strong = strong_scaling(args, L, N, corpus, dist, torch, np, dev, sh, rank, world, comp, offs, crcs, sizes, decode_loop)
 
     if rank == 0:
-        kern_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
         algo_bytes = float(d_in.numel() + out_bytes)  # C + U: compressed read once + output written once
         achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
         value = total_out * args.steps / elapsed / 1e9
@@ -141,6 +244,8 @@ def main():
                 "compressed_bytes_per_gpu": int(d_in.numel()), "ratio": round(out_bytes / d_in.numel(), 4),
                 "sharding": "members, one process per GPU" if world > 1 else "single GPU",
                 "gen_seconds": round(gen_s, 1)},
+            "check": {"crc32_device": "%08x" % got.value, "crc32_expected": "%08x" % want_crc, "ok": bool(crc_ok),
+                      "what": "CRC-32 of the decoded bytes (ahip_crc32_device) vs the member trailers' CRCs combined over GF(2); every rank"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
                          "kernel": "inflate_tokenize_kernel + inflate_resolve_kernel (one launch each per decode; "
@@ -161,12 +266,188 @@ def main():
                 line["roofline"]["traffic_unit"] = ("GB per decode (rocprofv3 FETCH_SIZE+WRITE_SIZE, calibrated, profiles/%s)" % os.path.basename(latest))
         except Exception:
             pass
+        if strong is not None:
+            line["strong"] = strong
+        if world == 1 and not args.no_extras:
+            del d_out
+            line["extras"] = extras(args, L, N, corpus, torch, np, dev, sh, comp, d_in, out_bytes, decode_loop)
         if args.cpu_seconds > 0 and world == 1:  # the CPU baseline is reported at N=1 only
             line["cpu_baseline"] = cpu_baseline(comp, args, out_bytes)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def strong_scaling(args, L, N, corpus, dist, torch, np, dev, sh, rank, world, comp0, offs0, crcs0, sizes0, decode_loop):
+    """BASELINE config 4 as written: ONE stream (rank 0's), partitioned over the ranks on compressed bytes
+    (archive_amd.sharding.partition_members); a rank indexes and decodes only its slice; the exchange is the size
+    all-gather; the shard CRCs (device kernel) must combine to the whole stream's."""
+    from archive_amd.sharding import exchange_output_offsets, partition_members
+    n_in = torch.tensor([len(comp0) if rank == 0 else 0], dtype=torch.int64, device=dev)
+    dist.broadcast(n_in, 0)
+    whole = torch.from_numpy(comp0).to(dev) if rank == 0 else torch.empty(int(n_in.item()), dtype=torch.uint8, device=dev)
+    dist.broadcast(whole, 0)  # setup, untimed: afterwards every rank only touches its own slice
+    meta = torch.tensor(offs0, dtype=torch.int64, device=dev) if rank == 0 else torch.empty(args.members + 1, dtype=torch.int64, device=dev)
+    dist.broadcast(meta, 0)
+    offs = [int(v) for v in meta.tolist()]
+    csize = [offs[i + 1] - offs[i] for i in range(args.members)]
+    lo, hi = partition_members(csize, world)[rank]
+    d_slice = whole[offs[lo]:offs[hi]]
+    expect = (hi - lo) * args.member_bytes
+    d_dst = torch.empty(expect + 64, dtype=torch.uint8, device=dev)
+    steps = max(3, args.steps // 2)
+    elapsed, kern_ms, n_out = decode_loop(d_slice, d_dst, expect, steps, 1, True)
+    offset, total, all_sizes = exchange_output_offsets(n_out, device=dev)
+    got = ctypes.c_uint32()
+    if L.ahip_crc32_device(d_dst.data_ptr(), n_out, 0, ctypes.byref(got), sh) != 0:
+        raise SystemExit("crc32_device: " + N.last_error())
+    shard = torch.tensor([got.value], dtype=torch.int64, device=dev)
+    allc = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(allc, shard)
+    if rank != 0:
+        return None
+    combined = crc32_of_concat([int(v) for v in allc.tolist()], all_sizes)
+    want = crc32_of_concat(crcs0, sizes0)
+    if combined != want or total != args.members * args.member_bytes:
+        raise SystemExit("strong scaling: shard CRCs combine to %08x, expected %08x (total %d bytes)" % (combined, want, total))
+    return {"scaling": "strong", "value": round(total * steps / elapsed / 1e9, 3), "unit": "GB/s", "steps": steps,
+            "ms_per_step": round(elapsed / steps * 1e3, 4), "n_gpus": world,
+            "workload": "ONE stream of %d members (%d B out), partitioned on compressed bytes; every rank indexes + decodes its slice" % (args.members, total),
+            "members_per_rank": [b - a for a, b in partition_members(csize, world)],
+            "check": {"crc32_combined": "%08x" % combined, "crc32_expected": "%08x" % want, "ok": True}}
+
+
+def extras(args, L, N, corpus, torch, np, dev, sh, comp, d_in, out_bytes, decode_loop):
+    """The other BASELINE configs on this GPU (short runs; every figure with its own (C+U)/t fraction of HBM peak)."""
+    import bz2
+    import zlib
+    res = {}
+
+    def timed(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts)[len(ts) // 2]
+
+    def frac(c_bytes, u_bytes, sec):
+        return round((c_bytes + u_bytes) / sec / 1e9 / HBM_PEAK_GBPS, 5)
+
+    try:  # config 4 without the BC subfield: the index has to measure every member first
+        c2, _ = corpus.make_gzip(kind=corpus.LOG, seed=1234, n_members=args.members, member_bytes=args.member_bytes, level=6, bc=False,
+                                 threads=os.cpu_count() or 1)
+        d2 = torch.from_numpy(c2).to(dev)
+        o2 = torch.empty(out_bytes + 64, dtype=torch.uint8, device=dev)
+        el, _, _ = decode_loop(d2, o2, out_bytes, 3, 1, False)
+        res["config4_no_bc"] = {"value": round(out_bytes * 3 / el / 1e9, 2), "unit": "GB/s out", "ms": round(el / 3 * 1e3, 2),
+                                "hbm_frac": frac(len(c2), out_bytes, el / 3), "what": "same members without BGZF BC: sizing run + decode"}
+        del d2, o2
+    except SystemExit as e:
+        res["config4_no_bc"] = {"error": str(e)}
+
+    try:  # host-pointer entry point, end to end (what a dart:ffi caller gets): H2D + decode + D2H
+        host_out = np.empty(out_bytes + 64, dtype=np.uint8)
+        olen = ctypes.c_size_t()
+
+        def call():
+            rc = L.ahip_gzip_decode(comp.ctypes.data, len(comp), 0, 0, host_out.ctypes.data, len(host_out), ctypes.byref(olen))
+            assert rc == 0 and olen.value == out_bytes, (rc, olen.value, N.last_error())
+        sec = timed(call, reps=2)
+        res["config4_host_pointers"] = {"value": round(out_bytes / sec / 1e9, 2), "unit": "GB/s out", "ms": round(sec * 1e3, 1),
+                                        "what": "ahip_gzip_decode(host in, host out): PCIe both ways included; bound ~ 63 GB/s x (C+U)/U",
+                                        "crc_ok": bool(zlib.crc32(host_out[:1 << 24].tobytes()) == zlib.crc32(corpus_plain_head(corpus, args, 1 << 24)))}
+        del host_out
+    except AssertionError as e:
+        res["config4_host_pointers"] = {"error": str(e)}
+
+    try:  # config 2b: 4 096 members of wiki-like text
+        c3, _ = corpus.make_gzip(kind=corpus.WIKI, seed=8, n_members=4096, member_bytes=65536, level=6, bc=True, threads=os.cpu_count() or 1)
+        d3 = torch.from_numpy(c3).to(dev)
+        o3 = torch.empty(4096 * 65536 + 64, dtype=torch.uint8, device=dev)
+        el, km, _ = decode_loop(d3, o3, 4096 * 65536, 5, 2, False)
+        res["config2b_wiki_4096_members"] = {"value": round(4096 * 65536 * 5 / el / 1e9, 2), "unit": "GB/s out", "ms": round(el / 5 * 1e3, 3),
+                                             "kernel_ms": round(km, 3), "hbm_frac": frac(len(c3), 4096 * 65536, km * 1e-3)}
+        del d3, o3
+    except SystemExit as e:
+        res["config2b_wiki_4096_members"] = {"error": str(e)}
+
+    try:  # config 2a: ONE 256 MiB member (chunked single-stream path)
+        data = bytes(corpus.text(corpus.WIKI, 8, 0, 256 << 20))
+        gz = bytes([0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 255])
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        gz += co.compress(data) + co.flush() + zlib.crc32(data).to_bytes(4, "little") + (len(data) & 0xffffffff).to_bytes(4, "little")
+        d4 = torch.frombuffer(bytearray(gz), dtype=torch.uint8).to(dev)
+        o4 = torch.empty(len(data) + 64, dtype=torch.uint8, device=dev)
+        olen = ctypes.c_size_t()
+
+        def call():
+            rc = L.ahip_gzip_decode_device(d4.data_ptr(), d4.numel(), o4.data_ptr(), o4.numel(), ctypes.byref(olen), None)
+            assert rc == 0 and olen.value == len(data), (rc, olen.value, N.last_error())
+        sec = timed(call)
+        got = ctypes.c_uint32()
+        L.ahip_crc32_device(o4.data_ptr(), len(data), 0, ctypes.byref(got), None)
+        res["config2a_one_256MiB_member"] = {"value": round(len(data) / sec / 1e9, 2), "unit": "GB/s out", "ms": round(sec * 1e3, 2),
+                                             "hbm_frac": frac(len(gz), len(data), sec), "crc_ok": bool(got.value == zlib.crc32(data))}
+        del d4, o4, data, gz
+    except AssertionError as e:
+        res["config2a_one_256MiB_member"] = {"error": str(e)}
+
+    try:  # config 3: Deflate level 6 on 1 GiB of log text
+        n = 1 << 30
+        buf = np.empty(n, dtype=np.uint8)
+        for c in range(n >> 20):
+            corpus.lib().corpus_log_text(1234, c * 16, buf[c << 20:].ctypes.data, 1 << 20)
+        d5 = torch.from_numpy(buf).to(dev)
+        o5 = torch.empty(L.ahip_deflate_bound(n), dtype=torch.uint8, device=dev)
+        olen = ctypes.c_size_t()
+
+        def call():
+            rc = L.ahip_deflate_raw_device(d5.data_ptr(), n, 6, 15, o5.data_ptr(), o5.numel(), ctypes.byref(olen), None)
+            assert rc == 0, (rc, N.last_error())
+        sec = timed(call)
+        from oracle import pyoracle  # the checker: reference size on a 4 MiB sample
+        sample = buf[:4 << 20].tobytes()
+        ref = len(pyoracle.deflate_raw(sample, 6)[0])
+        so = ctypes.c_size_t()
+        L.ahip_deflate_raw_device(d5.data_ptr(), len(sample), 6, 15, o5.data_ptr(), o5.numel(), ctypes.byref(so), None)
+        res["config3_deflate_L6_1GiB"] = {"value": round(n / sec / 1e9, 2), "unit": "GB/s in", "ms": round(sec * 1e3, 2), "ratio": round(n / olen.value, 4),
+                                          "size_vs_reference": round(so.value / ref, 4), "hbm_frac": frac(olen.value, n, sec),
+                                          "what": "ahip_deflate_raw_device; size / oracle size on the first 4 MiB"}
+        del d5, o5, buf
+    except AssertionError as e:
+        res["config3_deflate_L6_1GiB"] = {"error": str(e)}
+
+    try:  # config 5: bzip2 -9, 64 blocks of 900 k
+        data = bytes(corpus.text(corpus.WIKI, 8, 0, 64 * 900000))
+        cz = bz2.compress(data, 9)
+        d6 = torch.frombuffer(bytearray(cz), dtype=torch.uint8).to(dev)
+        o6 = torch.empty(len(data) + 64, dtype=torch.uint8, device=dev)
+        olen = ctypes.c_size_t()
+
+        def call():
+            rc = L.ahip_bzip2_decode_device(d6.data_ptr(), d6.numel(), 1, o6.data_ptr(), o6.numel(), ctypes.byref(olen), None)
+            assert rc == 0 and olen.value == len(data), (rc, olen.value, N.last_error())
+        sec = timed(call)
+        got = ctypes.c_uint32()
+        L.ahip_crc32_device(o6.data_ptr(), len(data), 0, ctypes.byref(got), None)
+        res["config5_bzip2_64x900k"] = {"value": round(len(data) / sec / 1e9, 3), "unit": "GB/s out", "ms": round(sec * 1e3, 1),
+                                        "hbm_frac": frac(len(cz), len(data), sec), "crc_ok": bool(got.value == zlib.crc32(data))}
+    except AssertionError as e:
+        res["config5_bzip2_64x900k"] = {"error": str(e)}
+    return res
+
+
+def corpus_plain_head(corpus, args, n):
+    """first n bytes of the headline workload's plain text (member 0.. of the log corpus)"""
+    import zlib
+    comp, plain = corpus.make_gzip(kind=corpus.LOG if args.kind == "log" else corpus.WIKI, seed=1234 if args.kind == "log" else 8,
+                                   n_members=(n + args.member_bytes - 1) // args.member_bytes, member_bytes=args.member_bytes, level=6, want_plain=True)
+    return plain[:n].tobytes()
 
 
 def cpu_baseline(comp, args, out_bytes):
@@ -177,55 +458,48 @@ def cpu_baseline(comp, args, out_bytes):
     from oracle import pyoracle
     lib = pyoracle.lib()
     ncores = os.cpu_count() or 1
-    # member boundaries of the sample via the BC subfield / a quick serial probe of the oracle itself
     buf = comp
     base = buf.ctypes.data
     # calibrate: one member on one thread
     probe_members = min(args.members, 16)
-    offs = member_offsets(buf, probe_members + 1)
+    offs, _, _ = member_table(buf, probe_members)
     out = ctypes.create_string_buffer(args.member_bytes + 64)
     olen = ctypes.c_size_t()
     t0 = time.perf_counter()
     for i in range(probe_members):
         lib.orc_gzip_decode(base + offs[i], offs[i + 1] - offs[i], 0, 0, out, len(out), ctypes.byref(olen))
     per_member = (time.perf_counter() - t0) / probe_members
-    n = int(min(args.members, max(ncores, args.cpu_seconds * ncores / max(per_member, 1e-9))))
-    offs = member_offsets(buf, n + 1)
-    chunks = [list(range(k, n, ncores)) for k in range(ncores)]
 
-    def work(idx):
-        o = ctypes.create_string_buffer(args.member_bytes + 64)
-        ol = ctypes.c_size_t()
-        tot = 0
-        for i in idx:
-            st = lib.orc_gzip_decode(base + offs[i], offs[i + 1] - offs[i], 0, 0, o, len(o), ctypes.byref(ol))
-            assert st == 0
-            tot += ol.value
-        return tot
-    t0 = time.perf_counter()
-    with cf.ThreadPoolExecutor(ncores) as ex:
-        total = sum(ex.map(work, chunks))
-    dt = time.perf_counter() - t0
-    return {"value": round(total / dt / 1e9, 4), "unit": "GB/s", "cores": ncores, "kind": "port",
+    def run(nthreads, seconds):
+        n = int(min(args.members, max(nthreads, seconds * nthreads / max(per_member, 1e-9))))
+        offs, _, _ = member_table(buf, n)
+        chunks = [list(range(k, n, nthreads)) for k in range(nthreads)]
+
+        def work(idx):
+            o = ctypes.create_string_buffer(args.member_bytes + 64)
+            ol = ctypes.c_size_t()
+            tot = 0
+            for i in idx:
+                st = lib.orc_gzip_decode(base + offs[i], offs[i + 1] - offs[i], 0, 0, o, len(o), ctypes.byref(ol))
+                assert st == 0
+                tot += ol.value
+            return tot
+        t0 = time.perf_counter()
+        with cf.ThreadPoolExecutor(nthreads) as ex:
+            total = sum(ex.map(work, chunks))
+        dt = time.perf_counter() - t0
+        return total / dt / 1e9, n, total, dt
+
+    v, n, total, dt = run(ncores, args.cpu_seconds)
+    line = {"value": round(v, 4), "unit": "GB/s", "cores": ncores, "kind": "port",
             "sample": "%d of %d members (%.0f MiB out), oracle/inflate_oracle.c, %d threads, %.1f s" % (
                 n, args.members, total / 2**20, ncores, dt)}
-
-
-def member_offsets(buf, count):
-    """Start offsets of the first `count` members (walks BC subfields; falls back to zlib for no-BC)."""
-    import zlib
-    offs, p, n = [0], 0, len(buf)
-    while len(offs) < count and p < n:
-        if buf[p + 3] & 4 and buf[p + 12] == 66 and buf[p + 13] == 67:
-            p += (int(buf[p + 16]) | (int(buf[p + 17]) << 8)) + 1
-        else:
-            d = zlib.decompressobj(31)
-            d.decompress(bytes(buf[p:p + 4 * 65536 + 4096]))
-            p += min(n - p, 4 * 65536 + 4096) - len(d.unused_data)
-        offs.append(p)
-    while len(offs) < count:
-        offs.append(n)
-    return offs
+    # the same restatement on 1 and on 8 threads (the reference itself is single-threaded)
+    v1, n1, _, d1 = run(1, min(3.0, args.cpu_seconds / 3))
+    v8, n8, _, d8 = run(min(8, ncores), min(3.0, args.cpu_seconds / 3))
+    line["one_thread"] = {"value": round(v1, 4), "unit": "GB/s", "cores": 1, "sample": "%d members, %.1f s" % (n1, d1)}
+    line["eight_threads"] = {"value": round(v8, 4), "unit": "GB/s", "cores": min(8, ncores), "sample": "%d members, %.1f s" % (n8, d8)}
+    return line
 
 
 if __name__ == "__main__":
