@@ -14,7 +14,7 @@ AHIP_E_CAP, AHIP_E_DEVICE, AHIP_E_UNSUPPORTED, AHIP_E_ARG = -1, -2, -3, -4
 
 # every symbol include/archive_hip.h declares
 EXPORTS = [
-    "ahip_init", "ahip_shutdown", "ahip_last_error", "ahip_abi_version",
+    "ahip_init", "ahip_init_devices", "ahip_device_count", "ahip_debug_last_shards", "ahip_shutdown", "ahip_last_error", "ahip_abi_version",
     "ahip_inflate_raw", "ahip_gzip_decode", "ahip_zlib_decode",
     "ahip_gzip_decode_device", "ahip_gzip_plan_create", "ahip_gzip_plan_info", "ahip_gzip_plan_run",
     "ahip_gzip_plan_status", "ahip_gzip_plan_destroy", "ahip_debug_plan_results",
@@ -48,6 +48,9 @@ def lib():
     vp, sz, i32, u32, u64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int32, ctypes.c_uint32, ctypes.c_uint64
     szp = ctypes.POINTER(sz)
     L.ahip_init.argtypes = [i32]; L.ahip_init.restype = i32
+    L.ahip_init_devices.argtypes = [u64]; L.ahip_init_devices.restype = i32
+    L.ahip_device_count.argtypes = []; L.ahip_device_count.restype = i32
+    L.ahip_debug_last_shards.argtypes = []; L.ahip_debug_last_shards.restype = i32
     L.ahip_shutdown.argtypes = []; L.ahip_shutdown.restype = None
     L.ahip_last_error.argtypes = []; L.ahip_last_error.restype = ctypes.c_char_p
     L.ahip_abi_version.argtypes = []; L.ahip_abi_version.restype = u32

@@ -9,7 +9,11 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <memory>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -196,7 +200,7 @@ int32_t fail(int32_t code, const std::string &msg) {
 // Device scratch with a process-wide free list: hipMalloc/hipFree cost far more than the index
 // kernels they would serve, so released blocks are kept and handed to the next plan.
 struct DevBlock { void *p; size_t cap; };
-std::vector<DevBlock> g_pool;  // guarded by g_mu (every entry point holds it)
+thread_local std::vector<DevBlock> g_pool;  // one per host thread: a thread works on ONE device (see Worker below)
 
 struct DevBuf {
   void *p = nullptr;
@@ -225,7 +229,7 @@ struct DevBuf {
   template <class T> T *as() const { return (T *)p; }
 };
 
-DevBuf g_scratch, g_tokens;
+thread_local DevBuf g_scratch, g_tokens;
 hipError_t scratch_reserve(size_t bytes, void **p) {
   hipError_t e = g_scratch.reserve(bytes);
   *p = g_scratch.p;
@@ -293,8 +297,8 @@ hipError_t launch_inflate_group(const u8 *in, u64 n, const MemberDesc *members, 
   hipError_t e = hipSuccess;
   // The token / directory scratch is shared by every launch of the process: a launch on another stream than the
   // previous one first waits for that one to be done with it.
-  static hipEvent_t scratch_free = nullptr;
-  static hipStream_t scratch_user = nullptr;
+  static thread_local hipEvent_t scratch_free = nullptr;
+  static thread_local hipStream_t scratch_user = nullptr;
   if (!scratch_free) { e = hipEventCreateWithFlags(&scratch_free, hipEventDisableTiming); if (e != hipSuccess) return e; scratch_user = st; }
   if (scratch_user != st) { e = hipStreamWaitEvent(st, scratch_free, 0); if (e != hipSuccess) return e; scratch_user = st; }
   if (WRITE) {
@@ -308,7 +312,7 @@ hipError_t launch_inflate_group(const u8 *in, u64 n, const MemberDesc *members, 
   }
   if (getenv("AHIP_DEBUG")) fprintf(stderr, "[ahip] inflate group first=%u count=%u grid=%u/%d out=%llu write=%d\n", first, count, grid1, res_resident, (unsigned long long)(out1 - out0), (int)WRITE);
   // the late list: a counter + the scratch of the exact (over-subscribed) tables
-  static DevBuf dlate, dexact;
+  static thread_local DevBuf dlate, dexact;
   e = dlate.reserve(64);
   if (e != hipSuccess) return e;
   e = dexact.reserve(2 * 32768 * 4);
@@ -355,6 +359,7 @@ hipError_t launch_inflate(const u8 *in, u64 n, const MemberDesc *members, u32 M,
   return hipSuccess;
 }
 
+void stop_workers();  // defined with the worker threads (multi-device section)
 int32_t ensure_init() {
   if (g_inited) return AHIP_OK;
   int n = 0;
@@ -587,9 +592,9 @@ int32_t plan_verdict(ahip_gzip_plan *pl, hipStream_t st, bool *needs_sizing) {
 struct OneResult { MemberResult r; };
 // ---- checksums of device-resident data (checksum_kernels.hpp) ----
 static u32 g_ck_tables[CK_TAB_WORDS];
-static bool g_ck_ready = false;
+static std::once_flag g_ck_once;
 static hipError_t ck_prepare(DevBuf &dtab, DevBuf &dacc) {
-  if (!g_ck_ready) { ck_build_tables(g_ck_tables); g_ck_ready = true; }
+  std::call_once(g_ck_once, [] { ck_build_tables(g_ck_tables); });
   hipError_t e = dacc.reserve(64);
   if (e != hipSuccess) return e;
   if (!dtab.p) {
@@ -606,7 +611,7 @@ static u32 ck_grid(size_t n) {
 }
 // getCrc32(d[0, n), crc0)  (util/crc32.dart:6-27)
 static int32_t crc32_device_impl(const u8 *d, size_t n, u32 crc0, u32 *out, hipStream_t st) {
-  static DevBuf dtab, dacc;
+  static thread_local DevBuf dtab, dacc;
   HIP_TRY(ck_prepare(dtab, dacc));
   u32 raw = 0;
   if (n) {
@@ -623,7 +628,7 @@ static int32_t crc32_device_impl(const u8 *d, size_t n, u32 crc0, u32 *out, hipS
 }
 // getAdler32(d[0, n), adler0)  (util/adler32.dart:29-52)
 static int32_t adler32_device_impl(const u8 *d, size_t n, u32 adler0, u32 *out, hipStream_t st) {
-  static DevBuf dtab, dacc;
+  static thread_local DevBuf dtab, dacc;
   HIP_TRY(ck_prepare(dtab, dacc));
   unsigned long long acc[2] = {0, 0};
   if (n) {
@@ -662,7 +667,7 @@ struct SmPlan {  // what the sizing pass learned, kept for the write pass of the
   u32 blocks = 0;
   bool valid = false;
 };
-static SmPlan g_sm;
+static thread_local SmPlan g_sm;
 
 static int sm_resident_waves() {
   static int v = 0;
@@ -682,7 +687,7 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
   *handled = false;
   if (getenv("AHIP_NO_SM") || n <= off || n - off < sm_min_bytes()) return AHIP_OK;
   const auto t_start = std::chrono::steady_clock::now();
-  static DevBuf dcand, dchunks, dres, dsym, dwin;
+  static thread_local DevBuf dcand, dchunks, dres, dsym, dwin;
   const bool dbg = getenv("AHIP_DEBUG") != nullptr;
   // the plan of a sizing call serves exactly one following write call on the same stream (device buffers are reused
   // between API calls, so a pointer match alone proves nothing)
@@ -783,7 +788,7 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
   hipLaunchKernelGGL(sm_resolve_kernel, dim3(grid), dim3(64), 0, st, d_in, dchunks.as<ChunkDesc>(), nch, dsym.as<u16>(), (const u32 *)tp,
                      (const uint2 *)sp, dres.as<MemberResult>());
   {
-    static DevBuf dwsym, dgwin;
+    static thread_local DevBuf dwsym, dgwin;
     u32 gs = 1;
     while ((u64)gs * gs < nch) ++gs;  // about sqrt(chunks) groups of sqrt(chunks) chunks: both serial parts equally short
     const u32 ng = (nch + gs - 1) / gs;
@@ -814,7 +819,7 @@ int32_t inflate_one(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool
   return inflate_one_wave(d_in, n, off, d_out, out_cap, write, res, st);
 }
 int32_t inflate_one_wave(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool write, MemberResult *res, hipStream_t st) {
-  static DevBuf dd, dr;
+  static thread_local DevBuf dd, dr;
   HIP_TRY(dd.reserve(sizeof(MemberDesc)));
   HIP_TRY(dr.reserve(sizeof(MemberResult)));
   MemberDesc d{off, 0, out_cap, POS_UNKNOWN, 0};
@@ -926,6 +931,7 @@ int32_t ahip_init(int32_t device) {
 
 void ahip_shutdown(void) {
   std::lock_guard<std::recursive_mutex> lk(g_mu);
+  stop_workers();
   for (auto &b : g_pool) (void)hipFree(b.p);
   g_pool.clear();
   g_inited = false;
@@ -974,7 +980,7 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
   if (level < 0 || level > 9) return AHIP_FALSE;
   if (in_len == 4) return AHIP_OK;  // while (!input.isEOS) never runs
   if (level == 0) return AHIP_FALSE;  // zero-sized tt: the first symbol already fails nblock >= nblockMAX
-  static DevBuf dcand, dcount, dtt, dsel, dres, dcrc, doff;
+  static thread_local DevBuf dcand, dcount, dtt, dsel, dres, dcrc, doff;
   hipStream_t st = nullptr;
   // B0: block / end-of-stream magics at any bit offset
   const u32 cap_c = (u32)(in_len / 32 + 64);
@@ -996,7 +1002,7 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
   HIP_TRY(hipMemcpy(dcand.p, cands.data(), (size_t)ncand * sizeof(BzCand), hipMemcpyHostToDevice));
   const u64 nblock_max = 100000ull * (u64)level;
   const u64 wstride = nblock_max / BZ_G + 2;
-  static DevBuf dpre, dwalk, drank, dspans;
+  static thread_local DevBuf dpre, dwalk, drank, dspans;
   // Candidates are taken in bounded batches in stream order (work memory O(batch x block size), about 5.4 MB per
   // block at level 9), following the chain of blocks exactly like decodeStream between them: a block ends where
   // the next magic starts.  A batch's blocks are placed and expanded before the next batch is decoded; nothing
@@ -1031,7 +1037,7 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
     HIP_TRY(hipMemcpy(dcrc.p, table, sizeof(table), hipMemcpyHostToDevice));
   }
   const u32 wgrid = (u32)cdiv(wstride, 256);
-  static DevBuf ddir;
+  static thread_local DevBuf ddir;
   // chain state (decodeStream's loop)
   u64 total = 0;        // bytes placed so far
   u64 keep = 0;         // bytes that count (a CRC mismatch stops the stream behind the block it was found in)
@@ -1146,7 +1152,7 @@ int32_t ahip_bzip2_decode(const uint8_t *in, size_t in_len, int32_t verify, uint
                           size_t *out_len) {
   std::lock_guard<std::recursive_mutex> lk(g_mu);
   if (out_len) *out_len = 0;
-  static DevBuf din, dout;
+  static thread_local DevBuf din, dout;
   // the header-only outcomes need no device
   if (in_len <= 4 || in[0] != 'B' || in[1] != 'Z' || in[2] != 'h' || in[3] < '1' || in[3] > '9')
     return bzip2_device_impl(in, nullptr, in_len, verify, nullptr, 0, out_len);
@@ -1195,7 +1201,7 @@ size_t ahip_deflate_bound(size_t in_len) {
 // Deflate on device memory.  Returns the compressed size through *out_len.
 static int32_t deflate_device_impl(const u8 *d_in, size_t n, int level, int window_bits, u8 *d_out, size_t cap, size_t *out_len,
                                    hipStream_t st) {
-  static DevBuf b_match, b_tok, b_ntok, b_slabs, b_csize, b_coff;
+  static thread_local DevBuf b_match, b_tok, b_ntok, b_slabs, b_csize, b_coff;
   if (out_len) *out_len = 0;
   if (level < 0 || level > 9 || window_bits < 9 || window_bits > 15) return AHIP_OK;  // the reference's _init fails silently: no output (deflate.dart:105-115)
   if (n == 0) {  // reference: one fixed-Huffman block holding only the end-of-block code (level >= 1), or an empty stored block
@@ -1288,7 +1294,7 @@ static int32_t deflate_host_impl(const uint8_t *in, size_t in_len, int32_t level
   if (window_bits < 9 || window_bits > 15 || level < 0 || level > 9) return AHIP_OK;  // reference: silent no-op
   int32_t rc = ensure_init();
   if (rc != AHIP_OK) return rc;
-  static DevBuf din, dout;
+  static thread_local DevBuf din, dout;
   HIP_TRY(din.reserve(in_len + 16));
   const size_t bound = ahip_deflate_bound(in_len);
   HIP_TRY(dout.reserve(bound));
@@ -1503,16 +1509,14 @@ int32_t ahip_gzip_decode_device(const void *d_in, size_t in_len, void *d_out, si
                           (hipStream_t)stream);
 }
 
-int32_t ahip_gzip_decode(const uint8_t *in, size_t in_len, int32_t verify, int32_t raw, uint8_t *out, size_t out_cap,
-                         size_t *out_len) {
-  std::lock_guard<std::recursive_mutex> lk(g_mu);
-  int32_t rc = ensure_init();
-  if (rc != AHIP_OK) return rc;
-  static DevBuf din, dout;
+// host buffers -> this thread's device -> host buffers (the whole stream, or one shard of it)
+static int32_t gzip_decode_host_impl(const uint8_t *in, size_t in_len, int32_t verify, int32_t raw, uint8_t *out, size_t out_cap,
+                                     size_t *out_len) {
+  static thread_local DevBuf din, dout;
   HIP_TRY(din.reserve(in_len + 16));
   if (in_len) HIP_TRY(hipMemcpy(din.p, in, in_len, hipMemcpyHostToDevice));
   size_t produced = 0;
-  rc = gzip_decode_impl(in, din.as<u8>(), in_len, verify, raw, nullptr, 0, true, &dout, &produced, nullptr);
+  int32_t rc = gzip_decode_impl(in, din.as<u8>(), in_len, verify, raw, nullptr, 0, true, &dout, &produced, nullptr);
   if (out_len) *out_len = produced;
   if (rc == AHIP_OK || rc == AHIP_FALSE) {
     if (produced > out_cap) return fail(AHIP_E_CAP, "output buffer too small");
@@ -1521,12 +1525,173 @@ int32_t ahip_gzip_decode(const uint8_t *in, size_t in_len, int32_t verify, int32
   return rc;
 }
 
+// ---- one process, several GPUs ----
+// ahip_init_devices() starts one worker thread per device; all library state is thread_local, so a worker IS a
+// device context (its own scratch pools, streams, plans).  A multi-member stream whose members all carry the BGZF
+// `BC` subfield is partitioned on the host -- contiguous member ranges balanced on compressed bytes, exactly
+// archive_amd.sharding.partition_members -- and every worker uploads, decodes and downloads only its slice; the
+// slices' output offsets are the prefix sums of the members' ISIZE trailers, checked against what was produced.
+// Anything else (no BC, one device, a shard that does not end cleanly) takes the single-device path, which has the
+// reference's exact semantics for every input.
+namespace {
+struct Worker {
+  int device = 0;
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::function<void()> job;
+  bool has_job = false, done = false, quit = false;
+  void loop() {
+    (void)hipSetDevice(device);
+    for (;;) {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return has_job || quit; });
+      if (quit) break;
+      lk.unlock();
+      job();
+      lk.lock();
+      has_job = false; done = true;
+      cv.notify_all();
+    }
+    for (auto &b : g_pool) (void)hipFree(b.p);  // this thread's pool
+    g_pool.clear();
+  }
+  void submit(std::function<void()> f) {
+    std::unique_lock<std::mutex> lk(mu);
+    job = std::move(f); has_job = true; done = false;
+    cv.notify_all();
+  }
+  void wait() {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return done; });
+  }
+};
+std::vector<std::unique_ptr<Worker>> g_workers;  // guarded by g_mu
+}  // namespace
+namespace {
+void stop_workers() {
+  for (auto &w : g_workers) {
+    { std::lock_guard<std::mutex> lk(w->mu); w->quit = true; w->cv.notify_all(); }
+    if (w->th.joinable()) w->th.join();
+  }
+  g_workers.clear();
+}
+
+struct GzMember { size_t begin, end; uint32_t isize; };
+// members of a stream in which EVERY member has a BC subfield and the chain ends exactly at the end of the input
+bool walk_bc_members(const uint8_t *in, size_t n, std::vector<GzMember> &ms) {
+  size_t pos = 0;
+  while (pos < n) {
+    if (n - pos < 26 || in[pos] != 0x1f || in[pos + 1] != 0x8b || in[pos + 2] != 8 || !(in[pos + 3] & 4)) return false;
+    const size_t xlen = in[pos + 10] | ((size_t)in[pos + 11] << 8);
+    size_t next = 0;
+    for (size_t q = pos + 12; q + 4 <= pos + 12 + xlen && q + 6 <= n;) {
+      const size_t slen = in[q + 2] | ((size_t)in[q + 3] << 8);
+      if (in[q] == 'B' && in[q + 1] == 'C' && slen == 2) { next = pos + (in[q + 4] | ((size_t)in[q + 5] << 8)) + 1; break; }
+      q += 4 + slen;
+    }
+    if (!next || next > n || next < pos + 26) return false;
+    ms.push_back({pos, next, (uint32_t)in[next - 4] | ((uint32_t)in[next - 3] << 8) | ((uint32_t)in[next - 2] << 16) | ((uint32_t)in[next - 1] << 24)});
+    pos = next;
+  }
+  return !ms.empty();
+}
+
+// returns true when the sharded path produced the final answer in *rc_out
+bool gzip_decode_sharded(const uint8_t *in, size_t in_len, int32_t verify, uint8_t *out, size_t out_cap, size_t *out_len, int32_t *rc_out) {
+  const size_t W = g_workers.size();
+  if (W < 2 || in_len < (4u << 20)) return false;
+  std::vector<GzMember> ms;
+  if (!walk_bc_members(in, in_len, ms) || ms.size() < 2 * W) return false;
+  // contiguous ranges balanced on compressed bytes (sharding.partition_members)
+  std::vector<size_t> bounds{0};
+  size_t acc = 0, r = 1;
+  for (size_t i = 0; i < ms.size(); ++i) {
+    acc += ms[i].end - ms[i].begin;
+    while (r < W && (unsigned __int128)acc * W >= (unsigned __int128)in_len * r && bounds.size() < W) { bounds.push_back(i + 1); ++r; }
+  }
+  while (bounds.size() < W) bounds.push_back(ms.size());
+  bounds.push_back(ms.size());
+  std::vector<size_t> o_off(W + 1, 0);
+  for (size_t w = 0; w < W; ++w) {
+    size_t sum = 0;
+    for (size_t i = bounds[w]; i < bounds[w + 1]; ++i) sum += ms[i].isize;
+    o_off[w + 1] = o_off[w] + sum;
+  }
+  if (out_len) *out_len = o_off[W];
+  if (o_off[W] > out_cap) { *rc_out = fail(AHIP_E_CAP, "output buffer too small"); return true; }
+  std::vector<int32_t> rcs(W, AHIP_OK);
+  std::vector<size_t> got(W, 0);
+  for (size_t w = 0; w < W; ++w) {
+    const size_t lo = bounds[w], hi = bounds[w + 1];
+    if (lo >= hi) { g_workers[w]->submit([] {}); continue; }
+    const uint8_t *src = in + ms[lo].begin;
+    const size_t len = ms[hi - 1].end - ms[lo].begin;
+    uint8_t *dst = out + o_off[w];
+    const size_t cap = o_off[w + 1] - o_off[w];
+    int32_t *rcp = &rcs[w];
+    size_t *gp = &got[w];
+    g_workers[w]->submit([=] { *rcp = gzip_decode_host_impl(src, len, verify, 0, dst, cap, gp); });
+  }
+  for (size_t w = 0; w < W; ++w) g_workers[w]->wait();
+  for (size_t w = 0; w < W; ++w)
+    if (rcs[w] != AHIP_OK || got[w] != o_off[w + 1] - o_off[w]) return false;  // lying ISIZE, damaged member, a reference into another shard: exact path
+  *rc_out = AHIP_OK;
+  return true;
+}
+}  // namespace
+
+int32_t ahip_init_devices(uint64_t device_mask) {
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  int32_t rc = ensure_init();
+  if (rc != AHIP_OK) return rc;
+  int n = 0;
+  HIP_TRY(hipGetDeviceCount(&n));
+  stop_workers();
+  std::vector<int> devs;
+  for (int d = 0; d < n && d < 64; ++d)
+    if ((device_mask >> d) & 1) devs.push_back(d);
+  if (device_mask == 0) return fail(AHIP_E_ARG, "empty device mask");
+  if (devs.empty()) return fail(AHIP_E_DEVICE, "no device of the mask is present");
+  if (const char *e = getenv("AHIP_FAKE_DEVICES")) {  // tests on a one-GPU box: several contexts on the same device
+    const int k = atoi(e);
+    while ((int)devs.size() < k && devs.size() < 16) devs.push_back(devs[0]);
+  }
+  HIP_TRY(hipSetDevice(devs[0]));  // the calling thread keeps working on the first one
+  if (devs.size() > 1)
+    for (int d : devs) {
+      g_workers.emplace_back(new Worker());
+      Worker *w = g_workers.back().get();
+      w->device = d;
+      w->th = std::thread([w] { w->loop(); });
+    }
+  return AHIP_OK;
+}
+
+static int32_t g_last_shards = 1;
+int32_t ahip_debug_last_shards(void) { return g_last_shards; }
+
+int32_t ahip_device_count(void) {
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  return g_workers.empty() ? 1 : (int32_t)g_workers.size();
+}
+
+int32_t ahip_gzip_decode(const uint8_t *in, size_t in_len, int32_t verify, int32_t raw, uint8_t *out, size_t out_cap,
+                         size_t *out_len) {
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  int32_t rc = ensure_init();
+  if (rc != AHIP_OK) return rc;
+  g_last_shards = 1;
+  if (!raw && !g_workers.empty() && gzip_decode_sharded(in, in_len, verify, out, out_cap, out_len, &rc)) { g_last_shards = (int32_t)g_workers.size(); return rc; }
+  return gzip_decode_host_impl(in, in_len, verify, raw, out, out_cap, out_len);
+}
+
 int32_t ahip_zlib_decode(const uint8_t *in, size_t in_len, int32_t verify, int32_t raw, uint8_t *out, size_t out_cap,
                          size_t *out_len) {
   std::lock_guard<std::recursive_mutex> lk(g_mu);
   int32_t rc = ensure_init();
   if (rc != AHIP_OK) return rc;
-  static DevBuf din, dout;
+  static thread_local DevBuf din, dout;
   HIP_TRY(din.reserve(in_len + 16));
   if (in_len) HIP_TRY(hipMemcpy(din.p, in, in_len, hipMemcpyHostToDevice));
   u64 committed = 0;
@@ -1544,7 +1709,7 @@ int32_t ahip_inflate_raw(const uint8_t *in, size_t in_len, uint8_t *out, size_t 
   std::lock_guard<std::recursive_mutex> lk(g_mu);
   int32_t rc = ensure_init();
   if (rc != AHIP_OK) return rc;
-  static DevBuf din, dout;
+  static thread_local DevBuf din, dout;
   HIP_TRY(din.reserve(in_len + 16));
   if (in_len) HIP_TRY(hipMemcpy(din.p, in, in_len, hipMemcpyHostToDevice));
   MemberResult r{};
@@ -1575,7 +1740,7 @@ static int32_t inflate_batch_impl(const u8 *d_in, size_t in_len, u32 n, const ui
   if (!in_off || !in_size || !out_off || !out_len || !status) return fail(AHIP_E_ARG, "NULL entry table");
   for (u32 i = 0; i < n; ++i)
     if (in_off[i] > in_len || in_size[i] > in_len - in_off[i]) return fail(AHIP_E_ARG, "entry outside the input");
-  static DevBuf ddesc, dres;
+  static thread_local DevBuf ddesc, dres;
   std::vector<MemberDesc> md(n);
   std::vector<MemberResult> res(n);
   HIP_TRY(ddesc.reserve((size_t)n * sizeof(MemberDesc)));
@@ -1654,7 +1819,7 @@ int32_t ahip_inflate_batch(const uint8_t *in, size_t in_len, uint32_t n_entries,
   std::lock_guard<std::recursive_mutex> lk(g_mu);
   int32_t rc = ensure_init();
   if (rc != AHIP_OK) return rc;
-  static DevBuf din, dout;
+  static thread_local DevBuf din, dout;
   HIP_TRY(din.reserve(in_len + 16));
   if (in_len) HIP_TRY(hipMemcpy(din.p, in, in_len, hipMemcpyHostToDevice));
   size_t total = 0;

@@ -96,8 +96,13 @@ class ArchiveHip {
   late final Pointer<Utf8> Function() _lastError =
       _lib.lookupFunction<Pointer<Utf8> Function(), Pointer<Utf8> Function()>('ahip_last_error');
 
-  ArchiveHip([String path = 'libarchive_hip.so']) : _lib = DynamicLibrary.open(path) {
-    final rc = _init(-1);
+  late final int Function(int) _initDevices =
+      _lib.lookupFunction<Int32 Function(Uint64), int Function(int)>('ahip_init_devices');
+
+  /// [deviceMask]: bit d selects GPU d; with more than one bit set, gzipDecode() spreads the members of a BGZF
+  /// stream over those GPUs (one process drives them all).  Default: the current device only.
+  ArchiveHip([String path = 'libarchive_hip.so', int? deviceMask]) : _lib = DynamicLibrary.open(path) {
+    final rc = deviceMask == null ? _init(-1) : _initDevices(deviceMask);
     if (rc != ok) throw StateError('ahip_init: ${_lastError().toDartString()}');
   }
 

@@ -43,6 +43,17 @@ extern "C" {
 /* Selects the HIP device for this process (one process per GPU).  device < 0 keeps the
  * current device.  Returns AHIP_OK or AHIP_E_DEVICE.  Idempotent. */
 int32_t ahip_init(int32_t device);
+/* One process driving several GPUs: bit d of device_mask selects HIP device d.  Starts one worker thread (= one device
+ * context: scratch pools, streams) per selected device; afterwards ahip_gzip_decode() partitions a multi-member stream
+ * whose members carry the BGZF `BC` subfield into contiguous member ranges balanced on compressed bytes, and every
+ * device uploads, decodes and downloads only its slice (output offsets = prefix sums of the ISIZE trailers, checked).
+ * Streams that cannot be partitioned that way, and every other entry point, run on the first selected device with
+ * unchanged semantics.  Calling it again replaces the set; ahip_shutdown() stops the workers. */
+int32_t ahip_init_devices(uint64_t device_mask);
+/* number of device contexts ahip_gzip_decode() fans out over (1 unless ahip_init_devices selected more) */
+int32_t ahip_device_count(void);
+/* Diagnostics: how many device contexts the last ahip_gzip_decode() on this process used (1 = the exact single-device path). */
+int32_t ahip_debug_last_shards(void);
 void ahip_shutdown(void);
 /* Text of the last AHIP_E_* error on this thread ("" if none).  Never NULL. */
 const char *ahip_last_error(void);
