@@ -3,6 +3,9 @@ sizes the CPU oracle finishes in seconds; here the checks are checksums and roun
 
   config 4   65 536 gzip members x 64 KiB (4 GiB out): decode verdict, size, and CRC-32 of the 4 GiB taken on the
              device == CRC-32 of the generator's plain text taken by zlib on the host.
+  config 2a  ONE gzip member holding 256 MiB of wiki-like text (the chunked single-stream path), and the same stream
+             without BGZF hints: size, device CRC-32 == host CRC-32, head and tail byte for byte.
+  config 2b  4 096 members x 64 KiB of wiki-like text, with and without the BC subfield: the same checks.
   config 3   1 GiB of log text, Deflate level 6: the stream inflates to the input through zlib (CRC-32 and length),
              its size is within the stated tolerance of what the reference's level 6 produces on a sample, and the
              device CRC-32 of the input equals the host's.
@@ -90,3 +93,41 @@ def test_config3_1gib_deflate_roundtrip(native_built):
                                        back.numel(), out_off, out_len, status, ctypes.byref(tot), None) == 0, N.last_error()
     assert status[0] in (0, 1) and out_len[0] == piece
     assert torch.equal(back[:piece], d_in[:piece])
+
+
+def _device_checks(L, N, d_in, n_out, want_crc, head, tail):
+    import torch
+    d_out = torch.empty(n_out + 64, dtype=torch.uint8, device="cuda")
+    olen = ctypes.c_size_t()
+    assert L.ahip_gzip_decode_device(d_in.data_ptr(), d_in.numel(), d_out.data_ptr(), d_out.numel(), ctypes.byref(olen), None) == 0, N.last_error()
+    assert olen.value == n_out
+    crc = ctypes.c_uint32()
+    assert L.ahip_crc32_device(d_out.data_ptr(), n_out, 0, ctypes.byref(crc), None) == 0
+    assert crc.value == want_crc
+    assert bytes(d_out[:len(head)].cpu().numpy()) == head and bytes(d_out[n_out - len(tail):n_out].cpu().numpy()) == tail
+
+
+def test_config2a_one_256mib_member(native_built):
+    import torch
+    from archive_amd import _native as N
+    from tools import corpus
+    L = N.lib()
+    assert L.ahip_init(0) == 0
+    data = bytes(corpus.text(corpus.WIKI, 8, 0, 256 << 20))
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    gz = bytes([0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 255]) + co.compress(data) + co.flush() + zlib.crc32(data).to_bytes(4, "little") + \
+        (len(data) & 0xffffffff).to_bytes(4, "little")
+    d_in = torch.frombuffer(bytearray(gz), dtype=torch.uint8).cuda()
+    _device_checks(L, N, d_in, len(data), zlib.crc32(data), data[:1 << 20], data[-(1 << 20):])
+
+
+@pytest.mark.parametrize("bc", [True, False])
+def test_config2b_4096_wiki_members(native_built, bc):
+    import torch
+    from archive_amd import _native as N
+    from tools import corpus
+    L = N.lib()
+    assert L.ahip_init(0) == 0
+    comp, plain = corpus.make_gzip(kind=corpus.WIKI, seed=8, n_members=4096, member_bytes=65536, level=6, bc=bc, want_plain=True)
+    plain = bytes(plain)
+    _device_checks(L, N, torch.from_numpy(comp).cuda(), len(plain), zlib.crc32(plain), plain[:65536], plain[-65536:])
