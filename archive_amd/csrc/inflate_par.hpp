@@ -50,10 +50,10 @@ namespace ahip {
 #define AHIP_EMIT_MIN 32
 #endif
 #ifndef AHIP_TOK_CAP
-#define AHIP_TOK_CAP 1024
+#define AHIP_TOK_CAP 384
 #endif
 #ifndef AHIP_OB_CAP
-#define AHIP_OB_CAP 4608
+#define AHIP_OB_CAP 1728
 #endif
 constexpr int SUB_BITS = AHIP_SUB_BITS;          // bits per work item ("subsequence") of the tokenizer
 constexpr int SUB_DW = SUB_BITS / 32;
@@ -805,24 +805,38 @@ AHIP_DEVINL void inflate_member(WaveLds &L, HeaderLds &H, TokLds *P, const u8 *i
       AHIP_TICK(t_h0);
       if (btype == 1) fixed_lengths(H.lens, lane);
       else {
-        if (PAR) {  // stage the (at most 569-byte) dynamic header into the idle window buffer
-          const u64 sb = (b.pos >> 3) & ~3ull;
-          constexpr u32 HDR_STAGE = 640;
-          if (sb + HDR_STAGE <= in_len) {
+        const u64 sb = (b.pos >> 3) & ~3ull;
+        constexpr u32 HDR_STAGE = 640;  // a dynamic header is at most 562 bytes
+#ifndef AHIP_HEADER_LDS
+        bool fast_ok = false;
+        if (sb + HDR_STAGE <= in_len) {
+          const BitCursor b0 = b;
+          r = dynamic_header_fast(H, b, in + sb, sb, lane, hlit, hdist);
+          fast_ok = r == MS_OK;
+          if (!fast_ok) b = b0;  // a damaged header: once more through the tracked path below
+        }
+        if (!fast_ok)
+#endif
+        {
+          if (PAR && sb + HDR_STAGE <= in_len) {  // stage the header into the idle ring buffer
             for (u32 k = lane * 4; k < HDR_STAGE / 4; k += 256)
               *(uint4 *)(P->inbuf + k) = load_u128_unaligned(in + sb + 4 * k);
             wave_sync();
             b.stage = P->inbuf; b.stage_byte = sb; b.stage_len = HDR_STAGE;
           }
+          r = dynamic_header(H, b, lane, hlit, hdist);
+          b.stage = nullptr;
         }
-        r = dynamic_header(H, b, lane, hlit, hdist);
-        b.stage = nullptr;
       }
       const u64 data_pos = b.pos;
       const u32 data_blen = b.blen;
       bool replayable = false;
+      AHIP_TICK(t_hm);
+      AHIP_ACC(st.cyc[5], t_h0, t_hm);
       if (r == MS_OK) {
         bool ok = build_decode_table<false>(H.lens, hlit, L.ll, LL_ROOT, L.lld, L.ll_sorted, lane);
+        AHIP_TICK(t_hn);
+        AHIP_ACC(st.cyc[6], t_hm, t_hn);
         ok &= build_decode_table<true>(H.lens + hlit, hdist, L.dt, D_ROOT, L.dd, L.d_sorted, lane);
         replayable = ok;
         AHIP_TICK(t_h1);
@@ -980,10 +994,29 @@ AHIP_DEVINL void resolve_member(ParLdsT<E> &P, const u8 *in, const u32 *area, co
       Chunk nxt = ck;
       if (more) nxt = prep(c + 64, run + ck.total);
       if (ck.pre) {
+#ifdef AHIP_DEPOSIT_BYTES
         E *dp = obw + ck.off;
 #pragma unroll
         for (u32 k = 0; k < 16; ++k)
           if (k < ck.len) dp[k] = (E)(u8)((k < 8 ? ck.w0 : ck.w1) >> (8 * (k & 7)));
+#else
+        // exactly ck.len (3..16) bytes with two overlapping stores at any alignment (gfx950 LDS takes unaligned
+        // 2/4/8-byte accesses): [0, w) and [len - w, len)
+        if constexpr (sizeof(E) == 1) {
+          u8 *dp = (u8 *)obw + ck.off;
+          if (ck.len >= 8) {
+            const u32 sh = 8 * (ck.len - 8);  // 0..64
+            const u64 tail = sh == 0 ? ck.w0 : (sh == 64 ? ck.w1 : ((ck.w0 >> sh) | (ck.w1 << (64 - sh))));
+            ((unaligned_u64 *)dp)->v = ck.w0;
+            ((unaligned_u64 *)(dp + ck.len - 8))->v = tail;
+          } else if (ck.len >= 4) {
+            ((unaligned_u32 *)dp)->v = (u32)ck.w0;
+            ((unaligned_u32 *)(dp + ck.len - 4))->v = (u32)(ck.w0 >> (8 * (ck.len - 4)));
+          } else {
+            dp[0] = (u8)ck.w0; dp[1] = (u8)(ck.w0 >> 8); dp[2] = (u8)(ck.w0 >> 16);
+          }
+        }
+#endif
       }
       if (ck.fits) P.tok[ck.idx] = ck.key | (ck.pre ? 0x8000u : 0u);
       if (ck.cut) {

@@ -321,6 +321,100 @@ AHIP_DEVINL u32 huffman_block(WaveLds &L, BitCursor &b, OutCursor &o, int lane) 
   }
 }
 
+// The same header decode with everything on the scalar side: the (<= 562-byte) header sits in three VGPRs (lane l holds
+// dwords l, 64 + l, 128 + l of the 640 bytes at `hw`), the bit buffer and the run-length state machine live in SGPRs, the
+// 128-entry code-length table in two VGPRs read with v_readlane -- no LDS round trip per symbol (the LDS-table version
+// spends ~550 cycles per code length on two of them).  Same results, same failure verdicts, same accumulator tracking;
+// only usable when the 640 bytes lie inside the input (then the input cannot end inside the header).
+AHIP_DEVINL u32 dynamic_header_fast(HeaderLds &L, BitCursor &b, const u8 *hw, u64 hw_byte, int lane, int &hlit_out, int &hdist_out) {
+  const u32 r0 = load_u32_unaligned(hw + 4 * lane), r1 = load_u32_unaligned(hw + 256 + 4 * lane), r2 = lane < 32 ? load_u32_unaligned(hw + 512 + 4 * lane) : 0u;
+  auto dword = [&](u32 i) -> u32 {  // i uniform, < 160
+    const u32 a = lane_bcast(r0, (int)(i & 63)), c = lane_bcast(r1, (int)(i & 63)), d = lane_bcast(r2, (int)(i & 63));
+    return i < 64 ? a : (i < 128 ? c : d);
+  };
+  const u32 bitoff = uniform((u32)(b.pos - hw_byte * 8));  // < 32; provably wave-uniform from here on: SGPRs
+  u64 sbuf = ((u64)dword(1) << 32 | dword(0)) >> bitoff;
+  u32 scnt = 64 - bitoff, nd = 2, used = 0;
+  auto take = [&](u32 n) -> u32 {  // n <= 16; at least 32 valid bits are kept in sbuf
+    const u32 v = (u32)sbuf & ((1u << n) - 1);
+    sbuf >>= n; scnt -= n; used += n;
+    if (scnt <= 32) { sbuf |= (u64)dword(nd) << scnt; scnt += 32; nd += 1; }
+    return v;
+  };
+  // a failure verdict is only a signal: the caller decodes the header again with dynamic_header(), which also keeps
+  // the reference's accumulator length (needed for the exact stream position after a failure)
+  auto leave = [&](u32 verdict) { if (verdict == MS_OK) { b.pos += used; b.blen = (8 - ((u32)b.pos & 7)) & 7; } return verdict; };
+  const int hlit = (int)take(5) + 257;
+  if (hlit > 288) return leave(MS_FALSE);
+  const int hdist = (int)take(5) + 1;
+  if (hdist > 32) return leave(MS_FALSE);
+  const int hclen = (int)take(4) + 4;
+  if (hclen > 19) return leave(MS_FALSE);
+  u32 cl_len[19];
+#pragma unroll
+  for (int i = 0; i < 19; ++i) cl_len[i] = 0;
+  const u8 order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+#pragma unroll
+  for (int i = 0; i < 19; ++i)
+    if (i < hclen) cl_len[order[i]] = take(3);
+  u32 cl_max = 0;
+#pragma unroll
+  for (int i = 0; i < 19; ++i) cl_max = cl_len[i] > cl_max ? cl_len[i] : cl_max;
+  const u32 cl_size = 1u << cl_max;
+  for (u32 i = lane; i < 128; i += 64) L.cl[i] = 0;
+  wave_sync();
+  if (lane == 0) {  // HuffmanTable(codeLengths): single level, the reference's fill order
+    u32 code = 0, skip = 2;
+    for (u32 bl = 1; bl <= cl_max; ++bl) {
+#pragma unroll
+      for (int i = 0; i < 19; ++i) {
+        if (cl_len[i] == bl) {
+          u32 rev = __brev(code) >> (32 - bl);
+          for (u32 j = rev; j < cl_size; j += skip) L.cl[j] = (bl << 16) | (u32)i;
+          ++code;
+        }
+      }
+      code <<= 1;
+      skip <<= 1;
+    }
+  }
+  wave_sync();
+  const u32 t0 = L.cl[lane], t1 = L.cl[64 + lane];
+  const int num = hlit + hdist;
+  int i = 0;
+  u32 prev = 0;
+  while (i < num) {
+    const u32 idx = (u32)sbuf & (cl_size - 1);
+    const u32 ea = lane_bcast(t0, (int)(idx & 63)), eb = lane_bcast(t1, (int)(idx & 63));
+    const u32 e = idx < 64 ? ea : eb;
+    {
+      const u32 n = e >> 16;
+      sbuf >>= n; scnt -= n; used += n;
+      if (scnt <= 32) { sbuf |= (u64)dword(nd) << scnt; scnt += 32; nd += 1; }
+    }
+    const u32 code = e & 0xffff;
+    int repeat;
+    u32 fill;
+    if (code < 16) { repeat = 1; fill = code; prev = code; }
+    else if (code == 16) { repeat = (int)take(2) + 3; fill = prev; }
+    else if (code == 17) { repeat = (int)take(3) + 3; fill = 0; prev = 0; }
+    else { repeat = (int)take(7) + 11; fill = 0; prev = 0; }
+    if (i + repeat > num) return leave(MS_RANGE);  // Dart: index past the end of the Uint8List
+    if (repeat == 1) {
+      if (lane == 0) L.lens[i] = (u8)fill;
+    } else {
+      if (lane < repeat) L.lens[i + lane] = (u8)fill;
+      if (lane + 64 < repeat) L.lens[i + lane + 64] = (u8)fill;
+      if (lane + 128 < repeat) L.lens[i + lane + 128] = (u8)fill;
+    }
+    i += repeat;
+  }
+  wave_sync();
+  hlit_out = hlit;
+  hdist_out = hdist;
+  return leave(MS_OK);
+}
+
 // A Huffman block ended in a bad litlen / distance symbol (MS_FALSE, not at the end of the input).  Walk the block
 // again from its first code, symbol by symbol, keeping the reference's accumulator length: b.pos / b.blen end up
 // where the reference's `return -1` leaves them (inflate.dart:300-343).  Only ever runs on corrupt data.
