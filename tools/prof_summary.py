@@ -66,6 +66,43 @@ def side_profile(rnd, tag, title, cmd):
                 f.write("    " + ln + "\n")
 
 
+def sq_table(rnd, bench_line):
+    """SQ counters of the two inflate kernels (three --pmc passes of tools/run_prof.sh) -> profiles/<rnd>_sq_counters.md"""
+    import collections
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    dur = collections.defaultdict(list)
+    files = sorted(glob.glob(os.path.join(OUT, "sq_%s_*" % rnd, "**", "*counter_collection.csv"), recursive=True))
+    if not files:
+        return
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            if not any(s_ in k for s_ in STAGE):
+                continue
+            acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    with open(os.path.join(PROF, "%s_sq_counters.md" % rnd), "w") as f:
+        f.write("# Round %s -- SQ counters of the inflate kernels (rocprofv3 --kernel-trace --pmc, three passes)\n\n" % rnd[1:].lstrip("0"))
+        f.write("    rocprofv3 --kernel-trace --pmc <8 SQ counters> --output-format csv ... -- python bench.py --cpu-seconds 0 --no-extras --steps 2 --warmup 1\n\n")
+        f.write("Per-dispatch means over the 65 536-member decode (config 4).  SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count\n"
+                "quad-cycles summed over waves; GRBM_GUI_ACTIVE is summed over the 8 XCDs.  Derived rows: VALU issue utilisation =\n"
+                "SQ_ACTIVE_INST_VALU / (1024 SIMDs x kernel quad-cycles), with kernel quad-cycles = GRBM_GUI_ACTIVE / 8 / 4.\n\n")
+        names = sorted({c for k in acc for c in acc[k]})
+        ks = sorted(acc)
+        f.write("| counter | " + " | ".join("`%s`" % k for k in ks) + " |\n|---|" + "---|" * len(ks) + "\n")
+        f.write("| dispatch (ms, under the profiler) | " + " | ".join("%.3f" % (sum(dur[k]) / len(dur[k])) for k in ks) + " |\n")
+        for c in names:
+            f.write("| %s | " % c + " | ".join(("%.4g" % (sum(acc[k][c]) / len(acc[k][c]))) if c in acc[k] else "" for k in ks) + " |\n")
+
+        def mean(k, c):
+            return sum(acc[k][c]) / len(acc[k][c]) if c in acc[k] else float("nan")
+        f.write("| **VALU issue utilisation** | " + " | ".join("%.0f %%" % (100 * mean(k, "SQ_ACTIVE_INST_VALU") / (1024 * mean(k, "GRBM_GUI_ACTIVE") / 32)) for k in ks) + " |\n")
+        f.write("| **waves waiting (WAIT_ANY / WAVE_CYCLES)** | " + " | ".join("%.0f %%" % (100 * mean(k, "SQ_WAIT_ANY") / mean(k, "SQ_WAVE_CYCLES")) for k in ks) + " |\n")
+        f.write("| **VALU wave-instructions per output byte** | " + " | ".join("%.2f" % (mean(k, "SQ_INSTS_VALU") / (65536 * 65536)) for k in ks) + " |\n")
+        f.write("\nEvery VALU instruction occupies its SIMD for one quad-cycle (SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU), so the chip issues at most\n"
+                "1024 SIMDs x 2.4 GHz / 4 = 614 G wave-instructions/s: the utilisation row is measured against that.\n")
+
+
 def main():
     rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
     os.makedirs(PROF, exist_ok=True)
@@ -180,6 +217,14 @@ def main():
                     "%.2f GB algorithmic (C + U): %.2fx.\n" % (
                         stage_f * rs / 1e9, stage_f / 1e9, stage_w * ws / 1e9, stage_w / 1e9,
                         (stage_f * rs + stage_w * ws) / 1e9, algo / 1e9, (stage_f * rs + stage_w * ws) / algo))
+    sq_table(rnd, bench_line)
+    for extra in ("bench_%s.log" % rnd, "pytest_gpu_%s.log" % rnd, "checksum_stats.log"):
+        src = os.path.join(OUT, extra)
+        if os.path.exists(src):
+            dst = extra if extra.startswith(("bench_", "pytest_")) else "%s_%s" % (rnd, extra)
+            dst = dst.replace("bench_%s" % rnd, "%s_bench" % rnd).replace("pytest_gpu_%s" % rnd, "%s_pytest_gpu" % rnd)
+            keep = [ln for ln in open(src) if not ln.startswith(("E2026", "W2026", "I2026")) and "amdgpu.ids" not in ln]
+            open(os.path.join(PROF, dst), "w").writelines(keep)
     print(open(os.path.join(PROF, "%s_pmc_traffic.md" % rnd)).read())
     print(open(os.path.join(PROF, "%s_kernel_stats.md" % rnd)).read())
 
