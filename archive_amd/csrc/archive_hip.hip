@@ -87,7 +87,8 @@ __global__ __launch_bounds__(64, AHIP_TOK_MIN_WAVES) void inflate_tokenize_kerne
     const u64 lim = uniform64(d.in_end) ? uniform64(d.in_end) : in_len;
     inflate_member<false, true>(lds.w, hdr, &lds.p, in, lim, d, (u8 *)nullptr,
                                 member_sink(tokens, dir, d.out_off - group_out0, d.out_limit, k), results[m], lane);
-    if (lane == 0 && member_is_late(results[m])) atomicAdd(late, 1u);  // rare: inflate_late_kernel finishes these
+    // rare: inflate_late_kernel finishes these (a sizing run only cares about the ones whose size it does not know yet)
+    if (lane == 0 && (tokens ? member_is_late(results[m]) : results[m].status == MS_OVERSUB)) atomicAdd(late, 1u);
   }
 }
 
@@ -132,27 +133,37 @@ __global__ __launch_bounds__(64) void inflate_late_kernel(const u8 *__restrict__
   __shared__ HeaderLds hdr;
   __shared__ ParLds par;
   const int lane = threadIdx.x;
-  for (u32 k = 0; k < n_members; ++k) {
-    const u32 m = first_member + k;
-    const u32 status = uniform(results[m].status), blocks = uniform(results[m].blocks);
-    if (status != MS_TOKFULL && status != MS_OVERSUB && !(blocks & MR_FAR)) continue;
-    MemberDesc d = members[m];
-    d.in_off = uniform64(d.in_off);
-    d.out_off = uniform64(d.out_off);
-    d.out_limit = uniform64(d.out_limit);
-    d.hist = uniform(d.hist);
-    if (status == MS_TOKFULL || status == MS_OVERSUB) {
-      const u64 lim = uniform64(d.in_end) ? uniform64(d.in_end) : in_len;
-      inflate_member<WRITE, false>(lds, hdr, nullptr, in, lim, d, out, TokSink{nullptr, 0, nullptr, 0, 0, ~0u, 0, 0, false}, results[m], lane,
-                                   nullptr, exact);
-    } else if (WRITE) {
-      u64 toff, doff;
-      u32 cc, dc;
-      tok_layout(d.out_off - group_out0, d.out_limit, k, toff, cc, doff, dc);
-      u32 cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      resolve_member(par, in, tokens + toff, dir + doff, (u32)uniform64(results[m].tok_words), out + d.out_off, cyc, lane);
+  // 64 members per look (one per lane, the next look's loads already in flight); the late ones of a look in order
+  u32 st_n = 0, bl_n = 0;
+  if ((u32)lane < n_members) { st_n = results[first_member + lane].status; bl_n = results[first_member + lane].blocks; }
+  for (u32 base = 0; base < n_members; base += 64) {
+    const u32 st_c = st_n, bl_c = bl_n;
+    if (base + 64 + (u32)lane < n_members) { st_n = results[first_member + base + 64 + lane].status; bl_n = results[first_member + base + 64 + lane].blocks; }
+    const bool have = base + (u32)lane < n_members;
+    u64 todo = __ballot(have && (WRITE ? (st_c == MS_TOKFULL || st_c == MS_OVERSUB || (bl_c & MR_FAR)) : st_c == MS_OVERSUB));
+    while (todo) {
+      const int j = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      const u32 k = base + (u32)j, m = first_member + k;
+      const u32 status = lane_bcast(st_c, j);
+      MemberDesc d = members[m];
+      d.in_off = uniform64(d.in_off);
+      d.out_off = uniform64(d.out_off);
+      d.out_limit = uniform64(d.out_limit);
+      d.hist = uniform(d.hist);
+      if (status == MS_TOKFULL || status == MS_OVERSUB) {
+        const u64 lim = uniform64(d.in_end) ? uniform64(d.in_end) : in_len;
+        inflate_member<WRITE, false>(lds, hdr, nullptr, in, lim, d, out, TokSink{nullptr, 0, nullptr, 0, 0, ~0u, 0, 0, false}, results[m], lane,
+                                     nullptr, exact);
+      } else if (WRITE) {
+        u64 toff, doff;
+        u32 cc, dc;
+        tok_layout(d.out_off - group_out0, d.out_limit, k, toff, cc, doff, dc);
+        u32 cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        resolve_member(par, in, tokens + toff, dir + doff, (u32)uniform64(results[m].tok_words), out + d.out_off, cyc, lane);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");  // the next late member may read these bytes
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");  // the next late member may read these bytes
   }
 }
 
