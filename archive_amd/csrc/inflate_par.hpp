@@ -164,59 +164,19 @@ AHIP_DEVINL void lb_normalize(LaneBits &d, const u32 *inbuf) {
 AHIP_DEVINL u32 lb_peek32(const LaneBits &d) { return __builtin_amdgcn_alignbit(d.hi, d.lo, d.sh); }
 AHIP_DEVINL u32 lb_pos(const LaneBits &d) { return (d.ptr - 2) * 32 + d.sh; }
 
-// Wave-uniform description of the codes LONGER than a primary table, held in scalar registers
-// for the whole block: first canonical code, symbol count and sorted-symbol offset of each
-// length root+1 .. root+N.  Resolving a long code then needs no dependent LDS chain: N
-// compare/select steps on the bit-reversed window and one read of the sorted symbol list.
-template <int N>
-struct LongMeta { u32 first[N], count[N], offset[N]; };
-template <int N>
-AHIP_DEVINL void load_long_meta(LongMeta<N> &m, const CodeDesc &cd, int root) {
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    const int Lk = root + 1 + k;
-    m.first[k] = Lk < 16 ? uniform(cd.first[Lk < 16 ? Lk : 15]) : 0u;
-    m.count[k] = Lk < 16 ? uniform(cd.count[Lk < 16 ? Lk : 15]) : 0u;
-    m.offset[k] = Lk < 16 ? uniform(cd.offset[Lk < 16 ? Lk : 15]) : 0u;
-  }
-}
-template <bool IS_DIST, int N>
-AHIP_DEVINL u32 long_resolve(const LongMeta<N> &m, const u32 *sorted, u32 bits, int root) {
-  const u32 rev = __brev(bits);
-  u32 pos = 0, len = 0;
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    const u32 Lk = root + 1 + k;
-    const u32 idx = (rev >> (32 - Lk)) - m.first[k];
-    const bool hit = idx < m.count[k];  // prefix-free: at most one length hits
-    pos = hit ? m.offset[k] + idx : pos;
-    len = hit ? Lk : len;
-  }
-  const u32 e = sorted[pos];
-  const u32 hole = IS_DIST ? dist_entry(0, 0) : (u32)E_HOLE;  // unfilled entry: symbol 0, length 0
-  return len ? e : hole;
-}
-constexpr int LL_LONG_N = 15 - LL_ROOT;
-constexpr int D_LONG_N = 15 - D_ROOT;
-struct BlockMeta {
-  LongMeta<LL_LONG_N> ll;
-  LongMeta<D_LONG_N> d;
-};
-
 // One token at the lane's cursor, straight-line: every lane runs the litlen AND the distance half (a 64-lane step
 // almost always contains a match anyway); selects pick the result.  The only branches skip the long-code
 // resolution when no lane needs it.  Returns the token -- literal (0x8000 | byte) << 16, match len << 16 | dist --
 // or, for anything else (end of block, bad litlen / distance symbol, unfilled entry), a word that is not negative
 // and has a zero distance field; `e` then says which.
 template <u32 MASK>
-AHIP_DEVINL u32 decode_token(LaneBits &d, const WaveLds &L, const BlockMeta &M, const u32 *inbuf, u32 &e) {
+AHIP_DEVINL u32 decode_token(LaneBits &d, const WaveLds &L, const u32 *inbuf, u32 &e) {
   lb_normalize<MASK>(d, inbuf);
   const u32 w = lb_peek32(d);  // 32 valid bits; litlen code + extra <= 20
   e = L.ll[w & ((1u << LL_ROOT) - 1)];
   if (__any(e & E_LONG)) {
     asm volatile("; long litlen code" ::: "memory");  // keep this a real branch: if-converted, its LDS read would sit on every step's critical path
-    const u32 e2 = long_resolve<false>(M.ll, L.ll_sorted, w, LL_ROOT);
-    e = (e & E_LONG) ? e2 : e;
+    if (e & E_LONG) e = long_lookup(L.ll_sub, e, w, LL_ROOT);
   }
   const u32 cl = e & 15;
   const u32 xb = (e >> 4) & 15;  // 0 unless a length symbol
@@ -228,8 +188,7 @@ AHIP_DEVINL u32 decode_token(LaneBits &d, const WaveLds &L, const BlockMeta &M, 
   u32 t = L.dt[w2 & ((1u << D_ROOT) - 1)];
   if (__any(is_match && (t & E_LONG))) {
     asm volatile("; long distance code" ::: "memory");
-    const u32 t2 = long_resolve<true>(M.d, L.d_sorted, w2, D_ROOT);
-    t = (t & E_LONG) ? t2 : t;
+    if (t & E_LONG) t = long_lookup(L.d_sub, t, w2, D_ROOT);
   }
   const u32 dl = t & 15;
   const u32 dxb = (t >> 4) & 15;
@@ -392,7 +351,7 @@ AHIP_DEVINL u32 huffman_token_emit(WaveLds &L, BitCursor &b, OutCursor &o, TokSi
   if (CAREFUL && b.pos + ll_max > b.total_bits) return 100 + MS_FALSE_EOS;
   u64 w = peek_bits(b);
   u32 e = uniform(L.ll[(u32)w & ((1u << LL_ROOT) - 1)]);
-  if (e & E_LONG) e = uniform(long_lookup<false>(L.lld, L.ll_sorted, (u32)w, LL_ROOT));
+  if (e & E_LONG) e = uniform(long_lookup(L.ll_sub, e, (u32)w, LL_ROOT));
   u32 cl = e & 15;
   if (e & (E_LIT | E_EOB | E_BAD | E_HOLE)) {
     if (e & E_LIT) {
@@ -414,7 +373,7 @@ AHIP_DEVINL u32 huffman_token_emit(WaveLds &L, BitCursor &b, OutCursor &o, TokSi
   else { len += (i32)((u32)w & ((1u << xb) - 1)); w >>= xb; used += xb; }
   if (CAREFUL && b.pos + used + d_max > b.total_bits) return 100 + MS_FALSE_EOS;
   u32 d = uniform(L.dt[(u32)w & ((1u << D_ROOT) - 1)]);
-  if (d & E_LONG) d = uniform(long_lookup<true>(L.dd, L.d_sorted, (u32)w, D_ROOT));
+  if (d & E_LONG) d = uniform(long_lookup(L.d_sub, d, (u32)w, D_ROOT));
   if (d & E_BAD) return 100 + MS_FALSE;
   u32 dl = d & 15;
   w >>= dl;
@@ -503,9 +462,6 @@ AHIP_DEVINL u32 stored_block_emit(BitCursor &b, OutCursor &o, TokSink &sink, u32
 // hands the rest of the block to the serial decoder, which restates the reference symbol by symbol.
 AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutCursor &o, TokSink &sink, int lane,
                                        ParStats &st, u64 hint_end_bits) {
-  BlockMeta M;
-  load_long_meta(M.ll, L.lld, LL_ROOT);
-  load_long_meta(M.d, L.dd, D_ROOT);
   const bool emit = sink.area != nullptr;
   constexpr u32 SLACK_DW = 4;  // a token may run 48 bits past its item and the reader looks two dwords ahead
   constexpr u32 SUB = SUB_BITS;
@@ -705,7 +661,7 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
         if (!__any(go)) break;
         if (go) {
           u32 e;
-          const u32 t = decode_token<RING_MASK>(d, L, M, P.inbuf, e);
+          const u32 t = decode_token<RING_MASK>(d, L, P.inbuf, e);
           endp = lb_pos(d);
           const bool spc = (i32)t >= 0 && (t & 0xffffu) == 0;
           if (__any(spc)) {
@@ -834,10 +790,10 @@ AHIP_DEVINL void inflate_member(WaveLds &L, HeaderLds &H, TokLds *P, const u8 *i
       AHIP_TICK(t_hm);
       AHIP_ACC(st.cyc[5], t_h0, t_hm);
       if (r == MS_OK) {
-        bool ok = build_decode_table<false>(H.lens, hlit, L.ll, LL_ROOT, L.lld, L.ll_sorted, lane);
+        bool ok = build_decode_table<false>(H.lens, hlit, L.ll, LL_ROOT, L.lld, L.ll_sub, LL_SUB, lane);
         AHIP_TICK(t_hn);
         AHIP_ACC(st.cyc[6], t_hm, t_hn);
-        ok &= build_decode_table<true>(H.lens + hlit, hdist, L.dt, D_ROOT, L.dd, L.d_sorted, lane);
+        ok &= build_decode_table<true>(H.lens + hlit, hdist, L.dt, D_ROOT, L.dd, L.d_sub, D_SUB, lane);
         replayable = ok;
         AHIP_TICK(t_h1);
         AHIP_ACC(st.cyc[0], t_h0, t_h1);

@@ -31,7 +31,7 @@ namespace ahip {
 constexpr u32 E_LIT = 0x100;   // value = 0x8000 | literal byte
 constexpr u32 E_EOB = 0x200;   // end of block (symbol 256)
 constexpr u32 E_BAD = 0x400;   // litlen 286/287, distance 30/31: reference returns -1
-constexpr u32 E_LONG = 0x800;  // code longer than the primary table: canonical search
+constexpr u32 E_LONG = 0x800;  // code longer than the primary table: bits 0-3 = index bits of its second-level table, value = that table's base
 constexpr u32 E_HOLE = 0x1000; // unfilled litlen entry (symbol 0, length 0): literal-0 forever
 
 #ifndef AHIP_LL_ROOT
@@ -60,14 +60,25 @@ AHIP_DEVINL u32 dist_entry(u32 sym, u32 len) {
   return (base << 16) | (xb << 4) | len;
 }
 
-// Canonical description of one Huffman code, kept in LDS next to its primary table.
+// What the decoders keep of a code next to its tables.
 struct CodeDesc {
-  u16 count[16];   // symbols per code length
-  u16 first[16];   // first canonical code of each length
-  u16 offset[16];  // index of the first symbol of each length in sorted[]
+  u16 first[16];   // first canonical code of each length (table build only)
   u32 maxlen;      // reference HuffmanTable.maxCodeLength
   u32 pad;
 };
+
+// Second-level tables (codes longer than the primary index), one per primary prefix that long codes start with,
+// indexed by the next (longest code under the prefix - root) stream bits.  Sized for every COMPLETE code over the
+// alphabet (a dynamic-programming sweep over the canonical count vectors gives 340 entries for 286 litlen symbols at
+// root 9 and 274 for 32 distance symbols at root 7); a code set that needs more -- an incomplete or padded one no
+// encoder emits -- is decoded through the reference's own table like the over-subscribed sets (MS_OVERSUB route).
+#ifndef AHIP_LL_SUB
+#define AHIP_LL_SUB 352
+#endif
+#ifndef AHIP_D_SUB
+#define AHIP_D_SUB 280
+#endif
+constexpr u32 LL_SUB = AHIP_LL_SUB, D_SUB = AHIP_D_SUB;
 
 // Block-header scratch: only alive between a block's 3-bit header and the end of its table build,
 // so the tokenizer overlays it on the (then idle) bitstream window.
@@ -79,8 +90,8 @@ struct WaveLds {
   u32 ll[1 << LL_ROOT];
   u32 dt[1 << D_ROOT];
   CodeDesc lld, dd;
-  u32 ll_sorted[288];  // decode-table ENTRY of every symbol in canonical (length, symbol) order
-  u32 d_sorted[32];
+  u32 ll_sub[LL_SUB];
+  u32 d_sub[D_SUB];
 };
 
 struct BitCursor {
@@ -134,25 +145,15 @@ AHIP_DEVINL int read_bits(BitCursor &b, u32 n) {
   return (int)v;
 }
 
-// Resolve a bit pattern against the canonical description (codes longer than `root`).
-template <bool IS_DIST>
-AHIP_DEVINL u32 long_lookup(const CodeDesc &cd, const u32 *sorted, u32 bits, int root) {
-  u32 rev = __brev(bits);
-  u32 maxlen = cd.maxlen;
-  for (u32 L = root + 1; L <= maxlen; ++L) {
-    u32 code = rev >> (32 - L);
-    u32 idx = code - cd.first[L];
-    if (idx < cd.count[L]) {
-      return sorted[cd.offset[L] + idx];
-    }
-  }
-  return IS_DIST ? dist_entry(0, 0) : E_HOLE;  // unfilled entry: symbol 0, length 0
+// Second-level lookup: `e` is the primary entry (E_LONG set), `bits` the stream bits the primary index came from.
+AHIP_DEVINL u32 long_lookup(const u32 *sub, u32 e, u32 bits, int root) {
+  return sub[(e >> 16) + __builtin_amdgcn_ubfe(bits, (u32)root, e & 15)];
 }
 
-// Build primary table + canonical description from `n` code lengths in LDS (wave-cooperative).
-// Returns false for an over-subscribed set (not reproduced).
+// Build primary + second-level tables from `n` code lengths in LDS (wave-cooperative).
+// Returns false for an over-subscribed set, or one whose second-level tables do not fit (neither reproduced here).
 template <bool IS_DIST>
-AHIP_DEVINL bool build_decode_table(const u8 *lens, int n, u32 *primary, int root, CodeDesc &cd, u32 *sorted,
+AHIP_DEVINL bool build_decode_table(const u8 *lens, int n, u32 *primary, int root, CodeDesc &cd, u32 *sub, u32 sub_cap,
                                     int lane) {
   constexpr int CHUNKS = IS_DIST ? 1 : 5;
   u32 mylen[CHUNKS], myrank[CHUNKS];
@@ -174,35 +175,63 @@ AHIP_DEVINL bool build_decode_table(const u8 *lens, int n, u32 *primary, int roo
     }
     myrank[c] = r;
   }
-  // canonical first codes / offsets (uniform)
-  u32 code = 0, off = 0, maxlen = 0;
+  // canonical first codes (uniform)
+  u32 code = 0, maxlen = 0;
   bool over = false;
-  u32 first[16], offs[16];
-  first[0] = 0; offs[0] = 0;
+  u32 first[16];
+  first[0] = 0;
 #pragma unroll
   for (int L = 1; L < 16; ++L) {
     first[L] = code;
-    offs[L] = off;
     if (cnt[L]) maxlen = L;
     if (code + cnt[L] > (1u << L)) over = true;
     code = (code + cnt[L]) << 1;
-    off += cnt[L];
   }
   if (lane < 16) {
-    u32 c = 0, f = 0, o = 0;
+    u32 f = 0;
 #pragma unroll
     for (int L = 0; L < 16; ++L)
-      if (lane == L) { c = cnt[L]; f = first[L]; o = offs[L]; }
-    cd.count[lane] = (u16)c;
+      if (lane == L) f = first[L];
     cd.first[lane] = (u16)f;
-    cd.offset[lane] = (u16)o;
   }
   if (lane == 0) cd.maxlen = maxlen;
-  // default fill
-  const u32 hole = ((int)maxlen > root) ? E_LONG : (IS_DIST ? dist_entry(0, 0) : E_HOLE);
+  // default fill: unfilled entries decode as symbol 0 with length 0
+  const u32 hole = IS_DIST ? dist_entry(0, 0) : (u32)E_HOLE;
   for (int i = lane; i < (1 << root); i += 64) primary[i] = hole;
+  const bool has_long = (int)maxlen > root && !over;
+  if (has_long)
+    for (u32 i = lane; i < sub_cap; i += 64) sub[i] = hole;
   wave_sync();
-  // symbols -> sorted[] and primary entries
+  // One second-level table per primary prefix q (canonical bit order) that long codes start with, as wide as the
+  // longest code under q: lengths never decrease along the canonical order, so that is the LAST code under q.
+  bool fits = true;
+  if (has_long) {
+    u32 q0 = 1u << root;  // first prefix with a long code
+#pragma unroll
+    for (int L = 15; L >= 1; --L)
+      if (L > root && cnt[L]) q0 = first[L] >> (L - root);
+    u32 used = 0;
+    for (u32 qb = q0; qb < (1u << root); qb += 64) {
+      const u32 q = qb + (u32)lane;
+      u32 sb = 0;
+#pragma unroll
+      for (int L = 1; L < 16; ++L) {
+        if (L > root && cnt[L]) {
+          const u32 lo = first[L] >> (L - root), hi = (first[L] + cnt[L] - 1) >> (L - root);
+          sb = (q >= lo && q <= hi) ? (u32)(L - root) : sb;
+        }
+      }
+      if (q >= (1u << root)) sb = 0;
+      const u32 size = sb ? 1u << sb : 0u;
+      u32 tot;
+      const u32 base = used + wave_excl_sum(size, tot);
+      if (sb && base + size <= sub_cap) primary[__brev(q) >> (32 - root)] = E_LONG | sb | (base << 16);
+      used += tot;
+    }
+    fits = used <= sub_cap;
+  }
+  wave_sync();
+  // symbols -> primary / second-level entries
 #pragma unroll
   for (int c = 0; c < CHUNKS; ++c) {
     u32 l = mylen[c];
@@ -210,15 +239,20 @@ AHIP_DEVINL bool build_decode_table(const u8 *lens, int n, u32 *primary, int roo
       u32 s = c * 64 + lane;
       u32 cde = cd.first[l] + myrank[c];
       const u32 e = IS_DIST ? dist_entry(s, l) : litlen_entry(s, l);
-      sorted[cd.offset[l] + myrank[c]] = e;
       if ((int)l <= root) {
         u32 rev = __brev(cde) >> (32 - l);
         for (u32 j = rev; j < (1u << root); j += (1u << l)) primary[j] = e;
+      } else if (has_long && fits) {
+        const u32 xl = l - root;  // bits below the prefix
+        const u32 pe = primary[__brev(cde >> xl) >> (32 - root)];
+        const u32 sb = pe & 15, base = pe >> 16;
+        const u32 j0 = __brev(cde & ((1u << xl) - 1)) >> (32 - xl);
+        for (u32 j = j0; j < (1u << sb); j += (1u << xl)) sub[base + j] = e;
       }
     }
   }
   wave_sync();
-  return !over;
+  return !over && fits;
 }
 
 // Fixed-Huffman code lengths (inflate.dart:408-735): 144x8, 112x9, 24x7, 8x8; 30 distance codes of 5.
@@ -258,7 +292,7 @@ AHIP_DEVINL u32 huffman_token(WaveLds &L, BitCursor &b, OutCursor &o, u32 ll_max
   if (CAREFUL && b.pos + ll_max > b.total_bits) return 100 + MS_FALSE_EOS;
   u64 w = peek_bits(b);
   u32 e = uniform(L.ll[(u32)w & ((1u << LL_ROOT) - 1)]);
-  if (e & E_LONG) e = uniform(long_lookup<false>(L.lld, L.ll_sorted, (u32)w, LL_ROOT));
+  if (e & E_LONG) e = uniform(long_lookup(L.ll_sub, e, (u32)w, LL_ROOT));
   u32 cl = e & 15;
   if (e & (E_LIT | E_EOB | E_BAD | E_HOLE)) {
     if (e & E_LIT) {
@@ -286,7 +320,7 @@ AHIP_DEVINL u32 huffman_token(WaveLds &L, BitCursor &b, OutCursor &o, u32 ll_max
   }
   if (CAREFUL && b.pos + used + d_max > b.total_bits) return 100 + MS_FALSE_EOS;
   u32 d = uniform(L.dt[(u32)w & ((1u << D_ROOT) - 1)]);
-  if (d & E_LONG) d = uniform(long_lookup<true>(L.dd, L.d_sorted, (u32)w, D_ROOT));
+  if (d & E_LONG) d = uniform(long_lookup(L.d_sub, d, (u32)w, D_ROOT));
   if (d & E_BAD) return 100 + MS_FALSE;
   u32 dl = d & 15;
   w >>= dl;
@@ -423,7 +457,7 @@ AHIP_DEVINL void replay_to_failure(const WaveLds &L, BitCursor &b) {
   for (u32 guard = 0; guard < (1u << 28); ++guard) {
     u64 w = peek_bits(b);
     u32 e = uniform(L.ll[(u32)w & ((1u << LL_ROOT) - 1)]);
-    if (e & E_LONG) e = uniform(long_lookup<false>(L.lld, L.ll_sorted, (u32)w, LL_ROOT));
+    if (e & E_LONG) e = uniform(long_lookup(L.ll_sub, e, (u32)w, LL_ROOT));
     acc_need(b, ll_max);
     const u32 cl = e & 15;
     b.blen -= cl; b.pos += cl;
@@ -433,7 +467,7 @@ AHIP_DEVINL void replay_to_failure(const WaveLds &L, BitCursor &b) {
     const u32 xb = (e >> 4) & 15;
     if (xb) { acc_need(b, xb); b.blen -= xb; b.pos += xb; w >>= xb; }
     u32 d = uniform(L.dt[(u32)w & ((1u << D_ROOT) - 1)]);
-    if (d & E_LONG) d = uniform(long_lookup<true>(L.dd, L.d_sorted, (u32)w, D_ROOT));
+    if (d & E_LONG) d = uniform(long_lookup(L.d_sub, d, (u32)w, D_ROOT));
     acc_need(b, d_max);
     const u32 dl = d & 15;
     b.blen -= dl; b.pos += dl;
