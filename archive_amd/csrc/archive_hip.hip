@@ -15,6 +15,7 @@
 #include <mutex>
 #include <thread>
 #include <string>
+#include <atomic>
 #include <vector>
 
 #include <chrono>
@@ -43,7 +44,7 @@ constexpr int WAVES_PER_BLOCK = 1;
 #define AHIP_RES_MIN_WAVES 1
 #endif
 #ifndef AHIP_TOK_MIN_WAVES
-#define AHIP_TOK_MIN_WAVES 1
+#define AHIP_TOK_MIN_WAVES 3
 #endif
 
 struct TokKernelLds {
@@ -59,7 +60,7 @@ AHIP_DEVINL bool member_is_late(const MemberResult &r) {
   return r.status == MS_TOKFULL || r.status == MS_OVERSUB || (r.blocks & MR_FAR);
 }
 AHIP_DEVINL TokSink member_sink(u32 *tokens, uint2 *dir, u64 out_rel, u64 out_limit, u32 k) {
-  TokSink sk{nullptr, 0, nullptr, 0, 0, ~0u, 0, 0, false};
+  TokSink sk{nullptr, 0, nullptr, 0, 0, ~0u, 0, 0, false, false};
   if (tokens) {
     u64 toff, doff;
     tok_layout(out_rel, out_limit, k, toff, sk.col_cap, doff, sk.dir_cap);
@@ -68,15 +69,43 @@ AHIP_DEVINL TokSink member_sink(u32 *tokens, uint2 *dir, u64 out_rel, u64 out_li
   }
   return sk;
 }
+// A launch over a LIST of members (ids[k], ascending) instead of a range; rel[k] = where member ids[k]'s token area
+// starts, counted in output bytes like tok_layout()'s out_rel.
+struct MemberSel { const u32 *ids; const u64 *rel; };
+AHIP_DEVINL u32 member_index(const MemberSel &sel, u32 first, u32 k) { return sel.ids ? uniform(sel.ids[k]) : first + k; }
+// Token areas laid out along the input (tok_layout_in): `pos` = the K candidate positions of the stream.
+struct InLayout { const u64 *pos; u32 K; u64 in_len; };
+AHIP_DEVINL void in_layout(const InLayout &lay, u32 c, u64 &toff, u32 &col_cap, u64 &doff, u32 &dir_cap) {
+  const u64 p0 = uniform64(lay.pos[c]);
+  const u64 p1 = c + 1 < lay.K ? uniform64(lay.pos[c + 1]) : lay.in_len;
+  tok_layout_in(p0, p1 > p0 ? p1 - p0 : 0, c, toff, col_cap, doff, dir_cap);
+}
+AHIP_DEVINL TokSink candidate_sink(u32 *tokens, uint2 *dir, const InLayout &lay, u32 c) {
+  TokSink sk{nullptr, 0, nullptr, 0, 0, ~0u, 0, 0, false, true};
+  u64 toff, doff;
+  in_layout(lay, c, toff, sk.col_cap, doff, sk.dir_cap);
+  sk.area = tokens + toff;
+  sk.dir = dir + doff;
+  return sk;
+}
+// Work is handed out by a counter (`next`), one member at a time in index order: a workgroup that only becomes
+// resident late (the occupancy the runtime reports is not always what the hardware grants) simply finds less to do.
+// KEEP: a sizing run that keeps its tokens, laid out along the input (InLayout).
+AHIP_DEVINL u32 next_member(u32 *next, int lane) {
+  u32 k = 0;
+  if (lane == 0) k = atomicAdd(next, 1u);
+  return uniform(k);  // lane 0's value
+}
+template <bool KEEP>
 __global__ __launch_bounds__(64, AHIP_TOK_MIN_WAVES) void inflate_tokenize_kernel(const u8 *__restrict__ in, u64 in_len,
                                                              const MemberDesc *__restrict__ members, u32 first_member,
                                                              u32 n_members, u32 *__restrict__ tokens, uint2 *__restrict__ dir,
                                                              u64 group_out0, MemberResult *__restrict__ results,
-                                                             u32 *__restrict__ late) {
+                                                             u32 *__restrict__ late, InLayout lay, MemberSel sel) {
   __shared__ TokKernelLds lds;
   const int lane = threadIdx.x;
-  for (u32 k = blockIdx.x; k < n_members; k += gridDim.x) {
-    const u32 m = first_member + k;
+  for (u32 k = next_member(late + 1, lane); k < n_members; k = next_member(late + 1, lane)) {
+    const u32 m = member_index(sel, first_member, k);
     MemberDesc d = members[m];
     d.in_off = uniform64(d.in_off);
     d.out_off = uniform64(d.out_off);
@@ -85,28 +114,47 @@ __global__ __launch_bounds__(64, AHIP_TOK_MIN_WAVES) void inflate_tokenize_kerne
     static_assert(sizeof(HeaderLds) + 1024 <= sizeof(TokLds), "header scratch must fit behind the staged header");
     HeaderLds &hdr = *(HeaderLds *)((u8 *)lds.p.inbuf + 1024);
     const u64 lim = uniform64(d.in_end) ? uniform64(d.in_end) : in_len;
-    inflate_member<false, true>(lds.w, hdr, &lds.p, in, lim, d, (u8 *)nullptr,
-                                member_sink(tokens, dir, d.out_off - group_out0, d.out_limit, k), results[m], lane);
+    const bool sizing = !tokens || KEEP;
+    TokSink sk = KEEP ? candidate_sink(tokens, dir, lay, m)
+                         : member_sink(tokens, dir, sel.ids ? uniform64(sel.rel[k]) : d.out_off - group_out0, d.out_limit, k);
+    // keep the sink in scalar registers whichever layout made it
+    sk.col_cap = uniform(sk.col_cap);
+    sk.dir_cap = uniform(sk.dir_cap);
+    inflate_member<false, true>(lds.w, hdr, &lds.p, in, lim, d, (u8 *)nullptr, sk, results[m], lane);
     // rare: inflate_late_kernel finishes these (a sizing run only cares about the ones whose size it does not know yet)
-    if (lane == 0 && (tokens ? member_is_late(results[m]) : results[m].status == MS_OVERSUB)) atomicAdd(late, 1u);
+    if (lane == 0 && (sizing ? results[m].status == MS_OVERSUB : member_is_late(results[m]))) atomicAdd(late, 1u);
   }
 }
 
+// KEPT: the tokens are those a sizing run kept (InLayout, `sized`); members it could not serve are skipped.
+template <bool KEPT>
 __global__ __launch_bounds__(64, AHIP_RES_MIN_WAVES) void inflate_resolve_kernel(const u8 *__restrict__ in,
                                                             const MemberDesc *__restrict__ members, u32 first_member,
                                                             u32 n_members, u8 *out, const u32 *__restrict__ tokens,
                                                             const uint2 *__restrict__ dir, u64 group_out0,
-                                                            MemberResult *__restrict__ results) {
+                                                            MemberResult *__restrict__ results, InLayout lay,
+                                                            const MemberResult *__restrict__ sized, MemberSel sel,
+                                                            u32 *__restrict__ next) {
   __shared__ ParLds lds;
   const int lane = threadIdx.x;
-  for (u32 k = blockIdx.x; k < n_members; k += gridDim.x) {
-    const u32 m = first_member + k;
+  for (u32 k = next_member(next, lane); k < n_members; k = next_member(next, lane)) {
+    const u32 m = member_index(sel, first_member, k);
     const u64 out_off = uniform64(members[m].out_off), out_limit = uniform64(members[m].out_limit);
-    if (uniform(results[m].status) == MS_TOKFULL || uniform(results[m].status) == MS_OVERSUB || (uniform(results[m].blocks) & MR_FAR)) continue;  // inflate_late_kernel
-    const u32 ndir = (u32)uniform64(results[m].tok_words);
+    u32 ndir;
     u64 toff, doff;
     u32 cc, dc;
-    tok_layout(out_off - group_out0, out_limit, k, toff, cc, doff, dc);
+    if (KEPT) {  // the tokens of the sizing run
+      const u32 c = uniform(members[m].pad);
+      if (uniform(sized[c].status) != MS_OK || (uniform(sized[c].blocks) & MR_FAR)) continue;  // HF_RETOK: tokenized again, afterwards
+      if (lane == 0) results[m] = sized[c];
+      if (uniform64(members[m].in_off) >= lay.in_len) continue;  // a long member: decoded by many waves, elsewhere
+      ndir = (u32)uniform64(sized[c].tok_words);
+      in_layout(lay, c, toff, cc, doff, dc);
+    } else {
+      if (uniform(results[m].status) == MS_TOKFULL || uniform(results[m].status) == MS_OVERSUB || (uniform(results[m].blocks) & MR_FAR)) continue;  // inflate_late_kernel
+      ndir = (u32)uniform64(results[m].tok_words);
+      tok_layout(sel.ids ? uniform64(sel.rel[k]) : out_off - group_out0, out_limit, k, toff, cc, doff, dc);
+    }
     u32 cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     resolve_member(lds, in, tokens + toff, dir + doff, ndir, out + out_off, cyc, lane);
 #if defined(AHIP_PROFILE) && !defined(AHIP_PROFILE_TOK_ONLY)
@@ -127,7 +175,7 @@ __global__ __launch_bounds__(64) void inflate_late_kernel(const u8 *__restrict__
                                                          u32 n_members, u8 *out, const u32 *__restrict__ tokens,
                                                          const uint2 *__restrict__ dir, u64 group_out0,
                                                          MemberResult *__restrict__ results, const u32 *__restrict__ late,
-                                                         u32 *__restrict__ exact) {
+                                                         u32 *__restrict__ exact, MemberSel sel) {
   if (*late == 0) return;
   __shared__ WaveLds lds;
   __shared__ HeaderLds hdr;
@@ -135,16 +183,17 @@ __global__ __launch_bounds__(64) void inflate_late_kernel(const u8 *__restrict__
   const int lane = threadIdx.x;
   // 64 members per look (one per lane, the next look's loads already in flight); the late ones of a look in order
   u32 st_n = 0, bl_n = 0;
-  if ((u32)lane < n_members) { st_n = results[first_member + lane].status; bl_n = results[first_member + lane].blocks; }
+  auto idx_of = [&](u32 k) { return sel.ids ? sel.ids[k] : first_member + k; };
+  if ((u32)lane < n_members) { st_n = results[idx_of(lane)].status; bl_n = results[idx_of(lane)].blocks; }
   for (u32 base = 0; base < n_members; base += 64) {
     const u32 st_c = st_n, bl_c = bl_n;
-    if (base + 64 + (u32)lane < n_members) { st_n = results[first_member + base + 64 + lane].status; bl_n = results[first_member + base + 64 + lane].blocks; }
+    if (base + 64 + (u32)lane < n_members) { st_n = results[idx_of(base + 64 + lane)].status; bl_n = results[idx_of(base + 64 + lane)].blocks; }
     const bool have = base + (u32)lane < n_members;
     u64 todo = __ballot(have && (WRITE ? (st_c == MS_TOKFULL || st_c == MS_OVERSUB || (bl_c & MR_FAR)) : st_c == MS_OVERSUB));
     while (todo) {
       const int j = __builtin_ctzll(todo);
       todo &= todo - 1;
-      const u32 k = base + (u32)j, m = first_member + k;
+      const u32 k = base + (u32)j, m = member_index(sel, first_member, k);
       const u32 status = lane_bcast(st_c, j);
       MemberDesc d = members[m];
       d.in_off = uniform64(d.in_off);
@@ -153,12 +202,13 @@ __global__ __launch_bounds__(64) void inflate_late_kernel(const u8 *__restrict__
       d.hist = uniform(d.hist);
       if (status == MS_TOKFULL || status == MS_OVERSUB) {
         const u64 lim = uniform64(d.in_end) ? uniform64(d.in_end) : in_len;
-        inflate_member<WRITE, false>(lds, hdr, nullptr, in, lim, d, out, TokSink{nullptr, 0, nullptr, 0, 0, ~0u, 0, 0, false}, results[m], lane,
+        inflate_member<WRITE, false>(lds, hdr, nullptr, in, lim, d, out, TokSink{nullptr, 0, nullptr, 0, 0, ~0u, 0, 0, false, false}, results[m], lane,
                                      nullptr, exact);
+        if (!WRITE && lane == 0) results[m].blocks |= MR_FAR;  // sized here: no tokens of it exist
       } else if (WRITE) {
         u64 toff, doff;
         u32 cc, dc;
-        tok_layout(d.out_off - group_out0, d.out_limit, k, toff, cc, doff, dc);
+        tok_layout(sel.ids ? uniform64(sel.rel[k]) : d.out_off - group_out0, d.out_limit, k, toff, cc, doff, dc);
         u32 cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         resolve_member(par, in, tokens + toff, dir + doff, (u32)uniform64(results[m].tok_words), out + d.out_off, cyc, lane);
       }
@@ -241,12 +291,18 @@ struct DevBuf {
 };
 
 thread_local DevBuf g_scratch, g_tokens;
+// What the token scratch of this thread holds: every (re)writer takes a fresh process-wide number, so a plan that kept
+// the tokens of its sizing run can tell whether they are still there.
+static std::atomic<u64> g_tok_gen_counter{0};
+thread_local u64 g_tok_gen = 0;
 hipError_t scratch_reserve(size_t bytes, void **p) {
+  g_tok_gen = ++g_tok_gen_counter;
   hipError_t e = g_scratch.reserve(bytes);
   *p = g_scratch.p;
   return e;
 }
 hipError_t tokens_reserve(size_t bytes, void **p) {
+  g_tok_gen = ++g_tok_gen_counter;
   hipError_t e = g_tokens.reserve(bytes);
   *p = g_tokens.p;
   return e;
@@ -279,25 +335,36 @@ static u64 group_out_max() {
 #define GROUP_OUT_MAX group_out_max()
 
 // members[first .. first+count) with output offsets [out0, out1): tokenize (+ resolve when WRITE)
+static int tok_resident = 0, res_resident = 0;  // workgroups of the tokenizer / resolver resident at once
+static thread_local DevBuf g_late, g_exact, g_tokens2, g_scratch2;
+// The token / directory scratch is shared by every launch of the thread: a launch on another stream than the
+// previous one first waits for that one to be done with it.
+static thread_local hipEvent_t scratch_free = nullptr;
+static thread_local hipStream_t scratch_user = nullptr;
+static hipError_t scratch_acquire(hipStream_t st) {
+  hipError_t e = hipSuccess;
+  if (!scratch_free) { e = hipEventCreateWithFlags(&scratch_free, hipEventDisableTiming); if (e != hipSuccess) return e; scratch_user = st; }
+  if (scratch_user != st) { e = hipStreamWaitEvent(st, scratch_free, 0); if (e != hipSuccess) return e; scratch_user = st; }
+  return e;
+}
+// lay_pos (sizing runs only): the K candidate positions -- the run keeps its tokens, laid out along the input, and
+// *gen_out names the scratch contents they are (0: not kept).
 template <bool WRITE>
 hipError_t launch_inflate_group(const u8 *in, u64 n, const MemberDesc *members, u32 first, u32 count, u64 out0, u64 out1,
-                                u8 *out, MemberResult *res, hipStream_t st) {
-  static int tok_resident = 0, res_resident = 0;
+                                u8 *out, MemberResult *res, hipStream_t st, const u64 *lay_pos = nullptr, u64 *gen_out = nullptr) {
+  if (gen_out) *gen_out = 0;
   if (!tok_resident) {
     int dev = 0, cus = 0, a = 0, b = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (e != hipSuccess) return e;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, inflate_tokenize_kernel, 64, 0);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, inflate_tokenize_kernel<false>, 64, 0);
     if (e != hipSuccess) return e;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, inflate_resolve_kernel, 64, 0);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, inflate_resolve_kernel<false>, 64, 0);
     if (e != hipSuccess) return e;
-    // hipOccupancyMaxActiveBlocksPerMultiprocessor over-reports these kernels by one workgroup per CU
-    // on gfx950 / ROCm 7.2 (MI355X_MICROARCH.md, "Residency"): with the API's number the surplus
-    // workgroups only start when resident ones finish, which cost 15-25 % here.  One less is what fits.
-    a = a > 1 ? a - 1 : a;
-    b = b > 1 ? b - 1 : b;
+    // (the number the runtime reports is sometimes one workgroup per CU more than the hardware grants -- MI355X_MICROARCH.md,
+    // "Residency"; members are handed out by a counter, so the surplus workgroups just find nothing left to do)
     if (const char *e1 = getenv("AHIP_TOK_WGS_PER_CU")) a = atoi(e1);  // tuning overrides
     if (const char *e2 = getenv("AHIP_RES_WGS_PER_CU")) b = atoi(e2);
     tok_resident = cus * (a > 0 ? a : 1);
@@ -306,12 +373,17 @@ hipError_t launch_inflate_group(const u8 *in, u64 n, const MemberDesc *members, 
   const u32 grid1 = count < (u32)tok_resident ? count : (u32)tok_resident;
   void *tp = nullptr, *dp = nullptr;
   hipError_t e = hipSuccess;
-  // The token / directory scratch is shared by every launch of the process: a launch on another stream than the
-  // previous one first waits for that one to be done with it.
-  static thread_local hipEvent_t scratch_free = nullptr;
-  static thread_local hipStream_t scratch_user = nullptr;
-  if (!scratch_free) { e = hipEventCreateWithFlags(&scratch_free, hipEventDisableTiming); if (e != hipSuccess) return e; scratch_user = st; }
-  if (scratch_user != st) { e = hipStreamWaitEvent(st, scratch_free, 0); if (e != hipSuccess) return e; scratch_user = st; }
+  e = scratch_acquire(st);
+  if (e != hipSuccess) return e;
+  InLayout lay{nullptr, 0, n};
+  if (!WRITE && lay_pos && first == 0 && !getenv("AHIP_NO_TOKEN_REUSE") && n <= (4ull << 30)) {
+    e = tokens_reserve(((size_t)n * IN_R + (size_t)count * IN_PAD + 64) * 4, &tp);
+    if (e != hipSuccess) return e;
+    e = scratch_reserve(((size_t)(n / 32) + (size_t)count * 64 + 64) * 8, &dp);
+    if (e != hipSuccess) return e;
+    lay = InLayout{lay_pos, count, n};
+    if (gen_out) *gen_out = g_tok_gen;
+  }
   if (WRITE) {
     // 1.5 token words + 1/16 directory entry per output byte, plus a fixed allowance per member (tok_layout)
     const u64 span = out1 - out0;
@@ -323,22 +395,77 @@ hipError_t launch_inflate_group(const u8 *in, u64 n, const MemberDesc *members, 
   }
   if (getenv("AHIP_DEBUG")) fprintf(stderr, "[ahip] inflate group first=%u count=%u grid=%u/%d out=%llu write=%d\n", first, count, grid1, res_resident, (unsigned long long)(out1 - out0), (int)WRITE);
   // the late list: a counter + the scratch of the exact (over-subscribed) tables
-  static thread_local DevBuf dlate, dexact;
+  DevBuf &dlate = g_late, &dexact = g_exact;
   e = dlate.reserve(64);
   if (e != hipSuccess) return e;
   e = dexact.reserve(2 * 32768 * 4);
   if (e != hipSuccess) return e;
-  e = hipMemsetAsync(dlate.p, 0, 4, st);
+  e = hipMemsetAsync(dlate.p, 0, 64, st);  // [0] late members, [1] / [2] the tokenizer's / resolver's next member
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(inflate_tokenize_kernel, dim3(grid1), dim3(64), 0, st, in, n, members, first, count, (u32 *)tp, (uint2 *)dp,
-                     out0, res, dlate.as<u32>());
+  if (lay.pos)
+    hipLaunchKernelGGL(inflate_tokenize_kernel<true>, dim3(grid1), dim3(64), 0, st, in, n, members, first, count, (u32 *)tp, (uint2 *)dp,
+                       out0, res, dlate.as<u32>(), lay, MemberSel{nullptr, nullptr});
+  else
+    hipLaunchKernelGGL(inflate_tokenize_kernel<false>, dim3(grid1), dim3(64), 0, st, in, n, members, first, count, (u32 *)tp, (uint2 *)dp,
+                       out0, res, dlate.as<u32>(), lay, MemberSel{nullptr, nullptr});
   if (WRITE) {
     const u32 grid2 = count < (u32)res_resident ? count : (u32)res_resident;
-    hipLaunchKernelGGL(inflate_resolve_kernel, dim3(grid2), dim3(64), 0, st, in, members, first, count, out,
-                       (const u32 *)tp, (const uint2 *)dp, out0, res);
+    hipLaunchKernelGGL(inflate_resolve_kernel<false>, dim3(grid2), dim3(64), 0, st, in, members, first, count, out,
+                       (const u32 *)tp, (const uint2 *)dp, out0, res, InLayout{nullptr, 0, n}, (const MemberResult *)nullptr,
+                       MemberSel{nullptr, nullptr}, dlate.as<u32>() + 2);
   }
   hipLaunchKernelGGL(inflate_late_kernel<WRITE>, dim3(1), dim3(64), 0, st, in, n, members, first, count, out, (const u32 *)tp,
-                     (const uint2 *)dp, out0, res, dlate.as<u32>(), dexact.as<u32>());
+                     (const uint2 *)dp, out0, res, dlate.as<u32>(), dexact.as<u32>(), MemberSel{nullptr, nullptr});
+  e = hipEventRecord(scratch_free, st);
+  if (e != hipSuccess) return e;
+  return hipGetLastError();
+}
+
+// The decode proper from the tokens a sizing run kept (launch_inflate_group<false> with lay_pos): every member's
+// candidate (MemberDesc::pad) has its runs in the scratch, so only the resolver runs; results are the sizing run's.
+hipError_t launch_resolve_kept(const u8 *in, u64 n, const MemberDesc *members, u32 M, u8 *out, MemberResult *res,
+                               const u64 *cand_pos, u32 K, const MemberResult *sized, hipStream_t st) {
+  hipError_t e = scratch_acquire(st);
+  if (e != hipSuccess) return e;
+  const u32 resident = res_resident > 0 ? (u32)res_resident : 4096u;
+  const u32 grid = M < resident ? M : resident;
+  e = g_late.reserve(64);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(g_late.p, 0, 64, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(inflate_resolve_kernel<true>, dim3(grid), dim3(64), 0, st, in, members, 0u, M, out, (const u32 *)g_tokens.p,
+                     (const uint2 *)g_scratch.p, (u64)0, res, InLayout{cand_pos, K, n}, sized, MemberSel{nullptr, nullptr},
+                     g_late.as<u32>() + 2);
+  e = hipEventRecord(scratch_free, st);
+  if (e != hipSuccess) return e;
+  return hipGetLastError();
+}
+// ... and the members whose kept tokens are no use (HF_RETOK; ids ascending, rel = running sum of their sizes, `span`
+// its total): tokenize + resolve + late as usual, with token areas of their own so that the kept ones survive.
+hipError_t launch_inflate_listed(const u8 *in, u64 n, const MemberDesc *members, const u32 *ids, const u64 *rel, u32 count,
+                                 u64 span, u8 *out, MemberResult *res, hipStream_t st) {
+  if (count == 0) return hipSuccess;
+  hipError_t e = scratch_acquire(st);
+  if (e != hipSuccess) return e;
+  e = g_tokens2.reserve(((size_t)(span * 3 / 2) + (size_t)count * 1024 + 64) * 4);
+  if (e != hipSuccess) return e;
+  e = g_scratch2.reserve(((size_t)(span / 16) + (size_t)count * 64 + 64) * 8);
+  if (e != hipSuccess) return e;
+  e = g_late.reserve(64);
+  if (e != hipSuccess) return e;
+  e = g_exact.reserve(2 * 32768 * 4);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(g_late.p, 0, 64, st);
+  if (e != hipSuccess) return e;
+  const MemberSel sel{ids, rel};
+  const u32 r1 = tok_resident > 0 ? (u32)tok_resident : 2048u, r2 = res_resident > 0 ? (u32)res_resident : 4096u;
+  hipLaunchKernelGGL(inflate_tokenize_kernel<false>, dim3(count < r1 ? count : r1), dim3(64), 0, st, in, n, members, 0u, count,
+                     g_tokens2.as<u32>(), g_scratch2.as<uint2>(), (u64)0, res, g_late.as<u32>(), InLayout{nullptr, 0, n}, sel);
+  hipLaunchKernelGGL(inflate_resolve_kernel<false>, dim3(count < r2 ? count : r2), dim3(64), 0, st, in, members, 0u, count, out,
+                     (const u32 *)g_tokens2.p, (const uint2 *)g_scratch2.p, (u64)0, res, InLayout{nullptr, 0, n},
+                     (const MemberResult *)nullptr, sel, g_late.as<u32>() + 2);
+  hipLaunchKernelGGL(inflate_late_kernel<true>, dim3(1), dim3(64), 0, st, in, n, members, 0u, count, out, (const u32 *)g_tokens2.p,
+                     (const uint2 *)g_scratch2.p, (u64)0, res, g_late.as<u32>(), g_exact.as<u32>(), sel);
   e = hipEventRecord(scratch_free, st);
   if (e != hipSuccess) return e;
   return hipGetLastError();
@@ -348,7 +475,9 @@ hipError_t launch_inflate_group(const u8 *in, u64 n, const MemberDesc *members, 
 // the whole range is known to be small / a sizing run.
 template <bool WRITE>
 hipError_t launch_inflate(const u8 *in, u64 n, const MemberDesc *members, u32 M, u8 *out, MemberResult *res,
-                          hipStream_t st, const u64 *host_out_off = nullptr, u64 total_out = 0) {
+                          hipStream_t st, const u64 *host_out_off = nullptr, u64 total_out = 0, const u64 *lay_pos = nullptr,
+                          u64 *gen_out = nullptr) {
+  if (gen_out) *gen_out = 0;
   if (M == 0) return hipSuccess;
   if (use_serial_kernel()) {
     hipLaunchKernelGGL(inflate_members_serial_kernel<WRITE>, dim3(M), dim3(64), 0, st, in, n, members, M, out, res);
@@ -356,7 +485,7 @@ hipError_t launch_inflate(const u8 *in, u64 n, const MemberDesc *members, u32 M,
   }
   if (!WRITE || !host_out_off) {
     const u64 total = host_out_off ? host_out_off[M] : total_out;
-    return launch_inflate_group<WRITE>(in, n, members, 0, M, 0, total, out, res, st);
+    return launch_inflate_group<WRITE>(in, n, members, 0, M, 0, total, out, res, st, lay_pos, gen_out);
   }
   u32 first = 0;
   while (first < M) {
@@ -388,10 +517,13 @@ struct ahip_gzip_plan {
   const u8 *d_in = nullptr;
   u64 in_len = 0;
   bool sized = false;  // sizes come from a sizing run (exact) rather than BC/ISIZE (trusted, verified)
+  u64 tok_gen = 0;     // ... which kept its tokens in the scratch, as contents number tok_gen (0: it did not)
+  u32 retok_n = 0;     //     except for retok_n members of the chain (ids / running sizes in retok_ids / retok_rel)
+  u64 retok_span = 0;
   u32 K = 0;           // candidates
   ChainSummary sum{};
   DevBuf tile_counts, tile_offsets, cand_pos, hdr, scratch_u32, members, expect_status, results, sizing_descs,
-      sizing_results, dsum, drun;
+      sizing_results, dsum, drun, retok_ids, retok_rel;
   bool ran = false;
   hipStream_t run_stream = nullptr;  // the stream the last ahip_gzip_plan_run was enqueued on
   std::vector<u64> host_out_off;  // M + 1 entries: output offset of every member, then the total
@@ -399,7 +531,7 @@ struct ahip_gzip_plan {
   std::vector<Big> big;           // long members decoded by many waves each (sm_inflate), outside the member launch
   ~ahip_gzip_plan() {
     for (DevBuf *b : {&tile_counts, &tile_offsets, &cand_pos, &hdr, &scratch_u32, &members, &expect_status, &results,
-                      &sizing_descs, &sizing_results, &dsum, &drun})
+                      &sizing_descs, &sizing_results, &dsum, &drun, &retok_ids, &retok_rel})
       b->release();
   }
 };
@@ -416,6 +548,9 @@ int32_t plan_build(ahip_gzip_plan *pl, bool force_sizing, hipStream_t st) {
   const u8 *in = pl->d_in;
   const u64 n = pl->in_len, start = 0;
   pl->sized = false;
+  pl->tok_gen = 0;
+  pl->retok_n = 0;
+  pl->retok_span = 0;
   pl->sum = ChainSummary{};
   pl->K = 0;
   HIP_TRY(pl->dsum.reserve(sizeof(ChainSummary)));
@@ -489,7 +624,7 @@ int32_t plan_build(ahip_gzip_plan *pl, bool force_sizing, hipStream_t st) {
         HIP_TRY(hipMemcpyAsync(pl->sizing_descs.p, sd.data(), (size_t)K * sizeof(MemberDesc), hipMemcpyHostToDevice, st));
     }
     HIP_TRY(launch_inflate<false>(in, n, pl->sizing_descs.as<MemberDesc>(), K, (u8 *)nullptr,
-                                  pl->sizing_results.as<MemberResult>(), st));
+                                  pl->sizing_results.as<MemberResult>(), st, nullptr, 0, pl->cand_pos.as<u64>(), &pl->tok_gen));
     for (auto &mr : measured)
       HIP_TRY(hipMemcpyAsync(pl->sizing_results.as<MemberResult>() + mr.first, &mr.second, sizeof(MemberResult), hipMemcpyHostToDevice, st));
     if (!measured.empty()) HIP_TRY(hipStreamSynchronize(st));
@@ -497,16 +632,43 @@ int32_t plan_build(ahip_gzip_plan *pl, bool force_sizing, hipStream_t st) {
                        pl->sizing_results.as<MemberResult>(), n);
     pl->sized = true;
   }
+  constexpr u32 RETOK_CAP = 4096;
+  HIP_TRY(pl->retok_ids.reserve((size_t)RETOK_CAP * 4));
   HIP_TRY(pl->scratch_u32.reserve((size_t)(K + 1) * 4 * 4));
   HIP_TRY(pl->members.reserve((size_t)K * sizeof(MemberDesc)));
   HIP_TRY(pl->expect_status.reserve((size_t)K * 4));
   u32 *s = pl->scratch_u32.as<u32>();
   hipLaunchKernelGGL(gz_chain, dim3(1), dim3(1024), 0, st, pl->cand_pos.as<u64>(), pl->hdr.as<GzHeader>(), K, start, n,
                      s, s + (K + 1), s + 2 * (size_t)(K + 1), s + 3 * (size_t)(K + 1), pl->members.as<MemberDesc>(),
-                     pl->expect_status.as<u32>(), pl->dsum.as<ChainSummary>());
+                     pl->expect_status.as<u32>(), pl->dsum.as<ChainSummary>(), pl->retok_ids.as<u32>(), RETOK_CAP);
   HIP_TRY(hipMemcpyAsync(&pl->sum, pl->dsum.p, sizeof(ChainSummary), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipGetLastError());
+  if (pl->tok_gen && pl->sum.retok > RETOK_CAP) pl->tok_gen = 0;  // too many to list: the decode tokenizes everything again
+  if (pl->tok_gen && pl->sum.retok) {
+    // the members tokenized again: ascending, with the running sum of their sizes (where their token areas go)
+    const u32 R = pl->sum.retok;
+    std::vector<u32> ids(R);
+    std::vector<u64> sz(R), rel(R);
+    HIP_TRY(hipMemcpyAsync(ids.data(), pl->retok_ids.p, (size_t)R * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    std::sort(ids.begin(), ids.end());
+    HIP_TRY(hipMemcpyAsync(pl->retok_ids.p, ids.data(), (size_t)R * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(pl->retok_rel.reserve((size_t)R * 8));
+    hipLaunchKernelGGL(gz_gather_sizes, dim3(cdiv(R, 256)), dim3(256), 0, st, pl->retok_ids.as<u32>(), R, pl->members.as<MemberDesc>(),
+                       pl->retok_rel.as<u64>());
+    HIP_TRY(hipMemcpyAsync(sz.data(), pl->retok_rel.p, (size_t)R * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    u64 acc = 0;
+    for (u32 i = 0; i < R; ++i) { rel[i] = acc; acc += sz[i]; if (acc > (1ull << 40)) break; }
+    if (acc > (1ull << 40)) pl->tok_gen = 0;
+    else {
+      HIP_TRY(hipMemcpyAsync(pl->retok_rel.p, rel.data(), (size_t)R * 8, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipStreamSynchronize(st));  // rel / ids are host vectors about to go out of scope
+      pl->retok_n = R;
+      pl->retok_span = acc;
+    }
+  }
   if (!pl->sum.first_is_gzip) { pl->sum.members = 0; pl->sum.total_out = 0; pl->sum.tail_pos = start; }
   if (force_sizing && !pl->big.empty() && pl->sum.members) {
     // which members are the long ones (false candidates among them never reach the chain); neutralise those
@@ -554,9 +716,20 @@ int32_t plan_run(ahip_gzip_plan *pl, u8 *d_out, size_t out_cap, hipStream_t st) 
   if (M == 0) return AHIP_OK;
   HIP_TRY(pl->results.reserve((size_t)M * sizeof(MemberResult)));
   const u64 whole[2] = {0, pl->sum.total_out};  // one group: only its total is needed
-  HIP_TRY(launch_inflate<true>(pl->d_in, pl->in_len, pl->members.as<MemberDesc>(), M, d_out,
-                               pl->results.as<MemberResult>(), st,
-                               pl->host_out_off.empty() ? nullptr : pl->host_out_off.data(), whole[1]));
+  if (getenv("AHIP_DEBUG")) fprintf(stderr, "[ahip] plan_run: sized=%d kept tokens %llu (scratch holds %llu) retok=%u\n", (int)pl->sized,
+                                    (unsigned long long)pl->tok_gen, (unsigned long long)g_tok_gen, pl->sum.retok);
+  if (pl->sized && pl->tok_gen && pl->tok_gen == g_tok_gen && !use_serial_kernel()) {
+    // the sizing run's tokens are still in the scratch: resolve them, then tokenize + resolve the few members whose
+    // tokens are no use (a full area -- a false candidate cut it short --, a reach into earlier members, an error)
+    HIP_TRY(launch_resolve_kept(pl->d_in, pl->in_len, pl->members.as<MemberDesc>(), M, d_out, pl->results.as<MemberResult>(),
+                                pl->cand_pos.as<u64>(), pl->K, pl->sizing_results.as<MemberResult>(), st));
+    HIP_TRY(launch_inflate_listed(pl->d_in, pl->in_len, pl->members.as<MemberDesc>(), pl->retok_ids.as<u32>(), pl->retok_rel.as<u64>(),
+                                  pl->retok_n, pl->retok_span, d_out, pl->results.as<MemberResult>(), st));
+  } else {
+    HIP_TRY(launch_inflate<true>(pl->d_in, pl->in_len, pl->members.as<MemberDesc>(), M, d_out,
+                                 pl->results.as<MemberResult>(), st,
+                                 pl->host_out_off.empty() ? nullptr : pl->host_out_off.data(), whole[1]));
+  }
   for (const auto &bg : pl->big) {  // long members: many waves each, straight into place
     MemberResult r{};
     bool handled = false;

@@ -25,6 +25,7 @@ constexpr u64 POS_UNKNOWN = ~0ull;
 constexpr u32 HF_BC = 1;     // size known from the BC subfield
 constexpr u32 HF_RANGE = 2;  // header runs past the end of the input: RangeError in the reference
 constexpr u32 HF_SIZED = 4;  // next_pos/size come from a sizing run
+constexpr u32 HF_RETOK = 8;  // ... whose tokens cannot serve the decode proper (error, q8 reach, full token area, late path)
 
 struct GzHeader {
   u64 payload_off;  // first DEFLATE byte
@@ -43,6 +44,8 @@ struct ChainSummary {
   u32 range_error;   // a header or trailer on the chain runs past the end
   u32 unknown;       // candidates whose size is not known yet (valid after gz_parse_headers)
   u32 stopped_unknown; // the chain reached a member of unknown size: a sizing run is needed
+  u32 retok;         // members on the chain that carry HF_RETOK
+  u32 pad;
 };
 
 // 16-bit mask of candidate positions base+0 .. base+15
@@ -220,6 +223,7 @@ __global__ __launch_bounds__(256) void gz_apply_sizing(GzHeader *hdr, u32 K, con
   if (h.flags & HF_RANGE) return;
   MemberResult r = res[i];
   h.flags = (h.flags & ~HF_BC) | HF_SIZED;
+  if (r.status != MS_OK || (r.blocks & MR_FAR)) h.flags |= HF_RETOK;
   h.size = r.out_len;
   h.status = r.status;
   h.next_pos = r.end_pos + 8;  // CRC32 + ISIZE are read unconditionally (:40-41)
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(256) void gz_apply_sizing(GzHeader *hdr, u32 K, con
 //   nxt/jmp/jmp2/reach: scratch arrays of K+1 u32.
 __global__ __launch_bounds__(1024) void gz_chain(const u64 *cand_pos, const GzHeader *hdr, u32 K, u64 start, u64 n,
                                                  u32 *nxt, u32 *jmp, u32 *jmp2, u32 *reach, MemberDesc *members,
-                                                 u32 *expect_status, ChainSummary *sum) {
+                                                 u32 *expect_status, ChainSummary *sum, u32 *retok_ids, u32 retok_cap) {
   const u32 tid = threadIdx.x;
   __shared__ u64 wsum_a[16], wsum_b[16], wsum_c[16];
   __shared__ u64 carry_a, carry_b, carry_c;
@@ -348,9 +352,13 @@ __global__ __launch_bounds__(1024) void gz_chain(const u64 *cand_pos, const GzHe
       d.expect_end = (h.flags & HF_RANGE) ? POS_UNKNOWN : h.next_pos - 8;
       d.in_end = 0;
       d.hist = d.out_off < 32768 ? (u32)d.out_off : 32768u;  // every member appends to the same OutputStream (q8)
-      d.pad = 0;
+      d.pad = i;  // its candidate: where a sizing run left its tokens
       members[m] = d;
       expect_status[m] = h.status;
+      if (h.flags & HF_RETOK) {  // listed (in no particular order) for the launch that tokenizes them again
+        const u32 slot = atomicAdd(&sum->retok, 1u);
+        if (slot < retok_cap) retok_ids[slot] = (u32)m;
+      }
       if (nxt[i] == K) {  // last member of the chain
         sum->tail_pos = h.next_pos;
         if (!(h.flags & (HF_BC | HF_SIZED | HF_RANGE))) sum->stopped_unknown = 1;
@@ -369,6 +377,11 @@ __global__ __launch_bounds__(1024) void gz_chain(const u64 *cand_pos, const GzHe
     sum->first_is_gzip = first_ok ? 1u : 0u;
     if (!first_ok) sum->tail_pos = start;
   }
+}
+
+__global__ __launch_bounds__(256) void gz_gather_sizes(const u32 *ids, u32 count, const MemberDesc *members, u64 *sizes) {
+  u32 i = blockIdx.x * 256 + threadIdx.x;
+  if (i < count) sizes[i] = members[ids[i]].out_limit;
 }
 
 // Post-decode check of the trusted (BC/ISIZE) index and of per-member verdicts.

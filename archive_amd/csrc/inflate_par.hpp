@@ -126,6 +126,7 @@ struct TokSink {
   u32 dir_cap, ndir;
   u32 scol, spos, srun;  // serial writer: its column (~0u: none yet), next word, first word of the open run
   bool full;
+  bool sizing;  // a sizing run that keeps its tokens: a full sink is reported as MR_FAR next to the true status
 };
 // member k of a launch group whose output starts out_rel bytes into the group's output
 AHIP_DEVINL void tok_layout(u64 out_rel, u64 out_limit, u32 k, u64 &tok_off, u32 &col_cap, u64 &dir_off, u32 &dir_cap) {
@@ -133,6 +134,32 @@ AHIP_DEVINL void tok_layout(u64 out_rel, u64 out_limit, u32 k, u64 &tok_off, u32
   col_cap = (u32)(((out_limit * 3) / 2 + 1023) / 64);
   dir_off = out_rel / 16 + (u64)k * 64;
   dir_cap = (u32)(out_limit / 16 + 63);
+}
+
+// The same areas laid out along the INPUT, for a sizing run that keeps its tokens (output offsets are what it is
+// about to find out): candidate k starts at byte `pos` of the stream and owns it up to the next candidate, `span`
+// bytes on.  3 words of area per compressed byte (a token takes >= 2 bits, usually >= 8), one directory entry per
+// 32 bytes (a run covers one 64-byte item).  A member that does not fit is tokenized again along the output.
+#ifndef AHIP_IN_R
+#define AHIP_IN_R 3
+#endif
+#ifndef AHIP_IN_ALIGN
+#define AHIP_IN_ALIGN 16
+#endif
+#ifndef AHIP_IN_PAD
+#define AHIP_IN_PAD 1024
+#endif
+constexpr u64 IN_R = AHIP_IN_R, IN_ALIGN = AHIP_IN_ALIGN, IN_PAD = AHIP_IN_PAD;  // words per input byte, area alignment and per-candidate allowance (words)
+AHIP_DEVINL void tok_layout_in(u64 pos, u64 span, u32 k, u64 &tok_off, u32 &col_cap, u64 &dir_off, u32 &dir_cap) {
+  // areas start on IN_ALIGN words, columns on 64-byte lines an odd number of lines apart; the allowance pays for the rounding
+  tok_off = (pos * IN_R + (u64)k * IN_PAD) & ~(IN_ALIGN - 1);
+  u64 c16 = (span * IN_R) / 1024;  // whole lines per column
+  if (c16 > 0x003fffffu) c16 = 0x003fffffu;
+  if (!(c16 & 1)) c16 = c16 ? c16 - 1 : 0;
+  col_cap = c16 ? (u32)c16 * 16 : 8u;
+  dir_off = pos / 32 + (u64)k * 64;
+  const u64 dc = span / 32 + 63;
+  dir_cap = dc > 0xffffffffu ? 0xffffffffu : (u32)dc;
 }
 
 struct ParStats { u32 windows, rounds, fallbacks, partial; u32 cyc[8]; u32 dbg; };
@@ -828,8 +855,8 @@ AHIP_DEVINL void inflate_member(WaveLds &L, HeaderLds &H, TokLds *P, const u8 *i
     res.end_pos = end > in_len ? in_len : end;
     if (CHUNK && status == MS_CHUNK_END) res.end_pos = b.pos;
     res.out_len = o.pos - hist;
-    res.status = (PAR && sink.full) ? (u32)MS_TOKFULL : status;
-    res.blocks = blocks | (o.far ? MR_FAR : 0u);
+    res.status = (PAR && sink.full && !sink.sizing) ? (u32)MS_TOKFULL : status;
+    res.blocks = blocks | ((o.far || (PAR && sink.full && sink.sizing)) ? MR_FAR : 0u);
     res.windows = st.windows;
     res.rounds = st.rounds;
     res.fallbacks = st.fallbacks;

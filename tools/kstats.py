@@ -10,12 +10,13 @@ from tools import corpus
 
 members = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 kind = corpus.WIKI if (len(sys.argv) > 2 and sys.argv[2] == "wiki") else corpus.LOG
+bc = not (len(sys.argv) > 3 and sys.argv[3] == "nobc")
 L = N.lib(); L.ahip_init(0)
-cache = "/tmp/ahip_corpus_%d_%d.npz" % (members, kind)
+cache = "/tmp/ahip_corpus_%d_%d_%d.npz" % (members, kind, bc)
 if os.path.exists(cache):
     z = np.load(cache); comp, plain = z["comp"], z["plain"]
 else:
-    comp, plain = corpus.make_gzip(kind=kind, seed=1234 if kind == corpus.LOG else 8, n_members=members, want_plain=True)
+    comp, plain = corpus.make_gzip(kind=kind, seed=1234 if kind == corpus.LOG else 8, n_members=members, bc=bc, want_plain=True)
     np.savez(cache, comp=comp, plain=plain)
 d_in = torch.from_numpy(comp).cuda(); d_out = torch.zeros(len(plain) + 64, dtype=torch.uint8, device="cuda")
 plan = ctypes.c_void_p()
