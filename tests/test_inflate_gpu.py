@@ -294,3 +294,49 @@ def test_position_after_a_failed_block(amd, orc):
         if want[0] != 3:
             assert _gz(amd, g) == _noneify(want), i
     assert n_false >= 8
+
+
+def test_kept_tokens_of_the_sizing_run(amd):
+    """Members without BC: the sizing run keeps its tokens (laid out along the input) and the decode proper resolves them.
+    Members whose token area a false candidate cut short (a stored block holding `1f 8b 08` in front of the Huffman
+    blocks) are tokenized again in a launch of their own; a plan run a second time resolves the kept tokens again;
+    after another call has used the token scratch the plan falls back to tokenizing everything."""
+    import torch
+    from archive_amd import _native as N
+    L = N.lib()
+    parts, blobs = [], []
+    for i in range(200):
+        body = streams.text(20000 + 211 * (i % 37), 100 + i)
+        if i % 19 == 3:  # false candidate 5 bytes into the payload: the real candidate's area ends there
+            head = b"\x1f\x8b\x08\x00" + bytes(range(i % 200, i % 200 + 20))
+            raw = streams.stored_block(head, final=False) + streams.raw_deflate(body)
+            parts.append(head + body)
+            blobs.append(streams.gz_wrap(raw, head + body))
+        else:
+            parts.append(body)
+            blobs.append(streams.gz_member(body))
+    g, want = b"".join(blobs), b"".join(parts)
+    assert gzip.decompress(g) == want
+    d_in = torch.frombuffer(bytearray(g), dtype=torch.uint8).cuda()
+    plan = ctypes.c_void_p()
+    assert L.ahip_gzip_plan_create(d_in.data_ptr(), d_in.numel(), None, ctypes.byref(plan)) == 0, N.last_error()
+    members, out_bytes, payload = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+    L.ahip_gzip_plan_info(plan, ctypes.byref(members), ctypes.byref(out_bytes), ctypes.byref(payload))
+    assert (members.value, out_bytes.value) == (200, len(want))
+    d_out = torch.zeros(len(want), dtype=torch.uint8, device="cuda")
+    olen = ctypes.c_size_t()
+
+    def run_and_check():
+        d_out.zero_()
+        assert L.ahip_gzip_plan_run(plan, d_out.data_ptr(), d_out.numel(), None) == 0, N.last_error()
+        torch.cuda.synchronize()
+        assert L.ahip_gzip_plan_status(plan, ctypes.byref(olen)) == 0 and olen.value == len(want)
+        assert bytes(d_out.cpu().numpy()) == want
+
+    run_and_check()   # kept tokens + the listed members
+    run_and_check()   # the kept tokens once more
+    other = b"".join(streams.gz_member(streams.text(30000, 900 + i)) for i in range(8))
+    assert _gz(amd, other)[0] == 0   # another decode writes the token scratch
+    run_and_check()   # the plan notices and tokenizes again
+    L.ahip_gzip_plan_destroy(plan)
+    assert _gz(amd, g) == (0, want)  # and the one-call path
