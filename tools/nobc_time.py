@@ -1,5 +1,10 @@
+"""Dev tool: config 4 WITHOUT the BGZF BC subfield through the plan API -- time of ahip_gzip_plan_create (index + sizing run
+that keeps its tokens) and of ahip_gzip_plan_run (resolve the kept tokens + the listed members), twice per plan.
+
+    python tools/nobc_time.py 65536        (AHIP_NO_TOKEN_REUSE=1: the two-pass form)
+"""
 import ctypes, os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from archive_amd import _native as N
 from tools import corpus
