@@ -181,13 +181,20 @@ __global__ __launch_bounds__(64) void inflate_late_kernel(const u8 *__restrict__
   __shared__ HeaderLds hdr;
   __shared__ ParLds par;
   const int lane = threadIdx.x;
-  // 64 members per look (one per lane, the next look's loads already in flight); the late ones of a look in order
+  // 64 members per look (one per lane, the next look's loads already in flight); the late ones of a look in order.
+  // A sizing run writes no output, so its members are independent: there the looks are dealt out over the workgroups of
+  // the launch (each with its own exact-table scratch); the decode proper is one workgroup walking all looks in order.
+  const u32 look0 = WRITE ? 0u : blockIdx.x * 64u, look_step = WRITE ? 64u : gridDim.x * 64u;
+  if (!WRITE) exact += (size_t)blockIdx.x * (2u * 32768u);
   u32 st_n = 0, bl_n = 0;
   auto idx_of = [&](u32 k) { return sel.ids ? sel.ids[k] : first_member + k; };
-  if ((u32)lane < n_members) { st_n = results[idx_of(lane)].status; bl_n = results[idx_of(lane)].blocks; }
-  for (u32 base = 0; base < n_members; base += 64) {
+  if (look0 + (u32)lane < n_members) { st_n = results[idx_of(look0 + lane)].status; bl_n = results[idx_of(look0 + lane)].blocks; }
+  for (u32 base = look0; base < n_members; base += look_step) {
     const u32 st_c = st_n, bl_c = bl_n;
-    if (base + 64 + (u32)lane < n_members) { st_n = results[idx_of(base + 64 + lane)].status; bl_n = results[idx_of(base + 64 + lane)].blocks; }
+    if (base + look_step + (u32)lane < n_members) {
+      st_n = results[idx_of(base + look_step + lane)].status;
+      bl_n = results[idx_of(base + look_step + lane)].blocks;
+    }
     const bool have = base + (u32)lane < n_members;
     u64 todo = __ballot(have && (WRITE ? (st_c == MS_TOKFULL || st_c == MS_OVERSUB || (bl_c & MR_FAR)) : st_c == MS_OVERSUB));
     while (todo) {
@@ -398,7 +405,8 @@ hipError_t launch_inflate_group(const u8 *in, u64 n, const MemberDesc *members, 
   DevBuf &dlate = g_late, &dexact = g_exact;
   e = dlate.reserve(64);
   if (e != hipSuccess) return e;
-  e = dexact.reserve(2 * 32768 * 4);
+  constexpr u32 SIZING_LATE_WGS = 64;  // workgroups of a sizing run's late kernel
+  e = dexact.reserve((size_t)2 * 32768 * 4 * (WRITE ? 1u : SIZING_LATE_WGS));
   if (e != hipSuccess) return e;
   e = hipMemsetAsync(dlate.p, 0, 64, st);  // [0] late members, [1] / [2] the tokenizer's / resolver's next member
   if (e != hipSuccess) return e;
@@ -414,7 +422,7 @@ hipError_t launch_inflate_group(const u8 *in, u64 n, const MemberDesc *members, 
                        (const u32 *)tp, (const uint2 *)dp, out0, res, InLayout{nullptr, 0, n}, (const MemberResult *)nullptr,
                        MemberSel{nullptr, nullptr}, dlate.as<u32>() + 2);
   }
-  hipLaunchKernelGGL(inflate_late_kernel<WRITE>, dim3(1), dim3(64), 0, st, in, n, members, first, count, out, (const u32 *)tp,
+  hipLaunchKernelGGL(inflate_late_kernel<WRITE>, dim3(WRITE ? 1u : SIZING_LATE_WGS), dim3(64), 0, st, in, n, members, first, count, out, (const u32 *)tp,
                      (const uint2 *)dp, out0, res, dlate.as<u32>(), dexact.as<u32>(), MemberSel{nullptr, nullptr});
   e = hipEventRecord(scratch_free, st);
   if (e != hipSuccess) return e;
@@ -521,6 +529,7 @@ struct ahip_gzip_plan {
   u32 retok_n = 0;     //     except for retok_n members of the chain (ids / running sizes in retok_ids / retok_rel)
   u64 retok_span = 0;
   u32 K = 0;           // candidates
+  bool cands_ready = false;  // cand_pos / hdr hold this stream's candidates (a rebuild with sizes from the data keeps them)
   ChainSummary sum{};
   DevBuf tile_counts, tile_offsets, cand_pos, hdr, scratch_u32, members, expect_status, results, sizing_descs,
       sizing_results, dsum, drun, retok_ids, retok_rel;
@@ -552,34 +561,39 @@ int32_t plan_build(ahip_gzip_plan *pl, bool force_sizing, hipStream_t st) {
   pl->retok_n = 0;
   pl->retok_span = 0;
   pl->sum = ChainSummary{};
-  pl->K = 0;
   HIP_TRY(pl->dsum.reserve(sizeof(ChainSummary)));
   HIP_TRY(hipMemsetAsync(pl->dsum.p, 0, sizeof(ChainSummary), st));
   if (n < 3) {
+    pl->K = 0;
     pl->sum.tail_pos = start;
     return AHIP_OK;
   }
-  const u32 tiles = cdiv(n - start, TILE_BYTES);
-  HIP_TRY(pl->tile_counts.reserve((size_t)tiles * 4 + 4));
-  HIP_TRY(pl->tile_offsets.reserve((size_t)tiles * 4 + 4));
-  u32 *d_total = pl->tile_offsets.as<u32>() + tiles;
-  hipLaunchKernelGGL(gz_count_candidates, dim3(tiles), dim3(256), 0, st, in, start, n, pl->tile_counts.as<u32>());
-  hipLaunchKernelGGL(scan_exclusive_u32, dim3(1), dim3(1024), 0, st, pl->tile_counts.as<u32>(),
-                     pl->tile_offsets.as<u32>(), (u64)tiles, d_total);
-  u32 K = 0;
-  HIP_TRY(hipMemcpyAsync(&K, d_total, 4, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  pl->K = K;
-  if (K == 0) {
-    pl->sum.tail_pos = start;
-    return AHIP_OK;
+  u32 K = pl->K;
+  if (!(force_sizing && pl->cands_ready)) {  // (the candidates and their parsed headers do not depend on where sizes come from)
+    pl->K = 0;
+    const u32 tiles = cdiv(n - start, TILE_BYTES);
+    HIP_TRY(pl->tile_counts.reserve((size_t)tiles * 4 + 4));
+    HIP_TRY(pl->tile_offsets.reserve((size_t)tiles * 4 + 4));
+    u32 *d_total = pl->tile_offsets.as<u32>() + tiles;
+    hipLaunchKernelGGL(gz_count_candidates, dim3(tiles), dim3(256), 0, st, in, start, n, pl->tile_counts.as<u32>());
+    hipLaunchKernelGGL(scan_exclusive_u32, dim3(1), dim3(1024), 0, st, pl->tile_counts.as<u32>(),
+                       pl->tile_offsets.as<u32>(), (u64)tiles, d_total);
+    K = 0;
+    HIP_TRY(hipMemcpyAsync(&K, d_total, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    pl->K = K;
+    if (K == 0) {
+      pl->sum.tail_pos = start;
+      return AHIP_OK;
+    }
+    HIP_TRY(pl->cand_pos.reserve((size_t)K * 8));
+    HIP_TRY(pl->hdr.reserve((size_t)K * sizeof(GzHeader)));
+    hipLaunchKernelGGL(gz_write_candidates, dim3(tiles), dim3(256), 0, st, in, start, n, pl->tile_counts.as<u32>(),
+                       pl->tile_offsets.as<u32>(), pl->cand_pos.as<u64>());
+    hipLaunchKernelGGL(gz_parse_headers, dim3(cdiv(K, 256)), dim3(256), 0, st, in, n, pl->cand_pos.as<u64>(), K,
+                       pl->hdr.as<GzHeader>(), pl->dsum.as<ChainSummary>());
+    pl->cands_ready = true;
   }
-  HIP_TRY(pl->cand_pos.reserve((size_t)K * 8));
-  HIP_TRY(pl->hdr.reserve((size_t)K * sizeof(GzHeader)));
-  hipLaunchKernelGGL(gz_write_candidates, dim3(tiles), dim3(256), 0, st, in, start, n, pl->tile_counts.as<u32>(),
-                     pl->tile_offsets.as<u32>(), pl->cand_pos.as<u64>());
-  hipLaunchKernelGGL(gz_parse_headers, dim3(cdiv(K, 256)), dim3(256), 0, st, in, n, pl->cand_pos.as<u64>(), K,
-                     pl->hdr.as<GzHeader>(), pl->dsum.as<ChainSummary>());
   if (force_sizing) {
     // sizing run over every candidate: exact end position, size and verdict, no stores
     HIP_TRY(pl->sizing_descs.reserve((size_t)K * sizeof(MemberDesc)));

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void gz_apply_sizing(GzHeader *hdr, u32 K, con
   GzHeader h = hdr[i];
   if (h.flags & HF_RANGE) return;
   MemberResult r = res[i];
-  h.flags = (h.flags & ~HF_BC) | HF_SIZED;
+  h.flags = (h.flags & ~(HF_BC | HF_RETOK)) | HF_SIZED;
   if (r.status != MS_OK || (r.blocks & MR_FAR)) h.flags |= HF_RETOK;
   h.size = r.out_len;
   h.status = r.status;
