@@ -52,7 +52,8 @@ struct TokKernelLds {
   TokLds p;
 };
 
-// Persistent workgroups: the grid is sized to what is resident at once and strides over the members.
+// Persistent workgroups: the grid is sized to what the runtime says is resident at once; members are handed out by a
+// device counter (next_member), so a workgroup that starts late simply finds less to do.
 //  tokens == nullptr: sizing run (end position, size and verdict only).
 //  tokens / dir: the launch group's token areas and run directories (TokSink, tok_layout).
 // members the fast kernels leave to inflate_late_kernel
