@@ -949,12 +949,19 @@ AHIP_DEVINL void resolve_member(ParLdsT<E> &P, const u8 *in, const u32 *area, co
     E *obw = P.obuf + A;
     // software-pipelined by one chunk of 64 tokens: the history loads of chunk c+1 are in flight while
     // chunk c is deposited
+#ifdef AHIP_TOKEN_RESOLVER
+    struct Chunk { u32 idx, len, off, key, total, nf, nin, tokw; bool fits, pre, cut; u64 w0, w1; };
+#else
     struct Chunk { u32 idx, len, off, key, total, nf, nin; bool fits, pre, cut; u64 w0, w1; };
+#endif
     auto prep = [&](u32 c, u32 run) -> Chunk {
       Chunk q;
       q.idx = c + lane;
       const bool inb = q.idx < ntok;
       const u32 t = inb ? P.tok[q.idx] : 0u;
+#ifdef AHIP_TOKEN_RESOLVER
+      q.tokw = t;
+#endif
       const bool lit = t >> 31;
       q.len = inb ? (lit ? 1u : (t >> 16)) : 0u;
       q.off = run + wave_excl_sum(q.len, q.total);
@@ -1001,6 +1008,64 @@ AHIP_DEVINL void resolve_member(ParLdsT<E> &P, const u8 *in, const u32 *area, co
         }
 #endif
       }
+#ifdef AHIP_TOKEN_RESOLVER
+      // EXPERIMENT (off by default, not yet run on a GPU; the algorithm is checked byte for byte by
+      // tools/analysis/resolver_model.c): finish every token of the chunk right here, 64 tokens per step, and drop
+      // the byte pass.  Literals store their byte; matches from flushed output were deposited above (ck.pre); the
+      // rest goes in ROUNDS: the first pending match is always ready (all bytes in front of its destination are
+      // final), a later one when its source ends at or before the first pending destination.  Ready matches of
+      // <= 16 bytes whose source does not overlap their destination read 16 window bytes and deposit like the far
+      // ones; long, self-overlapping or window-straddling ones are copied by the whole wave, one token at a time.
+      if constexpr (!MARK) {
+        const bool t_lit = ck.tokw >> 31;
+        const u32 t_dist = ck.tokw & 0xffffu;
+        const i32 srel = (i32)ck.off - (i32)t_dist;  // source start relative to the window (negative: flushed output)
+        if (ck.fits && t_lit) P.obuf[A + ck.off] = (E)(u8)(ck.tokw >> 16);
+        bool pend = ck.fits && !t_lit && !ck.pre;
+        wave_sync();  // phase-1 bytes (literals, deposits) are in the window
+        u64 pm = __ballot(pend);
+        u32 rguard = 0;
+        while (pm && ++rguard <= 64) {
+          const int first = __builtin_ctzll(pm);
+          const u32 first_dst = lane_bcast(ck.off, first);
+          const bool ready = pend && (lane == first || srel + (i32)ck.len <= (i32)first_dst);
+          const bool simple = ready && ck.len <= 16 && t_dist >= ck.len && srel >= 0;
+          if (simple) {
+            const u64 w0 = ((const unaligned_u64 *)&P.obuf[A + (u32)srel])->v, w1 = ((const unaligned_u64 *)&P.obuf[A + (u32)srel + 8])->v;
+            E *dp = &P.obuf[A + ck.off];
+            if (ck.len >= 8) {
+              const u32 sh = 8 * (ck.len - 8);
+              const u64 tail = sh == 0 ? w0 : (sh == 64 ? w1 : ((w0 >> sh) | (w1 << (64 - sh))));
+              ((unaligned_u64 *)dp)->v = w0;
+              ((unaligned_u64 *)(dp + ck.len - 8))->v = tail;
+            } else if (ck.len >= 4) {
+              ((unaligned_u32 *)dp)->v = (u32)w0;
+              ((unaligned_u32 *)(dp + ck.len - 4))->v = (u32)(w0 >> (8 * (ck.len - 4)));
+            } else {
+              dp[0] = (u8)w0; dp[1] = (u8)(w0 >> 8); dp[2] = (u8)(w0 >> 16);
+            }
+          }
+          u64 hm = __ballot(ready && !simple);
+          while (hm) {  // one token at a time, a byte per lane (sources are final: they end in front of first_dst)
+            const int j = __builtin_ctzll(hm);
+            hm &= hm - 1;
+            const u32 L_ = lane_bcast(ck.len, j), D_ = lane_bcast(t_dist, j), O_ = lane_bcast(ck.off, j);
+            const i32 S_ = (i32)O_ - (i32)D_;
+            for (u32 k = (u32)lane; k < L_; k += 64) {
+              const i32 si = S_ + (i32)(D_ < L_ ? k % D_ : k);
+              // (values are selected, not pointers: an LDS / global pointer select trips the gfx950 backend)
+              const u32 lv = P.obuf[A + (u32)(si >= 0 ? si : 0)];
+              u32 gv = 0;
+              if (si < 0) gv = hist_get((const E *)g, si, opos);
+              P.obuf[A + O_ + k] = (E)(si >= 0 ? lv : gv);
+            }
+          }
+          pend = pend && !ready;
+          pm = __ballot(pend);
+          wave_sync();  // this round's bytes are final for the next one
+        }
+      } else
+#endif
       if (ck.fits) P.tok[ck.idx] = ck.key | (ck.pre ? 0x8000u : 0u);
       if (ck.cut) {
         kept = c + ck.nf;
@@ -1018,6 +1083,9 @@ AHIP_DEVINL void resolve_member(ParLdsT<E> &P, const u8 *in, const u32 *area, co
     AHIP_TICK(t_1);
     AHIP_ACC(cyc[6], t_0, t_1);
     const u32 nbytes = run;
+#ifdef AHIP_TOKEN_RESOLVER
+    if constexpr (MARK)
+#endif
     resolve_bytes(P, ntok, nbytes, (const E *)g, opos, A, lane);
     wave_sync();
     AHIP_TICK(t_2);
