@@ -1,6 +1,6 @@
 // Micro test (GPU box): two adjacent unaligned 8-byte LDS reads are fused by hipcc into ONE ds_read_b128 at an
 // arbitrary byte address (the token-centric resolver variant, -DAHIP_TOKEN_RESOLVER, relies on it).  Does gfx950 return
-// the right 16 bytes at every alignment?  NOT YET RUN (written when the round's GPU budget was spent).
+// the right 16 bytes at every alignment?  Round 2, MI355X: CORRECT at all 16 alignments (64 lanes, stride 48).
 //   hipcc --offload-arch=gfx950 -O3 -o /tmp/lds_unaligned128 tools/micro/lds_unaligned128.hip && /tmp/lds_unaligned128
 #include <hip/hip_runtime.h>
 #include <stdint.h>
