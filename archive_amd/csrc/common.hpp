@@ -1,6 +1,10 @@
 // common.hpp -- shared device/host types for libarchive_hip (gfx950 only).
 #pragma once
+#ifdef AHIP_HOST_EMU  // CPU emulation of one wave for tests (tests/emu/wave_emu.hpp); never defined in the product build
+#include "../../tests/emu/wave_emu.hpp"
+#else
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
 namespace ahip {
@@ -74,6 +78,14 @@ struct MemberResult {
 };
 
 #define AHIP_DEVINL __device__ __forceinline__
+
+// A place where the code relies on a wave executing its LDS instructions in lock step (all lanes' earlier store before
+// any lane's later one) without needing a compiler fence.  Nothing on the device; a barrier in the CPU emulation.
+#ifdef AHIP_HOST_EMU
+#define AHIP_LOCKSTEP() wave_emu::barrier()
+#else
+#define AHIP_LOCKSTEP() do { } while (0)
+#endif
 
 #ifdef AHIP_PROFILE
 #define AHIP_TICK(var) const u64 var = __builtin_amdgcn_s_memtime()

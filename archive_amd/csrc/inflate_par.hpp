@@ -252,6 +252,7 @@ AHIP_DEVINL GroupFront resolve_front(ParLdsT<E> &P, u32 ntok, u32 nbytes, const 
   u32 *slot = P.slot + ((g0 >> 6) & 1) * 64;  // two slot arrays alternate: no write-after-read stall
   wave_sync();
   slot[lane] = 0;
+  AHIP_LOCKSTEP();  // every lane's zero lands before any lane's key
   const u32 kidx = tcur + lane;
   const u32 k = kidx < ntok ? P.tok[kidx] : 0u;
   const u32 offk = (k >> 17) & 0x1fff;

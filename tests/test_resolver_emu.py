@@ -1,0 +1,62 @@
+"""The resolver's DEVICE code (archive_amd/csrc/inflate_par.hpp: resolve_member and everything under it) run on the CPU:
+64 host threads are the 64 lanes of one wave, the cross-lane primitives of common.hpp are exchanges between barriers
+(tests/emu/wave_emu.hpp).  Token streams are made from real DEFLATE data by a plain tokenizer inside
+tests/emu/resolver_emu.cc, cut into runs of random length like the tokenizer's directory, and the result is compared byte for
+byte with a sequential LZ77 replay.  Two builds: the production byte pass (what the GPU runs) and the token-centric variant
+behind -DAHIP_TOKEN_RESOLVER that has not been on a GPU yet."""
+import os
+import random
+import subprocess
+import zlib
+
+import pytest
+
+from tests import streams
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUILD = os.path.join(ROOT, "tests", "emu", "_build")
+
+
+def _binary(variant):
+    os.makedirs(BUILD, exist_ok=True)
+    exe = os.path.join(BUILD, "resolver_emu_" + variant)
+    src = os.path.join(ROOT, "tests", "emu", "resolver_emu.cc")
+    deps = [src, os.path.join(ROOT, "tests", "emu", "wave_emu.hpp")] + [os.path.join(ROOT, "archive_amd", "csrc", f)
+                                                                        for f in ("common.hpp", "inflate_wave.hpp", "inflate_par.hpp")]
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps):
+        cmd = ["g++", "-std=c++17", "-O2", "-pthread", "-o", exe, src] + (["-DAHIP_TOKEN_RESOLVER"] if variant == "tokres" else [])
+        subprocess.check_call(cmd)
+    return exe
+
+
+def _corpus():
+    rnd = random.Random(7)
+    noise = bytes(rnd.getrandbits(8) for _ in range(9000))
+    parts = [
+        (streams.text(30000, 1), 6),                        # text: short matches, mostly far
+        (bytes(70000), 6),                                  # zeros: 258-byte matches at distance 1 (self-overlapping)
+        (b"abc" * 5000 + b"0123456789" * 900, 6),           # periods 3 and 10
+        (noise, 6),                                         # incompressible: literals (zlib may store it)
+        (noise[:5000], 0),                                  # stored blocks: one 3-word record
+        (streams.text(3000, 2) + bytes(range(256)) * 20 + streams.text(3000, 2), 9),
+        (b"", 6), (b"x", 6), (b"xy" * 2, 1),                # empty and tiny members
+        (streams.text(2000, 3) * 12, 6),                    # long matches (> 16 bytes) at 2 000-byte distance: inside the window
+        ((streams.text(5000, 4) + noise[:3000]) * 6, 6),    # long matches at 8 000 bytes: flushed output
+        (streams.text(66000, 5), 1),                        # level 1: shorter matches, more literals
+    ]
+    blob = b"".join(streams.gz_member(p, level=lv) for p, lv in parts)
+    # the plain tokenizer of the test rejects references across members; every member stands alone
+    assert all(zlib.crc32(p) is not None for p, _ in parts)
+    return blob, sum(len(p) for p, _ in parts), len(parts)
+
+
+@pytest.mark.parametrize("variant", ["production", "tokres"])
+def test_resolver_device_code_on_the_cpu(tmp_path, variant):
+    exe = _binary(variant)
+    blob, total, members = _corpus()
+    path = tmp_path / "members.gz"
+    path.write_bytes(blob)
+    for seed in (1, 2):  # different cuts of the token stream into runs
+        r = subprocess.run([exe, str(path), str(seed)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "resolver emu ok" in r.stdout and "%d members, %d bytes" % (members, total) in r.stdout, r.stdout
