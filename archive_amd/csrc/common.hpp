@@ -86,6 +86,17 @@ struct MemberResult {
 #else
 #define AHIP_LOCKSTEP() do { } while (0)
 #endif
+// A wave vote under a PER-LANE condition that only decides whether a branch can be skipped by everybody (the branch
+// body tests the lane's own predicate again): the active lanes' vote on the device, the lane's own predicate in the
+// CPU emulation (where lanes that are not in the branch cannot take part in an exchange).
+// AHIP_ASM_NOTE: a comment in the ISA that also keeps the compiler from if-converting the branch around it.
+#ifdef AHIP_HOST_EMU
+#define AHIP_ANY_HINT(p) (p)
+#define AHIP_ASM_NOTE(text) do { } while (0)
+#else
+#define AHIP_ANY_HINT(p) __any(p)
+#define AHIP_ASM_NOTE(text) asm volatile("; " text ::: "memory")
+#endif
 
 #ifdef AHIP_PROFILE
 #define AHIP_TICK(var) const u64 var = __builtin_amdgcn_s_memtime()

@@ -201,8 +201,8 @@ AHIP_DEVINL u32 decode_token(LaneBits &d, const WaveLds &L, const u32 *inbuf, u3
   lb_normalize<MASK>(d, inbuf);
   const u32 w = lb_peek32(d);  // 32 valid bits; litlen code + extra <= 20
   e = L.ll[w & ((1u << LL_ROOT) - 1)];
-  if (__any(e & E_LONG)) {
-    asm volatile("; long litlen code" ::: "memory");  // keep this a real branch: if-converted, its LDS read would sit on every step's critical path
+  if (AHIP_ANY_HINT(e & E_LONG)) {
+    AHIP_ASM_NOTE("long litlen code");  // keep this a real branch: if-converted, its LDS read would sit on every step's critical path
     if (e & E_LONG) e = long_lookup(L.ll_sub, e, w, LL_ROOT);
   }
   const u32 cl = e & 15;
@@ -213,8 +213,8 @@ AHIP_DEVINL u32 decode_token(LaneBits &d, const WaveLds &L, const u32 *inbuf, u3
   lb_normalize<MASK>(d, inbuf);
   const u32 w2 = lb_peek32(d);  // distance code + extra <= 28
   u32 t = L.dt[w2 & ((1u << D_ROOT) - 1)];
-  if (__any(is_match && (t & E_LONG))) {
-    asm volatile("; long distance code" ::: "memory");
+  if (AHIP_ANY_HINT(is_match && (t & E_LONG))) {
+    AHIP_ASM_NOTE("long distance code");
     if (t & E_LONG) t = long_lookup(L.d_sub, t, w2, D_ROOT);
   }
   const u32 dl = t & 15;
@@ -692,8 +692,8 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
           const u32 t = decode_token<RING_MASK>(d, L, P.inbuf, e);
           endp = lb_pos(d);
           const bool spc = (i32)t >= 0 && (t & 0xffffu) == 0;
-          if (__any(spc)) {
-            asm volatile("; special symbol" ::: "memory");
+          if (AHIP_ANY_HINT(spc)) {
+            AHIP_ASM_NOTE("special symbol");
             if (spc) { fl = (e & E_EOB) ? LR_EOB : LR_ERR; bound = 0; }
           }
           if (!spc) {

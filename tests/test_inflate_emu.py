@@ -1,0 +1,53 @@
+"""The WHOLE device path of a member on the CPU: the flow tokenizer (inflate_member<false, true>: block headers, table build
+with second-level tables, huffman_block_tokenize, the serial token emitter) and the resolver, executed by 64 host threads as
+the 64 lanes of one wave (tests/emu/wave_emu.hpp, tests/emu/inflate_emu.cc), glued like the two kernels of archive_hip.hip.
+The decoded bytes must equal what zlib's compressor was given.  Runs without a GPU: it is the device code's own logic that
+is checked here, not the hardware."""
+import os
+import random
+import subprocess
+
+import pytest
+
+from tests import streams
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUILD = os.path.join(ROOT, "tests", "emu", "_build")
+
+
+def _binary(variant):
+    os.makedirs(BUILD, exist_ok=True)
+    exe = os.path.join(BUILD, "inflate_emu_" + variant)
+    src = os.path.join(ROOT, "tests", "emu", "inflate_emu.cc")
+    deps = [src, os.path.join(ROOT, "tests", "emu", "wave_emu.hpp")] + [os.path.join(ROOT, "archive_amd", "csrc", f)
+                                                                        for f in ("common.hpp", "inflate_wave.hpp", "inflate_par.hpp")]
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps):
+        cmd = ["g++", "-std=c++17", "-O2", "-pthread", "-o", exe, src] + (["-DAHIP_TOKEN_RESOLVER"] if variant == "tokres" else [])
+        subprocess.check_call(cmd)
+    return exe
+
+
+def _parts():
+    from tools import corpus
+    rnd = random.Random(7)
+    noise = bytes(rnd.getrandbits(8) for _ in range(9000))
+    return [
+        (streams.text(30000, 1), 6), (bytes(70000), 6), (b"abc" * 5000 + b"0123456789" * 900, 6), (noise, 6), (noise[:5000], 0),
+        (streams.text(3000, 2) + bytes(range(256)) * 20 + streams.text(3000, 2), 9), (b"", 6), (b"x", 6), (b"xy" * 2, 1),
+        (streams.text(2000, 3) * 12, 6), ((streams.text(5000, 4) + noise[:3000]) * 6, 6), (streams.text(66000, 5), 1),
+        (bytes(corpus.text(corpus.LOG, 1234, 0, 65536)), 6),   # one member of the benchmark stream (config 4)
+        (bytes(corpus.text(corpus.WIKI, 8, 0, 65536)), 6),     # one member of config 2b
+        (bytes(corpus.text(corpus.LOG, 1234, 5, 200000)), 9),  # several blocks, level 9
+    ]
+
+
+@pytest.mark.parametrize("variant", ["production", "tokres"])
+def test_device_path_on_the_cpu(tmp_path, variant):
+    exe = _binary(variant)
+    parts = _parts()
+    (tmp_path / "m.gz").write_bytes(b"".join(streams.gz_member(p, level=lv) for p, lv in parts))
+    (tmp_path / "m.bin").write_bytes(b"".join(p for p, _ in parts))
+    (tmp_path / "m.sz").write_text(" ".join(str(len(p)) for p, _ in parts))
+    r = subprocess.run([exe, str(tmp_path / "m.gz"), str(tmp_path / "m.bin"), str(tmp_path / "m.sz")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "inflate emu ok: %d members, %d bytes" % (len(parts), sum(len(p) for p, _ in parts)) in r.stdout, r.stdout
