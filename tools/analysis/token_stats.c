@@ -50,6 +50,7 @@ static int token(const Code *ll, const Code *dc, uint64_t *p, int *len, int *dis
   return 0;
 }
 
+static uint64_t far_len_hist[6], far_len_bytes[6], win_len_hist[6], win_len_bytes[6];
 static uint64_t n_lit, n_match, len_sum, dh[8], by_lit, by_win, by_far, far_tok, far_tok_le16, groups, groups_dep, depth_sum, tok_in_group_sum, members;
 static uint32_t BATCH = 1728;
 /* per member: source index of every output byte (-1 literal) */
@@ -113,6 +114,7 @@ int main(int argc, char **argv) {
           dh[dist < 4 ? 0 : dist < 16 ? 1 : dist < 64 ? 2 : dist < 256 ? 3 : dist < 1728 ? 4 : dist < 8192 ? 5 : 6]++;
           size_t batch0 = out - out % BATCH;
           int far = (size_t)dist > out - batch0;  /* source starts in front of the batch window */
+          { int b = len <= 8 ? 0 : len <= 16 ? 1 : len <= 32 ? 2 : len <= 64 ? 3 : len <= 128 ? 4 : 5; if (far) { far_len_hist[b]++; far_len_bytes[b] += len; } else { win_len_hist[b]++; win_len_bytes[b] += len; } }
           if (far) { far_tok++; if (len <= 16 && (size_t)dist >= out - batch0 + 16) far_tok_le16++; }
           for (int i = 0; i < len; ++i) { size_t sidx = out - dist; src[out] = (int32_t)sidx; if (sidx < batch0) by_far++; else by_win++; out++; }
         }
@@ -129,6 +131,10 @@ int main(int argc, char **argv) {
   printf("match distances:"); for (int i = 0; i < 7; ++i) printf("  %s: %.1f %%", nm[i], 100.0 * dh[i] / n_match); printf("\n");
   printf("output bytes: literal %.1f %%, copied inside the %u-byte batch window %.1f %%, copied from flushed output %.1f %%\n", 100.0 * by_lit / bytes, BATCH, 100.0 * by_win / bytes, 100.0 * by_far / bytes);
   printf("matches whose source starts in front of the batch: %.1f %% of the matches; %.1f %% of those are <= 16 bytes with the whole 16-byte load in flushed output (the per-token deposit path)\n", 100.0 * far_tok / n_match, 100.0 * far_tok_le16 / far_tok);
+  { const char *lb[6] = {"<= 8", "<= 16", "<= 32", "<= 64", "<= 128", "<= 258"}; uint64_t ft = 0, fb = 0, wt = 0, wb = 0;
+    for (int i = 0; i < 6; ++i) { ft += far_len_hist[i]; fb += far_len_bytes[i]; wt += win_len_hist[i]; wb += win_len_bytes[i]; }
+    printf("match lengths (share of matches / of their bytes), source in flushed output:"); for (int i = 0; i < 6; ++i) printf("  %s: %.1f / %.1f %%", lb[i], 100.0 * far_len_hist[i] / ft, 100.0 * far_len_bytes[i] / fb); printf("\n");
+    printf("match lengths (share of matches / of their bytes), source inside the batch window:"); for (int i = 0; i < 6; ++i) printf("  %s: %.1f / %.1f %%", lb[i], 100.0 * win_len_hist[i] / wt, 100.0 * win_len_bytes[i] / wb); printf("\n"); }
   printf("64-byte groups: %llu, with a source inside the same group %.1f %% (mean pointer-doubling steps when so: %.2f)\n", (unsigned long long)groups, 100.0 * groups_dep / groups, groups_dep ? (double)depth_sum / groups_dep : 0.0);
   return 0;
 }
