@@ -51,3 +51,24 @@ def test_device_path_on_the_cpu(tmp_path, variant):
     r = subprocess.run([exe, str(tmp_path / "m.gz"), str(tmp_path / "m.bin"), str(tmp_path / "m.sz")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "inflate emu ok: %d members, %d bytes" % (len(parts), sum(len(p) for p, _ in parts)) in r.stdout, r.stdout
+
+
+def test_back_references_into_earlier_members_on_the_cpu(tmp_path):
+    """Quirk q8 (tests/test_inflate_gpu.py::test_back_reference_into_previous_gzip_member) through the device code: the
+    tokenizer flags the member, it is resolved once its predecessors' bytes exist."""
+    from oracle import pyoracle as orc
+    first = streams.text(40000, 77)
+    far = streams.gz_wrap(streams.raw_far_reference())
+    far2 = streams.gz_wrap(streams.raw_far_reference(lit=b"xy", length=5, dist_extra=0))
+    exe = _binary("production")
+    for i, g in enumerate([streams.gz_member(first) + far,
+                           streams.gz_member(first) + far + far2 + streams.gz_member(streams.text(3000, 78)),
+                           streams.gz_member(b"12345") + far]):
+        st, want = orc.gzip_decode(g)
+        assert st == 0
+        (tmp_path / "q.gz").write_bytes(g)
+        (tmp_path / "q.bin").write_bytes(want)
+        (tmp_path / "q.sz").write_text("auto")
+        r = subprocess.run([exe, str(tmp_path / "q.gz"), str(tmp_path / "q.bin"), str(tmp_path / "q.sz")], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "inflate emu ok" in r.stdout, (i, r.stdout + r.stderr)
+        assert "members reaching into earlier ones 0" not in r.stdout, r.stdout
