@@ -950,11 +950,17 @@ AHIP_DEVINL void resolve_member(ParLdsT<E> &P, const u8 *in, const u32 *area, co
     E *obw = P.obuf + A;
     // software-pipelined by one chunk of 64 tokens: the history loads of chunk c+1 are in flight while
     // chunk c is deposited
+    struct Chunk {
+      u32 idx, len, off, key, total, nf, nin;
+      bool fits, pre, cut;
+      u64 w0, w1;
 #ifdef AHIP_TOKEN_RESOLVER
-    struct Chunk { u32 idx, len, off, key, total, nf, nin, tokw; bool fits, pre, cut; u64 w0, w1; };
-#else
-    struct Chunk { u32 idx, len, off, key, total, nf, nin; bool fits, pre, cut; u64 w0, w1; };
+      u32 tokw;
 #endif
+#ifdef AHIP_DEPOSIT32
+      u64 w2, w3;  // EXPERIMENT (off by default): matches of 17..32 bytes from flushed output are deposited per token too
+#endif
+    };
     auto prep = [&](u32 c, u32 run) -> Chunk {
       Chunk q;
       q.idx = c + lane;
@@ -970,8 +976,16 @@ AHIP_DEVINL void resolve_member(ParLdsT<E> &P, const u8 *in, const u32 *area, co
       q.key = (1u << 30) | (q.off << 17) | (lit ? (0x10000u | ((t >> 16) & 0xff)) : ((t & 0xffff) - 1));
       const i32 srel = (i32)q.off - (i32)(t & 0xffff);  // source start relative to the window
       q.pre = !MARK && q.fits && !lit && q.len <= 16 && srel + 16 <= 0;  // (symbols take the per-element path)
+#ifdef AHIP_DEPOSIT32
+      const bool pre32 = !MARK && q.fits && !lit && q.len > 16 && q.len <= 32 && srel + 32 <= 0;
+      q.pre = q.pre || pre32;
+      q.w2 = q.w3 = 0;
+#endif
       q.w0 = q.w1 = 0;
       if (q.pre) { const u8 *sp = (const u8 *)g + srel; q.w0 = load_u64_unaligned(sp); q.w1 = load_u64_unaligned(sp + 8); }
+#ifdef AHIP_DEPOSIT32
+      if (pre32) { const u8 *sp = (const u8 *)g + srel; q.w2 = load_u64_unaligned(sp + 16); q.w3 = load_u64_unaligned(sp + 24); }
+#endif
       const u64 fm = __ballot(q.fits), im = __ballot(inb);
       q.nf = (u32)__popcll(fm);
       q.nin = (u32)__popcll(im);
@@ -995,6 +1009,20 @@ AHIP_DEVINL void resolve_member(ParLdsT<E> &P, const u8 *in, const u32 *area, co
         // 2/4/8-byte accesses): [0, w) and [len - w, len)
         if constexpr (sizeof(E) == 1) {
           u8 *dp = (u8 *)obw + ck.off;
+#ifdef AHIP_DEPOSIT32
+          if (ck.len > 16) {
+            // the first 16 bytes, then the LAST 16 (bytes [len - 16, len) of the 32 loaded ones), overlapping in between
+            const u32 o = ck.len - 16;  // 1..16
+            const u64 a = o < 8 ? ck.w0 : ck.w1, b = o < 8 ? ck.w1 : ck.w2, c = o < 8 ? ck.w2 : ck.w3;
+            const u32 sh = 8 * (o & 7);
+            const u64 lo = o == 16 ? ck.w2 : (sh ? ((a >> sh) | (b << (64 - sh))) : a);
+            const u64 hi = o == 16 ? ck.w3 : (sh ? ((b >> sh) | (c << (64 - sh))) : b);
+            ((unaligned_u64 *)dp)->v = ck.w0;
+            ((unaligned_u64 *)(dp + 8))->v = ck.w1;
+            ((unaligned_u64 *)(dp + o))->v = lo;
+            ((unaligned_u64 *)(dp + o + 8))->v = hi;
+          } else
+#endif
           if (ck.len >= 8) {
             const u32 sh = 8 * (ck.len - 8);  // 0..64
             const u64 tail = sh == 0 ? ck.w0 : (sh == 64 ? ck.w1 : ((ck.w0 >> sh) | (ck.w1 << (64 - sh))));

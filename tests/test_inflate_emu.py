@@ -31,6 +31,7 @@ def _parts():
     from tools import corpus
     rnd = random.Random(7)
     noise = bytes(rnd.getrandbits(8) for _ in range(9000))
+    recs = [bytes(rnd.getrandbits(8) for _ in range(25)) for _ in range(160)]
     return [
         (streams.text(30000, 1), 6), (bytes(70000), 6), (b"abc" * 5000 + b"0123456789" * 900, 6), (noise, 6), (noise[:5000], 0),
         (streams.text(3000, 2) + bytes(range(256)) * 20 + streams.text(3000, 2), 9), (b"", 6), (b"x", 6), (b"xy" * 2, 1),
@@ -38,6 +39,7 @@ def _parts():
         (bytes(corpus.text(corpus.LOG, 1234, 0, 65536)), 6),   # one member of the benchmark stream (config 4)
         (bytes(corpus.text(corpus.WIKI, 8, 0, 65536)), 6),     # one member of config 2b
         (bytes(corpus.text(corpus.LOG, 1234, 5, 200000)), 9),  # several blocks, level 9
+        (b"".join(r + bytes([rnd.getrandbits(8)]) for _ in range(6) for r in recs), 6),  # 25-byte matches from flushed output
     ]
 
 

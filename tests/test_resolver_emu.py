@@ -2,8 +2,8 @@
 64 host threads are the 64 lanes of one wave, the cross-lane primitives of common.hpp are exchanges between barriers
 (tests/emu/wave_emu.hpp).  Token streams are made from real DEFLATE data by a plain tokenizer inside
 tests/emu/resolver_emu.cc, cut into runs of random length like the tokenizer's directory, and the result is compared byte for
-byte with a sequential LZ77 replay.  Two builds: the production byte pass (what the GPU runs) and the token-centric variant
-behind -DAHIP_TOKEN_RESOLVER that has not been on a GPU yet."""
+byte with a sequential LZ77 replay.  Builds: the production byte pass (what the GPU runs) and the experiments that have not been on a GPU yet (DESIGN.md
+section 12): the token-centric variant (-DAHIP_TOKEN_RESOLVER) and the 32-byte deposit of far matches (-DAHIP_DEPOSIT32)."""
 import os
 import random
 import subprocess
@@ -19,14 +19,21 @@ BUILD = os.path.join(ROOT, "tests", "emu", "_build")
 
 def _binary(variant):
     os.makedirs(BUILD, exist_ok=True)
-    exe = os.path.join(BUILD, "resolver_emu_" + variant)
+    exe = os.path.join(BUILD, "resolver_emu_" + variant.replace("+", "_"))
     src = os.path.join(ROOT, "tests", "emu", "resolver_emu.cc")
     deps = [src, os.path.join(ROOT, "tests", "emu", "wave_emu.hpp")] + [os.path.join(ROOT, "archive_amd", "csrc", f)
                                                                         for f in ("common.hpp", "inflate_wave.hpp", "inflate_par.hpp")]
     if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps):
-        cmd = ["g++", "-std=c++17", "-O2", "-pthread", "-o", exe, src] + (["-DAHIP_TOKEN_RESOLVER"] if variant == "tokres" else [])
+        flags = {"production": [], "tokres": ["-DAHIP_TOKEN_RESOLVER"], "deposit32": ["-DAHIP_DEPOSIT32"],
+                 "tokres+deposit32": ["-DAHIP_TOKEN_RESOLVER", "-DAHIP_DEPOSIT32"]}[variant]
+        cmd = ["g++", "-std=c++17", "-O2", "-pthread", "-o", exe, src] + flags
         subprocess.check_call(cmd)
     return exe
+
+
+def _records(rnd):
+    recs = [bytes(rnd.getrandbits(8) for _ in range(25)) for _ in range(160)]
+    return b"".join(r + bytes([rnd.getrandbits(8)]) for _ in range(6) for r in recs)
 
 
 def _corpus():
@@ -43,6 +50,7 @@ def _corpus():
         (streams.text(2000, 3) * 12, 6),                    # long matches (> 16 bytes) at 2 000-byte distance: inside the window
         ((streams.text(5000, 4) + noise[:3000]) * 6, 6),    # long matches at 8 000 bytes: flushed output
         (streams.text(66000, 5), 1),                        # level 1: shorter matches, more literals
+        (_records(rnd), 6),                                 # 25-byte matches at ~4 KB distance: flushed output, 17..32 bytes
     ]
     blob = b"".join(streams.gz_member(p, level=lv) for p, lv in parts)
     # the plain tokenizer of the test rejects references across members; every member stands alone
@@ -50,7 +58,7 @@ def _corpus():
     return blob, sum(len(p) for p, _ in parts), len(parts)
 
 
-@pytest.mark.parametrize("variant", ["production", "tokres"])
+@pytest.mark.parametrize("variant", ["production", "tokres", "deposit32", "tokres+deposit32"])
 def test_resolver_device_code_on_the_cpu(tmp_path, variant):
     exe = _binary(variant)
     blob, total, members = _corpus()
