@@ -1058,21 +1058,45 @@ AHIP_DEVINL void resolve_member(ParLdsT<E> &P, const u8 *in, const u32 *area, co
           const int first = __builtin_ctzll(pm);
           const u32 first_dst = lane_bcast(ck.off, first);
           const bool ready = pend && (lane == first || srel + (i32)ck.len <= (i32)first_dst);
-          const bool simple = ready && ck.len <= 16 && t_dist >= ck.len && srel >= 0;
-          if (simple) {
-            const u64 w0 = ((const unaligned_u64 *)&P.obuf[A + (u32)srel])->v, w1 = ((const unaligned_u64 *)&P.obuf[A + (u32)srel + 8])->v;
-            E *dp = &P.obuf[A + ck.off];
-            if (ck.len >= 8) {
-              const u32 sh = 8 * (ck.len - 8);
-              const u64 tail = sh == 0 ? w0 : (sh == 64 ? w1 : ((w0 >> sh) | (w1 << (64 - sh))));
-              ((unaligned_u64 *)dp)->v = w0;
-              ((unaligned_u64 *)(dp + ck.len - 8))->v = tail;
-            } else if (ck.len >= 4) {
-              ((unaligned_u32 *)dp)->v = (u32)w0;
-              ((unaligned_u32 *)(dp + ck.len - 4))->v = (u32)(w0 >> (8 * (ck.len - 4)));
-            } else {
-              dp[0] = (u8)w0; dp[1] = (u8)(w0 >> 8); dp[2] = (u8)(w0 >> 16);
+          // simple: the source lies in the window and either does not overlap the destination or trails it by >= 16
+          // bytes (a 16-byte piece then never reads what it is about to write); dist == 1 is a byte splat.
+          // Pieces of 16 bytes at offsets 0, 16, ... and a last one ending exactly at len (it may overlap the piece
+          // before it: same bytes again); a match of <= 16 bytes is one piece of exactly len bytes.
+          const bool splat = ready && srel >= 0 && t_dist == 1 && ck.len > 1;
+          const bool simple = ready && srel >= 0 && (t_dist >= ck.len || t_dist >= 16 || splat);
+          u32 done = 0;
+          bool act = simple;
+          u64 sw = 0;
+          if (splat) sw = (u64)P.obuf[A + (u32)srel] * 0x0101010101010101ull;
+          while (__any(act)) {
+            if (act) {
+              const u32 rem = ck.len - done;
+              const u32 at = (ck.len > 16 && rem < 16) ? ck.len - 16 : done;  // the last piece ends at len
+              u64 w0 = sw, w1 = sw;
+              if (!splat) {
+                w0 = ((const unaligned_u64 *)&P.obuf[A + (u32)srel + at])->v;
+                w1 = ((const unaligned_u64 *)&P.obuf[A + (u32)srel + at + 8])->v;
+              }
+              E *dp = &P.obuf[A + ck.off + at];
+              if (ck.len >= 16) {
+                ((unaligned_u64 *)dp)->v = w0;
+                ((unaligned_u64 *)(dp + 8))->v = w1;
+              } else if (ck.len >= 8) {
+                const u32 sh = 8 * (ck.len - 8);
+                const u64 tail = sh == 0 ? w0 : ((w0 >> sh) | (w1 << (64 - sh)));
+                ((unaligned_u64 *)dp)->v = w0;
+                ((unaligned_u64 *)(dp + ck.len - 8))->v = tail;
+              } else if (ck.len >= 4) {
+                ((unaligned_u32 *)dp)->v = (u32)w0;
+                ((unaligned_u32 *)(dp + ck.len - 4))->v = (u32)(w0 >> (8 * (ck.len - 4)));
+              } else {
+                dp[0] = (u8)w0; dp[1] = (u8)(w0 >> 8);
+                if (ck.len > 2) dp[2] = (u8)(w0 >> 16);
+              }
+              done += 16;
+              act = done < ck.len;
             }
+            wave_sync();  // a later piece of the same lane may read what this one wrote
           }
           u64 hm = __ballot(ready && !simple);
           while (hm) {  // one token at a time, a byte per lane (sources are final: they end in front of first_dst)
