@@ -60,7 +60,7 @@ struct TokKernelLds {
 AHIP_DEVINL bool member_is_late(const MemberResult &r) {
   return r.status == MS_TOKFULL || r.status == MS_OVERSUB || (r.blocks & MR_FAR);
 }
-AHIP_DEVINL TokSink member_sink(u32 *tokens, uint2 *dir, u64 out_rel, u64 out_limit, u32 k) {
+AHIP_DEVINL TokSink member_sink(u32 *tokens, DirEnt *dir, u64 out_rel, u64 out_limit, u32 k) {
   TokSink sk{nullptr, 0, nullptr, 0, 0, ~0u, 0, 0, false, false};
   if (tokens) {
     u64 toff, doff;
@@ -81,7 +81,7 @@ AHIP_DEVINL void in_layout(const InLayout &lay, u32 c, u64 &toff, u32 &col_cap, 
   const u64 p1 = c + 1 < lay.K ? uniform64(lay.pos[c + 1]) : lay.in_len;
   tok_layout_in(p0, p1 > p0 ? p1 - p0 : 0, c, toff, col_cap, doff, dir_cap);
 }
-AHIP_DEVINL TokSink candidate_sink(u32 *tokens, uint2 *dir, const InLayout &lay, u32 c) {
+AHIP_DEVINL TokSink candidate_sink(u32 *tokens, DirEnt *dir, const InLayout &lay, u32 c) {
   TokSink sk{nullptr, 0, nullptr, 0, 0, ~0u, 0, 0, false, true};
   u64 toff, doff;
   in_layout(lay, c, toff, sk.col_cap, doff, sk.dir_cap);
@@ -100,7 +100,7 @@ AHIP_DEVINL u32 next_member(u32 *next, int lane) {
 template <bool KEEP>
 __global__ __launch_bounds__(64, AHIP_TOK_MIN_WAVES) void inflate_tokenize_kernel(const u8 *__restrict__ in, u64 in_len,
                                                              const MemberDesc *__restrict__ members, u32 first_member,
-                                                             u32 n_members, u32 *__restrict__ tokens, uint2 *__restrict__ dir,
+                                                             u32 n_members, u32 *__restrict__ tokens, DirEnt *__restrict__ dir,
                                                              u64 group_out0, MemberResult *__restrict__ results,
                                                              u32 *__restrict__ late, InLayout lay, MemberSel sel) {
   __shared__ TokKernelLds lds;
@@ -132,11 +132,11 @@ template <bool KEPT>
 __global__ __launch_bounds__(64, AHIP_RES_MIN_WAVES) void inflate_resolve_kernel(const u8 *__restrict__ in,
                                                             const MemberDesc *__restrict__ members, u32 first_member,
                                                             u32 n_members, u8 *out, const u32 *__restrict__ tokens,
-                                                            const uint2 *__restrict__ dir, u64 group_out0,
+                                                            const DirEnt *__restrict__ dir, u64 group_out0,
                                                             MemberResult *__restrict__ results, InLayout lay,
                                                             const MemberResult *__restrict__ sized, MemberSel sel,
                                                             u32 *__restrict__ next) {
-  __shared__ ParLds lds;
+  __shared__ ResLds lds;
   const int lane = threadIdx.x;
   for (u32 k = next_member(next, lane); k < n_members; k = next_member(next, lane)) {
     const u32 m = member_index(sel, first_member, k);
@@ -174,13 +174,13 @@ template <bool WRITE>
 __global__ __launch_bounds__(64) void inflate_late_kernel(const u8 *__restrict__ in, u64 in_len,
                                                          const MemberDesc *__restrict__ members, u32 first_member,
                                                          u32 n_members, u8 *out, const u32 *__restrict__ tokens,
-                                                         const uint2 *__restrict__ dir, u64 group_out0,
+                                                         const DirEnt *__restrict__ dir, u64 group_out0,
                                                          MemberResult *__restrict__ results, const u32 *__restrict__ late,
                                                          u32 *__restrict__ exact, MemberSel sel) {
   if (*late == 0) return;
   __shared__ WaveLds lds;
   __shared__ HeaderLds hdr;
-  __shared__ ParLds par;
+  __shared__ ResLds par;
   const int lane = threadIdx.x;
   // 64 members per look (one per lane, the next look's loads already in flight); the late ones of a look in order.
   // A sizing run writes no output, so its members are independent: there the looks are dealt out over the workgroups of
@@ -387,7 +387,7 @@ hipError_t launch_inflate_group(const u8 *in, u64 n, const MemberDesc *members, 
   if (!WRITE && lay_pos && first == 0 && !getenv("AHIP_NO_TOKEN_REUSE") && n <= (4ull << 30)) {
     e = tokens_reserve(((size_t)n * IN_R + (size_t)count * IN_PAD + 64) * 4, &tp);
     if (e != hipSuccess) return e;
-    e = scratch_reserve(((size_t)(n / 32) + (size_t)count * 64 + 64) * 8, &dp);
+    e = scratch_reserve(((size_t)(n / 32) + (size_t)count * 64 + 64) * DIR_BYTES, &dp);
     if (e != hipSuccess) return e;
     lay = InLayout{lay_pos, count, n};
     if (gen_out) *gen_out = g_tok_gen;
@@ -398,7 +398,7 @@ hipError_t launch_inflate_group(const u8 *in, u64 n, const MemberDesc *members, 
     if (span > (1ull << 40)) return hipErrorInvalidValue;
     e = tokens_reserve(((size_t)(span * 3 / 2) + (size_t)count * 1024 + 64) * 4, &tp);
     if (e != hipSuccess) return e;
-    e = scratch_reserve(((size_t)(span / 16) + (size_t)count * 64 + 64) * 8, &dp);
+    e = scratch_reserve(((size_t)(span / 16) + (size_t)count * 64 + 64) * DIR_BYTES, &dp);
     if (e != hipSuccess) return e;
   }
   if (getenv("AHIP_DEBUG")) fprintf(stderr, "[ahip] inflate group first=%u count=%u grid=%u/%d out=%llu write=%d\n", first, count, grid1, res_resident, (unsigned long long)(out1 - out0), (int)WRITE);
@@ -412,19 +412,19 @@ hipError_t launch_inflate_group(const u8 *in, u64 n, const MemberDesc *members, 
   e = hipMemsetAsync(dlate.p, 0, 64, st);  // [0] late members, [1] / [2] the tokenizer's / resolver's next member
   if (e != hipSuccess) return e;
   if (lay.pos)
-    hipLaunchKernelGGL(inflate_tokenize_kernel<true>, dim3(grid1), dim3(64), 0, st, in, n, members, first, count, (u32 *)tp, (uint2 *)dp,
+    hipLaunchKernelGGL(inflate_tokenize_kernel<true>, dim3(grid1), dim3(64), 0, st, in, n, members, first, count, (u32 *)tp, (DirEnt *)dp,
                        out0, res, dlate.as<u32>(), lay, MemberSel{nullptr, nullptr});
   else
-    hipLaunchKernelGGL(inflate_tokenize_kernel<false>, dim3(grid1), dim3(64), 0, st, in, n, members, first, count, (u32 *)tp, (uint2 *)dp,
+    hipLaunchKernelGGL(inflate_tokenize_kernel<false>, dim3(grid1), dim3(64), 0, st, in, n, members, first, count, (u32 *)tp, (DirEnt *)dp,
                        out0, res, dlate.as<u32>(), lay, MemberSel{nullptr, nullptr});
   if (WRITE) {
     const u32 grid2 = count < (u32)res_resident ? count : (u32)res_resident;
     hipLaunchKernelGGL(inflate_resolve_kernel<false>, dim3(grid2), dim3(64), 0, st, in, members, first, count, out,
-                       (const u32 *)tp, (const uint2 *)dp, out0, res, InLayout{nullptr, 0, n}, (const MemberResult *)nullptr,
+                       (const u32 *)tp, (const DirEnt *)dp, out0, res, InLayout{nullptr, 0, n}, (const MemberResult *)nullptr,
                        MemberSel{nullptr, nullptr}, dlate.as<u32>() + 2);
   }
   hipLaunchKernelGGL(inflate_late_kernel<WRITE>, dim3(WRITE ? 1u : SIZING_LATE_WGS), dim3(64), 0, st, in, n, members, first, count, out, (const u32 *)tp,
-                     (const uint2 *)dp, out0, res, dlate.as<u32>(), dexact.as<u32>(), MemberSel{nullptr, nullptr});
+                     (const DirEnt *)dp, out0, res, dlate.as<u32>(), dexact.as<u32>(), MemberSel{nullptr, nullptr});
   e = hipEventRecord(scratch_free, st);
   if (e != hipSuccess) return e;
   return hipGetLastError();
@@ -443,7 +443,7 @@ hipError_t launch_resolve_kept(const u8 *in, u64 n, const MemberDesc *members, u
   e = hipMemsetAsync(g_late.p, 0, 64, st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(inflate_resolve_kernel<true>, dim3(grid), dim3(64), 0, st, in, members, 0u, M, out, (const u32 *)g_tokens.p,
-                     (const uint2 *)g_scratch.p, (u64)0, res, InLayout{cand_pos, K, n}, sized, MemberSel{nullptr, nullptr},
+                     (const DirEnt *)g_scratch.p, (u64)0, res, InLayout{cand_pos, K, n}, sized, MemberSel{nullptr, nullptr},
                      g_late.as<u32>() + 2);
   e = hipEventRecord(scratch_free, st);
   if (e != hipSuccess) return e;
@@ -458,7 +458,7 @@ hipError_t launch_inflate_listed(const u8 *in, u64 n, const MemberDesc *members,
   if (e != hipSuccess) return e;
   e = g_tokens2.reserve(((size_t)(span * 3 / 2) + (size_t)count * 1024 + 64) * 4);
   if (e != hipSuccess) return e;
-  e = g_scratch2.reserve(((size_t)(span / 16) + (size_t)count * 64 + 64) * 8);
+  e = g_scratch2.reserve(((size_t)(span / 16) + (size_t)count * 64 + 64) * DIR_BYTES);
   if (e != hipSuccess) return e;
   e = g_late.reserve(64);
   if (e != hipSuccess) return e;
@@ -469,12 +469,12 @@ hipError_t launch_inflate_listed(const u8 *in, u64 n, const MemberDesc *members,
   const MemberSel sel{ids, rel};
   const u32 r1 = tok_resident > 0 ? (u32)tok_resident : 2048u, r2 = res_resident > 0 ? (u32)res_resident : 4096u;
   hipLaunchKernelGGL(inflate_tokenize_kernel<false>, dim3(count < r1 ? count : r1), dim3(64), 0, st, in, n, members, 0u, count,
-                     g_tokens2.as<u32>(), g_scratch2.as<uint2>(), (u64)0, res, g_late.as<u32>(), InLayout{nullptr, 0, n}, sel);
+                     g_tokens2.as<u32>(), g_scratch2.as<DirEnt>(), (u64)0, res, g_late.as<u32>(), InLayout{nullptr, 0, n}, sel);
   hipLaunchKernelGGL(inflate_resolve_kernel<false>, dim3(count < r2 ? count : r2), dim3(64), 0, st, in, members, 0u, count, out,
-                     (const u32 *)g_tokens2.p, (const uint2 *)g_scratch2.p, (u64)0, res, InLayout{nullptr, 0, n},
+                     (const u32 *)g_tokens2.p, (const DirEnt *)g_scratch2.p, (u64)0, res, InLayout{nullptr, 0, n},
                      (const MemberResult *)nullptr, sel, g_late.as<u32>() + 2);
   hipLaunchKernelGGL(inflate_late_kernel<true>, dim3(1), dim3(64), 0, st, in, n, members, 0u, count, out, (const u32 *)g_tokens2.p,
-                     (const uint2 *)g_scratch2.p, (u64)0, res, g_late.as<u32>(), g_exact.as<u32>(), sel);
+                     (const DirEnt *)g_scratch2.p, (u64)0, res, g_late.as<u32>(), g_exact.as<u32>(), sel);
   e = hipEventRecord(scratch_free, st);
   if (e != hipSuccess) return e;
   return hipGetLastError();
@@ -923,7 +923,7 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
     HIP_TRY(hipMemcpyAsync(dchunks.p, cd.data(), (size_t)nc * sizeof(ChunkDesc), hipMemcpyHostToDevice, st));
     const u32 grid = nc < (u32)sm_resident_waves() ? nc : (u32)sm_resident_waves();
     hipLaunchKernelGGL(sm_tokenize_kernel, dim3(grid), dim3(64), 0, st, d_in, n, dchunks.as<ChunkDesc>(), nc, dcand.as<u64>(), nc,
-                       (u32 *)nullptr, (uint2 *)nullptr, dres.as<MemberResult>());
+                       (u32 *)nullptr, (DirEnt *)nullptr, dres.as<MemberResult>());
     std::vector<MemberResult> rs(nc);
     HIP_TRY(hipMemcpyAsync(rs.data(), dres.p, (size_t)nc * sizeof(MemberResult), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -962,7 +962,7 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
   const u64 total = g_sm.total_out;
   void *tp = nullptr, *sp = nullptr;
   HIP_TRY(tokens_reserve(((size_t)(total * 3 / 2) + (size_t)nch * 1024 + 64) * 4, &tp));
-  HIP_TRY(scratch_reserve(((size_t)(total / 16) + (size_t)nch * 64 + 64) * 8, &sp));
+  HIP_TRY(scratch_reserve(((size_t)(total / 16) + (size_t)nch * 64 + 64) * DIR_BYTES, &sp));
   HIP_TRY(dsym.reserve((size_t)total * 2 + 64));
   HIP_TRY(dwin.reserve((size_t)nch * SM_WINDOW));
   HIP_TRY(dcand.reserve((size_t)nc * 8));
@@ -972,7 +972,7 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
   HIP_TRY(hipMemcpyAsync(dchunks.p, g_sm.chain.data(), (size_t)nch * sizeof(ChunkDesc), hipMemcpyHostToDevice, st));
   const u32 grid = nch < (u32)sm_resident_waves() ? nch : (u32)sm_resident_waves();
   hipLaunchKernelGGL(sm_tokenize_kernel, dim3(grid), dim3(64), 0, st, d_in, n, dchunks.as<ChunkDesc>(), nch, dcand.as<u64>(), nc,
-                     (u32 *)tp, (uint2 *)sp, dres.as<MemberResult>());
+                     (u32 *)tp, (DirEnt *)sp, dres.as<MemberResult>());
   std::vector<MemberResult> rs(nch);
   HIP_TRY(hipMemcpyAsync(rs.data(), dres.p, (size_t)nch * sizeof(MemberResult), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
@@ -985,7 +985,7 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
       return AHIP_OK;
     }
   hipLaunchKernelGGL(sm_resolve_kernel, dim3(grid), dim3(64), 0, st, d_in, dchunks.as<ChunkDesc>(), nch, dsym.as<u16>(), (const u32 *)tp,
-                     (const uint2 *)sp, dres.as<MemberResult>());
+                     (const DirEnt *)sp, dres.as<MemberResult>());
   {
     static thread_local DevBuf dwsym, dgwin;
     u32 gs = 1;

@@ -1,34 +1,29 @@
-// inflate_par.hpp -- wave-parallel decode of ONE Huffman-coded DEFLATE block.
+// inflate_par.hpp -- wave-parallel decode of one DEFLATE stream ("member"): tokenizer and resolver.
 //
-// The reference decodes a block strictly symbol by symbol (inflate.dart:300-343).  A wave that
-// does the same keeps 63 of its 64 lanes idle and is bound by the LDS/HBM latency of every
-// symbol.  Here all 64 lanes decode the SAME block at once:
+// The reference decodes strictly symbol by symbol (inflate.dart:300-343) and copies every back-reference as it
+// meets it (output_memory_stream.dart:79-98).  Here one wave64 works on one member in two stages that run as two
+// kernels (archive_hip.hip):
 //
-//   window      the next WIN_BITS of the bitstream are staged into LDS with coalesced loads and
-//               cut into 64 subsequences of SUB_BITS; lane i owns subsequence i.
-//   pass A      lane 0 starts at the known token boundary; every other lane starts blind at the
-//               first bit of its subsequence and decodes until it crosses into the next one.
-//               Huffman streams self-synchronise, so most blind lanes end on a true boundary.
-//   pass B..    lane i restarts from the end position lane i-1 reported, counts tokens and
-//               output bytes and records its tokens (one coalesced row store per step into a
-//               per-workgroup slab in device scratch).  Lanes up to the first one whose end
-//               position changed are final (their start was true); the rest repeat.
-//   gather      wave prefix sums of the per-lane counts give every lane its slot in the LDS token
-//               queue; whole lanes are taken in batches that fit the queue / output window.
-//   resolve     pass 1: wave scans of token lengths give each token its output offset (the
-//               literal/match boundary scan).  pass 2: 64 output BYTES at a time, one per lane:
-//               a start-slot scatter + wave prefix-max finds the token covering each byte; the
-//               byte is a literal, an earlier byte of the LDS window, a byte of already flushed
-//               output (L2-resident), or -- runs and very short distances -- the byte of a lower
-//               lane, resolved by pointer doubling.  The window is flushed to HBM with coalesced
-//               16-byte stores.
+//   tokenizer   huffman_block_tokenize(): the block's bitstream is cut into ITEMS of SUB_BITS; the 64 lanes are
+//               independent workers in a continuous flow -- SPEC(s) decodes blind over the tail of item s to predict
+//               where item s+1 starts (Huffman streams self-synchronise), RUN(s) decodes item s from a start and
+//               records its tokens into the lane's own column of the member's token area.  A scoreboard in LDS
+//               validates the runs in order, repairs mispredicted items at once and retires final items into the
+//               member's RUN DIRECTORY {where the run's tokens are, how many, at which output offset the run starts}.
+//               Every token already carries the output offset behind it, relative to its run (the lane counts the
+//               bytes of its run anyway), so nobody ever needs a prefix sum over token lengths again.
+//   resolver    resolve_member(): 64 TOKENS per step.  A lane takes one token: literals store their byte, matches
+//               whose source lies in flushed output are fetched per token (16 / 32 bytes, one chunk ahead) and
+//               deposited into an LDS output window with exact-length unaligned stores, matches whose source is
+//               still in the window go in rounds (the first pending match is always ready, a later one when its
+//               source ends in front of the first pending destination).  The window is flushed to HBM with 16-byte
+//               stores.  resolve_member_sym() is the older byte-per-lane formulation, kept for the 16-bit symbols of
+//               the chunked single-stream decode (sm_inflate.hpp).
 //
-// Any anomaly (bad symbol on the true path, back-reference before the member start, output
-// window exhausted, input too close to its end for unchecked reads) drops to the serial
-// decoder of inflate_wave.hpp at the start of the current window; that path reproduces the
-// reference's behaviour for malformed data exactly, so the parallel path only ever commits
-// tokens of well-formed data.  Results are bit-identical by construction: both paths produce
-// the same token sequence and writeBackReference semantics.
+// Anything irregular (bad symbol on the true path, back-reference before the start of the output, output window
+// exhausted, input too close to its end for unchecked reads) drops to the serial decoder of inflate_wave.hpp at the
+// last retired item; that path restates the reference symbol by symbol and emits tokens into the same store, so the
+// parallel path only ever commits tokens of well-formed data and malformed data takes exactly the reference's path.
 #pragma once
 #include "inflate_wave.hpp"
 
@@ -71,10 +66,31 @@ static_assert((RING_DW & (RING_DW - 1)) == 0 && (ITEMS & (ITEMS - 1)) == 0, "rin
 static_assert(SUB_BITS % 128 == 0 && SPEC_BITS <= (u32)SUB_BITS && SUB_BITS + 64 < 4096, "item geometry");
 static_assert(EMIT_MIN >= 1 && EMIT_MIN <= 64 && (u32)ITEMS >= 2 * EMIT_MIN && ITEMS >= 32, "scheduler geometry");
 
+// ---- the token store: what the tokenizer hands to the resolver ----
+// The decode step works on a STEP WORD: literal (0x8000 | byte) << 16 (negative), match len << 16 | dist
+// (len <= 258, dist <= 32768); anything else is not negative and has a zero distance field.
 constexpr u32 TK_LIT = 0x80000000u;  // | byte << 16
-constexpr u32 TK_EOB = 0x40000000u;
-constexpr u32 TK_ERR = 0x20000000u;
-// match: len << 16 | dist   (len <= 258, dist <= 32768)
+// What is RECORDED per token is  end << 16 | payload:
+//   end      the low 16 bits of the output bytes the token's RUN has produced up to and including this token -- the
+//            recording lane counts them anyway; a token's length is end - (end of the token before it), its output
+//            offset is the run's offset (directory) + the end before it;
+//   payload  0x8000 | byte for a literal, dist - 1 (< 0x8000) for a match.
+constexpr u32 REC_LIT = 0x8000u;
+AHIP_DEVINL u32 rec_word(u32 end_bytes, u32 step_word) {
+  const bool lit = (i32)step_word < 0;
+  return (end_bytes << 16) | (lit ? (step_word >> 16) : (step_word & 0xffffu) - 1u);
+}
+// Run directory entry (16 bytes, stream order):
+//   x  word offset of the run's first token in the member's token area
+//   y  tokens of the run (DF_CNT) | flags
+//   z,w  output offset of the run's first byte, relative to the member's own first byte (64 bits)
+// DF_BIG: `end` may wrap inside the run (it produced more than 65535 bytes, or the serial decoder wrote it): lengths
+//         are still exact modulo 2^16, offsets come from a prefix sum over them.
+// DF_STORED: not tokens at all but a stored block of (y & DF_CNT) >= 3 bytes; area[x], area[x + 1] = the absolute
+//         input byte offset of its first byte (lo, hi).
+typedef uint4 DirEnt;
+constexpr u32 DF_BIG = 0x80000000u, DF_STORED = 0x40000000u, DF_CNT = 0x00ffffffu;
+constexpr u32 DIR_BYTES = 16;
 
 // LDS of the tokenizer (next to WaveLds): the staged bitstream ring and the per-item scoreboard
 struct TokLds {
@@ -96,9 +112,7 @@ struct ParLdsT {
   u32 tok[TOK_CAP];
   E obuf[OB_CAP + 32] __attribute__((aligned(16)));
   u32 slot[3 * 64];  // two alternating 64-entry start-slot rows + one dump row
-  u32 misc[4];       // [0] index of the first stored-run record in the current batch
 };
-using ParLds = ParLdsT<u8>;
 constexpr u32 SYM_MARK = 0x8000;
 // history element at window-relative offset si < 0; opos = elements of this chunk in front of the window
 template <typename E>
@@ -108,25 +122,25 @@ AHIP_DEVINL u32 hist_get(const E *hist, i32 si, u64 opos) {
   return a >= 0 ? (u32)hist[si] : (u32)(SYM_MARK + 32768 + a);
 }
 
-constexpr u32 TK_STORED = 0x60000000u;  // | len (3..65535), followed by two words: absolute input byte offset lo, hi
-
 // Token store of one member in device memory (tokenizer -> resolver hand-off).
 //   area  64 columns of col_cap words.  Lane l of the flow decoder records the tokens of its runs into column l, one
 //         behind the other, and they stay there: nothing is transposed or copied.  The serial decoder (irregular
 //         blocks, stored blocks) fills whatever the columns have left, column after column.
-//   dir   the run directory, in stream order: {word offset in area, tokens}.  The resolver walks it and gathers the
-//         runs into its LDS queue, a whole wave on one run at a time (coalesced).
+//   dir   the run directory (DirEnt), in stream order.  The resolver walks it; a lane of the resolver finds its token
+//         by (run, index in the run).
 // Sizes (tok_layout): 1.5 words of area and 1/16 directory entry per output byte -- a token covers >= 1 byte, a
-// stored run of >= 3 bytes takes 3 words, repeated runs waste some; a member that still runs out (MS_TOKFULL) is
+// stored run of >= 3 bytes takes 2 words, repeated runs waste some; a member that still runs out (MS_TOKFULL) is
 // decoded by the byte-writing serial kernel afterwards.
 struct TokSink {
   u32 *area;   // nullptr: sizing run, nothing is stored
   u32 col_cap;
-  uint2 *dir;
+  DirEnt *dir;
   u32 dir_cap, ndir;
   u32 scol, spos, srun;  // serial writer: its column (~0u: none yet), next word, first word of the open run
   bool full;
   bool sizing;  // a sizing run that keeps its tokens: a full sink is reported as MR_FAR next to the true status
+  u64 sbase;    // serial writer: output offset (member-relative) of the open run's first byte
+  u32 sbytes;   //   bytes the open run has produced
 };
 // member k of a launch group whose output starts out_rel bytes into the group's output
 AHIP_DEVINL void tok_layout(u64 out_rel, u64 out_limit, u32 k, u64 &tok_off, u32 &col_cap, u64 &dir_off, u32 &dir_cap) {
@@ -317,22 +331,8 @@ AHIP_DEVINL void resolve_bytes(ParLdsT<E> &P, u32 ntok, u32 nbytes, const E *his
   resolve_back(P, cur, g0, ob, lane);
 }
 
-// Flush the assembled window to HBM: byte head up to 16-byte alignment, 16-byte body, byte tail.
-// obuf index A + i holds output byte i, with A = (address of byte 0) & 15, so LDS and global
-// addresses are congruent mod 16.
 AHIP_DEVINL void flush_window(const ParLdsT<u16> &P, u16 *g, u32 A, u32 n, int lane) {  // symbols: plain copy
   for (u32 i = lane; i < n; i += 64) g[i] = P.obuf[A + i];
-}
-AHIP_DEVINL void flush_window(const ParLds &P, u8 *g, u32 A, u32 nbytes, int lane) {
-  u32 head = (16 - A) & 15;
-  if (head > nbytes) head = nbytes;
-  if ((u32)lane < head) g[lane] = P.obuf[A + lane];
-  u32 body = (nbytes - head) & ~15u;
-  const uint4 *src = (const uint4 *)(P.obuf + A + head);
-  uint4 *dst = (uint4 *)(g + head);
-  for (u32 i = lane; i < body / 16; i += 64) dst[i] = src[i];
-  u32 tail0 = head + body;
-  if (tail0 + lane < nbytes) g[tail0 + lane] = P.obuf[A + tail0 + lane];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -340,35 +340,47 @@ AHIP_DEVINL void flush_window(const ParLds &P, u8 *g, u32 A, u32 nbytes, int lan
 // ------------------------------------------------------------------------------------------
 
 // ---- the serial writer: one lane-uniform token at a time into the free space of the columns ----
+// Its runs are always flagged DF_BIG (they may be of any length; the resolver takes their offsets from a prefix sum).
 AHIP_DEVINL void sink_close(TokSink &k, u32 *colpos, int lane) {  // close the open run, note how far its column is used
   if (!k.area || k.scol >= 64) return;
   if (k.spos > k.srun) {
-    if (k.ndir < k.dir_cap) { if (lane == 0) k.dir[k.ndir] = make_uint2(k.srun, k.spos - k.srun); k.ndir++; }
-    else k.full = true;
+    if (k.ndir < k.dir_cap) {
+      if (lane == 0) k.dir[k.ndir] = make_uint4(k.srun, (k.spos - k.srun) | DF_BIG, (u32)k.sbase, (u32)(k.sbase >> 32));
+      k.ndir++;
+    } else k.full = true;
   }
   if (lane == 0) colpos[k.scol] = k.spos - k.scol * k.col_cap;
   wave_sync();
   k.srun = k.spos;
+  k.sbase += k.sbytes;
+  k.sbytes = 0;
 }
-AHIP_DEVINL void sink_open(TokSink &k, const u32 *colpos) {  // (re)start: the flow decoder may have used this column meanwhile
+// (re)start at output offset `out_rel`: the flow decoder may have used this column meanwhile
+AHIP_DEVINL void sink_open(TokSink &k, const u32 *colpos, u64 out_rel) {
+  k.sbase = out_rel;
+  k.sbytes = 0;
   if (!k.area || k.scol >= 64) return;
   k.spos = k.scol * k.col_cap + uniform(colpos[k.scol]);
   k.srun = k.spos;
 }
 AHIP_DEVINL bool sink_room(TokSink &k, u32 *colpos, u32 words, int lane) {  // `words` contiguous words
   for (;;) {
-    if (k.scol < 64 && k.spos + words <= (k.scol + 1) * k.col_cap) return true;
+    if (k.scol < 64 && k.spos + words <= (k.scol + 1) * k.col_cap && k.spos - k.srun < (1u << 22)) return true;
+    const bool split = k.scol < 64 && k.spos + words <= (k.scol + 1) * k.col_cap;  // only the run got too long
     sink_close(k, colpos, lane);
+    if (split) continue;
     k.scol += 1;  // ~0u -> 0
     if (k.scol >= 64) { k.scol = 64; k.full = true; return false; }
     k.spos = k.scol * k.col_cap + uniform(colpos[k.scol]);
     k.srun = k.spos;
   }
 }
-AHIP_DEVINL void sink_put(TokSink &k, u32 *colpos, u32 tok, int lane) {
+// one token: `step_word` as the decode step makes it (literal / match), `adv` the bytes it produces
+AHIP_DEVINL void sink_put(TokSink &k, u32 *colpos, u32 step_word, u32 adv, int lane) {
   if (!k.area || k.full) return;
   if (!sink_room(k, colpos, 1, lane)) return;
-  if (lane == 0) k.area[k.spos] = tok;
+  k.sbytes += adv;
+  if (lane == 0) k.area[k.spos] = rec_word(k.sbytes, step_word);
   k.spos += 1;
 }
 
@@ -384,7 +396,7 @@ AHIP_DEVINL u32 huffman_token_emit(WaveLds &L, BitCursor &b, OutCursor &o, TokSi
   if (e & (E_LIT | E_EOB | E_BAD | E_HOLE)) {
     if (e & E_LIT) {
       if (o.pos >= o.limit) return 100 + MS_CAP;
-      sink_put(sink, colpos, e & 0xffff0000u, lane);  // (0x8000 | byte) << 16
+      sink_put(sink, colpos, e & 0xffff0000u, 1u, lane);  // (0x8000 | byte) << 16
       o.pos += 1;
       b.pos += cl;
       return 0;
@@ -414,13 +426,13 @@ AHIP_DEVINL u32 huffman_token_emit(WaveLds &L, BitCursor &b, OutCursor &o, TokSi
   if ((u64)dist > o.pos) return 100 + MS_FARREF;
   if (o.pos + (u64)len > o.limit) return 100 + MS_CAP;
   if ((u64)dist > o.pos - o.hist) o.far = 1;
-  sink_put(sink, colpos, ((u32)len << 16) | (u32)dist, lane);
+  sink_put(sink, colpos, ((u32)len << 16) | (u32)dist, (u32)len, lane);
   o.pos += (u64)len;
   return 0;
 }
 AHIP_DEVINL u32 huffman_block_emit(WaveLds &L, BitCursor &b, OutCursor &o, TokSink &sink, u32 *colpos, int lane) {
   const u32 ll_max = L.lld.maxlen, d_max = L.dd.maxlen;
-  sink_open(sink, colpos);
+  sink_open(sink, colpos, o.pos - o.org);
   u32 rs;
   for (;;) {
     u32 r;
@@ -433,7 +445,8 @@ AHIP_DEVINL u32 huffman_block_emit(WaveLds &L, BitCursor &b, OutCursor &o, TokSi
   sink_close(sink, colpos, lane);
   return rs;
 }
-// _parseUncompressedBlock as tokens: runs of >= 3 bytes become one TK_STORED record (3 words, never split)
+// _parseUncompressedBlock as a directory entry: a block of >= 3 bytes becomes one DF_STORED entry (two area words hold
+// its input offset); shorter ones are literals
 AHIP_DEVINL u32 stored_block_emit(BitCursor &b, OutCursor &o, TokSink &sink, u32 *colpos, int lane) {
   b.pos = (b.pos + 7) & ~7ull;
   b.blen = 0;
@@ -444,18 +457,22 @@ AHIP_DEVINL u32 stored_block_emit(BitCursor &b, OutCursor &o, TokSink &sink, u32
   u64 byte = b.pos >> 3;
   if ((u64)len > b.in_len - byte) return MS_FALSE;
   if (o.pos + (u64)len > o.limit) return MS_CAP;
-  sink_open(sink, colpos);
+  sink_open(sink, colpos, o.pos - o.org);
   if (len >= 3) {
-    if (sink.area && !sink.full && sink_room(sink, colpos, 3, lane)) {
-      if (lane == 0) {
-        sink.area[sink.spos] = TK_STORED | (u32)len;
-        sink.area[sink.spos + 1] = (u32)byte;
-        sink.area[sink.spos + 2] = (u32)(byte >> 32);
-      }
-      sink.spos += 3;
+    if (sink.area && !sink.full && sink_room(sink, colpos, 2, lane)) {
+      if (sink.ndir < sink.dir_cap) {
+        if (lane == 0) {
+          sink.area[sink.spos] = (u32)byte;
+          sink.area[sink.spos + 1] = (u32)(byte >> 32);
+          sink.dir[sink.ndir] = make_uint4(sink.spos, (u32)len | DF_STORED, (u32)sink.sbase, (u32)(sink.sbase >> 32));
+        }
+        sink.ndir++;
+      } else sink.full = true;
+      sink.spos += 2;
+      sink.srun = sink.spos;  // the two words belong to the entry above, not to a token run
     }
   } else {
-    for (int i = 0; i < len; ++i) sink_put(sink, colpos, TK_LIT | ((u32)b.in[byte + i] << 16), lane);
+    for (int i = 0; i < len; ++i) sink_put(sink, colpos, TK_LIT | ((u32)b.in[byte + i] << 16), 1u, lane);
   }
   sink_close(sink, colpos, lane);
   o.pos += (u64)len;
@@ -608,7 +625,11 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
         }
         if (__any(mine && (u64)nd > o.pos - o.hist + B)) o.far = 1;  // reaches into earlier output (q8): resolved late
         if (emit) {
-          if (mine && cnt != 0) sink.dir[sink.ndir + (u32)__popcll(hm & lt_mask)] = make_uint2(cl * sink.col_cap + r0, cnt);
+          if (mine && cnt != 0) {
+            const u64 ob = o.pos - o.org + B;  // where the run's first byte goes, counted from the member's own first byte
+            sink.dir[sink.ndir + (u32)__popcll(hm & lt_mask)] =
+                make_uint4(cl * sink.col_cap + r0, cnt | (nby > 0xffffu ? DF_BIG : 0u), (u32)ob, (u32)(ob >> 32));
+          }
           sink.ndir += nh;
         }
         o.pos += tot_bytes;
@@ -697,11 +718,11 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
             if (spc) { fl = (e & E_EOB) ? LR_EOB : LR_ERR; bound = 0; }
           }
           if (!spc) {
-            if (ms >> 29) { if (emit) col[rowctr] = t; rowctr += 1; }
             const bool lit = (i32)t < 0;
             const i32 req = lit ? 0 : (i32)(t & 0xffff) - (i32)nbytes;
             need = req > need ? req : need;
             nbytes += lit ? 1u : (t >> 16);
+            if (ms >> 29) { if (emit) col[rowctr] = rec_word(nbytes, t); rowctr += 1; }
           }
         }
         ++g;
@@ -761,7 +782,7 @@ AHIP_DEVINL void inflate_member(WaveLds &L, HeaderLds &H, TokLds *P, const u8 *i
   ParStats st{};
   BitCursor b{in, in_len, in_len * 8, m.in_off * 8 + (CHUNK ? cx->start_bit : 0u), nullptr, 0, 0, 0};
   const u64 hist = CHUNK ? cx->hist : m.hist;
-  OutCursor o{out + m.out_off - hist, hist, m.out_limit > ~0ull - hist ? ~0ull : m.out_limit + hist, CHUNK ? 0u : hist, 0};
+  OutCursor o{out + m.out_off - hist, hist, m.out_limit > ~0ull - hist ? ~0ull : m.out_limit + hist, CHUNK ? 0u : hist, 0, hist};
   if (PAR) { P->colpos[lane] = 0; wave_sync(); }
   // where the index expects the deflate data to end (a hint for speculation only: the decode itself never trusts it)
   const u64 hint_end_bits = (!CHUNK && m.expect_end != ~0ull) ? m.expect_end * 8 : 0ull;
@@ -875,278 +896,391 @@ AHIP_DEVINL void inflate_member(WaveLds &L, HeaderLds &H, TokLds *P, const u8 *i
 // ------------------------------------------------------------------------------------------
 // Resolver side: replay one member's token stream into its output window
 // ------------------------------------------------------------------------------------------
-template <typename E>
-AHIP_DEVINL void resolve_member(ParLdsT<E> &P, const u8 *in, const u32 *area, const uint2 *dir, u32 ndir, E *out_base, u32 *cyc,
+// exactly `len` (1..16) bytes of the 16 in (w0, w1) to dp, any alignment: two overlapping unaligned stores [0, w) and
+// [len - w, len), w = 8 / 4; gfx950's LDS takes unaligned 2/4/8-byte accesses (tools/micro/lds_unaligned.hip)
+AHIP_DEVINL void deposit16(u8 *dp, u32 len, u64 w0, u64 w1) {
+  if (len >= 8) {
+    const u32 sh = 8 * (len - 8);  // 0..64
+    const u64 tail = sh == 0 ? w0 : (sh == 64 ? w1 : ((w0 >> sh) | (w1 << (64 - sh))));
+    ((unaligned_u64 *)dp)->v = w0;
+    ((unaligned_u64 *)(dp + len - 8))->v = tail;
+  } else if (len >= 4) {
+    ((unaligned_u32 *)dp)->v = (u32)w0;
+    ((unaligned_u32 *)(dp + len - 4))->v = (u32)(w0 >> (8 * (len - 4)));
+  } else {
+    dp[0] = (u8)w0;
+    if (len > 1) dp[1] = (u8)(w0 >> 8);
+    if (len > 2) dp[2] = (u8)(w0 >> 16);
+  }
+}
+
+#ifndef AHIP_WIN_CAP
+#define AHIP_WIN_CAP 2560
+#endif
+#ifndef AHIP_WIN_KEEP
+#define AHIP_WIN_KEEP 640
+#endif
+constexpr u32 WIN_CAP = AHIP_WIN_CAP;              // bytes of output the LDS window holds
+constexpr u32 WIN_FLUSH = WIN_CAP - AHIP_WIN_KEEP;  // ... and it is flushed once a chunk leaves it fuller than this
+static_assert(WIN_CAP % 16 == 0 && WIN_FLUSH >= 512 && AHIP_WIN_KEEP >= 264, "window geometry");
+struct ResLds {
+  u8 obuf[WIN_CAP + 64] __attribute__((aligned(16)));  // + alignment offset (<= 15) + a 16-byte read past the last source byte
+};
+
+// One member: token runs (area, dir) -> bytes at out_base.  64 tokens per step, one per lane.
+//   offsets  every lane knows where its token goes without a scan: the run's output offset (directory) + the `end` of
+//            the token before it.  All lane offsets are relative to `borg`, the window position when the current look at
+//            the directory began; `wrel` (scalar) = window position - borg, so window index = offset - wrel.
+//   sources  a match whose 16 (32) source bytes are flushed output is fetched per token one chunk ahead (prep) and
+//            deposited with exact-length stores; a source inside the window is read from LDS when every byte of it is
+//            final: in ROUNDS -- the first pending match of a chunk is always ready (everything in front of its
+//            destination is final), a later one when its source ends at or before the first pending destination.
+//   hard     matches longer than 32 bytes, overlapping their own source, or straddling the window start are copied by
+//            the whole wave, one token at a time, when they are the first pending one.
+AHIP_DEVINL void resolve_member(ResLds &P, const u8 *in, const u32 *area, const DirEnt *dir, u32 ndir, u8 *out_base, u32 *cyc,
                                 int lane) {
-  constexpr bool MARK = sizeof(E) == 2;
+  u64 wpos = 0;                                   // output offset (member-relative) of the window's first byte
+  u32 wfill = 0;                                  // bytes assembled in the window
+  u32 A = (u32)((uintptr_t)out_base & 15);        // obuf[A + i] <-> out_base[wpos + i]: LDS and global congruent mod 16
+  auto flush = [&]() {  // window -> HBM: byte head up to 16-byte alignment, 16-byte body, byte tail
+    wave_sync();
+    u8 *g = out_base + wpos;
+    u32 head = (16 - A) & 15;
+    if (head > wfill) head = wfill;
+    if ((u32)lane < head) g[lane] = P.obuf[A + lane];
+    const u32 body = (wfill - head) & ~15u;
+    const uint4 *src = (const uint4 *)(P.obuf + A + head);
+    uint4 *dst = (uint4 *)(g + head);
+    for (u32 i = lane; i < body / 16; i += 64) dst[i] = src[i];
+    const u32 tail0 = head + body;
+    if (tail0 + lane < wfill) g[tail0 + lane] = P.obuf[A + tail0 + lane];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // later matches read this output back
+    wave_sync();
+    wpos += wfill;
+    A = (A + wfill) & 15;
+    wfill = 0;
+  };
+  struct Tok { u32 t; i32 base; bool first, inb; };          // a chunk's tokens as loaded: word, run offset (rel. borg)
+  struct Ck { u32 t, len; i32 ob; bool inb, pre; u64 w0, w1, w2, w3; };  // ... decoded: ob = output offset rel. borg
+  u32 de = 0;
+  while (de < ndir) {
+    AHIP_TICK(t_0);
+    const u32 ei = de + (u32)lane;
+    const bool have = ei < ndir;
+    const DirEnt dv = have ? dir[ei] : make_uint4(0u, 0u, 0u, 0u);
+    const u64 special = __ballot(have && (dv.y & (DF_BIG | DF_STORED)) != 0);
+    const u32 nleft = ndir - de < 64u ? ndir - de : 64u;
+    const u32 nplain = special ? (u32)__builtin_ctzll(special) : nleft;  // ordinary runs in front of the first special entry
+    const u64 borg = wpos;
+    u32 wrel = 0;
+    // ---- one chunk (any lanes `inb`): literals, deposits, rounds; splits where the window is full ----
+    auto process = [&](Ck &c) {
+      const bool lit = (c.t & REC_LIT) != 0;
+      const u32 dist = (c.t & 0x7fffu) + 1u;
+      const bool isM = c.inb && !lit;
+      const bool simple = c.len <= 32 && dist >= c.len;  // two 16-byte pieces, source and destination apart
+      u64 rem = __ballot(c.inb);
+      while (rem) {
+        const i32 wo = c.ob - (i32)wrel;  // window index of the destination
+        const bool fit = ((rem >> lane) & 1) && (u32)wo + c.len <= WIN_CAP;
+        const u64 fm = __ballot(fit);     // a prefix of rem: destinations increase with the lane
+        if (!fm) {
+          if (wfill == 0) return;         // (cannot happen: a token is at most 258 bytes) never spin
+          flush();
+          wrel = (u32)(wpos - borg);
+          continue;
+        }
+        u8 *const ob = P.obuf + A;
+        if (fit && lit) ob[wo] = (u8)c.t;
+        const i32 so = wo - (i32)dist;    // window index of the source (negative: flushed output)
+        const i32 span = c.len > 16 ? (i32)c.len : 16;
+        const bool inL = so >= 0, inG = so + span <= 0;
+        const bool hard = !simple || (!inL && !inG);
+        u64 pend = __ballot(fit && isM);
+        wave_sync();
+        u32 guard = 0;
+        while (pend && ++guard <= 80) {
+          const int f = __builtin_ctzll(pend);
+          const u32 fd = lane_bcast((u32)wo, f);
+          const bool mine = (pend >> lane) & 1;
+          if (lane_bcast(hard ? 1u : 0u, f)) {
+            // the first pending match, copied by the whole wave: every byte in front of its destination is final
+            const u32 L_ = lane_bcast(c.len, f), D_ = lane_bcast(dist, f);
+            const i32 S_ = (i32)fd - (i32)D_;
+            const u8 *gsrc = out_base + wpos;  // window index i < 0 <-> gsrc[i]
+            const u32 n0 = D_ < L_ ? D_ : L_;  // the part that does not read its own output
+            for (u32 k = (u32)lane; k < n0; k += 64) {
+              const i32 si = S_ + (i32)k;
+              // (values are selected, not pointers: an LDS / global pointer select trips the gfx950 backend)
+              const u32 lv = ob[si >= 0 ? si : 0];
+              u32 gv = 0;
+              if (si < 0) gv = gsrc[si];
+              ob[fd + k] = (u8)(si >= 0 ? lv : gv);
+            }
+            wave_sync();
+            u32 filled = n0;  // a multiple of D_ from here on: the destination repeats with period D_
+            while (filled < L_) {
+              const u32 n = filled < L_ - filled ? filled : L_ - filled;
+              for (u32 k = (u32)lane; k < n; k += 64) ob[fd + filled + k] = ob[fd + k];
+              wave_sync();
+              filled += n;
+            }
+            pend &= pend - 1;
+            continue;
+          }
+          const bool act = mine && !hard && ((u32)lane == (u32)f || so + (i32)c.len <= (i32)fd);
+          u64 w0 = c.w0, w1 = c.w1, w2 = c.w2, w3 = c.w3;
+          if (act && !c.pre) {
+            if (inL) {
+              w0 = ((const unaligned_u64 *)(ob + so))->v;
+              w1 = ((const unaligned_u64 *)(ob + so + 8))->v;
+              if (c.len > 16) {
+                w2 = ((const unaligned_u64 *)(ob + so + c.len - 16))->v;
+                w3 = ((const unaligned_u64 *)(ob + so + c.len - 8))->v;
+              }
+            } else {  // flushed output that was still in the window when the chunk was prepared
+              const u8 *sp = out_base + wpos + so;
+              w0 = load_u64_unaligned(sp);
+              w1 = load_u64_unaligned(sp + 8);
+              if (c.len > 16) { w2 = load_u64_unaligned(sp + c.len - 16); w3 = load_u64_unaligned(sp + c.len - 8); }
+            }
+          }
+          if (act) {
+            u8 *dp = ob + wo;
+            if (c.len > 16) {
+              ((unaligned_u64 *)dp)->v = w0;
+              ((unaligned_u64 *)(dp + 8))->v = w1;
+              ((unaligned_u64 *)(dp + c.len - 16))->v = w2;
+              ((unaligned_u64 *)(dp + c.len - 8))->v = w3;
+            } else {
+              deposit16(dp, c.len, w0, w1);
+            }
+          }
+          pend &= ~__ballot(act);
+          wave_sync();  // this round's bytes are final for the next one
+        }
+        const int last = 63 - __builtin_clzll(fm);
+        wfill = lane_bcast((u32)wo + c.len, last);
+        rem &= ~fm;
+        if (rem) {
+          flush();
+          wrel = (u32)(wpos - borg);
+          // sources that were fetched ahead stay valid (flushed output never changes); everything else is looked at again
+        }
+      }
+    };
+    if (nplain == 0) {
+      // ---- a special entry at the head of the look ----
+      const u32 y = lane_bcast(dv.y, 0), x = lane_bcast(dv.x, 0);
+      const u32 cnt = y & DF_CNT;
+      if (y & DF_STORED) {  // stored block: input -> output copy, past the window
+        if (wfill) flush();
+        const u64 src = (u64)uniform(area[x]) | ((u64)uniform(area[x + 1]) << 32);
+        u8 *g = out_base + wpos;
+        for (u32 i = lane; i < cnt; i += 64) g[i] = in[src + i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        wpos += cnt;
+        A = (A + cnt) & 15;
+      } else {
+        // a run whose `end` fields may wrap: lengths are exact modulo 2^16, offsets from a prefix sum
+        u32 carry_end = 0;
+        u32 run = wfill;  // offset (rel. borg) of the next chunk's first byte
+        for (u32 c0 = 0; c0 < cnt; c0 += 64) {
+          Ck c;
+          c.inb = c0 + (u32)lane < cnt;
+          c.t = c.inb ? area[x + c0 + lane] : 0u;
+          const u32 end = c.t >> 16;
+          u32 pe = lane_prev(end);
+          pe = lane == 0 ? carry_end : pe;
+          c.len = c.inb ? ((end - pe) & 0xffffu) : 0u;
+          u32 tot;
+          c.ob = (i32)(run + wave_excl_sum(c.len, tot));
+          c.pre = false;
+          c.w0 = c.w1 = c.w2 = c.w3 = 0;
+          carry_end = lane_bcast(end, 63);
+          // (a chunk of long matches may be larger than the window: process() splits it)
+          process(c);
+          run += tot;
+          if (wfill >= WIN_FLUSH) { flush(); wrel = (u32)(wpos - borg); }
+        }
+      }
+      de += 1;
+      continue;
+    }
+    // ---- ordinary runs: lane r holds run r of the look ----
+    const bool rmine = (u32)lane < nplain;
+    const u32 rcnt = rmine ? (dv.y & DF_CNT) : 0u;
+    u32 total;
+    const u32 ts = wave_excl_sum(rcnt, total);                                   // first token of the run within the look
+    const i32 rb = (i32)((((u64)dv.w << 32) | dv.z) - borg);                     // where its output starts, rel. borg
+    u32 r0 = 0;  // the run the next gathered chunk starts in
+    auto gather = [&](u32 c0) -> Tok {
+      Tok q;
+      const u32 idx = c0 + (u32)lane;
+      q.inb = idx < total;
+      u32 k = 0, ta = 0;
+      q.base = 0;
+      u32 r = r0, s = lane_bcast(ts, (int)r0);
+      for (;;) {
+        const u32 ao = lane_bcast(dv.x, (int)r);
+        const i32 bo = (i32)lane_bcast((u32)rb, (int)r);
+        const bool sel = idx >= s;
+        k = sel ? idx - s : k;
+        ta = sel ? ao : ta;
+        q.base = sel ? bo : q.base;
+        if (r + 1 >= nplain) break;
+        const u32 sn = lane_bcast(ts, (int)r + 1);
+        if (sn >= c0 + 64) { if (sn == c0 + 64) r += 1; break; }
+        r += 1;
+        s = sn;
+      }
+      r0 = r;
+      q.first = k == 0;
+      q.t = q.inb ? area[ta + k] : 0u;
+      return q;
+    };
+    u32 carry_end = 0;  // `end` of the token in front of the chunk being prepared
+    auto prep = [&](const Tok &q) -> Ck {
+      Ck c;
+      c.t = q.t;
+      c.inb = q.inb;
+      const u32 end = q.t >> 16;
+      u32 pe = lane_prev(end);
+      pe = lane == 0 ? carry_end : pe;
+      pe = q.first ? 0u : pe;
+      carry_end = lane_bcast(end, 63);
+      c.len = q.inb ? end - pe : 0u;
+      c.ob = q.base + (i32)pe;
+      const bool lit = (q.t & REC_LIT) != 0;
+      const u32 dist = (q.t & 0x7fffu) + 1u;
+      const i32 so = c.ob - (i32)wrel - (i32)dist;  // against the window as it is NOW: what is flushed stays flushed
+      const i32 span = c.len > 16 ? (i32)c.len : 16;
+      c.pre = q.inb && !lit && c.len <= 32 && dist >= c.len && so + span <= 0;
+      c.w0 = c.w1 = c.w2 = c.w3 = 0;
+      if (c.pre) {
+        const u8 *sp = out_base + wpos + so;
+        c.w0 = load_u64_unaligned(sp);
+        c.w1 = load_u64_unaligned(sp + 8);
+        if (c.len > 16) { c.w2 = load_u64_unaligned(sp + c.len - 16); c.w3 = load_u64_unaligned(sp + c.len - 8); }
+      }
+      return c;
+    };
+    Tok t1 = gather(0);
+    Ck c1 = prep(t1);
+    Tok t2 = t1;
+    if (64 < total) t2 = gather(64);
+    AHIP_TICK(t_1);
+    AHIP_ACC(cyc[6], t_0, t_1);
+    for (u32 c0 = 0; c0 < total; c0 += 64) {
+      Ck c = c1;
+      if (c0 + 64 < total) c1 = prep(t2);          // decode + fetch the flushed sources of the next chunk
+      if (c0 + 128 < total) t2 = gather(c0 + 128);  // load the tokens of the one after
+      process(c);
+      if (wfill >= WIN_FLUSH) { flush(); wrel = (u32)(wpos - borg); }
+    }
+    AHIP_TICK(t_2);
+    AHIP_ACC(cyc[5], t_1, t_2);
+    de += nplain;
+  }
+  if (wfill) flush();
+}
+
+
+// ------------------------------------------------------------------------------------------
+// The byte-per-lane resolver (resolve_front / resolve_back / resolve_bytes above), kept for the 16-bit SYMBOLS of the
+// chunked single-stream decode (sm_inflate.hpp): a symbol is a byte value or 0x8000 + j, "byte j of the 32 KiB in
+// front of this chunk".  Tokens are converted from the recorded form (end, payload) to step words while they are
+// gathered into the LDS queue; offsets then come from prefix sums over the lengths, 64 tokens at a time.
+// ------------------------------------------------------------------------------------------
+template <typename E>
+AHIP_DEVINL void resolve_member_sym(ParLdsT<E> &P, const u8 *in, const u32 *area, const DirEnt *dir, u32 ndir, E *out_base, u32 *cyc,
+                                    int lane) {
+  static_assert(sizeof(E) == 2, "symbols only: bytes go through resolve_member()");
   u32 de = 0, df = 0;  // cursor into the token stream: directory entry, tokens of it already consumed
   u64 opos = 0;
-  if (lane == 0) P.misc[0] = 0xffffffffu;
-  wave_sync();
   while (de < ndir) {
     AHIP_TICK(t_0);
     // ---- gather up to TOK_CAP tokens of the next runs into the queue, a whole wave on one run at a time
-    //      (coalesced); a stored-run record ends the batch (it is handled at a batch head) ----
+    //      (coalesced); a stored block ends the batch (it is handled at a batch head) ----
     const u32 ei = de + (u32)lane;
-    const uint2 dv = ei < ndir ? dir[ei] : make_uint2(0u, 0u);
-    const u32 rcnt = lane == 0 ? dv.y - df : dv.y, roff = lane == 0 ? dv.x + df : dv.x;
+    const DirEnt dv = ei < ndir ? dir[ei] : make_uint4(0u, 0u, 0u, 0u);
+    const u64 sm = __ballot(ei < ndir && (dv.y & DF_STORED) != 0);
+    const u32 nplain = sm ? (u32)__builtin_ctzll(sm) : 64u;
+    if (nplain == 0) {  // stored block at the head (df == 0): input -> output copy
+      const u32 len = lane_bcast(dv.y, 0) & DF_CNT, x = lane_bcast(dv.x, 0);
+      const u64 src = (u64)uniform(area[x]) | ((u64)uniform(area[x + 1]) << 32);
+      for (u32 i = lane; i < len; i += 64) out_base[opos + i] = (E)in[src + i];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      opos += len;
+      de += 1;
+      continue;
+    }
+    const bool mine = ei < ndir && (u32)lane < nplain;
+    const u32 cnt = mine ? (dv.y & DF_CNT) : 0u;
+    const u32 rcnt = lane == 0 ? cnt - df : cnt, roff = lane == 0 ? dv.x + df : dv.x;
     u32 rtot;
     const u32 rT = wave_excl_sum(rcnt, rtot);
     const u32 take = rT < (u32)TOK_CAP ? (rcnt < (u32)TOK_CAP - rT ? rcnt : (u32)TOK_CAP - rT) : 0u;
     const u32 nrun = (u32)__popcll(__ballot(take != 0));
     const u32 want = rtot < (u32)TOK_CAP ? rtot : (u32)TOK_CAP;
-    for (u32 j = 0; j < nrun; j += 4) {  // four runs' loads in flight
-      u32 v[4], qd[4];
-#pragma unroll
-      for (u32 q = 0; q < 4; ++q) {
-        const int jj = (int)(j + q < nrun ? j + q : nrun - 1);
-        const u32 o_ = lane_bcast(roff, jj), c_ = j + q < nrun ? lane_bcast(take, jj) : 0u, t_ = lane_bcast(rT, jj);
-        qd[q] = (u32)lane < c_ ? t_ + (u32)lane : 0xffffffffu;
-        v[q] = (u32)lane < c_ ? area[o_ + (u32)lane] : 0u;
-        for (u32 u = 64 + (u32)lane; u < c_; u += 64) {  // a long run (the serial decoder's)
-          const u32 t = area[o_ + u];
-          P.tok[t_ + u] = t;
-          if ((t & 0xe0000000u) == TK_STORED) atomicMin(&P.misc[0], t_ + u);
-        }
+    // recorded token + the one before it in the run -> step word
+    auto step_word = [&](u32 t, u32 pw) -> u32 {
+      const u32 len = ((t >> 16) - (pw >> 16)) & 0xffffu;
+      return (t & REC_LIT) ? (TK_LIT | ((t & 0xffu) << 16)) : ((len << 16) | ((t & 0x7fffu) + 1u));
+    };
+    for (u32 j = 0; j < nrun; ++j) {
+      const u32 o_ = lane_bcast(roff, (int)j), c_ = lane_bcast(take, (int)j), t_ = lane_bcast(rT, (int)j), x_ = lane_bcast(dv.x, (int)j);
+      for (u32 u = (u32)lane; u < c_; u += 64) {
+        const u32 t = area[o_ + u];
+        const u32 pw = o_ + u > x_ ? area[o_ + u - 1] : 0u;
+        P.tok[t_ + u] = step_word(t, pw);
       }
-#pragma unroll
-      for (u32 q = 0; q < 4; ++q)
-        if (qd[q] != 0xffffffffu) {
-          P.tok[qd[q]] = v[q];
-          if ((v[q] & 0xe0000000u) == TK_STORED) atomicMin(&P.misc[0], qd[q]);  // lowest index wins
-        }
     }
     wave_sync();
-    u32 first_stored = uniform(P.misc[0]) < want ? uniform(P.misc[0]) : want;
-    // NOTE: the two words after a TK_STORED header are raw offsets and may alias the pattern; only the
-    // FIRST hit is trusted, and the scan restarts after it.
     // cursor += adv tokens
     auto advance = [&](u32 adv) {
-      const u32 nfull = (u32)__popcll(__ballot(ei < ndir && rT + rcnt <= adv));  // runs used up (a prefix)
+      const u32 nfull = (u32)__popcll(__ballot(mine && rT + rcnt <= adv));  // runs used up (a prefix)
       const u32 base = nfull < 64 ? lane_bcast(rT, (int)nfull) : rtot;
       df = nfull ? adv - base : df + adv;
       de += nfull;
     };
-    if (first_stored == 0) {
-      // stored run at the head: input -> output copy
-      const u32 len = P.tok[0] & 0xffff;
-      const u64 src = (u64)P.tok[1] | ((u64)P.tok[2] << 32);
-      for (u32 i = lane; i < len; i += 64) out_base[opos + i] = (E)in[src + i];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      opos += len;
-      advance(3);
-      if (lane == 0) P.misc[0] = 0xffffffffu;
-      wave_sync();
-      continue;
-    }
-    u32 ntok = first_stored;
-    wave_sync();
-    if (lane == 0) P.misc[0] = 0xffffffffu;
-    // ---- pass 1 (keys) with the byte cut at OB_CAP; matches whose whole source is flushed history (and
-    //      at most 16 bytes long) are fetched per TOKEN with two 8-byte loads and deposited into the window
-    //      right here -- one vector-memory instruction per 64 tokens instead of one byte gather per 64 bytes ----
+    u32 ntok = want;
+    // ---- pass 1 (keys) with the element cut at OB_CAP ----
     E *g = out_base + opos;
-    const u32 A = MARK ? 0u : (u32)((uintptr_t)g & 15);
-    E *obw = P.obuf + A;
-    // software-pipelined by one chunk of 64 tokens: the history loads of chunk c+1 are in flight while
-    // chunk c is deposited
-    struct Chunk {
-      u32 idx, len, off, key, total, nf, nin;
-      bool fits, pre, cut;
-      u64 w0, w1;
-#ifdef AHIP_TOKEN_RESOLVER
-      u32 tokw;
-#endif
-#ifdef AHIP_DEPOSIT32
-      u64 w2, w3;  // EXPERIMENT (off by default): matches of 17..32 bytes from flushed output are deposited per token too
-#endif
-    };
-    auto prep = [&](u32 c, u32 run) -> Chunk {
-      Chunk q;
-      q.idx = c + lane;
-      const bool inb = q.idx < ntok;
-      const u32 t = inb ? P.tok[q.idx] : 0u;
-#ifdef AHIP_TOKEN_RESOLVER
-      q.tokw = t;
-#endif
+    const u32 A = 0u;
+    u32 run = 0, kept = 0;
+    for (u32 c = 0; c < ntok; c += 64) {
+      const u32 idx = c + lane;
+      const bool inb = idx < ntok;
+      const u32 t = inb ? P.tok[idx] : 0u;
       const bool lit = t >> 31;
-      q.len = inb ? (lit ? 1u : (t >> 16)) : 0u;
-      q.off = run + wave_excl_sum(q.len, q.total);
-      q.fits = inb && q.off + q.len <= (u32)OB_CAP;
-      q.key = (1u << 30) | (q.off << 17) | (lit ? (0x10000u | ((t >> 16) & 0xff)) : ((t & 0xffff) - 1));
-      const i32 srel = (i32)q.off - (i32)(t & 0xffff);  // source start relative to the window
-      q.pre = !MARK && q.fits && !lit && q.len <= 16 && srel + 16 <= 0;  // (symbols take the per-element path)
-#ifdef AHIP_DEPOSIT32
-      const bool pre32 = !MARK && q.fits && !lit && q.len > 16 && q.len <= 32 && srel + 32 <= 0;
-      q.pre = q.pre || pre32;
-      q.w2 = q.w3 = 0;
-#endif
-      q.w0 = q.w1 = 0;
-      if (q.pre) { const u8 *sp = (const u8 *)g + srel; q.w0 = load_u64_unaligned(sp); q.w1 = load_u64_unaligned(sp + 8); }
-#ifdef AHIP_DEPOSIT32
-      if (pre32) { const u8 *sp = (const u8 *)g + srel; q.w2 = load_u64_unaligned(sp + 16); q.w3 = load_u64_unaligned(sp + 24); }
-#endif
-      const u64 fm = __ballot(q.fits), im = __ballot(inb);
-      q.nf = (u32)__popcll(fm);
-      q.nin = (u32)__popcll(im);
-      q.cut = fm != im;  // the window is full: cut after the last fitting token
-      return q;
-    };
-    u32 run = 0, kept = 0, c = 0;
-    Chunk ck = prep(0, 0);
-    for (;;) {
-      const bool more = !ck.cut && c + 64 < ntok;
-      Chunk nxt = ck;
-      if (more) nxt = prep(c + 64, run + ck.total);
-      if (ck.pre) {
-#ifdef AHIP_DEPOSIT_BYTES
-        E *dp = obw + ck.off;
-#pragma unroll
-        for (u32 k = 0; k < 16; ++k)
-          if (k < ck.len) dp[k] = (E)(u8)((k < 8 ? ck.w0 : ck.w1) >> (8 * (k & 7)));
-#else
-        // exactly ck.len (3..16) bytes with two overlapping stores at any alignment (gfx950 LDS takes unaligned
-        // 2/4/8-byte accesses): [0, w) and [len - w, len)
-        if constexpr (sizeof(E) == 1) {
-          u8 *dp = (u8 *)obw + ck.off;
-#ifdef AHIP_DEPOSIT32
-          if (ck.len > 16) {
-            // the first 16 bytes, then the LAST 16 (bytes [len - 16, len) of the 32 loaded ones), overlapping in between
-            const u32 o = ck.len - 16;  // 1..16
-            const u64 a = o < 8 ? ck.w0 : ck.w1, b = o < 8 ? ck.w1 : ck.w2, c = o < 8 ? ck.w2 : ck.w3;
-            const u32 sh = 8 * (o & 7);
-            const u64 lo = o == 16 ? ck.w2 : (sh ? ((a >> sh) | (b << (64 - sh))) : a);
-            const u64 hi = o == 16 ? ck.w3 : (sh ? ((b >> sh) | (c << (64 - sh))) : b);
-            ((unaligned_u64 *)dp)->v = ck.w0;
-            ((unaligned_u64 *)(dp + 8))->v = ck.w1;
-            ((unaligned_u64 *)(dp + o))->v = lo;
-            ((unaligned_u64 *)(dp + o + 8))->v = hi;
-          } else
-#endif
-          if (ck.len >= 8) {
-            const u32 sh = 8 * (ck.len - 8);  // 0..64
-            const u64 tail = sh == 0 ? ck.w0 : (sh == 64 ? ck.w1 : ((ck.w0 >> sh) | (ck.w1 << (64 - sh))));
-            ((unaligned_u64 *)dp)->v = ck.w0;
-            ((unaligned_u64 *)(dp + ck.len - 8))->v = tail;
-          } else if (ck.len >= 4) {
-            ((unaligned_u32 *)dp)->v = (u32)ck.w0;
-            ((unaligned_u32 *)(dp + ck.len - 4))->v = (u32)(ck.w0 >> (8 * (ck.len - 4)));
-          } else {
-            dp[0] = (u8)ck.w0; dp[1] = (u8)(ck.w0 >> 8); dp[2] = (u8)(ck.w0 >> 16);
-          }
-        }
-#endif
-      }
-#ifdef AHIP_TOKEN_RESOLVER
-      // EXPERIMENT (off by default, not yet run on a GPU; the algorithm is checked byte for byte by
-      // tools/analysis/resolver_model.c): finish every token of the chunk right here, 64 tokens per step, and drop
-      // the byte pass.  Literals store their byte; matches from flushed output were deposited above (ck.pre); the
-      // rest goes in ROUNDS: the first pending match is always ready (all bytes in front of its destination are
-      // final), a later one when its source ends at or before the first pending destination.  Ready matches of
-      // <= 16 bytes whose source does not overlap their destination read 16 window bytes and deposit like the far
-      // ones; long, self-overlapping or window-straddling ones are copied by the whole wave, one token at a time.
-      if constexpr (!MARK) {
-        const bool t_lit = ck.tokw >> 31;
-        const u32 t_dist = ck.tokw & 0xffffu;
-        const i32 srel = (i32)ck.off - (i32)t_dist;  // source start relative to the window (negative: flushed output)
-        if (ck.fits && t_lit) P.obuf[A + ck.off] = (E)(u8)(ck.tokw >> 16);
-        bool pend = ck.fits && !t_lit && !ck.pre;
-        wave_sync();  // phase-1 bytes (literals, deposits) are in the window
-        u64 pm = __ballot(pend);
-        u32 rguard = 0;
-        while (pm && ++rguard <= 64) {
-          const int first = __builtin_ctzll(pm);
-          const u32 first_dst = lane_bcast(ck.off, first);
-          const bool ready = pend && (lane == first || srel + (i32)ck.len <= (i32)first_dst);
-          // simple: the source lies in the window and either does not overlap the destination or trails it by >= 16
-          // bytes (a 16-byte piece then never reads what it is about to write); dist == 1 is a byte splat.
-          // Pieces of 16 bytes at offsets 0, 16, ... and a last one ending exactly at len (it may overlap the piece
-          // before it: same bytes again); a match of <= 16 bytes is one piece of exactly len bytes.
-          const bool splat = ready && srel >= 0 && t_dist == 1 && ck.len > 1;
-          const bool simple = ready && srel >= 0 && (t_dist >= ck.len || t_dist >= 16 || splat);
-          u32 done = 0;
-          bool act = simple;
-          u64 sw = 0;
-          if (splat) sw = (u64)P.obuf[A + (u32)srel] * 0x0101010101010101ull;
-          while (__any(act)) {
-            if (act) {
-              const u32 rem = ck.len - done;
-              const u32 at = (ck.len > 16 && rem < 16) ? ck.len - 16 : done;  // the last piece ends at len
-              u64 w0 = sw, w1 = sw;
-              if (!splat) {
-                w0 = ((const unaligned_u64 *)&P.obuf[A + (u32)srel + at])->v;
-                w1 = ((const unaligned_u64 *)&P.obuf[A + (u32)srel + at + 8])->v;
-              }
-              E *dp = &P.obuf[A + ck.off + at];
-              if (ck.len >= 16) {
-                ((unaligned_u64 *)dp)->v = w0;
-                ((unaligned_u64 *)(dp + 8))->v = w1;
-              } else if (ck.len >= 8) {
-                const u32 sh = 8 * (ck.len - 8);
-                const u64 tail = sh == 0 ? w0 : ((w0 >> sh) | (w1 << (64 - sh)));
-                ((unaligned_u64 *)dp)->v = w0;
-                ((unaligned_u64 *)(dp + ck.len - 8))->v = tail;
-              } else if (ck.len >= 4) {
-                ((unaligned_u32 *)dp)->v = (u32)w0;
-                ((unaligned_u32 *)(dp + ck.len - 4))->v = (u32)(w0 >> (8 * (ck.len - 4)));
-              } else {
-                dp[0] = (u8)w0; dp[1] = (u8)(w0 >> 8);
-                if (ck.len > 2) dp[2] = (u8)(w0 >> 16);
-              }
-              done += 16;
-              act = done < ck.len;
-            }
-            wave_sync();  // a later piece of the same lane may read what this one wrote
-          }
-          u64 hm = __ballot(ready && !simple);
-          while (hm) {  // one token at a time, a byte per lane (sources are final: they end in front of first_dst)
-            const int j = __builtin_ctzll(hm);
-            hm &= hm - 1;
-            const u32 L_ = lane_bcast(ck.len, j), D_ = lane_bcast(t_dist, j), O_ = lane_bcast(ck.off, j);
-            const i32 S_ = (i32)O_ - (i32)D_;
-            for (u32 k = (u32)lane; k < L_; k += 64) {
-              const i32 si = S_ + (i32)(D_ < L_ ? k % D_ : k);
-              // (values are selected, not pointers: an LDS / global pointer select trips the gfx950 backend)
-              const u32 lv = P.obuf[A + (u32)(si >= 0 ? si : 0)];
-              u32 gv = 0;
-              if (si < 0) gv = hist_get((const E *)g, si, opos);
-              P.obuf[A + O_ + k] = (E)(si >= 0 ? lv : gv);
-            }
-          }
-          pend = pend && !ready;
-          pm = __ballot(pend);
-          wave_sync();  // this round's bytes are final for the next one
-        }
-      } else
-#endif
-      if (ck.fits) P.tok[ck.idx] = ck.key | (ck.pre ? 0x8000u : 0u);
-      if (ck.cut) {
-        kept = c + ck.nf;
-        run = ck.nf ? lane_bcast(ck.off + ck.len, (int)ck.nf - 1) : run;
+      const u32 len = inb ? (lit ? 1u : (t >> 16)) : 0u;
+      u32 total;
+      const u32 off = run + wave_excl_sum(len, total);
+      const bool fits = inb && off + len <= (u32)OB_CAP;
+      const u32 key = (1u << 30) | (off << 17) | (lit ? (0x10000u | ((t >> 16) & 0xff)) : ((t & 0xffff) - 1));
+      if (fits) P.tok[idx] = key;
+      const u64 fm = __ballot(fits), im = __ballot(inb);
+      if (fm != im) {  // the window is full: cut after the last fitting token
+        const u32 nf = (u32)__popcll(fm);
+        kept = c + nf;
+        run = nf ? lane_bcast(off + len, (int)nf - 1) : run;
         break;
       }
-      run += ck.total;
-      kept = c + ck.nin;
-      if (!more) break;
-      ck = nxt;
-      c += 64;
+      run += total;
+      kept = c + (u32)__popcll(im);
     }
     ntok = kept;
     wave_sync();
     AHIP_TICK(t_1);
     AHIP_ACC(cyc[6], t_0, t_1);
     const u32 nbytes = run;
-#ifdef AHIP_TOKEN_RESOLVER
-    if constexpr (MARK)
-#endif
     resolve_bytes(P, ntok, nbytes, (const E *)g, opos, A, lane);
     wave_sync();
     AHIP_TICK(t_2);
     AHIP_ACC(cyc[5], t_1, t_2);
     flush_window(P, g, A, nbytes, lane);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // later batches read this output back
-    AHIP_TICK(t_3);
-    AHIP_ACC(cyc[5], t_2, t_3);
     opos += nbytes;
     advance(ntok);
   }

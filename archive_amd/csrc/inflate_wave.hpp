@@ -268,6 +268,7 @@ struct OutCursor {
   u64 limit;  // window size + hist
   u64 hist;   // bytes of earlier output in front of this stream that a back-reference may reach (quirk q8)
   u32 far;    // some back-reference did reach into them
+  u64 org;    // `pos` of the stream's own first byte (what the token store counts output offsets from)
 };
 
 // writeBackReference(distance, count): every lane copies bytes lane, lane+64, ...

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64) void sm_find_kernel(const u8 *__restrict__ in, 
 __global__ __launch_bounds__(64) void sm_tokenize_kernel(const u8 *__restrict__ in, u64 in_len,
                                                         const ChunkDesc *__restrict__ chunks, u32 n_chunks,
                                                         const u64 *__restrict__ cand_bits, u32 n_cand,
-                                                        u32 *__restrict__ tokens, uint2 *__restrict__ dir,
+                                                        u32 *__restrict__ tokens, DirEnt *__restrict__ dir,
                                                         MemberResult *__restrict__ results) {
   __shared__ SmLds lds;
   const int lane = threadIdx.x;
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(64) void sm_tokenize_kernel(const u8 *__restrict__ 
 // tokens -> symbols
 __global__ __launch_bounds__(64) void sm_resolve_kernel(const u8 *__restrict__ in, const ChunkDesc *__restrict__ chunks,
                                                        u32 n_chunks, u16 *sym, const u32 *__restrict__ tokens,
-                                                       const uint2 *__restrict__ dir, const MemberResult *__restrict__ results) {
+                                                       const DirEnt *__restrict__ dir, const MemberResult *__restrict__ results) {
   __shared__ ParLdsT<u16> lds;
   const int lane = threadIdx.x;
   for (u32 k = blockIdx.x; k < n_chunks; k += gridDim.x) {
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(64) void sm_resolve_kernel(const u8 *__restrict__ i
     u32 cc, dc;
     tok_layout(out_off, out_limit, k, toff, cc, doff, dc);
     u32 cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    resolve_member<u16>(lds, in, tokens + toff, dir + doff, ndir, sym + out_off, cyc, lane);
+    resolve_member_sym<u16>(lds, in, tokens + toff, dir + doff, ndir, sym + out_off, cyc, lane);
   }
 }
 

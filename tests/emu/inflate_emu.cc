@@ -3,7 +3,7 @@
 // executed by 64 threads as the 64 lanes of a wave (tests/emu/wave_emu.hpp), glued together the way
 // inflate_tokenize_kernel / inflate_resolve_kernel of archive_hip.hip do it.  Test infrastructure only.
 //
-//   g++ -std=c++17 -O2 -pthread [-DAHIP_TOKEN_RESOLVER] -o inflate_emu tests/emu/inflate_emu.cc
+//   g++ -std=c++17 -O2 -pthread -o inflate_emu tests/emu/inflate_emu.cc
 //   inflate_emu <gzip members> <expected plain bytes> <sizes: one decimal per member, whitespace separated, or the word auto>
 // (auto: a member's window is what is left of the expected bytes -- for streams whose members are not told apart beforehand)
 #define AHIP_HOST_EMU 1
@@ -15,7 +15,7 @@
 using namespace ahip;
 
 static struct TokKernelLds { WaveLds w; TokLds p; } TL;  // the tokenizer wave's LDS
-static ParLds PL;                                         // the resolver wave's LDS
+static ResLds PL;                                         // the resolver wave's LDS
 
 static std::vector<uint8_t> slurp(const char *path) {
   FILE *f = fopen(path, "rb"); if (!f) { perror(path); exit(2); }
@@ -51,7 +51,7 @@ int main(int argc, char **argv) {
     u64 toff, doff; TokSink sk{nullptr, 0, nullptr, 0, 0, ~0u, 0, 0, false, false};
     tok_layout(0, d.out_limit, 0, toff, sk.col_cap, doff, sk.dir_cap);
     std::vector<u32> area((size_t)sk.col_cap * 64 + 64, 0xdeadbeefu);
-    std::vector<uint2> dir((size_t)sk.dir_cap + 64);
+    std::vector<DirEnt> dir((size_t)sk.dir_cap + 64);
     sk.area = area.data(); sk.dir = dir.data();
     MemberResult res{};
     HeaderLds &hdr = *(HeaderLds *)((u8 *)TL.p.inbuf + 1024);  // as in inflate_tokenize_kernel
@@ -59,7 +59,7 @@ int main(int argc, char **argv) {
     if (res.status != MS_OK || (auto_sizes ? res.out_len > limit : res.out_len != limit)) { printf("member %zu: tokenizer status %u out_len %llu (want %llu) blocks %x\n", k, res.status, (unsigned long long)res.out_len, (unsigned long long)limit, res.blocks); return 1; }
     flow_windows += res.windows; fallbacks += res.fallbacks; runs += res.tok_words;
     if (res.blocks & MR_FAR) late++;  // reaches into earlier members' output (q8): the late kernel resolves it after them -- as here, in order
-    wave([&](int lane) { u32 cyc[8] = {}; resolve_member<u8>(PL, comp.data(), area.data(), dir.data(), (u32)res.tok_words, out.data() + out_off, cyc, lane); });
+    wave([&](int lane) { u32 cyc[8] = {}; resolve_member(PL, comp.data(), area.data(), dir.data(), (u32)res.tok_words, out.data() + out_off, cyc, lane); });
     const uint64_t got_len = res.out_len;
     if (memcmp(out.data() + out_off, want.data() + out_off, got_len)) {
       size_t i = 0; while (out[out_off + i] == want[out_off + i]) ++i;

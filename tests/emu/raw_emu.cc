@@ -16,7 +16,7 @@
 using namespace ahip;
 
 static struct TokKernelLds { WaveLds w; TokLds p; } TL;
-static ParLds PL;
+static ResLds PL;
 static WaveLds LL;   // the late kernel's own tables / header scratch
 static HeaderLds LH;
 
@@ -43,7 +43,7 @@ int main(int argc, char **argv) {
     u64 toff, doff; TokSink sk{nullptr, 0, nullptr, 0, 0, ~0u, 0, 0, false, false};
     tok_layout(0, d.out_limit, 0, toff, sk.col_cap, doff, sk.dir_cap);
     std::vector<u32> area((size_t)sk.col_cap * 64 + 64);
-    std::vector<uint2> dir((size_t)sk.dir_cap + 64);
+    std::vector<DirEnt> dir((size_t)sk.dir_cap + 64);
     std::vector<uint8_t> out(CAP + 64, 0);
     sk.area = area.data(); sk.dir = dir.data();
     MemberResult res{};
@@ -55,7 +55,7 @@ int main(int argc, char **argv) {
       wave([&](int lane) { inflate_member<true, false>(LL, LH, nullptr, in.data(), len, d, out.data(), TokSink{nullptr, 0, nullptr, 0, 0, ~0u, 0, 0, false, false}, res, lane, nullptr, exact.data()); });
     } else {
       if (res.blocks & MR_FAR) route = "late:far";
-      wave([&](int lane) { u32 cyc[8] = {}; resolve_member<u8>(PL, in.data(), area.data(), dir.data(), (u32)res.tok_words, out.data(), cyc, lane); });
+      wave([&](int lane) { u32 cyc[8] = {}; resolve_member(PL, in.data(), area.data(), dir.data(), (u32)res.tok_words, out.data(), cyc, lane); });
     }
     const u64 n = res.out_len <= CAP ? res.out_len : 0;
     uint64_t h = 1469598103934665603ull;

@@ -2,7 +2,7 @@
 // it) executed on the CPU by 64 threads (tests/emu/wave_emu.hpp), on token streams made from real DEFLATE data, and
 // compared byte for byte with a sequential LZ77 replay.  Test infrastructure only.
 //
-//   g++ -std=c++17 -O2 -pthread [-DAHIP_TOKEN_RESOLVER] -o resolver_emu tests/emu/resolver_emu.cc
+//   g++ -std=c++17 -O2 -pthread -o resolver_emu tests/emu/resolver_emu.cc
 //   resolver_emu <file of concatenated gzip members> [seed]
 #define AHIP_HOST_EMU 1
 #include "../../archive_amd/csrc/inflate_par.hpp"
@@ -36,7 +36,7 @@ static const uint8_t LX[29] = {0,0,0,0,0,0,0,0,1,1,1,1,2,2,2,2,3,3,3,3,4,4,4,4,5
 static const uint16_t DB[30] = {1,2,3,4,5,7,9,13,17,25,33,49,65,97,129,193,257,385,513,769,1025,1537,2049,3073,4097,6145,8193,12289,16385,24577};
 static const uint8_t DX[30] = {0,0,0,0,1,1,2,2,3,3,4,4,5,5,6,6,7,7,8,8,9,9,10,10,11,11,12,12,13,13};
 
-static ParLds P;  // the wave's LDS
+static ResLds P;  // the wave's LDS
 
 int main(int argc, char **argv) {
   if (argc < 2) return 2;
@@ -53,15 +53,16 @@ int main(int argc, char **argv) {
     if (flg & 16) { while (in_[q]) ++q; ++q; }
     if (flg & 2) q += 2;
     uint64_t p = (uint64_t)q * 8;
-    std::vector<uint32_t> tok;            // the member's token stream in the GPU's format
-    std::vector<size_t> rec_at;           // indices where a 3-word stored record starts (never split over runs)
+    std::vector<uint32_t> tok;            // the member's token stream as step words (literal / len << 16 | dist)
+    std::vector<size_t> rec_at;           // indices where a stored block sits: one word STORED_MARK | len, then the offset (lo, hi)
+    const uint32_t STORED_MARK = 0x60000000u;
     const size_t out0 = ref.size();
     for (;;) {
       int final = bits(&p, 1), type = bits(&p, 2);
       if (type == 0) {
         p = (p + 7) & ~7ull; uint32_t len = bits(&p, 16); bits(&p, 16);
         const uint64_t byte = p >> 3;
-        if (len >= 3) { rec_at.push_back(tok.size()); tok.push_back(TK_STORED | len); tok.push_back((uint32_t)byte); tok.push_back((uint32_t)(byte >> 32)); stored_recs++; }
+        if (len >= 3) { rec_at.push_back(tok.size()); tok.push_back(STORED_MARK | len); tok.push_back((uint32_t)byte); tok.push_back((uint32_t)(byte >> 32)); stored_recs++; }
         else for (uint32_t i = 0; i < len; ++i) tok.push_back(0x80000000u | ((uint32_t)in_[byte + i] << 16));
         for (uint32_t i = 0; i < len; ++i) ref.push_back(in_[byte + i]);
         p += 8ull * len;
@@ -96,18 +97,36 @@ int main(int argc, char **argv) {
       }
       if (final) break;
     }
-    // ---- runs: pseudo-random lengths, scattered over the area with gaps; stored records stay whole ----
-    std::vector<uint32_t> area; std::vector<uint2> dir;
+    // ---- runs: pseudo-random lengths, scattered over the area with gaps; a stored block is a directory entry of its
+    //      own; every token is recorded as (end of the run's output so far) << 16 | payload, like the tokenizer does.
+    //      Some runs are flagged DF_BIG although they are short (the flag only selects how offsets are found). ----
+    std::vector<uint32_t> area; std::vector<DirEnt> dir;
     size_t t = 0, ri = 0;
+    uint64_t opos = 0;
     while (t < tok.size()) {
       seed = seed * 1664525u + 1013904223u;
+      while (ri < rec_at.size() && rec_at[ri] < t) ++ri;
+      if (ri < rec_at.size() && rec_at[ri] == t) {  // stored block
+        const uint32_t len = tok[t] & 0xffffu;
+        area.resize(area.size() + (seed >> 4) % 7, 0xdeadbeefu);
+        dir.push_back(make_uint4((unsigned)area.size(), len | DF_STORED, (unsigned)opos, (unsigned)(opos >> 32)));
+        area.push_back(tok[t + 1]); area.push_back(tok[t + 2]);
+        opos += len; t += 3;
+        continue;
+      }
       size_t want = 1 + (seed >> 8) % ((seed >> 28) == 0 ? 400 : 90), end = t + want < tok.size() ? t + want : tok.size();
-      while (ri < rec_at.size() && rec_at[ri] + 3 <= t) ++ri;
-      for (size_t k = ri; k < rec_at.size() && rec_at[k] < end; ++k) if (rec_at[k] + 3 > end) end = rec_at[k] + 3;  // do not cut a record
-      if (end > tok.size()) end = tok.size();
+      if (ri < rec_at.size() && rec_at[ri] < end) end = rec_at[ri];
       area.resize(area.size() + (seed >> 4) % 7, 0xdeadbeefu);  // a gap
-      dir.push_back(make_uint2((unsigned)area.size(), (unsigned)(end - t)));
-      area.insert(area.end(), tok.begin() + t, tok.begin() + end);
+      const size_t a0 = area.size();
+      uint64_t bytes = 0;
+      for (size_t i = t; i < end; ++i) {
+        const uint32_t w = tok[i];
+        bytes += (int32_t)w < 0 ? 1u : (w >> 16);
+        area.push_back(rec_word((u32)bytes, w));
+      }
+      const bool big = bytes > 0xffffu || ((seed >> 20) & 7) == 0;
+      dir.push_back(make_uint4((unsigned)a0, (unsigned)(end - t) | (big ? DF_BIG : 0u), (unsigned)opos, (unsigned)(opos >> 32)));
+      opos += bytes;
       t = end;
     }
     runs_total += dir.size(); toks_total += tok.size();
@@ -116,7 +135,7 @@ int main(int argc, char **argv) {
     u32 cyc_all[64][8] = {};
     std::vector<std::thread> th;
     for (int l = 0; l < 64; ++l)
-      th.emplace_back([&, l]() { wave_emu::lane = l; resolve_member<u8>(P, in_, area.data(), dir.data(), (u32)dir.size(), out.data() + out0, cyc_all[l], l); });
+      th.emplace_back([&, l]() { wave_emu::lane = l; resolve_member(P, in_, area.data(), dir.data(), (u32)dir.size(), out.data() + out0, cyc_all[l], l); });
     for (auto &x : th) x.join();
     out.resize(out0 + produced);
     if (memcmp(out.data() + out0, ref.data() + out0, produced)) {
@@ -127,11 +146,7 @@ int main(int argc, char **argv) {
     members++;
     pos = (size_t)((p + 7) >> 3) + 8;
   }
-#ifdef AHIP_TOKEN_RESOLVER
-  const char *what = "token-centric variant (-DAHIP_TOKEN_RESOLVER)";
-#else
-  const char *what = "production byte pass";
-#endif
+  const char *what = "token-centric resolver";
   printf("resolver emu ok [%s]: %zu members, %zu bytes, %llu token words in %llu runs, %llu stored records\n", what, members, ref.size(),
          (unsigned long long)toks_total, (unsigned long long)runs_total, (unsigned long long)stored_recs);
   return members ? 0 : 7;

@@ -15,6 +15,7 @@
 struct uint2 { unsigned x, y; };
 struct uint4 { unsigned x, y, z, w; };
 static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 #define __device__
 #define __forceinline__ inline
 #define __shared__ static

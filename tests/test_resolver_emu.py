@@ -1,9 +1,9 @@
 """The resolver's DEVICE code (archive_amd/csrc/inflate_par.hpp: resolve_member and everything under it) run on the CPU:
 64 host threads are the 64 lanes of one wave, the cross-lane primitives of common.hpp are exchanges between barriers
 (tests/emu/wave_emu.hpp).  Token streams are made from real DEFLATE data by a plain tokenizer inside
-tests/emu/resolver_emu.cc, cut into runs of random length like the tokenizer's directory, and the result is compared byte for
-byte with a sequential LZ77 replay.  Builds: the production byte pass (what the GPU runs) and the experiments that have not been on a GPU yet (DESIGN.md
-section 12): the token-centric variant (-DAHIP_TOKEN_RESOLVER) and the 32-byte deposit of far matches (-DAHIP_DEPOSIT32)."""
+tests/emu/resolver_emu.cc, cut into runs of random length like the tokenizer's directory (stored blocks as directory
+entries of their own, some runs flagged DF_BIG), and the result is compared byte for byte with a sequential LZ77 replay.
+Builds: the production window geometry, a small window (chunks split at the window's end all the time) and a large one."""
 import os
 import random
 import subprocess
@@ -24,8 +24,8 @@ def _binary(variant):
     deps = [src, os.path.join(ROOT, "tests", "emu", "wave_emu.hpp")] + [os.path.join(ROOT, "archive_amd", "csrc", f)
                                                                         for f in ("common.hpp", "inflate_wave.hpp", "inflate_par.hpp")]
     if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps):
-        flags = {"production": [], "tokres": ["-DAHIP_TOKEN_RESOLVER"], "deposit32": ["-DAHIP_DEPOSIT32"],
-                 "tokres+deposit32": ["-DAHIP_TOKEN_RESOLVER", "-DAHIP_DEPOSIT32"]}[variant]
+        flags = {"production": [], "small_window": ["-DAHIP_WIN_CAP=1024", "-DAHIP_WIN_KEEP=400"],
+                 "big_window": ["-DAHIP_WIN_CAP=8192", "-DAHIP_WIN_KEEP=2048"]}[variant]
         cmd = ["g++", "-std=c++17", "-O2", "-pthread", "-o", exe, src] + flags
         subprocess.check_call(cmd)
     return exe
@@ -58,7 +58,7 @@ def _corpus():
     return blob, sum(len(p) for p, _ in parts), len(parts)
 
 
-@pytest.mark.parametrize("variant", ["production", "tokres", "deposit32", "tokres+deposit32"])
+@pytest.mark.parametrize("variant", ["production", "small_window", "big_window"])
 def test_resolver_device_code_on_the_cpu(tmp_path, variant):
     exe = _binary(variant)
     blob, total, members = _corpus()
