@@ -158,8 +158,8 @@ __global__ __launch_bounds__(64, AHIP_RES_MIN_WAVES) void inflate_resolve_kernel
     }
     u32 cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     resolve_member(lds, in, tokens + toff, dir + doff, ndir, out + out_off, cyc, lane);
-#if defined(AHIP_PROFILE) && !defined(AHIP_PROFILE_TOK_ONLY)
-    if (lane == 0) { results[m].cyc[4] += cyc[4]; results[m].cyc[5] += cyc[5]; results[m].cyc[6] += cyc[6]; }
+#ifdef AHIP_PROFILE_RES
+    if (lane == 0) for (int q = 0; q < 8; ++q) results[m].cyc[q] = cyc[q];
 #endif
   }
 }

@@ -98,6 +98,14 @@ struct MemberResult {
 #define AHIP_ASM_NOTE(text) asm volatile("; " text ::: "memory")
 #endif
 
+// The value has to be in its register here: the compiler's wait for the load that makes it is placed at this point
+// (inside a rarely taken branch) instead of at the next use on the common path.  Nothing in the CPU emulation.
+#ifdef AHIP_HOST_EMU
+#define AHIP_PIN(x) do { } while (0)
+#else
+#define AHIP_PIN(x) asm volatile("" : "+v"(x))
+#endif
+
 #ifdef AHIP_PROFILE
 #define AHIP_TICK(var) const u64 var = __builtin_amdgcn_s_memtime()
 #define AHIP_ACC(slot, t0, t1) (slot) += (u32)(((t1) - (t0)) >> 4)

@@ -914,35 +914,159 @@ AHIP_DEVINL void deposit16(u8 *dp, u32 len, u64 w0, u64 w1) {
   }
 }
 
+// -DAHIP_PROFILE_RES: shader-clock cycles / 16 of the resolver's phases into cyc[0..7] (tools/kstats.py)
+//   0 look setup  1 gather  2 prep  3 classify + literals + late fetch  4 rounds  5 hard matches  6 flush  7 whole member
+#ifdef AHIP_PROFILE_RES
+#define RTICK(var) const u64 var = __builtin_amdgcn_s_memtime()
+#define RACC(slot, t0, t1) cyc[slot] += (u32)(((t1) - (t0)) >> 4)
+#else
+#define RTICK(var) do { } while (0)
+#define RACC(slot, t0, t1) do { } while (0)
+#endif
+
 #ifndef AHIP_WIN_CAP
 #define AHIP_WIN_CAP 2560
 #endif
 #ifndef AHIP_WIN_KEEP
 #define AHIP_WIN_KEEP 640
 #endif
+#ifndef AHIP_PEND_CAP
+#define AHIP_PEND_CAP 384
+#endif
 constexpr u32 WIN_CAP = AHIP_WIN_CAP;              // bytes of output the LDS window holds
 constexpr u32 WIN_FLUSH = WIN_CAP - AHIP_WIN_KEEP;  // ... and it is flushed once a chunk leaves it fuller than this
-static_assert(WIN_CAP % 16 == 0 && WIN_FLUSH >= 512 && AHIP_WIN_KEEP >= 264, "window geometry");
+constexpr u32 PEND_CAP = AHIP_PEND_CAP;            // deferred matches per window
+static_assert(WIN_CAP % 32 == 0 && WIN_CAP <= 32768 && WIN_FLUSH >= 512 && AHIP_WIN_KEEP >= 264 && PEND_CAP >= 128, "window geometry");
 struct ResLds {
   u8 obuf[WIN_CAP + 64] __attribute__((aligned(16)));  // + alignment offset (<= 15) + a 16-byte read past the last source byte
+  u32 pmap[WIN_CAP / 32 + 4];  // one bit per window byte: a deferred match has yet to write it
+  uint2 plist[PEND_CAP];       // the window's deferred matches in stream order: {window index | len << 16, distance}
 };
 
 // One member: token runs (area, dir) -> bytes at out_base.  64 tokens per step, one per lane.
 //   offsets  every lane knows where its token goes without a scan: the run's output offset (directory) + the `end` of
 //            the token before it.  All lane offsets are relative to `borg`, the window position when the current look at
 //            the directory began; `wrel` (scalar) = window position - borg, so window index = offset - wrel.
-//   sources  a match whose 16 (32) source bytes are flushed output is fetched per token one chunk ahead (prep) and
-//            deposited with exact-length stores; a source inside the window is read from LDS when every byte of it is
-//            final: in ROUNDS -- the first pending match of a chunk is always ready (everything in front of its
-//            destination is final), a later one when its source ends at or before the first pending destination.
-//   hard     matches longer than 32 bytes, overlapping their own source, or straddling the window start are copied by
-//            the whole wave, one token at a time, when they are the first pending one.
+//   chunk    straight-line, nothing waits on LDS: literals store their byte; a match whose 16 (32) source bytes are
+//            flushed output was fetched per token one chunk ahead (prep) and is deposited with exact-length unaligned
+//            stores; a match whose source touches the window is DEFERRED: appended to the window's pending list, its
+//            destination bytes marked in a bitmap.
+//   flush    the deferred matches, 64 per step, in rounds: one is ready when no byte of its source is still marked
+//            (exact dependences: about as many rounds as the longest chain of matches copying from matches); ready
+//            ones read 16 (32) window bytes, deposit, and clear their marks.  Matches longer than 32 bytes, overlapping
+//            their own source or straddling the window start are copied by the whole wave when they are the first
+//            pending one (everything in front of their destination is final then).  Then the window goes to HBM with
+//            16-byte stores.
 AHIP_DEVINL void resolve_member(ResLds &P, const u8 *in, const u32 *area, const DirEnt *dir, u32 ndir, u8 *out_base, u32 *cyc,
                                 int lane) {
   u64 wpos = 0;                                   // output offset (member-relative) of the window's first byte
   u32 wfill = 0;                                  // bytes assembled in the window
+  u32 npend = 0;                                  // deferred matches of the window
   u32 A = (u32)((uintptr_t)out_base & 15);        // obuf[A + i] <-> out_base[wpos + i]: LDS and global congruent mod 16
-  auto flush = [&]() {  // window -> HBM: byte head up to 16-byte alignment, 16-byte body, byte tail
+  for (u32 i = lane; i < WIN_CAP / 32 + 4; i += 64) P.pmap[i] = 0;
+  wave_sync();
+  RTICK(r_begin);
+  // marks of window bytes [b, b + len): set or cleared by the owning lane -- two dwords cover 32 bytes, longer ones loop
+  auto mark = [&](u32 b, u32 len, bool set) {
+    const u32 w = b >> 5;
+    const u64 m = (len >= 32 ? 0xffffffffull : (1ull << len) - 1) << (b & 31);
+    if (set) { atomicOr(&P.pmap[w], (u32)m); atomicOr(&P.pmap[w + 1], (u32)(m >> 32)); }
+    else { atomicAnd(&P.pmap[w], ~(u32)m); atomicAnd(&P.pmap[w + 1], ~(u32)(m >> 32)); }
+    if (len > 32) {
+      const u32 e = b + len;
+      for (u32 q = b + 32; q < e; q += 32) {  // (b + 32 .. e) in pieces of <= 32 bits, each inside two dwords
+        const u32 n = e - q < 32 ? e - q : 32u;
+        const u64 mq = (n >= 32 ? 0xffffffffull : (1ull << n) - 1) << (q & 31);
+        if (set) { atomicOr(&P.pmap[q >> 5], (u32)mq); atomicOr(&P.pmap[(q >> 5) + 1], (u32)(mq >> 32)); }
+        else { atomicAnd(&P.pmap[q >> 5], ~(u32)mq); atomicAnd(&P.pmap[(q >> 5) + 1], ~(u32)(mq >> 32)); }
+      }
+    }
+  };
+  // the first pending match, copied by the whole wave: every byte in front of its destination is final
+  auto wave_copy = [&](u32 fd, u32 L_, u32 D_) {
+    u8 *const ob = P.obuf + A;
+    const i32 S_ = (i32)fd - (i32)D_;
+    const u8 *gsrc = out_base + wpos;  // window index i < 0 <-> gsrc[i]
+    const u32 n0 = D_ < L_ ? D_ : L_;  // the part that does not read its own output
+#pragma nounroll
+    for (u32 k = (u32)lane; k < n0; k += 64) {
+      const i32 si = S_ + (i32)k;
+      // (values are selected, not pointers: an LDS / global pointer select trips the gfx950 backend)
+      const u32 lv = ob[si >= 0 ? si : 0];
+      u32 gv = 0;
+      if (si < 0) gv = gsrc[si];
+      ob[fd + k] = (u8)(si >= 0 ? lv : gv);
+    }
+    wave_sync();
+    u32 filled = n0;  // a multiple of D_ from here on: the destination repeats with period D_
+    while (filled < L_) {
+      const u32 n = filled < L_ - filled ? filled : L_ - filled;
+#pragma nounroll
+      for (u32 k = (u32)lane; k < n; k += 64) ob[fd + filled + k] = ob[fd + k];
+      wave_sync();
+      filled += n;
+    }
+  };
+  auto store_match = [&](u8 *dp, u32 len, u64 w0, u64 w1, u64 w2, u64 w3) {  // len <= 32: two 16-byte pieces, the second ends at len
+    if (len > 16) {
+      ((unaligned_u64 *)dp)->v = w0;
+      ((unaligned_u64 *)(dp + 8))->v = w1;
+      ((unaligned_u64 *)(dp + len - 16))->v = w2;
+      ((unaligned_u64 *)(dp + len - 8))->v = w3;
+    }
+    if (len <= 16) deposit16(dp, len, w0, w1);
+  };
+  auto resolve_pending = [&]() {
+    RTICK(r_r0);
+    u8 *const ob = P.obuf + A;
+    wave_sync();
+    for (u32 b0 = 0; b0 < npend; b0 += 64) {
+      const bool have = b0 + (u32)lane < npend;
+      const uint2 e = P.plist[have ? b0 + lane : 0];
+      const u32 wo = e.x & 0xffffu, len = e.x >> 16, dist = e.y;
+      const i32 so = (i32)wo - (i32)dist;
+      const bool simple = have && so >= 0 && len <= 32 && dist >= len;
+      const u32 sa = simple ? (u32)so : 0u;             // (every lane reads somewhere harmless)
+      const u32 sa2 = (simple && len > 16) ? sa + len - 16 : sa;
+      const u64 lmask = len >= 32 ? 0xffffffffull : ((1ull << len) - 1);
+      bool pl = have;
+      u32 guard = 0;
+      for (;;) {
+        const u64 pend = __ballot(pl);
+        if (!pend || ++guard > 80) break;
+        // marks over the source, and the source bytes themselves, in one LDS round trip
+        const u32 m0 = P.pmap[sa >> 5], m1 = P.pmap[(sa >> 5) + 1];
+        const u64 w0 = ((const unaligned_u64 *)(ob + sa))->v, w1 = ((const unaligned_u64 *)(ob + sa + 8))->v;
+        const u64 w2 = ((const unaligned_u64 *)(ob + sa2))->v, w3 = ((const unaligned_u64 *)(ob + sa2 + 8))->v;
+        const u64 marks = ((((u64)m1 << 32) | m0) >> (sa & 31)) & lmask;
+        const bool act = pl && simple && marks == 0;
+        const int f = __builtin_ctzll(pend);
+        const u64 am = __ballot(act);
+        wave_sync();
+        if (!((am >> f) & 1)) {  // the first pending one is not a simple one (a simple first one is never blocked)
+          RTICK(r_h0);
+          const u32 fd = lane_bcast(wo, f), L_ = lane_bcast(len, f), D_ = lane_bcast(dist, f);
+          wave_copy(fd, L_, D_);
+          if (lane == f) mark(wo, len, false);
+          pl = pl && lane != f;
+          RTICK(r_h1);
+          RACC(5, r_h0, r_h1);
+        }
+        if (act) {
+          store_match(ob + wo, len, w0, w1, w2, w3);
+          mark(wo, len, false);
+        }
+        pl = pl && !act;
+        wave_sync();  // this round's bytes and marks are final for the next one
+      }
+    }
+    npend = 0;
+    RTICK(r_r1);
+    RACC(4, r_r0, r_r1);
+  };
+  auto flush = [&]() {  // deferred matches, then window -> HBM: byte head up to 16-byte alignment, 16-byte body, byte tail
+    if (npend) resolve_pending();
+    RTICK(r_f0);
     wave_sync();
     u8 *g = out_base + wpos;
     u32 head = (16 - A) & 15;
@@ -959,12 +1083,14 @@ AHIP_DEVINL void resolve_member(ResLds &P, const u8 *in, const u32 *area, const 
     wpos += wfill;
     A = (A + wfill) & 15;
     wfill = 0;
+    RTICK(r_f1);
+    RACC(6, r_f0, r_f1);
   };
   struct Tok { u32 t; i32 base; bool first, inb; };          // a chunk's tokens as loaded: word, run offset (rel. borg)
   struct Ck { u32 t, len; i32 ob; bool inb, pre; u64 w0, w1, w2, w3; };  // ... decoded: ob = output offset rel. borg
   u32 de = 0;
   while (de < ndir) {
-    AHIP_TICK(t_0);
+    RTICK(r_l0);
     const u32 ei = de + (u32)lane;
     const bool have = ei < ndir;
     const DirEnt dv = have ? dir[ei] : make_uint4(0u, 0u, 0u, 0u);
@@ -973,100 +1099,74 @@ AHIP_DEVINL void resolve_member(ResLds &P, const u8 *in, const u32 *area, const 
     const u32 nplain = special ? (u32)__builtin_ctzll(special) : nleft;  // ordinary runs in front of the first special entry
     const u64 borg = wpos;
     u32 wrel = 0;
-    // ---- one chunk (any lanes `inb`): literals, deposits, rounds; splits where the window is full ----
-    auto process = [&](Ck &c) {
+    // ---- one pass over a chunk, straight-line: the lanes of `rem` that fit the window (and its pending list), a prefix;
+    //      returns the rest (the caller flushes and comes back) ----
+    auto pass = [&](Ck &c, u64 rem) -> u64 {
+      RTICK(r_p0);
       const bool lit = (c.t & REC_LIT) != 0;
       const u32 dist = (c.t & 0x7fffu) + 1u;
       const bool isM = c.inb && !lit;
       const bool simple = c.len <= 32 && dist >= c.len;  // two 16-byte pieces, source and destination apart
+      const i32 wo = c.ob - (i32)wrel;  // window index of the destination
+      const i32 so = wo - (i32)dist;    // window index of the source (negative: flushed output)
+      bool fit = ((rem >> lane) & 1) && (u32)wo + c.len <= WIN_CAP;
+      // A match is deposited right here when its source is flushed output and two 16-byte pieces do it.  The first
+      // piece may read past the source (the deposit ignores what lies behind `len`): with dist >= 16 those bytes are
+      // still this member's own output -- allocated, just not written yet.  Everything else is deferred to the flush.
+      const i32 span = c.len > 16 ? (i32)c.len : 16;
+      const bool Gc = isM && simple && so + (i32)c.len <= 0 && (so + span <= 0 || dist >= 16);
+      const bool defer_ = isM && !Gc;
+      {  // the pending list must take the deferred ones too; what fits has to be a prefix of what remains
+        const u64 dm = __ballot(fit && defer_);
+        const u32 before = (u32)__popcll(dm & ((1ull << lane) - 1));
+        fit = fit && npend + before + (defer_ ? 1u : 0u) <= PEND_CAP;
+        const u64 fm0 = __ballot(fit), low = rem & (0 - rem);
+        const u64 run = (fm0 & low) ? fm0 & ~(fm0 + low) : 0ull;  // the lanes from the first remaining one up to the first that does not fit
+        fit = (run >> lane) & 1;
+      }
+      const u64 fm = __ballot(fit);
+      if (!fm) return rem;
+      u8 *const ob = P.obuf + A;
+      if (fit && lit) ob[wo] = (u8)c.t;
+      const bool G = fit && Gc;
+      const bool D = fit && defer_;
+      // flushed sources that were not fetched ahead (the window was flushed after the chunk was prepared): fetched
+      // now, and waited for inside this branch, so that nothing else waits for the loads of the NEXT chunk
+      const bool late = G && !c.pre;
+      if (__any(late)) {
+        if (late) {
+          const u8 *sp = out_base + wpos + so;
+          c.w0 = load_u64_unaligned(sp);
+          c.w1 = load_u64_unaligned(sp + 8);
+          if (c.len > 16) { c.w2 = load_u64_unaligned(sp + c.len - 16); c.w3 = load_u64_unaligned(sp + c.len - 8); }
+          c.pre = true;
+        }
+        AHIP_PIN(c.w0); AHIP_PIN(c.w1); AHIP_PIN(c.w2); AHIP_PIN(c.w3);
+      }
+      if (G) store_match(ob + wo, c.len, c.w0, c.w1, c.w2, c.w3);
+      const u64 dm = __ballot(D);
+      if (dm) {
+        if (D) {
+          P.plist[npend + (u32)__popcll(dm & ((1ull << lane) - 1))] = make_uint2((u32)wo | (c.len << 16), dist);
+          mark((u32)wo, c.len, true);
+        }
+        npend += (u32)__popcll(dm);
+      }
+      const int last = 63 - __builtin_clzll(fm);
+      wfill = lane_bcast((u32)wo + c.len, last);
+      RTICK(r_p1);
+      RACC(3, r_p0, r_p1);
+      return rem & ~fm;
+    };
+    // a whole chunk: passes and flushes (ONE flush site per loop: the flush is a lot of code and registers)
+    auto process = [&](Ck &c) {
       u64 rem = __ballot(c.inb);
-      while (rem) {
-        const i32 wo = c.ob - (i32)wrel;  // window index of the destination
-        const bool fit = ((rem >> lane) & 1) && (u32)wo + c.len <= WIN_CAP;
-        const u64 fm = __ballot(fit);     // a prefix of rem: destinations increase with the lane
-        if (!fm) {
-          if (wfill == 0) return;         // (cannot happen: a token is at most 258 bytes) never spin
-          flush();
-          wrel = (u32)(wpos - borg);
-          continue;
-        }
-        u8 *const ob = P.obuf + A;
-        if (fit && lit) ob[wo] = (u8)c.t;
-        const i32 so = wo - (i32)dist;    // window index of the source (negative: flushed output)
-        const i32 span = c.len > 16 ? (i32)c.len : 16;
-        const bool inL = so >= 0, inG = so + span <= 0;
-        const bool hard = !simple || (!inL && !inG);
-        u64 pend = __ballot(fit && isM);
-        wave_sync();
-        u32 guard = 0;
-        while (pend && ++guard <= 80) {
-          const int f = __builtin_ctzll(pend);
-          const u32 fd = lane_bcast((u32)wo, f);
-          const bool mine = (pend >> lane) & 1;
-          if (lane_bcast(hard ? 1u : 0u, f)) {
-            // the first pending match, copied by the whole wave: every byte in front of its destination is final
-            const u32 L_ = lane_bcast(c.len, f), D_ = lane_bcast(dist, f);
-            const i32 S_ = (i32)fd - (i32)D_;
-            const u8 *gsrc = out_base + wpos;  // window index i < 0 <-> gsrc[i]
-            const u32 n0 = D_ < L_ ? D_ : L_;  // the part that does not read its own output
-            for (u32 k = (u32)lane; k < n0; k += 64) {
-              const i32 si = S_ + (i32)k;
-              // (values are selected, not pointers: an LDS / global pointer select trips the gfx950 backend)
-              const u32 lv = ob[si >= 0 ? si : 0];
-              u32 gv = 0;
-              if (si < 0) gv = gsrc[si];
-              ob[fd + k] = (u8)(si >= 0 ? lv : gv);
-            }
-            wave_sync();
-            u32 filled = n0;  // a multiple of D_ from here on: the destination repeats with period D_
-            while (filled < L_) {
-              const u32 n = filled < L_ - filled ? filled : L_ - filled;
-              for (u32 k = (u32)lane; k < n; k += 64) ob[fd + filled + k] = ob[fd + k];
-              wave_sync();
-              filled += n;
-            }
-            pend &= pend - 1;
-            continue;
-          }
-          const bool act = mine && !hard && ((u32)lane == (u32)f || so + (i32)c.len <= (i32)fd);
-          u64 w0 = c.w0, w1 = c.w1, w2 = c.w2, w3 = c.w3;
-          if (act && !c.pre) {
-            if (inL) {
-              w0 = ((const unaligned_u64 *)(ob + so))->v;
-              w1 = ((const unaligned_u64 *)(ob + so + 8))->v;
-              if (c.len > 16) {
-                w2 = ((const unaligned_u64 *)(ob + so + c.len - 16))->v;
-                w3 = ((const unaligned_u64 *)(ob + so + c.len - 8))->v;
-              }
-            } else {  // flushed output that was still in the window when the chunk was prepared
-              const u8 *sp = out_base + wpos + so;
-              w0 = load_u64_unaligned(sp);
-              w1 = load_u64_unaligned(sp + 8);
-              if (c.len > 16) { w2 = load_u64_unaligned(sp + c.len - 16); w3 = load_u64_unaligned(sp + c.len - 8); }
-            }
-          }
-          if (act) {
-            u8 *dp = ob + wo;
-            if (c.len > 16) {
-              ((unaligned_u64 *)dp)->v = w0;
-              ((unaligned_u64 *)(dp + 8))->v = w1;
-              ((unaligned_u64 *)(dp + c.len - 16))->v = w2;
-              ((unaligned_u64 *)(dp + c.len - 8))->v = w3;
-            } else {
-              deposit16(dp, c.len, w0, w1);
-            }
-          }
-          pend &= ~__ballot(act);
-          wave_sync();  // this round's bytes are final for the next one
-        }
-        const int last = 63 - __builtin_clzll(fm);
-        wfill = lane_bcast((u32)wo + c.len, last);
-        rem &= ~fm;
-        if (rem) {
-          flush();
-          wrel = (u32)(wpos - borg);
-          // sources that were fetched ahead stay valid (flushed output never changes); everything else is looked at again
-        }
+      for (u32 guard = 0; guard < 300; ++guard) {  // (a pass after a flush always takes at least one token: never spins)
+        if (rem) rem = pass(c, rem);
+        if (!rem && wfill < WIN_FLUSH) break;
+        flush();
+        wrel = (u32)(wpos - borg);
+        // sources that were fetched ahead stay valid (flushed output never changes); everything else is looked at again
       }
     };
     if (nplain == 0) {
@@ -1101,7 +1201,6 @@ AHIP_DEVINL void resolve_member(ResLds &P, const u8 *in, const u32 *area, const 
           // (a chunk of long matches may be larger than the window: process() splits it)
           process(c);
           run += tot;
-          if (wfill >= WIN_FLUSH) { flush(); wrel = (u32)(wpos - borg); }
         }
       }
       de += 1;
@@ -1114,7 +1213,10 @@ AHIP_DEVINL void resolve_member(ResLds &P, const u8 *in, const u32 *area, const 
     const u32 ts = wave_excl_sum(rcnt, total);                                   // first token of the run within the look
     const i32 rb = (i32)((((u64)dv.w << 32) | dv.z) - borg);                     // where its output starts, rel. borg
     u32 r0 = 0;  // the run the next gathered chunk starts in
+    RTICK(r_l1);
+    RACC(0, r_l0, r_l1);
     auto gather = [&](u32 c0) -> Tok {
+      RTICK(r_g0);
       Tok q;
       const u32 idx = c0 + (u32)lane;
       q.inb = idx < total;
@@ -1136,11 +1238,15 @@ AHIP_DEVINL void resolve_member(ResLds &P, const u8 *in, const u32 *area, const 
       }
       r0 = r;
       q.first = k == 0;
-      q.t = q.inb ? area[ta + k] : 0u;
+      q.t = area[q.inb ? ta + k : 0u];  // (no branch around the load and no use of it here: it stays in flight; lanes
+                                         //  outside the look read some token, which `inb` keeps anyone from using)
+      RTICK(r_g1);
+      RACC(1, r_g0, r_g1);
       return q;
     };
     u32 carry_end = 0;  // `end` of the token in front of the chunk being prepared
     auto prep = [&](const Tok &q) -> Ck {
+      RTICK(r_q0);
       Ck c;
       c.t = q.t;
       c.inb = q.inb;
@@ -1155,7 +1261,15 @@ AHIP_DEVINL void resolve_member(ResLds &P, const u8 *in, const u32 *area, const 
       const u32 dist = (q.t & 0x7fffu) + 1u;
       const i32 so = c.ob - (i32)wrel - (i32)dist;  // against the window as it is NOW: what is flushed stays flushed
       const i32 span = c.len > 16 ? (i32)c.len : 16;
-      c.pre = q.inb && !lit && c.len <= 32 && dist >= c.len && so + span <= 0;
+      c.pre = q.inb && !lit && c.len <= 32 && dist >= c.len && so + (i32)c.len <= 0 && (so + span <= 0 || dist >= 16);  // = process()'s Gc, now
+#ifdef AHIP_RES_UNCOND_LOADS
+      const u8 *sp = c.pre ? out_base + wpos + so : (const u8 *)area;
+      const u8 *sp2 = (c.pre && c.len > 16) ? sp + c.len - 16 : sp;
+      c.w0 = load_u64_unaligned(sp);
+      c.w1 = load_u64_unaligned(sp + 8);
+      c.w2 = load_u64_unaligned(sp2);
+      c.w3 = load_u64_unaligned(sp2 + 8);
+#else
       c.w0 = c.w1 = c.w2 = c.w3 = 0;
       if (c.pre) {
         const u8 *sp = out_base + wpos + so;
@@ -1163,28 +1277,27 @@ AHIP_DEVINL void resolve_member(ResLds &P, const u8 *in, const u32 *area, const 
         c.w1 = load_u64_unaligned(sp + 8);
         if (c.len > 16) { c.w2 = load_u64_unaligned(sp + c.len - 16); c.w3 = load_u64_unaligned(sp + c.len - 8); }
       }
+#endif
+      RTICK(r_q1);
+      RACC(2, r_q0, r_q1);
       return c;
     };
     Tok t1 = gather(0);
     Ck c1 = prep(t1);
     Tok t2 = t1;
     if (64 < total) t2 = gather(64);
-    AHIP_TICK(t_1);
-    AHIP_ACC(cyc[6], t_0, t_1);
     for (u32 c0 = 0; c0 < total; c0 += 64) {
       Ck c = c1;
       if (c0 + 64 < total) c1 = prep(t2);          // decode + fetch the flushed sources of the next chunk
       if (c0 + 128 < total) t2 = gather(c0 + 128);  // load the tokens of the one after
       process(c);
-      if (wfill >= WIN_FLUSH) { flush(); wrel = (u32)(wpos - borg); }
     }
-    AHIP_TICK(t_2);
-    AHIP_ACC(cyc[5], t_1, t_2);
     de += nplain;
   }
   if (wfill) flush();
+  RTICK(r_end);
+  RACC(7, r_begin, r_end);
 }
-
 
 // ------------------------------------------------------------------------------------------
 // The byte-per-lane resolver (resolve_front / resolve_back / resolve_bytes above), kept for the 16-bit SYMBOLS of the

@@ -94,3 +94,5 @@ static inline unsigned atomicMin(unsigned *p, unsigned v) {
   while (v < cur && !__atomic_compare_exchange_n(p, &cur, v, false, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED)) { }
   return cur;
 }
+static inline unsigned atomicOr(unsigned *p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_ACQ_REL); }
+static inline unsigned atomicAnd(unsigned *p, unsigned v) { return __atomic_fetch_and(p, v, __ATOMIC_ACQ_REL); }

@@ -3,7 +3,8 @@
 (tests/emu/wave_emu.hpp).  Token streams are made from real DEFLATE data by a plain tokenizer inside
 tests/emu/resolver_emu.cc, cut into runs of random length like the tokenizer's directory (stored blocks as directory
 entries of their own, some runs flagged DF_BIG), and the result is compared byte for byte with a sequential LZ77 replay.
-Builds: the production window geometry, a small window (chunks split at the window's end all the time) and a large one."""
+Builds: the production window geometry, a small window (chunks split at the window's end all the time), a large one, and a
+large one with a short list of deferred matches (chunks split where the list is full)."""
 import os
 import random
 import subprocess
@@ -25,7 +26,8 @@ def _binary(variant):
                                                                         for f in ("common.hpp", "inflate_wave.hpp", "inflate_par.hpp")]
     if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps):
         flags = {"production": [], "small_window": ["-DAHIP_WIN_CAP=1024", "-DAHIP_WIN_KEEP=400"],
-                 "big_window": ["-DAHIP_WIN_CAP=8192", "-DAHIP_WIN_KEEP=2048"]}[variant]
+                 "big_window": ["-DAHIP_WIN_CAP=8192", "-DAHIP_WIN_KEEP=2048"],
+                 "small_pending": ["-DAHIP_WIN_CAP=8192", "-DAHIP_WIN_KEEP=512", "-DAHIP_PEND_CAP=128"]}[variant]
         cmd = ["g++", "-std=c++17", "-O2", "-pthread", "-o", exe, src] + flags
         subprocess.check_call(cmd)
     return exe
@@ -58,7 +60,7 @@ def _corpus():
     return blob, sum(len(p) for p, _ in parts), len(parts)
 
 
-@pytest.mark.parametrize("variant", ["production", "small_window", "big_window"])
+@pytest.mark.parametrize("variant", ["production", "small_window", "big_window", "small_pending"])
 def test_resolver_device_code_on_the_cpu(tmp_path, variant):
     exe = _binary(variant)
     blob, total, members = _corpus()

@@ -42,8 +42,11 @@ print("status histogram", np.bincount(r[:, 4]))
 print("debug codes", sorted(set(hex(v) for v in r[:, 17] if (v >> 16) == 0xdead)))
 cyc = r[:, 10:18].astype(np.float64).mean(axis=0) * 16
 if cyc.sum() > 0:
-    names = ["tok header+tables", "tok stage", "tok passA", "tok passB", "tok emit", "res bytes+flush", "res keys+deposit", "tok serial"]
+    names = ["tok header+tables", "tok stage", "tok decode steps", "tok scan+assign", "tok retire", "tok header decode", "tok litlen table", "tok serial"]
     tot = cyc.sum()
+    if os.environ.get("AHIP_KSTATS_RES"):  # a -DAHIP_PROFILE_RES build: the resolver's phases
+        names = ["res look setup", "res gather", "res prep", "res classify+lit+late", "res rounds", "res hard", "res flush", "res whole member"]
+        tot = cyc[7]
     print("cycles per member: total %.0f" % tot)
     for nme, c in zip(names, cyc):
         print("  %-18s %10.0f  %5.1f%%" % (nme, c, 100 * c / tot))
