@@ -183,6 +183,7 @@ AHIP_DEVINL u32 wave_umax(u32 v) {
 
 struct __attribute__((packed, aligned(1))) unaligned_u64 { u64 v; };
 struct __attribute__((packed, aligned(1))) unaligned_u32 { u32 v; };
+struct __attribute__((packed, aligned(1))) unaligned_u16 { u16 v; };
 struct __attribute__((packed, aligned(1))) unaligned_u128 { uint4 v; };
 AHIP_DEVINL uint4 load_u128_unaligned(const u8 *p) { return ((const unaligned_u128 *)p)->v; }
 AHIP_DEVINL u64 load_u64_unaligned(const u8 *p) { return ((const unaligned_u64 *)p)->v; }

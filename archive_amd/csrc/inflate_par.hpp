@@ -907,10 +907,9 @@ AHIP_DEVINL void deposit16(u8 *dp, u32 len, u64 w0, u64 w1) {
   } else if (len >= 4) {
     ((unaligned_u32 *)dp)->v = (u32)w0;
     ((unaligned_u32 *)(dp + len - 4))->v = (u32)(w0 >> (8 * (len - 4)));
-  } else {
-    dp[0] = (u8)w0;
-    if (len > 1) dp[1] = (u8)(w0 >> 8);
-    if (len > 2) dp[2] = (u8)(w0 >> 16);
+  } else {  // a match is at least 3 bytes (RFC 1951; the reference's EOS quirk only shortens lengths >= 11): exactly 3 here
+    ((unaligned_u16 *)dp)->v = (u16)w0;
+    dp[2] = (u8)(w0 >> 16);
   }
 }
 
@@ -936,11 +935,14 @@ AHIP_DEVINL void deposit16(u8 *dp, u32 len, u64 w0, u64 w1) {
 constexpr u32 WIN_CAP = AHIP_WIN_CAP;              // bytes of output the LDS window holds
 constexpr u32 WIN_FLUSH = WIN_CAP - AHIP_WIN_KEEP;  // ... and it is flushed once a chunk leaves it fuller than this
 constexpr u32 PEND_CAP = AHIP_PEND_CAP;            // deferred matches per window
+constexpr u32 LOOK_TOK = 4096;                     // tokens per look at the directory (a flow run has at most 4095)
 static_assert(WIN_CAP % 32 == 0 && WIN_CAP <= 32768 && WIN_FLUSH >= 512 && AHIP_WIN_KEEP >= 264 && PEND_CAP >= 128, "window geometry");
 struct ResLds {
   u8 obuf[WIN_CAP + 64] __attribute__((aligned(16)));  // + alignment offset (<= 15) + a 16-byte read past the last source byte
   u32 pmap[WIN_CAP / 32 + 4];  // one bit per window byte: a deferred match has yet to write it
   uint2 plist[PEND_CAP];       // the window's deferred matches in stream order: {window index | len << 16, distance}
+  u32 rbits[LOOK_TOK / 32 + 2];  // the current look at the directory: bit i = token i of the look is the first of its run
+  uint2 rtab[64];              //   run r of the look: {area offset of its token 0 - index of that token in the look, output offset rel. borg}
 };
 
 // One member: token runs (area, dir) -> bytes at out_base.  64 tokens per step, one per lane.
@@ -1086,8 +1088,13 @@ AHIP_DEVINL void resolve_member(ResLds &P, const u8 *in, const u32 *area, const 
     RTICK(r_f1);
     RACC(6, r_f0, r_f1);
   };
-  struct Tok { u32 t; i32 base; bool first, inb; };          // a chunk's tokens as loaded: word, run offset (rel. borg)
-  struct Ck { u32 t, len; i32 ob; bool inb, pre; u64 w0, w1, w2, w3; };  // ... decoded: ob = output offset rel. borg
+  struct Tok { u32 t; i32 base; bool first, inb; u32 nin; };  // a chunk's tokens as loaded: word, run offset (rel. borg); nin = lanes in the look
+  struct Ck {  // ... decoded
+    u32 t, len; i32 ob;  // ob = output offset rel. borg
+    bool inb, pre, gc;   // pre: the source bytes are in w0..w3; gc: classified "deposit now" when prepared
+    u64 w0, w1, w2, w3;
+    u32 wrel0; i32 cend; u64 inbm;  // (uniform) the window position it was classified against; end of the chunk's output rel. borg; ballot(inb)
+  };
   u32 de = 0;
   while (de < ndir) {
     RTICK(r_l0);
@@ -1109,14 +1116,19 @@ AHIP_DEVINL void resolve_member(ResLds &P, const u8 *in, const u32 *area, const 
       const bool simple = c.len <= 32 && dist >= c.len;  // two 16-byte pieces, source and destination apart
       const i32 wo = c.ob - (i32)wrel;  // window index of the destination
       const i32 so = wo - (i32)dist;    // window index of the source (negative: flushed output)
-      bool fit = ((rem >> lane) & 1) && (u32)wo + c.len <= WIN_CAP;
       // A match is deposited right here when its source is flushed output and two 16-byte pieces do it.  The first
       // piece may read past the source (the deposit ignores what lies behind `len`): with dist >= 16 those bytes are
       // still this member's own output -- allocated, just not written yet.  Everything else is deferred to the flush.
-      const i32 span = c.len > 16 ? (i32)c.len : 16;
-      const bool Gc = isM && simple && so + (i32)c.len <= 0 && (so + span <= 0 || dist >= 16);
+      bool Gc = c.gc;  // as classified when the chunk was prepared ...
+      if (wrel != c.wrel0) {  // ... unless the window has moved since
+        const i32 span = c.len > 16 ? (i32)c.len : 16;
+        Gc = isM && simple && so + (i32)c.len <= 0 && (so + span <= 0 || dist >= 16);
+      }
       const bool defer_ = isM && !Gc;
-      {  // the pending list must take the deferred ones too; what fits has to be a prefix of what remains
+      bool fit = c.inb;
+      const bool whole = rem == c.inbm && (u32)(c.cend - (i32)wrel) <= WIN_CAP && npend + 64 <= PEND_CAP;
+      if (!whole) {  // the window or its pending list ends inside the chunk: what fits has to be a prefix of what remains
+        fit = ((rem >> lane) & 1) && (u32)wo + c.len <= WIN_CAP;
         const u64 dm = __ballot(fit && defer_);
         const u32 before = (u32)__popcll(dm & ((1ull << lane) - 1));
         fit = fit && npend + before + (defer_ ? 1u : 0u) <= PEND_CAP;
@@ -1160,7 +1172,7 @@ AHIP_DEVINL void resolve_member(ResLds &P, const u8 *in, const u32 *area, const 
     };
     // a whole chunk: passes and flushes (ONE flush site per loop: the flush is a lot of code and registers)
     auto process = [&](Ck &c) {
-      u64 rem = __ballot(c.inb);
+      u64 rem = c.inbm;
       for (u32 guard = 0; guard < 300; ++guard) {  // (a pass after a flush always takes at least one token: never spins)
         if (rem) rem = pass(c, rem);
         if (!rem && wfill < WIN_FLUSH) break;
@@ -1196,6 +1208,10 @@ AHIP_DEVINL void resolve_member(ResLds &P, const u8 *in, const u32 *area, const 
           u32 tot;
           c.ob = (i32)(run + wave_excl_sum(c.len, tot));
           c.pre = false;
+          c.gc = false;
+          c.wrel0 = ~0u;  // (classified in pass())
+          c.cend = (i32)(run + tot);
+          c.inbm = __ballot(c.inb);
           c.w0 = c.w1 = c.w2 = c.w3 = 0;
           carry_end = lane_bcast(end, 63);
           // (a chunk of long matches may be larger than the window: process() splits it)
@@ -1206,40 +1222,40 @@ AHIP_DEVINL void resolve_member(ResLds &P, const u8 *in, const u32 *area, const 
       de += 1;
       continue;
     }
-    // ---- ordinary runs: lane r holds run r of the look ----
-    const bool rmine = (u32)lane < nplain;
-    const u32 rcnt = rmine ? (dv.y & DF_CNT) : 0u;
+    // ---- ordinary runs: lane r holds run r of the look (as many as LOOK_TOK tokens allow, at least one) ----
+    u32 rcnt = (u32)lane < nplain ? (dv.y & DF_CNT) : 0u;
     u32 total;
     const u32 ts = wave_excl_sum(rcnt, total);                                   // first token of the run within the look
+    const u32 nlook = (u32)__popcll(__ballot((u32)lane < nplain && ts + rcnt <= LOOK_TOK));  // (a prefix: ts grows with the lane)
+    const bool rmine = (u32)lane < nlook;
+    total = nlook < 64 ? lane_bcast(ts, (int)nlook) : total;
     const i32 rb = (i32)((((u64)dv.w << 32) | dv.z) - borg);                     // where its output starts, rel. borg
-    u32 r0 = 0;  // the run the next gathered chunk starts in
+    // token -> run without a search: a bit per token of the look marks the first token of every run, so the run of token i
+    // is the number of marks in [0, i] - 1; what a lane needs of its run comes from a table
+    for (u32 i = lane; i < LOOK_TOK / 32 + 2; i += 64) P.rbits[i] = 0;
+    wave_sync();
+    if (rmine) {
+      P.rtab[lane] = make_uint2(dv.x - ts, (u32)rb);
+      atomicOr(&P.rbits[ts >> 5], 1u << (ts & 31));
+    }
+    wave_sync();
+    u32 gruns = 0;  // runs that begin in front of the next gathered chunk
     RTICK(r_l1);
     RACC(0, r_l0, r_l1);
-    auto gather = [&](u32 c0) -> Tok {
+    auto gather = [&](u32 c0) -> Tok {  // (called with c0 = 0, 64, 128, ... in this order)
       RTICK(r_g0);
       Tok q;
       const u32 idx = c0 + (u32)lane;
       q.inb = idx < total;
-      u32 k = 0, ta = 0;
-      q.base = 0;
-      u32 r = r0, s = lane_bcast(ts, (int)r0);
-      for (;;) {
-        const u32 ao = lane_bcast(dv.x, (int)r);
-        const i32 bo = (i32)lane_bcast((u32)rb, (int)r);
-        const bool sel = idx >= s;
-        k = sel ? idx - s : k;
-        ta = sel ? ao : ta;
-        q.base = sel ? bo : q.base;
-        if (r + 1 >= nplain) break;
-        const u32 sn = lane_bcast(ts, (int)r + 1);
-        if (sn >= c0 + 64) { if (sn == c0 + 64) r += 1; break; }
-        r += 1;
-        s = sn;
-      }
-      r0 = r;
-      q.first = k == 0;
-      q.t = area[q.inb ? ta + k : 0u];  // (no branch around the load and no use of it here: it stays in flight; lanes
-                                         //  outside the look read some token, which `inb` keeps anyone from using)
+      q.nin = total - c0 < 64u ? total - c0 : 64u;
+      const u64 bits = (u64)uniform(P.rbits[c0 >> 5]) | ((u64)uniform(P.rbits[(c0 >> 5) + 1]) << 32);
+      const u32 r = gruns + (u32)__popcll(bits & ((2ull << lane) - 1)) - 1u;  // (token 0 of the look is marked: never negative)
+      gruns += (u32)__popcll(bits);
+      q.first = (bits >> lane) & 1;
+      const uint2 e = P.rtab[r & 63u];
+      q.base = (i32)e.y;
+      q.t = area[q.inb ? e.x + idx : 0u];  // (no branch around the load and no use of it here: it stays in flight; lanes
+                                           //  outside the look read some token, which `inb` keeps anyone from using)
       RTICK(r_g1);
       RACC(1, r_g0, r_g1);
       return q;
@@ -1261,7 +1277,11 @@ AHIP_DEVINL void resolve_member(ResLds &P, const u8 *in, const u32 *area, const 
       const u32 dist = (q.t & 0x7fffu) + 1u;
       const i32 so = c.ob - (i32)wrel - (i32)dist;  // against the window as it is NOW: what is flushed stays flushed
       const i32 span = c.len > 16 ? (i32)c.len : 16;
-      c.pre = q.inb && !lit && c.len <= 32 && dist >= c.len && so + (i32)c.len <= 0 && (so + span <= 0 || dist >= 16);  // = process()'s Gc, now
+      c.gc = q.inb && !lit && c.len <= 32 && dist >= c.len && so + (i32)c.len <= 0 && (so + span <= 0 || dist >= 16);
+      c.pre = c.gc;
+      c.wrel0 = wrel;
+      c.inbm = q.nin >= 64 ? ~0ull : (1ull << q.nin) - 1;
+      c.cend = (i32)lane_bcast((u32)c.ob + c.len, (int)q.nin - 1);
 #ifdef AHIP_RES_UNCOND_LOADS
       const u8 *sp = c.pre ? out_base + wpos + so : (const u8 *)area;
       const u8 *sp2 = (c.pre && c.len > 16) ? sp + c.len - 16 : sp;
@@ -1272,7 +1292,11 @@ AHIP_DEVINL void resolve_member(ResLds &P, const u8 *in, const u32 *area, const 
 #else
       c.w0 = c.w1 = c.w2 = c.w3 = 0;
       if (c.pre) {
+#ifdef AHIP_ABLATE_SRC  // EXPERIMENT (wrong bytes): every source fetch goes to the member's first 4 KiB -- what do the cache misses cost?
+        const u8 *sp = out_base + ((u32)(wpos + so) & 0xfffu);
+#else
         const u8 *sp = out_base + wpos + so;
+#endif
         c.w0 = load_u64_unaligned(sp);
         c.w1 = load_u64_unaligned(sp + 8);
         if (c.len > 16) { c.w2 = load_u64_unaligned(sp + c.len - 16); c.w3 = load_u64_unaligned(sp + c.len - 8); }
@@ -1292,7 +1316,7 @@ AHIP_DEVINL void resolve_member(ResLds &P, const u8 *in, const u32 *area, const 
       if (c0 + 128 < total) t2 = gather(c0 + 128);  // load the tokens of the one after
       process(c);
     }
-    de += nplain;
+    de += nlook;
   }
   if (wfill) flush();
   RTICK(r_end);
