@@ -343,7 +343,7 @@ static u64 group_out_max() {
 #define GROUP_OUT_MAX group_out_max()
 
 // members[first .. first+count) with output offsets [out0, out1): tokenize (+ resolve when WRITE)
-static int tok_resident = 0, res_resident = 0;  // workgroups of the tokenizer / resolver resident at once
+static thread_local int tok_resident = 0, res_resident = 0;  // workgroups of the tokenizer / resolver resident at once (per device context)
 static thread_local DevBuf g_late, g_exact, g_tokens2, g_scratch2;
 // The token / directory scratch is shared by every launch of the thread: a launch on another stream than the
 // previous one first waits for that one to be done with it.
@@ -733,11 +733,34 @@ int32_t plan_run(ahip_gzip_plan *pl, u8 *d_out, size_t out_cap, hipStream_t st) 
   const u64 whole[2] = {0, pl->sum.total_out};  // one group: only its total is needed
   if (getenv("AHIP_DEBUG")) fprintf(stderr, "[ahip] plan_run: sized=%d kept tokens %llu (scratch holds %llu) retok=%u\n", (int)pl->sized,
                                     (unsigned long long)pl->tok_gen, (unsigned long long)g_tok_gen, pl->sum.retok);
-  if (pl->sized && pl->tok_gen && pl->tok_gen == g_tok_gen && !use_serial_kernel()) {
+  // Long members first: many waves each, straight into place.  They come before the member launch because its late
+  // kernel resolves back-references into EARLIER members' output (quirk q8) in stream order at its very end -- the
+  // bytes of a long member in front of such a member have to exist by then.  (A long member that itself reaches
+  // into earlier output is not reproduced: it reports the reference's RangeError verdict for a reach in front of
+  // the stream)
+  std::vector<MemberResult> big_res(pl->big.size());
+  const bool kept = pl->sized && pl->tok_gen && pl->tok_gen == g_tok_gen && !use_serial_kernel();
+  for (size_t b = 0; b < pl->big.size() && !kept; ++b) {
+    const auto &bg = pl->big[b];
+    bool handled = false;
+    int32_t rc = sm_inflate(pl->d_in, pl->in_len, bg.in_off, d_out + bg.out_off, bg.out_len, true, &big_res[b], &handled, st);
+    if (rc != AHIP_OK) return rc;
+    if (!handled) { rc = inflate_one_wave(pl->d_in, pl->in_len, bg.in_off, d_out + bg.out_off, bg.out_len, true, &big_res[b], st); if (rc != AHIP_OK) return rc; }
+  }
+  if (kept) {
     // the sizing run's tokens are still in the scratch: resolve them, then tokenize + resolve the few members whose
-    // tokens are no use (a full area -- a false candidate cut it short --, a reach into earlier members, an error)
+    // tokens are no use (a full area -- a false candidate cut it short --, a reach into earlier members, an error).
+    // (The long members use the same scratch: they follow, and a member that reaches into one of them is among the
+    // few -- those are launched last.)
     HIP_TRY(launch_resolve_kept(pl->d_in, pl->in_len, pl->members.as<MemberDesc>(), M, d_out, pl->results.as<MemberResult>(),
                                 pl->cand_pos.as<u64>(), pl->K, pl->sizing_results.as<MemberResult>(), st));
+    for (size_t b = 0; b < pl->big.size(); ++b) {
+      const auto &bg = pl->big[b];
+      bool handled = false;
+      int32_t rc = sm_inflate(pl->d_in, pl->in_len, bg.in_off, d_out + bg.out_off, bg.out_len, true, &big_res[b], &handled, st);
+      if (rc != AHIP_OK) return rc;
+      if (!handled) { rc = inflate_one_wave(pl->d_in, pl->in_len, bg.in_off, d_out + bg.out_off, bg.out_len, true, &big_res[b], st); if (rc != AHIP_OK) return rc; }
+    }
     HIP_TRY(launch_inflate_listed(pl->d_in, pl->in_len, pl->members.as<MemberDesc>(), pl->retok_ids.as<u32>(), pl->retok_rel.as<u64>(),
                                   pl->retok_n, pl->retok_span, d_out, pl->results.as<MemberResult>(), st));
   } else {
@@ -745,15 +768,9 @@ int32_t plan_run(ahip_gzip_plan *pl, u8 *d_out, size_t out_cap, hipStream_t st) 
                                  pl->results.as<MemberResult>(), st,
                                  pl->host_out_off.empty() ? nullptr : pl->host_out_off.data(), whole[1]));
   }
-  for (const auto &bg : pl->big) {  // long members: many waves each, straight into place
-    MemberResult r{};
-    bool handled = false;
-    int32_t rc = sm_inflate(pl->d_in, pl->in_len, bg.in_off, d_out + bg.out_off, bg.out_len, true, &r, &handled, st);
-    if (rc != AHIP_OK) return rc;
-    if (!handled) { rc = inflate_one_wave(pl->d_in, pl->in_len, bg.in_off, d_out + bg.out_off, bg.out_len, true, &r, st); if (rc != AHIP_OK) return rc; }
-    HIP_TRY(hipMemcpyAsync(pl->results.as<MemberResult>() + bg.member, &r, sizeof r, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));
-  }
+  for (size_t b = 0; b < pl->big.size(); ++b)
+    HIP_TRY(hipMemcpyAsync(pl->results.as<MemberResult>() + pl->big[b].member, &big_res[b], sizeof(MemberResult), hipMemcpyHostToDevice, st));
+  if (!pl->big.empty()) HIP_TRY(hipStreamSynchronize(st));  // (big_res lives on this stack frame)
   hipLaunchKernelGGL(gz_verify, dim3(cdiv(M, 256)), dim3(256), 0, st, pl->members.as<MemberDesc>(),
                      pl->expect_status.as<u32>(), pl->results.as<MemberResult>(), M, pl->drun.as<RunSummary>());
   HIP_TRY(hipGetLastError());
@@ -1116,7 +1133,7 @@ int32_t zlib_stream_device(const u8 *host_in, const u8 *d_in, u64 n, u64 pos, bo
 // ------------------------------------------------------------------------------------------
 extern "C" {
 
-uint32_t ahip_abi_version(void) { return (2u << 16) | 0u; }
+uint32_t ahip_abi_version(void) { return (2u << 16) | 1u; }
 
 const char *ahip_last_error(void) { return g_err.c_str(); }
 
@@ -1128,9 +1145,11 @@ int32_t ahip_init(int32_t device) {
   return AHIP_OK;
 }
 
+void rccl_drop();
 void ahip_shutdown(void) {
   std::lock_guard<std::recursive_mutex> lk(g_mu);
   stop_workers();
+  rccl_drop();
   for (auto &b : g_pool) (void)hipFree(b.p);
   g_pool.clear();
   g_inited = false;
@@ -1420,6 +1439,7 @@ static int32_t deflate_device_impl(const u8 *d_in, size_t n, int level, int wind
   P.store = level == 0 ? 1u : 0u;
   P.max_cmp = 258;
   P.max_dist = (1u << window_bits) - 262;
+  P.nice = level <= 3 ? DF_CAP : (level <= 6 ? 128u : 258u);
   HIP_TRY(b_match.reserve(n * 4 + 64 + (size_t)P.chunks * 32 + 64));
   HIP_TRY(b_tok.reserve(n * 4 + 64));
   HIP_TRY(b_ntok.reserve((size_t)P.chunks * 4));
@@ -1428,9 +1448,11 @@ static int32_t deflate_device_impl(const u8 *d_in, size_t n, int level, int wind
   HIP_TRY(b_coff.reserve((size_t)P.chunks * 8));
   if (!P.store)
   {
+    // levels 4-6 add a table of 8-byte strings (4096 entries: 76 KiB of LDS, still two workgroups per CU), levels 7-9
+    // tables of 8- and 16-byte strings (16384 and 8192 entries: one workgroup per CU either way)
     if (level <= 3) hipLaunchKernelGGL((deflate_match_kernel<12, 2>), dim3(P.chunks), dim3(256), 0, st, d_in, P, b_match.as<u32>());
-    else if (level <= 6) hipLaunchKernelGGL((deflate_match_kernel<12, 4>), dim3(P.chunks), dim3(256), 0, st, d_in, P, b_match.as<u32>());
-    else hipLaunchKernelGGL((deflate_match_kernel<13, 4>), dim3(P.chunks), dim3(256), 0, st, d_in, P, b_match.as<u32>());
+    else if (level <= 6) hipLaunchKernelGGL((deflate_match_kernel<12, 4, 12>), dim3(P.chunks), dim3(256), 0, st, d_in, P, b_match.as<u32>());
+    else hipLaunchKernelGGL((deflate_match_kernel<13, 4, 14, 13>), dim3(P.chunks), dim3(256), 0, st, d_in, P, b_match.as<u32>());
   }
 #ifdef AHIP_PROFILE
   if (!P.store && getenv("AHIP_DEBUG")) {
@@ -1565,6 +1587,55 @@ int32_t ahip_zlib_encode(const uint8_t *in, size_t in_len, int32_t level, int32_
   uint8_t *t = out + 2 + clen;
   t[0] = (uint8_t)(a >> 24); t[1] = (uint8_t)(a >> 16); t[2] = (uint8_t)(a >> 8); t[3] = (uint8_t)a;
   return AHIP_OK;
+}
+
+// Device-resident encoders: the DEFLATE stream is written straight behind the header bytes in d_out, the checksum of
+// the trailer comes from the device copy of the input; header and trailer are a few bytes copied from the host.
+static int32_t framed_encode_device(const void *d_in, size_t in_len, int32_t level, int32_t window_bits, const uint8_t *head, size_t head_len,
+                                    bool gzip, void *d_out, size_t out_cap, size_t *out_len, void *stream) {
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  const size_t tail_len = gzip ? 8 : 4;
+  if (out_len) *out_len = 0;
+  int32_t rc = ensure_init();
+  if (rc != AHIP_OK) return rc;
+  if (out_cap < head_len + tail_len) { if (out_len) *out_len = ahip_deflate_bound(in_len) + head_len + tail_len; return fail(AHIP_E_CAP, "output buffer too small"); }
+  hipStream_t st = (hipStream_t)stream;
+  size_t clen = 0;
+  u8 *o = (u8 *)d_out;
+  if (!(window_bits < 9 || window_bits > 15 || level < 0 || level > 9)) {  // (the reference's silent no-op otherwise)
+    rc = deflate_device_impl((const u8 *)d_in, in_len, level, window_bits, o + head_len, out_cap - head_len - tail_len, &clen, st);
+    if (out_len) *out_len = clen + head_len + tail_len;
+    if (rc != AHIP_OK) return rc;
+  }
+  uint32_t ck = gzip ? 0u : 1u;
+  if (!(window_bits < 9 || window_bits > 15 || level < 0 || level > 9)) {
+    rc = gzip ? crc32_device_impl((const u8 *)d_in, in_len, 0, &ck, st) : adler32_device_impl((const u8 *)d_in, in_len, 1, &ck, st);
+    if (rc != AHIP_OK) return rc;
+  }
+  uint8_t t[8];
+  if (gzip) for (int k = 0; k < 4; k++) { t[k] = (uint8_t)(ck >> (8 * k)); t[4 + k] = (uint8_t)(((uint32_t)in_len) >> (8 * k)); }
+  else { t[0] = (uint8_t)(ck >> 24); t[1] = (uint8_t)(ck >> 16); t[2] = (uint8_t)(ck >> 8); t[3] = (uint8_t)ck; }
+  HIP_TRY(hipMemcpyAsync(o, head, head_len, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(o + head_len + clen, t, tail_len, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (out_len) *out_len = clen + head_len + tail_len;
+  return AHIP_OK;
+}
+
+int32_t ahip_gzip_encode_device(const void *d_in, size_t in_len, int32_t level, int32_t window_bits, uint32_t mtime, void *d_out,
+                                size_t out_cap, size_t *out_len, void *stream) {
+  const uint8_t h[10] = {0x1f, 0x8b, 8, 0, (uint8_t)mtime, (uint8_t)(mtime >> 8), (uint8_t)(mtime >> 16), (uint8_t)(mtime >> 24), 0, 0xff};
+  return framed_encode_device(d_in, in_len, level, window_bits, h, 10, true, d_out, out_cap, out_len, stream);
+}
+
+int32_t ahip_zlib_encode_device(const void *d_in, size_t in_len, int32_t level, int32_t window_bits, void *d_out, size_t out_cap,
+                                size_t *out_len, void *stream) {
+  const int wb = window_bits < 0 ? 0 : (window_bits > 15 ? 15 : window_bits);
+  const uint32_t cmf = (uint32_t)(((wb - 8) << 4) | 8) & 0xff;
+  uint32_t flg = 0;
+  while ((cmf * 256 + flg) % 31 != 0) ++flg;
+  const uint8_t h[2] = {(uint8_t)cmf, (uint8_t)flg};
+  return framed_encode_device(d_in, in_len, level, window_bits, h, 2, false, d_out, out_cap, out_len, stream);
 }
 
 int32_t ahip_gzip_plan_create(const void *d_in, size_t in_len, void *stream, ahip_gzip_plan **plan) {
@@ -1869,6 +1940,158 @@ int32_t ahip_init_devices(uint64_t device_mask) {
 
 static int32_t g_last_shards = 1;
 int32_t ahip_debug_last_shards(void) { return g_last_shards; }
+
+// ---- device-resident shards on several GPUs + the size exchange ----
+// The one exchange step of the path: every device contributes the number of bytes its shard produced, all of them
+// end up with all the sizes, the exclusive prefix sum is a shard's offset in the logical output.  Between distinct
+// devices that is an all-gather of one uint64 per device over RCCL (ncclAllGather on the devices' own buffers, one
+// communicator per device made by ncclCommInitAll; librccl is loaded at run time so that the library does not depend
+// on it); several contexts on ONE device (AHIP_FAKE_DEVICES), a missing librccl or AHIP_NO_RCCL=1 take host sums.
+#include <dlfcn.h>
+namespace {
+struct Rccl {
+  void *h = nullptr;
+  int (*CommInitAll)(void **, int, const int *) = nullptr;
+  int (*CommDestroy)(void *) = nullptr;
+  int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  bool tried = false, ok = false;
+  std::vector<int> devs;      // the devices the communicators below were made for
+  std::vector<void *> comms;
+  std::vector<u64 *> send, recv;
+  bool load() {
+    if (tried) return ok;
+    tried = true;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (h) break;
+    }
+    if (!h) return false;
+    CommInitAll = (int (*)(void **, int, const int *))dlsym(h, "ncclCommInitAll");
+    CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
+    AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(h, "ncclAllGather");
+    GroupStart = (int (*)())dlsym(h, "ncclGroupStart");
+    GroupEnd = (int (*)())dlsym(h, "ncclGroupEnd");
+    ok = CommInitAll && CommDestroy && AllGather && GroupStart && GroupEnd;
+    return ok;
+  }
+  void drop() {
+    for (size_t i = 0; i < comms.size(); ++i) {
+      (void)hipSetDevice(devs[i]);
+      if (comms[i]) CommDestroy(comms[i]);
+      if (send[i]) (void)hipFree(send[i]);
+      if (recv[i]) (void)hipFree(recv[i]);
+    }
+    comms.clear(); send.clear(); recv.clear(); devs.clear();
+  }
+  bool prepare(const std::vector<int> &d) {
+    if (!load()) return false;
+    if (d == devs) return true;
+    drop();
+    comms.assign(d.size(), nullptr); send.assign(d.size(), nullptr); recv.assign(d.size(), nullptr);
+    devs = d;
+    if (CommInitAll(comms.data(), (int)d.size(), d.data()) != 0) { comms.assign(d.size(), nullptr); drop(); return false; }
+    for (size_t i = 0; i < d.size(); ++i) {
+      if (hipSetDevice(d[i]) != hipSuccess || hipMalloc((void **)&send[i], 8) != hipSuccess ||
+          hipMalloc((void **)&recv[i], 8 * d.size()) != hipSuccess) { drop(); return false; }
+    }
+    return true;
+  }
+  // sizes[i] of device devs[i] -> every device holds all of them; `all` = what device 0 ended up with
+  bool all_gather(const std::vector<u64> &sizes, std::vector<u64> &all) {
+    const size_t n = devs.size();
+    for (size_t i = 0; i < n; ++i) {
+      if (hipSetDevice(devs[i]) != hipSuccess) return false;
+      if (hipMemcpy(send[i], &sizes[i], 8, hipMemcpyHostToDevice) != hipSuccess) return false;
+    }
+    constexpr int kNcclUint64 = 5;
+    if (GroupStart() != 0) return false;
+    bool good = true;
+    for (size_t i = 0; i < n; ++i) {
+      (void)hipSetDevice(devs[i]);
+      good = good && AllGather(send[i], recv[i], 1, kNcclUint64, comms[i], (hipStream_t) nullptr) == 0;
+    }
+    if (GroupEnd() != 0 || !good) return false;
+    for (size_t i = 0; i < n; ++i) {
+      if (hipSetDevice(devs[i]) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return false;
+    }
+    all.resize(n);
+    (void)hipSetDevice(devs[0]);
+    return hipMemcpy(all.data(), recv[0], 8 * n, hipMemcpyDeviceToHost) == hipSuccess;
+  }
+};
+Rccl g_rccl;      // guarded by g_mu
+int32_t g_last_exchange = 0;
+}  // namespace
+
+void rccl_drop() { if (g_rccl.ok) g_rccl.drop(); }
+int32_t ahip_debug_last_exchange(void) { return g_last_exchange; }
+
+int32_t ahip_gzip_decode_shards(uint32_t n_shards, const int32_t *devices, const void *const *d_in, const size_t *in_len,
+                                void *const *d_out, const size_t *out_cap, size_t *out_len, uint64_t *offsets, int32_t *status) {
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  int32_t rc = ensure_init();
+  if (rc != AHIP_OK) return rc;
+  if (n_shards == 0 || !devices || !d_in || !in_len || !d_out || !out_cap || !out_len || !offsets) return fail(AHIP_E_ARG, "NULL shard table");
+  int cur = 0;
+  HIP_TRY(hipGetDevice(&cur));
+  // a shard runs in the context of its device: worker k of ahip_init_devices (several shards of one device take turns),
+  // or this thread when no workers exist and the shard sits on the current device
+  std::vector<int> wk(n_shards, -1);
+  for (u32 s = 0; s < n_shards; ++s) {
+    if (g_workers.empty()) {
+      if (devices[s] != cur) return fail(AHIP_E_ARG, "shard on a device that ahip_init_devices() did not select");
+      continue;
+    }
+    // contexts of the same device (AHIP_FAKE_DEVICES) are dealt out round robin
+    int pick = -1, seen = 0;
+    for (size_t w = 0; w < g_workers.size(); ++w)
+      if (g_workers[w]->device == devices[s]) { if (pick < 0 || seen <= (int)(s % g_workers.size())) pick = (int)w; ++seen; }
+    if (pick < 0) return fail(AHIP_E_ARG, "shard on a device that ahip_init_devices() did not select");
+    wk[s] = pick;
+  }
+  std::vector<int32_t> rcs(n_shards, AHIP_OK);
+  std::vector<std::string> errs(n_shards);
+  std::vector<size_t> got(n_shards, 0);
+  auto run_shard = [&](u32 s) {
+    rcs[s] = gzip_decode_impl(nullptr, (const u8 *)d_in[s], in_len[s], 0, 0, (u8 *)d_out[s], out_cap[s], false, nullptr, &got[s], nullptr);
+    if (rcs[s] < 0) errs[s] = g_err;
+  };
+  if (g_workers.empty()) {
+    for (u32 s = 0; s < n_shards; ++s) run_shard(s);
+  } else {
+    // every worker takes its shards in order; the workers run side by side
+    for (size_t w = 0; w < g_workers.size(); ++w) {
+      std::vector<u32> mine;
+      for (u32 s = 0; s < n_shards; ++s) if (wk[s] == (int)w) mine.push_back(s);
+      g_workers[w]->submit([mine, &run_shard] { for (u32 s : mine) run_shard(s); });
+    }
+    for (auto &w : g_workers) w->wait();
+  }
+  int32_t worst = AHIP_OK;
+  for (u32 s = 0; s < n_shards; ++s) {
+    out_len[s] = got[s];
+    if (status) status[s] = rcs[s];
+    if (rcs[s] < 0 && worst >= 0) { worst = rcs[s]; g_err = "shard " + std::to_string(s) + ": " + errs[s]; }
+    else if (worst >= 0 && rcs[s] > worst) worst = rcs[s];
+  }
+  // ---- the exchange: sizes -> offsets ----
+  std::vector<u64> sizes(n_shards), all;
+  for (u32 s = 0; s < n_shards; ++s) sizes[s] = got[s];
+  g_last_exchange = 0;
+  bool distinct = true;
+  std::vector<int> devs(devices, devices + n_shards);
+  for (u32 a = 0; a < n_shards; ++a) for (u32 b = a + 1; b < n_shards; ++b) if (devs[a] == devs[b]) distinct = false;
+  const char *no = getenv("AHIP_NO_RCCL");
+  if (distinct && !(no && no[0] == '1') && g_rccl.prepare(devs) && g_rccl.all_gather(sizes, all)) g_last_exchange = 1;
+  else all = sizes;
+  (void)hipSetDevice(cur);
+  u64 acc = 0;
+  for (u32 s = 0; s < n_shards; ++s) { offsets[s] = acc; acc += all[s]; }
+  offsets[n_shards] = acc;
+  return worst;
+}
 
 int32_t ahip_device_count(void) {
   std::lock_guard<std::recursive_mutex> lk(g_mu);

@@ -54,9 +54,15 @@ struct DeflateParams {
   u32 store;    // 1 = level 0: stored blocks only
   u32 max_cmp;  // longest match searched (258)
   u32 max_dist; // farthest match: 2^windowBits - 262 (deflate.dart:1120-1131, MAX_DIST)
+  u32 nice;     // candidates that still tie after DF_CAP bytes are compared on up to this length (the reference's
+                // nice_length, deflate.dart:1253-1272: 128 at level 6, 258 at level 9); DF_CAP = never
 };
 
 template <u32 HB> AHIP_DEVINL u32 df_hash4(u32 w) { return (w * 2654435761u) >> (32 - HB); }
+// hashes of LONGER strings (8 and 16 bytes): a candidate that shares that much context is worth what a deep walk
+// down the reference's hash chain finds (_longestMatch, deflate.dart:1120-1206, up to 128 / 4096 candidates)
+template <u32 HB> AHIP_DEVINL u32 df_hash8(u64 w) { return (u32)(((w * 0x9E3779B97F4A7C15ull) >> 32) * 2654435761u) >> (32 - HB); }
+template <u32 HB> AHIP_DEVINL u32 df_hash16(u64 a, u64 b) { return df_hash8<HB>(a * 0xC2B2AE3D27D4EB4Full + (b ^ (b >> 29))); }
 
 // ------------------------------------------------------------------------------------------
 // D1: per-position best match
@@ -82,11 +88,11 @@ AHIP_DEVINL u64 df_rd8(const u32 *ring, u32 r) {
 // round costs ONE LDS round trip for all of them -- the kernel is bound by dependent LDS latency (two waves
 // per SIMD), not by LDS bandwidth.
 template <int NW>
-AHIP_DEVINL void df_match_lens(const u32 *ring, const u32 (&rc)[NW], u32 rp, u32 maxl, bool (&alive)[NW], u32 (&len)[NW]) {
+AHIP_DEVINL void df_match_lens(const u32 *ring, const u32 (&rc)[NW], u32 rp, u32 maxl, bool (&alive)[NW], u32 (&len)[NW], u32 l0 = 0) {
   bool any = false;
 #pragma unroll
-  for (int k = 0; k < NW; ++k) { len[k] = 0; any |= alive[k]; }  // (maxl >= 4: the position has four bytes to hash)
-  for (u32 l = 0; any; l += 8) {  // the first round doubles as the check that the bucket-mate really shares 4 bytes
+  for (int k = 0; k < NW; ++k) { if (l0 == 0) len[k] = 0; any |= alive[k]; }  // (maxl >= 4: the position has four bytes to hash)
+  for (u32 l = l0; any; l += 8) {  // the first round doubles as the check that the bucket-mate really shares 4 bytes
     const u64 pw = df_rd8(ring, rp + l);
     u64 cw[NW];
 #pragma unroll
@@ -109,10 +115,14 @@ AHIP_DEVINL void df_match_lens(const u32 *ring, const u32 (&rc)[NW], u32 rp, u32
 AHIP_DEVINL void df_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // match[] holds len << 16 | dist per input position (0 = no match of >= 4 bytes)
-template <u32 DF_HASH_BITS, u32 DF_WAYS>
+// LA / LB: index bits of the one-way tables keyed by 8-byte / 16-byte strings (0 = no such table)
+template <u32 DF_HASH_BITS, u32 DF_WAYS, u32 LA = 0, u32 LB = 0>
 __global__ __launch_bounds__(256) void deflate_match_kernel(const u8 *__restrict__ in, DeflateParams P,
                                                             u32 *__restrict__ match) {
   __shared__ u16 tbl[(1u << DF_HASH_BITS) * DF_WAYS];
+  __shared__ u16 tblA[LA ? (1u << LA) : 1u];
+  __shared__ u16 tblB[LB ? (1u << LB) : 1u];
+  constexpr u32 NX = (LA ? 1u : 0u) + (LB ? 1u : 0u);  // candidates from the long-string tables
   constexpr u32 MERGE = DF_WAYS < 4 ? DF_WAYS : 4;  // history steps inserted per barrier (distinct ways)
   __shared__ u32 ring[(DF_RING + DF_MIRROR) / 4 + 2];
   const u32 chunk = blockIdx.x, tid = threadIdx.x;
@@ -123,6 +133,8 @@ __global__ __launch_bounds__(256) void deflate_match_kernel(const u8 *__restrict
   const u32 wlen = dict + clen;
   if (P.store) return;
   for (u32 i = tid; i < (1u << DF_HASH_BITS) * DF_WAYS; i += 256) tbl[i] = (u16)DF_EMPTY;
+  if (LA) for (u32 i = tid; i < (1u << LA); i += 256) tblA[i] = (u16)DF_EMPTY;
+  if (LB) for (u32 i = tid; i < (1u << LB); i += 256) tblB[i] = (u16)DF_EMPTY;
   // bytes [q, q + 4) of the window (zero past the end) ...
   auto fetch = [&](u32 q) -> u32 {
     u32 v = 0;
@@ -149,6 +161,8 @@ __global__ __launch_bounds__(256) void deflate_match_kernel(const u8 *__restrict
     for (u32 k = 0; k < MERGE; ++k) {
       const u32 p = base + k * DF_SUB + tid;  // p + 4 <= wlen: the chunk follows
       tbl[df_hash4<DF_HASH_BITS>(df_rd4(ring, df_rc(p))) * DF_WAYS + (((base / DF_SUB) + k) & (DF_WAYS - 1))] = (u16)p;
+      if (LA && p + 8 <= wlen) tblA[df_hash8<LA ? LA : 1>(df_rd8(ring, df_rc(p)))] = (u16)p;
+      if (LB && p + 16 <= wlen) tblB[df_hash16<LB ? LB : 1>(df_rd8(ring, df_rc(p)), df_rd8(ring, df_rc(p) + 8))] = (u16)p;
     }
     __syncthreads();
   }
@@ -178,36 +192,64 @@ __global__ __launch_bounds__(256) void deflate_match_kernel(const u8 *__restrict
     u32 maxl = (wlen - p) < P.max_cmp ? (wlen - p) : P.max_cmp;
     maxl = maxl < DF_CAP ? maxl : DF_CAP;
     if (has4) { w = df_rd4(ring, rp); h = df_hash4<DF_HASH_BITS>(w); }
-    u32 cand[DF_WAYS + 1];
+    u32 cand[DF_WAYS + 1 + NX];
 #pragma unroll
     for (u32 way = 0; way < DF_WAYS; ++way) cand[way] = search ? tbl[h * DF_WAYS + way] : DF_EMPTY;
     const u32 slot = h * DF_WAYS + ((base / DF_SUB) & (DF_WAYS - 1));
+    u32 hA = 0, hB = 0;
+    const bool has8 = p + 8 <= wlen, has16 = p + 16 <= wlen;
+    if (LA) {
+      if (has8) hA = df_hash8<LA ? LA : 1>(df_rd8(ring, rp));
+      cand[DF_WAYS + 1] = (search && has8) ? tblA[hA] : DF_EMPTY;
+    }
+    if (LB) {
+      if (has16) hB = df_hash16<LB ? LB : 1>(df_rd8(ring, rp), df_rd8(ring, rp + 8));
+      cand[DF_WAYS + NX] = (search && has16) ? tblB[hB] : DF_EMPTY;
+    }
     AHIP_TICK(t1);
     df_lds_barrier();
     if (has4) tbl[slot] = (u16)p;  // same-hash writers of one step race: any winner is valid
+    if (LA && has8) tblA[hA] = (u16)p;
+    if (LB && has16) tblB[hB] = (u16)p;
     df_lds_barrier();
     AHIP_TICK(t2);
     AHIP_ACC(pc[0], t0, t1);
     AHIP_ACC(pc[1], t1, t2);
     if (search) {
       cand[DF_WAYS] = tbl[slot];
-      u32 rc[DF_WAYS + 1], dist[DF_WAYS + 1], len[DF_WAYS + 1];
-      bool alive[DF_WAYS + 1];
+      constexpr u32 NC = DF_WAYS + 1 + NX;
+      u32 rc[NC], dist[NC], len[NC];
+      bool alive[NC];
 #pragma unroll
-      for (u32 k = 0; k <= DF_WAYS; ++k) {
+      for (u32 k = 0; k < NC; ++k) {
         const u32 c = cand[k];
         dist[k] = p - c;
-        alive[k] = k < DF_WAYS ? (c != DF_EMPTY && dist[k] <= P.max_dist) : (c < p && c >= base && dist[k] <= P.max_dist);
+        alive[k] = k != DF_WAYS ? (c != DF_EMPTY && c < p && dist[k] <= P.max_dist) : (c < p && c >= base && dist[k] <= P.max_dist);
         rc[k] = alive[k] ? df_rc(c) : rp;
       }
       AHIP_TICK(t3);
       AHIP_ACC(pc[2], t2, t3);
-      df_match_lens<DF_WAYS + 1>(ring, rc, rp, maxl, alive, len);
+      df_match_lens<NC>(ring, rc, rp, maxl, alive, len);
+      // Candidates that all reached the cap are told apart by comparing on (to `nice` bytes): the nearest one is not
+      // the longest one on repetitive input.  Short periods (a tied candidate closer than the cap) are left alone --
+      // the nearest candidate of a run is as good as any, and every position of the run would walk it again.
+      const u32 room = (wlen - p) < P.max_cmp ? (wlen - p) : P.max_cmp;
+      if (P.nice > DF_CAP && maxl == DF_CAP && room > DF_CAP) {
+        u32 tied = 0, near = 0xffffffffu;
+#pragma unroll
+        for (u32 k = 0; k < NC; ++k) {
+          const bool t = len[k] == DF_CAP;
+          tied += t ? 1u : 0u;
+          near = (t && dist[k] < near) ? dist[k] : near;
+          alive[k] = t;
+        }
+        if (tied >= 2 && near >= DF_CAP) df_match_lens<NC>(ring, rc, rp, room < P.nice ? room : P.nice, alive, len, DF_CAP);
+      }
       AHIP_TICK(t4);
       AHIP_ACC(pc[3], t3, t4);
 #pragma unroll
-      for (u32 k = 0; k < DF_WAYS; ++k)
-        if (len[k] > best_len || (len[k] == best_len && len[k] && dist[k] < best_dist)) { best_len = len[k]; best_dist = dist[k]; }
+      for (u32 k = 0; k < NC; ++k)
+        if (k != DF_WAYS && (len[k] > best_len || (len[k] == best_len && len[k] && dist[k] < best_dist))) { best_len = len[k]; best_dist = dist[k]; }
       if (len[DF_WAYS] > best_len) { best_len = len[DF_WAYS]; best_dist = dist[DF_WAYS]; }
     }
     if (p >= dict && p < wlen) match[cstart + (p - dict)] = best_len >= DF_MINLEN ? ((best_len << 16) | best_dist) : 0u;

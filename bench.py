@@ -116,6 +116,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration (0 = skip)")
     ap.add_argument("--check", action="store_true", help="also compare the decoded bytes with the generator's plain text")
     ap.add_argument("--no-extras", action="store_true", help="skip the other configs (N = 1) / the strong-scaling leg (N > 1)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collectives of the N > 1 run: nccl (= RCCL over xGMI, GPU tensors) or gloo (CPU tensors; for boxes with fewer GPUs than ranks)")
+    ap.add_argument("--one-device", action="store_true",
+                    help="every rank decodes on cuda:0 (with --backend gloo: runs the whole N > 1 path on a one-GPU box; a functional run, not a scaling figure)")
     args = ap.parse_args()
 
     import numpy as np
@@ -131,16 +135,21 @@ def main():
             print("bench.py: --gpus %d needs `python -m torch.distributed.run --nproc-per-node %d`" % (args.gpus, args.gpus),
                   file=sys.stderr)
             sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = 0 if args.one_device else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where the tensors of the collectives live
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     from archive_amd import _native as N
     from tools import corpus
     L = N.lib()
-    if L.ahip_init(local_rank) != 0:
+    if L.ahip_init(dev_index) != 0:
         raise SystemExit("ahip_init failed: " + N.last_error())
 
     # ---- synthetic workload, generated on the host and made resident in HBM before timing ----
@@ -182,7 +191,7 @@ def main():
                 raise SystemExit("decode verdict %d, %d bytes (expected %s): %s" % (rc, olen.value, expect_bytes, N.last_error()))
             if exchange and world > 1:  # the path's one exchange: output-size all-gather -> shard offsets (RCCL)
                 from archive_amd.sharding import exchange_output_offsets
-                exchange_output_offsets(olen.value, device=dev)
+                exchange_output_offsets(olen.value, device=cdev)
             return olen.value
 
         for _ in range(warmup):
@@ -197,14 +206,14 @@ def main():
         if world > 1:
             dist.barrier()
         elapsed = time.perf_counter() - t0
-        el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        el = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         if world > 1:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         kern_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / steps
         return float(el.item()), kern_ms, n_out
 
     elapsed, kern_ms, _ = decode_loop(d_in, d_out, out_bytes, args.steps, args.warmup, True)
-    tot = torch.tensor([float(out_bytes)], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(out_bytes)], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     total_out = float(tot.item())
@@ -219,7 +228,7 @@ def main():
     if args.check:
         if not np.array_equal(d_out[:out_bytes].cpu().numpy(), plain):
             raise SystemExit("decoded bytes differ from the generator's plain text")
-    ok_all = torch.tensor([1.0 if crc_ok else 0.0], dtype=torch.float64, device=dev)
+    ok_all = torch.tensor([1.0 if crc_ok else 0.0], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
     if float(ok_all.item()) != 1.0:
@@ -227,7 +236,7 @@ def main():
 
     strong = None
     if world > 1 and not args.no_extras:
-        strong = strong_scaling(args, L, N, corpus, dist, torch, np, dev, sh, rank, world, comp, offs, crcs, sizes, decode_loop)
+        strong = strong_scaling(args, L, N, corpus, dist, torch, np, dev, cdev, sh, rank, world, comp, offs, crcs, sizes, decode_loop)
 
     if rank == 0:
         algo_bytes = float(d_in.numel() + out_bytes)  # C + U: compressed read once + output written once
@@ -242,7 +251,8 @@ def main():
                 args.members, args.member_bytes, args.kind, "BGZF BC subfield" if not args.no_bc else "no BC"),
                 "members_per_gpu": args.members, "member_bytes": args.member_bytes,
                 "compressed_bytes_per_gpu": int(d_in.numel()), "ratio": round(out_bytes / d_in.numel(), 4),
-                "sharding": "members, one process per GPU" if world > 1 else "single GPU",
+                "sharding": ("members, one process per GPU" if not args.one_device else "members, %d processes on ONE GPU (functional run)" % world) if world > 1 else "single GPU",
+                "collectives": ("RCCL (nccl backend), GPU tensors" if args.backend == "nccl" else "gloo, CPU tensors") if world > 1 else None,
                 "gen_seconds": round(gen_s, 1)},
             "check": {"crc32_device": "%08x" % got.value, "crc32_expected": "%08x" % want_crc, "ok": bool(crc_ok),
                       "what": "CRC-32 of the decoded bytes (ahip_crc32_device) vs the member trailers' CRCs combined over GF(2); every rank"},
@@ -279,16 +289,17 @@ def main():
         dist.destroy_process_group()
 
 
-def strong_scaling(args, L, N, corpus, dist, torch, np, dev, sh, rank, world, comp0, offs0, crcs0, sizes0, decode_loop):
+def strong_scaling(args, L, N, corpus, dist, torch, np, dev, cdev, sh, rank, world, comp0, offs0, crcs0, sizes0, decode_loop):
     """BASELINE config 4 as written: ONE stream (rank 0's), partitioned over the ranks on compressed bytes
     (archive_amd.sharding.partition_members); a rank indexes and decodes only its slice; the exchange is the size
     all-gather; the shard CRCs (device kernel) must combine to the whole stream's."""
     from archive_amd.sharding import exchange_output_offsets, partition_members
-    n_in = torch.tensor([len(comp0) if rank == 0 else 0], dtype=torch.int64, device=dev)
+    n_in = torch.tensor([len(comp0) if rank == 0 else 0], dtype=torch.int64, device=cdev)
     dist.broadcast(n_in, 0)
-    whole = torch.from_numpy(comp0).to(dev) if rank == 0 else torch.empty(int(n_in.item()), dtype=torch.uint8, device=dev)
+    whole = torch.from_numpy(comp0).to(cdev) if rank == 0 else torch.empty(int(n_in.item()), dtype=torch.uint8, device=cdev)
     dist.broadcast(whole, 0)  # setup, untimed: afterwards every rank only touches its own slice
-    meta = torch.tensor(offs0, dtype=torch.int64, device=dev) if rank == 0 else torch.empty(args.members + 1, dtype=torch.int64, device=dev)
+    whole = whole.to(dev)
+    meta = torch.tensor(offs0, dtype=torch.int64, device=cdev) if rank == 0 else torch.empty(args.members + 1, dtype=torch.int64, device=cdev)
     dist.broadcast(meta, 0)
     offs = [int(v) for v in meta.tolist()]
     csize = [offs[i + 1] - offs[i] for i in range(args.members)]
@@ -298,12 +309,12 @@ def strong_scaling(args, L, N, corpus, dist, torch, np, dev, sh, rank, world, co
     d_dst = torch.empty(expect + 64, dtype=torch.uint8, device=dev)
     steps = max(3, args.steps // 2)
     elapsed, kern_ms, n_out = decode_loop(d_slice, d_dst, expect, steps, 1, True)
-    offset, total, all_sizes = exchange_output_offsets(n_out, device=dev)
+    offset, total, all_sizes = exchange_output_offsets(n_out, device=cdev)
     got = ctypes.c_uint32()
     if L.ahip_crc32_device(d_dst.data_ptr(), n_out, 0, ctypes.byref(got), sh) != 0:
         raise SystemExit("crc32_device: " + N.last_error())
-    shard = torch.tensor([got.value], dtype=torch.int64, device=dev)
-    allc = torch.zeros(world, dtype=torch.int64, device=dev)
+    shard = torch.tensor([got.value], dtype=torch.int64, device=cdev)
+    allc = torch.zeros(world, dtype=torch.int64, device=cdev)
     dist.all_gather_into_tensor(allc, shard)
     if rank != 0:
         return None

@@ -58,7 +58,7 @@ void ahip_shutdown(void);
 /* Text of the last AHIP_E_* error on this thread ("" if none).  Never NULL. */
 const char *ahip_last_error(void);
 /* ABI version of this header (major << 16 | minor). */
-uint32_t ahip_abi_version(void);
+uint32_t ahip_abi_version(void);  /* 2.1: + ahip_gzip_decode_shards, ahip_gzip_encode_device, ahip_zlib_encode_device */
 
 /* ---- Inflate: host-pointer entry points (what dart:ffi binds) ---- */
 
@@ -93,6 +93,24 @@ size_t ahip_decode_bound(const uint8_t *in, size_t in_len);
 int32_t ahip_gzip_decode_device(const void *d_in, size_t in_len, void *d_out, size_t out_cap,
                                 size_t *out_len, void *stream);
 
+/* One process, several GPUs, everything device-resident (SURVEY.md section 8b "one process drives all 8 GPUs", 8e): shard s
+ * -- a run of WHOLE gzip members, cut by the caller (e.g. along the BGZF `BC` chain, balanced on compressed bytes) --
+ * lives on HIP device devices[s] at d_in[s] (in_len[s] bytes) and is decoded into d_out[s] (out_cap[s] bytes, same
+ * device) by that device's context; ahip_init_devices() must have selected the device (without it every shard has to
+ * sit on the current device).  The loop being sharded is the reference's member loop, _gzip_decoder_web.dart:29-55.
+ * out_len[s] = bytes shard s produced, status[s] (may be NULL) = its verdict.  The only exchange between the devices
+ * is the size prefix-scan: an all-gather of one uint64 per device over RCCL (ncclAllGather; librccl is loaded at run
+ * time) when the shards sit on distinct devices, host sums otherwise (or with AHIP_NO_RCCL=1);
+ * offsets[s] = where shard s goes in the logical output (exclusive prefix sum), offsets[n_shards] = the total.
+ * The concatenation of the shards at those offsets is what ahip_gzip_decode() returns for the whole stream whenever
+ * no member refers back across a shard boundary (quirk q8: such a shard reports AHIP_RANGE and the caller falls back
+ * to the one-device call).  Returns the worst shard verdict. */
+int32_t ahip_gzip_decode_shards(uint32_t n_shards, const int32_t *devices, const void *const *d_in, const size_t *in_len,
+                                void *const *d_out, const size_t *out_cap, size_t *out_len, uint64_t *offsets,
+                                int32_t *status);
+/* Diagnostics: how the last ahip_gzip_decode_shards() exchanged the sizes (1 = RCCL all-gather, 0 = host sums). */
+int32_t ahip_debug_last_exchange(void);
+
 /* Plan/run split of the same path: the plan holds the member index (payload offsets, output
  * offsets) in device memory, so repeated runs time only the decode (bench.py times run). */
 typedef struct ahip_gzip_plan ahip_gzip_plan;
@@ -126,6 +144,14 @@ int32_t ahip_gzip_encode(const uint8_t *in, size_t in_len, int32_t level, int32_
 /* ref: codecs/zlib/_zlib_encoder_web.dart:27-73 (CMF from window_bits, FLEVEL 0: `78 01` for 15; Adler-32 big-endian) */
 int32_t ahip_zlib_encode(const uint8_t *in, size_t in_len, int32_t level, int32_t window_bits, uint8_t *out, size_t out_cap,
                          size_t *out_len);
+/* device-resident forms of the two framed encoders (ref: _gzip_encoder_web.dart:27-100, _zlib_encoder_web.dart:27-73): the
+ * same bytes as ahip_gzip_encode / ahip_zlib_encode, d_in / d_out on the current device (header, DEFLATE stream and
+ * trailer are assembled in d_out; the trailer's CRC-32 / Adler-32 come from the device copy of the input);
+ * synchronise `stream` before returning */
+int32_t ahip_gzip_encode_device(const void *d_in, size_t in_len, int32_t level, int32_t window_bits, uint32_t mtime, void *d_out,
+                                size_t out_cap, size_t *out_len, void *stream);
+int32_t ahip_zlib_encode_device(const void *d_in, size_t in_len, int32_t level, int32_t window_bits, void *d_out, size_t out_cap,
+                                size_t *out_len, void *stream);
 /* device-resident form: d_in/d_out on the current device; synchronises `stream` before returning */
 int32_t ahip_deflate_raw_device(const void *d_in, size_t in_len, int32_t level, int32_t window_bits, void *d_out, size_t out_cap,
                                 size_t *out_len, void *stream);

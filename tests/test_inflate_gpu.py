@@ -255,6 +255,27 @@ def test_back_reference_into_previous_gzip_member(amd, orc):
     assert orc.gzip_decode(cases[0])[1].endswith(b"a" + first[-5:-2])
 
 
+def test_back_reference_into_a_long_member(amd, orc):
+    """q8 next to a LONG member (>= 2 MiB compressed: decoded by many waves, outside the member launch): a member behind
+    it that reaches into its output is resolved when those bytes exist -- with and without the BGZF size fields."""
+    import random
+    rnd = random.Random(5)
+    words = [bytes(rnd.getrandbits(8) for _ in range(rnd.randrange(3, 9))) for _ in range(6000)]
+    big = b" ".join(rnd.choice(words) for _ in range(900000))          # ~ 5.8 MB, compresses to > 2 MiB
+    comp_big = streams.gz_member(big, level=1)
+    assert len(comp_big) > (2 << 20) + 4096
+    far = streams.gz_wrap(streams.raw_far_reference())               # 'a' + copy 3 bytes from 6 back
+    far2 = streams.gz_wrap(streams.raw_far_reference(lit=b"xy", length=5, dist_extra=0))
+    small = streams.text(30000, 9)
+    cases = [streams.gz_member(small) + comp_big + far + streams.gz_member(small[:777]) + far2,
+             comp_big + far,
+             streams.gz_member(small) + far + comp_big + far2 + comp_big + far]
+    for i, c in enumerate(cases):
+        want = _noneify(orc.gzip_decode(c, cap=3 * len(big) + (1 << 20)))
+        assert want[0] == 0 and want[1].count(b"a" + big[-5:-2]) >= 1, i
+        assert _gz(amd, c) == want, i
+
+
 def test_over_subscribed_code_lengths(amd, orc):
     """HuffmanTable never checks the Kraft sum (_huffman_table.dart:24-45): later codes overwrite earlier ones."""
     raw = streams.oversubscribed_dynamic_block()

@@ -69,3 +69,140 @@ def test_two_ranks_one_stream_rccl(native_built):
     import json
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["check"]["ok"] and line["strong"]["check"]["ok"]
+
+
+def test_two_ranks_on_one_device_gloo(native_built):
+    """Every line of the N > 1 path the driver launches on 8 GPUs, on the hardware there is: two ranks of bench.py on
+    ONE device, the collectives on CPU tensors (gloo) -- weak leg (every rank its own members, size exchange every step),
+    strong leg (ONE stream partitioned on compressed bytes, shard CRCs combined over GF(2))."""
+    import json
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--one-device",
+                        "--steps", "2", "--warmup", "1", "--members", "2048", "--cpu-seconds", "0"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["check"]["ok"]
+    assert line["config"]["collectives"].startswith("gloo")
+    st = line["strong"]
+    assert st["check"]["ok"] and st["n_gpus"] == 2 and sum(st["members_per_rank"]) == 2048 and min(st["members_per_rank"]) > 0
+
+
+def _decode_shards(L, N, devs, d_ins, out_caps):
+    import ctypes
+    import torch
+    n = len(d_ins)
+    d_outs = [torch.empty(c + 64, dtype=torch.uint8, device="cuda") for c in out_caps]
+    arr_dev = (ctypes.c_int32 * n)(*devs)
+    arr_in = (ctypes.c_void_p * n)(*[t.data_ptr() for t in d_ins])
+    arr_len = (ctypes.c_size_t * n)(*[t.numel() for t in d_ins])
+    arr_out = (ctypes.c_void_p * n)(*[t.data_ptr() for t in d_outs])
+    arr_cap = (ctypes.c_size_t * n)(*[t.numel() for t in d_outs])
+    out_len = (ctypes.c_size_t * n)()
+    offsets = (ctypes.c_uint64 * (n + 1))()
+    status = (ctypes.c_int32 * n)()
+    rc = L.ahip_gzip_decode_shards(n, arr_dev, arr_in, arr_len, arr_out, arr_cap, out_len, offsets, status)
+    return rc, d_outs, list(out_len), list(offsets), list(status)
+
+
+def test_device_resident_shards(native_built, monkeypatch):
+    """ahip_gzip_decode_shards: per-device resident shards of one BGZF stream, decoded by the device contexts, offsets
+    from the size exchange.  Three contexts on the one device there is (host sums: RCCL refuses the same device
+    twice), then one context, one shard -- the exchange goes through RCCL (a communicator of one rank): the dlopen'd
+    ncclCommInitAll / ncclAllGather path runs on this box."""
+    import numpy as np
+    import torch
+    from archive_amd import _native as N
+    from archive_amd.sharding import partition_members
+    from tools import corpus
+    L = N.lib()
+    assert L.ahip_init(0) == 0
+    comp, plain = corpus.make_gzip(n_members=240, want_plain=True)
+    comp_b = bytes(comp)
+    # member boundaries along the BC chain
+    offs, pos = [0], 0
+    while pos < len(comp_b):
+        bsize = comp_b[pos + 16] | (comp_b[pos + 17] << 8)
+        pos += bsize + 1
+        offs.append(pos)
+    assert offs[-1] == len(comp_b) and len(offs) == 241
+    monkeypatch.setenv("AHIP_FAKE_DEVICES", "3")
+    assert L.ahip_init_devices(1) == 0, N.last_error()
+    try:
+        ranges = partition_members([offs[i + 1] - offs[i] for i in range(240)], 3)
+        d_ins = [torch.from_numpy(comp[offs[lo]:offs[hi]].copy()).cuda() for lo, hi in ranges]
+        caps = [(hi - lo) * 65536 for lo, hi in ranges]
+        rc, d_outs, out_len, offsets, status = _decode_shards(L, N, [0, 0, 0], d_ins, caps)
+        assert rc == 0 and status == [0, 0, 0], N.last_error()
+        assert out_len == caps and offsets == [0, caps[0], caps[0] + caps[1], sum(caps)]
+        assert L.ahip_debug_last_exchange() == 0
+        got = np.concatenate([o[:n].cpu().numpy() for o, n in zip(d_outs, out_len)])
+        assert np.array_equal(got, plain)
+        # a damaged shard reports its own verdict and the others are unaffected
+        bad = d_ins[1].clone()
+        bad[40:48] = 0xff
+        rc, d_outs, out_len, offsets, status = _decode_shards(L, N, [0, 0, 0], [d_ins[0], bad, d_ins[2]], caps)
+        assert status[0] == 0 and status[2] == 0 and status[1] != 0 and rc == status[1]
+        assert offsets[1] == caps[0] and offsets[3] == sum(out_len)
+        # a device nobody selected
+        rc = _decode_shards(L, N, [5], d_ins[:1], caps[:1])[0]
+        assert rc == -4
+    finally:
+        monkeypatch.delenv("AHIP_FAKE_DEVICES")
+        assert L.ahip_init_devices(1) == 0 and L.ahip_device_count() == 1
+    whole = torch.from_numpy(comp).cuda()
+    rc, d_outs, out_len, offsets, status = _decode_shards(L, N, [0], [whole], [len(plain)])
+    assert rc == 0 and out_len == [len(plain)] and offsets == [0, len(plain)], N.last_error()
+    assert np.array_equal(d_outs[0][:len(plain)].cpu().numpy(), plain)
+    assert L.ahip_debug_last_exchange() == 1, "the size exchange did not go through RCCL"
+    monkeypatch.setenv("AHIP_NO_RCCL", "1")
+    rc, d_outs, out_len, offsets, status = _decode_shards(L, N, [0], [whole], [len(plain)])
+    assert rc == 0 and offsets == [0, len(plain)] and L.ahip_debug_last_exchange() == 0
+
+
+def test_device_resident_framed_encoders(native_built):
+    """ahip_gzip_encode_device / ahip_zlib_encode_device: the framing bytes of the host-pointer encoders (the reference's,
+    _gzip_encoder_web.dart:27-100 / _zlib_encoder_web.dart:27-73) around a DEFLATE stream that inflates to the input.
+    (Two encodes of the same input need not be byte-identical: same-hash insertions of one step race in the match kernel,
+    any winner is a valid candidate.)"""
+    import ctypes
+    import gzip as _gz
+    import numpy as np
+    import struct
+    import torch
+    from archive_amd import _native as N
+    L = N.lib()
+    assert L.ahip_init(0) == 0
+    data = (streams.text(300000, 5) + bytes(70000)) * 2
+    src = np.frombuffer(data, dtype=np.uint8)
+    d_in = torch.from_numpy(src.copy()).cuda()
+    cap = L.ahip_deflate_bound(len(data)) + 32
+    for level, wb in ((6, 15), (1, 12), (0, 15)):
+        host = np.zeros(cap, dtype=np.uint8)
+        n = ctypes.c_size_t()
+        assert L.ahip_gzip_encode(src.ctypes.data, len(data), level, wb, 1234567, host.ctypes.data, cap, ctypes.byref(n)) == 0
+        d_out = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+        m = ctypes.c_size_t()
+        assert L.ahip_gzip_encode_device(d_in.data_ptr(), len(data), level, wb, 1234567, d_out.data_ptr(), cap, ctypes.byref(m), None) == 0, N.last_error()
+        dev = bytes(d_out[:m.value].cpu().numpy())
+        ref = bytes(host[:n.value])
+        assert dev[:10] == ref[:10] == bytes([0x1f, 0x8b, 8, 0]) + struct.pack("<I", 1234567) + bytes([0, 0xff])
+        assert dev[-8:] == ref[-8:] == struct.pack("<II", zlib.crc32(data), len(data))
+        assert abs(m.value - n.value) <= max(64, n.value // 200)
+        assert _gz.decompress(dev) == data and _gz.decompress(ref) == data
+        assert L.ahip_zlib_encode(src.ctypes.data, len(data), level, wb, host.ctypes.data, cap, ctypes.byref(n)) == 0
+        assert L.ahip_zlib_encode_device(d_in.data_ptr(), len(data), level, wb, d_out.data_ptr(), cap, ctypes.byref(m), None) == 0, N.last_error()
+        dev = bytes(d_out[:m.value].cpu().numpy())
+        ref = bytes(host[:n.value])
+        assert dev[:2] == ref[:2] and dev[-4:] == ref[-4:] == struct.pack(">I", zlib.adler32(data))
+        assert zlib.decompress(dev) == data and zlib.decompress(ref) == data
+    # too small a buffer reports the bound
+    m = ctypes.c_size_t()
+    tiny = torch.zeros(8, dtype=torch.uint8, device="cuda")
+    assert L.ahip_gzip_encode_device(d_in.data_ptr(), len(data), 6, 15, 0, tiny.data_ptr(), 8, ctypes.byref(m), None) == -1 and m.value > len(data) // 100
