@@ -1448,11 +1448,15 @@ static int32_t deflate_device_impl(const u8 *d_in, size_t n, int level, int wind
   HIP_TRY(b_coff.reserve((size_t)P.chunks * 8));
   if (!P.store)
   {
-    // levels 4-6 add a table of 8-byte strings (4096 entries: 76 KiB of LDS, still two workgroups per CU), levels 7-9
-    // tables of 8- and 16-byte strings (16384 and 8192 entries: one workgroup per CU either way)
-    if (level <= 3) hipLaunchKernelGGL((deflate_match_kernel<12, 2>), dim3(P.chunks), dim3(256), 0, st, d_in, P, b_match.as<u32>());
-    else if (level <= 6) hipLaunchKernelGGL((deflate_match_kernel<12, 4, 12>), dim3(P.chunks), dim3(256), 0, st, d_in, P, b_match.as<u32>());
-    else hipLaunchKernelGGL((deflate_match_kernel<13, 4, 14, 13>), dim3(P.chunks), dim3(256), 0, st, d_in, P, b_match.as<u32>());
+    // levels 1-3: 4096 x 2 entries, 256 threads, three workgroups per CU.  Levels 4-9: ONE workgroup of 512 threads per
+    // CU (the same 8 waves as two workgroups of 256) owns the whole LDS: 8192 x 4 entries of 4-byte strings (every window
+    // position indexed), 16384 of 8-byte and 8192 of 16-byte strings; the levels differ in nice_length (P.nice).
+    // A position only sees the strings of EARLIER steps (plus one of its own step), so the step has to stay well
+    // below the window: small windows (windowBits 9..12) take smaller workgroups.
+    if (window_bits <= 10) hipLaunchKernelGGL((deflate_match_kernel<12, 4, 0, 0, 64>), dim3(P.chunks), dim3(64), 0, st, d_in, P, b_match.as<u32>());
+    else if (window_bits <= 12) hipLaunchKernelGGL((deflate_match_kernel<12, 4, 12, 0, 256>), dim3(P.chunks), dim3(256), 0, st, d_in, P, b_match.as<u32>());
+    else if (level <= 3) hipLaunchKernelGGL((deflate_match_kernel<12, 2>), dim3(P.chunks), dim3(256), 0, st, d_in, P, b_match.as<u32>());
+    else hipLaunchKernelGGL((deflate_match_kernel<13, 4, 14, 13, 512>), dim3(P.chunks), dim3(512), 0, st, d_in, P, b_match.as<u32>());
   }
 #ifdef AHIP_PROFILE
   if (!P.store && getenv("AHIP_DEBUG")) {

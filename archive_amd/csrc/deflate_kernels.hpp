@@ -39,7 +39,6 @@ constexpr u32 DF_SLAB = DF_CHUNK + 512;  // per-chunk output slab (a stored bloc
 //   levels 1-3: 4096 x 2 ( 8 K entries, 16 KiB, three workgroups per CU)   fastest
 //   levels 4-6: 4096 x 4 (16 K entries, 32 KiB, two workgroups per CU)
 //   levels 7-9: 8192 x 4 (32 K entries, 64 KiB, one workgroup per CU)      every window position indexed
-constexpr u32 DF_SUB = 256;              // positions probed, then inserted, per step (one workgroup)
 constexpr u32 DF_MINLEN = 4;             // 4-byte hash: 3-byte matches are not searched
 constexpr u32 DF_EMPTY = 0xffff;
 #ifndef AHIP_DF_CAP
@@ -74,6 +73,12 @@ template <u32 HB> AHIP_DEVINL u32 df_hash16(u64 a, u64 b) { return df_hash8<HB>(
 // address coalescer (64 different lines per load instruction).
 constexpr u32 DF_RING = 36864, DF_MIRROR = 272, DF_AHEAD = 1024;
 AHIP_DEVINL u32 df_rc(u32 x) { return x >= DF_RING ? x - DF_RING : x; }  // window position -> ring offset (x < 2 * DF_RING)
+// (gfx950's LDS also serves unaligned 4- and 8-byte reads directly, tools/micro/lds_unaligned.hip -- one DS instruction
+// instead of two / three aligned dwords + v_alignbyte -- but not faster:)
+#ifdef AHIP_DF_UNALIGNED_READS  // measured SLOWER (config 3 level 6: 20.6 against 25.2 GB/s): unaligned 8-byte LDS reads are split by the hardware
+AHIP_DEVINL u32 df_rd4(const u32 *ring, u32 r) { return ((const unaligned_u32 *)((const u8 *)ring + r))->v; }
+AHIP_DEVINL u64 df_rd8(const u32 *ring, u32 r) { return ((const unaligned_u64 *)((const u8 *)ring + r))->v; }
+#else
 AHIP_DEVINL u32 df_rd4(const u32 *ring, u32 r) {
   const u32 i = r >> 2;
   return __builtin_amdgcn_alignbyte(ring[i + 1], ring[i], r & 3);
@@ -83,6 +88,7 @@ AHIP_DEVINL u64 df_rd8(const u32 *ring, u32 r) {
   const u32 a = ring[i], b = ring[i + 1], c = ring[i + 2];
   return (u64)__builtin_amdgcn_alignbyte(b, a, r & 3) | ((u64)__builtin_amdgcn_alignbyte(c, b, r & 3) << 32);
 }
+#endif
 // Lengths of up to NW candidate matches at once.  rc[k] = ring offset of candidate k (alive[k]: there is one;
 // a bucket-mate that does not even share 4 bytes ends with len < 4).  The candidates advance together, 8 bytes per round, so one
 // round costs ONE LDS round trip for all of them -- the kernel is bound by dependent LDS latency (two waves
@@ -116,9 +122,12 @@ AHIP_DEVINL void df_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barr
 
 // match[] holds len << 16 | dist per input position (0 = no match of >= 4 bytes)
 // LA / LB: index bits of the one-way tables keyed by 8-byte / 16-byte strings (0 = no such table)
-template <u32 DF_HASH_BITS, u32 DF_WAYS, u32 LA = 0, u32 LB = 0>
-__global__ __launch_bounds__(256) void deflate_match_kernel(const u8 *__restrict__ in, DeflateParams P,
+// SUB: threads of the workgroup = positions probed, then inserted, per step
+template <u32 DF_HASH_BITS, u32 DF_WAYS, u32 LA = 0, u32 LB = 0, u32 SUB = 256>
+__global__ __launch_bounds__(SUB) void deflate_match_kernel(const u8 *__restrict__ in, DeflateParams P,
                                                             u32 *__restrict__ match) {
+  constexpr u32 DF_SUB = SUB;
+  static_assert(SUB % 64 == 0 && DF_AHEAD % SUB == 0 && DF_AHEAD >= 2 * SUB, "step geometry");
   __shared__ u16 tbl[(1u << DF_HASH_BITS) * DF_WAYS];
   __shared__ u16 tblA[LA ? (1u << LA) : 1u];
   __shared__ u16 tblB[LB ? (1u << LB) : 1u];
@@ -132,9 +141,9 @@ __global__ __launch_bounds__(256) void deflate_match_kernel(const u8 *__restrict
   const u8 *win = in + cstart - dict;                            // window base; positions are relative to it
   const u32 wlen = dict + clen;
   if (P.store) return;
-  for (u32 i = tid; i < (1u << DF_HASH_BITS) * DF_WAYS; i += 256) tbl[i] = (u16)DF_EMPTY;
-  if (LA) for (u32 i = tid; i < (1u << LA); i += 256) tblA[i] = (u16)DF_EMPTY;
-  if (LB) for (u32 i = tid; i < (1u << LB); i += 256) tblB[i] = (u16)DF_EMPTY;
+  for (u32 i = tid; i < (1u << DF_HASH_BITS) * DF_WAYS; i += SUB) tbl[i] = (u16)DF_EMPTY;
+  if (LA) for (u32 i = tid; i < (1u << LA); i += SUB) tblA[i] = (u16)DF_EMPTY;
+  if (LB) for (u32 i = tid; i < (1u << LB); i += SUB) tblB[i] = (u16)DF_EMPTY;
   // bytes [q, q + 4) of the window (zero past the end) ...
   auto fetch = [&](u32 q) -> u32 {
     u32 v = 0;
@@ -149,13 +158,13 @@ __global__ __launch_bounds__(256) void deflate_match_kernel(const u8 *__restrict
     if (r < DF_MIRROR) ring[(DF_RING + r) >> 2] = v;
   };
   auto stage = [&](u32 q) { put(q, fetch(q)); };
-  stage(4 * tid);  // [0, DF_AHEAD)
+  for (u32 q = 4 * tid; q < DF_AHEAD; q += 4 * SUB) stage(q);  // [0, DF_AHEAD)
   __syncthreads();
   // History before the chunk is only inserted.  Consecutive steps write different ways, so up to four are
   // done as one (same table as step by step, a quarter of the barriers).
   u32 base = 0;
   for (; base + MERGE * DF_SUB <= dict; base += MERGE * DF_SUB) {
-    if (tid < MERGE * 64) stage(base + DF_AHEAD + 4 * tid);
+    if (tid < MERGE * (SUB / 4)) stage(base + DF_AHEAD + 4 * tid);
     __syncthreads();  // the last position's 4 bytes reach into what was just staged
 #pragma unroll
     for (u32 k = 0; k < MERGE; ++k) {
@@ -175,10 +184,10 @@ __global__ __launch_bounds__(256) void deflate_match_kernel(const u8 *__restrict
   AHIP_TICK(t_dict);
   // window prefetch: wave 0 loads the 256 bytes at base + DF_AHEAD during one step and stores them into the
   // ring at the top of the next, so the load's latency is never waited for
-  u32 pf = tid < 64 ? fetch(base + DF_AHEAD + 4 * tid) : 0u;
+  u32 pf = tid < SUB / 4 ? fetch(base + DF_AHEAD + 4 * tid) : 0u;
   for (; base < wlen; base += DF_SUB) {
     AHIP_TICK(t0);
-    if (tid < 64) {  // nobody reads these slots during this step
+    if (tid < SUB / 4) {  // nobody reads these slots during this step
       put(base + DF_AHEAD + 4 * tid, pf);
       pf = fetch(base + DF_SUB + DF_AHEAD + 4 * tid);
     }

@@ -81,7 +81,7 @@ def test_config3_1gib_deflate_roundtrip(native_built):
     ref = len(orc.deflate_raw(sample, 6)[0])
     so = ctypes.c_size_t()
     assert L.ahip_deflate_raw_device(d_in.data_ptr(), len(sample), 6, 15, d_out.data_ptr(), d_out.numel(), ctypes.byref(so), None) == 0
-    assert so.value <= ref * 1.085, (so.value, ref)  # <= +8.5 % at level 6 on this 4 MiB sample (measured +7.9 %)
+    assert so.value <= ref * 1.05, (so.value, ref)  # <= +5 % at level 6 on the log text (measured +3.5 % on this 4 MiB sample)
     # the first 64 MiB of the stream's source also survive the HIP inflate (one wave: a single member)
     piece = 64 << 20
     po = ctypes.c_size_t()
