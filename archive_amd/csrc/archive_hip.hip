@@ -1784,18 +1784,22 @@ int32_t ahip_gzip_decode_device(const void *d_in, size_t in_len, void *d_out, si
 }
 
 // host buffers -> this thread's device -> host buffers (the whole stream, or one shard of it)
+// the stream of this thread's device context (a worker's own non-blocking stream; the default stream otherwise)
+static thread_local hipStream_t g_ctx_stream = nullptr;
 static int32_t gzip_decode_host_impl(const uint8_t *in, size_t in_len, int32_t verify, int32_t raw, uint8_t *out, size_t out_cap,
                                      size_t *out_len) {
   static thread_local DevBuf din, dout;
+  hipStream_t st = g_ctx_stream;
   HIP_TRY(din.reserve(in_len + 16));
-  if (in_len) HIP_TRY(hipMemcpy(din.p, in, in_len, hipMemcpyHostToDevice));
+  if (in_len) HIP_TRY(hipMemcpyAsync(din.p, in, in_len, hipMemcpyHostToDevice, st));
   size_t produced = 0;
-  int32_t rc = gzip_decode_impl(in, din.as<u8>(), in_len, verify, raw, nullptr, 0, true, &dout, &produced, nullptr);
+  int32_t rc = gzip_decode_impl(in, din.as<u8>(), in_len, verify, raw, nullptr, 0, true, &dout, &produced, st);
   if (out_len) *out_len = produced;
   if (rc == AHIP_OK || rc == AHIP_FALSE) {
     if (produced > out_cap) return fail(AHIP_E_CAP, "output buffer too small");
-    if (produced) HIP_TRY(hipMemcpy(out, dout.p, produced, hipMemcpyDeviceToHost));
+    if (produced) HIP_TRY(hipMemcpyAsync(out, dout.p, produced, hipMemcpyDeviceToHost, st));
   }
+  HIP_TRY(hipStreamSynchronize(st));
   return rc;
 }
 
@@ -1817,6 +1821,10 @@ struct Worker {
   bool has_job = false, done = false, quit = false;
   void loop() {
     (void)hipSetDevice(device);
+    // its own non-blocking stream: copies and kernels of different contexts overlap (H2D of one slice, decode of
+    // another, D2H of a third) instead of queueing on the legacy default stream
+    hipStream_t own = nullptr;
+    if (hipStreamCreateWithFlags(&own, hipStreamNonBlocking) == hipSuccess) g_ctx_stream = own;
     for (;;) {
       std::unique_lock<std::mutex> lk(mu);
       cv.wait(lk, [&] { return has_job || quit; });
@@ -1829,6 +1837,8 @@ struct Worker {
     }
     for (auto &b : g_pool) (void)hipFree(b.p);  // this thread's pool
     g_pool.clear();
+    if (own) (void)hipStreamDestroy(own);
+    g_ctx_stream = nullptr;
   }
   void submit(std::function<void()> f) {
     std::unique_lock<std::mutex> lk(mu);
@@ -1841,14 +1851,27 @@ struct Worker {
   }
 };
 std::vector<std::unique_ptr<Worker>> g_workers;  // guarded by g_mu
+// One device, host pointers: contexts on the SAME device that only exist to overlap PCIe traffic with the decode
+// (started on first use by a large stream when ahip_init_devices() selected nothing; AHIP_HOST_PIPE=0 turns it off,
+// =k asks for k contexts)
+std::vector<std::unique_ptr<Worker>> g_pipe;  // guarded by g_mu
 }  // namespace
 namespace {
-void stop_workers() {
-  for (auto &w : g_workers) {
+void stop_set(std::vector<std::unique_ptr<Worker>> &set) {
+  for (auto &w : set) {
     { std::lock_guard<std::mutex> lk(w->mu); w->quit = true; w->cv.notify_all(); }
     if (w->th.joinable()) w->th.join();
   }
-  g_workers.clear();
+  set.clear();
+}
+void stop_workers() { stop_set(g_workers); stop_set(g_pipe); }
+// Worker threads must be gone before the process tears its statics down (a joinable std::thread in a static is
+// std::terminate, and a thread blocked inside the HIP runtime at exit hangs the process): stop them at exit.
+void stop_at_exit() {
+  static bool registered = false;
+  if (registered) return;
+  registered = true;
+  atexit([] { std::lock_guard<std::recursive_mutex> lk(g_mu); stop_workers(); });  // (RCCL communicators are left to the process teardown)
 }
 
 struct GzMember { size_t begin, end; uint32_t isize; };
@@ -1871,46 +1894,70 @@ bool walk_bc_members(const uint8_t *in, size_t n, std::vector<GzMember> &ms) {
   return !ms.empty();
 }
 
-// returns true when the sharded path produced the final answer in *rc_out
-bool gzip_decode_sharded(const uint8_t *in, size_t in_len, int32_t verify, uint8_t *out, size_t out_cap, size_t *out_len, int32_t *rc_out) {
-  const size_t W = g_workers.size();
+// returns true when the sharded path produced the final answer in *rc_out.  The stream is cut into `per` slices per
+// context (contiguous member ranges balanced on compressed bytes, sharding.partition_members); context w takes slices
+// w, w + W, ... one after the other, so that while it downloads one slice the others upload and decode theirs.
+bool gzip_decode_sharded(std::vector<std::unique_ptr<Worker>> &set, size_t per, const uint8_t *in, size_t in_len, int32_t verify, uint8_t *out,
+                         size_t out_cap, size_t *out_len, int32_t *rc_out) {
+  const size_t W = set.size();
   if (W < 2 || in_len < (4u << 20)) return false;
   std::vector<GzMember> ms;
   if (!walk_bc_members(in, in_len, ms) || ms.size() < 2 * W) return false;
-  // contiguous ranges balanced on compressed bytes (sharding.partition_members)
+  size_t S = W * per;
+  while (S > W && ms.size() < 2 * S) S -= W;
   std::vector<size_t> bounds{0};
   size_t acc = 0, r = 1;
   for (size_t i = 0; i < ms.size(); ++i) {
     acc += ms[i].end - ms[i].begin;
-    while (r < W && (unsigned __int128)acc * W >= (unsigned __int128)in_len * r && bounds.size() < W) { bounds.push_back(i + 1); ++r; }
+    while (r < S && (unsigned __int128)acc * S >= (unsigned __int128)in_len * r && bounds.size() < S) { bounds.push_back(i + 1); ++r; }
   }
-  while (bounds.size() < W) bounds.push_back(ms.size());
+  while (bounds.size() < S) bounds.push_back(ms.size());
   bounds.push_back(ms.size());
-  std::vector<size_t> o_off(W + 1, 0);
-  for (size_t w = 0; w < W; ++w) {
+  std::vector<size_t> o_off(S + 1, 0);
+  for (size_t w = 0; w < S; ++w) {
     size_t sum = 0;
     for (size_t i = bounds[w]; i < bounds[w + 1]; ++i) sum += ms[i].isize;
     o_off[w + 1] = o_off[w] + sum;
   }
-  if (out_len) *out_len = o_off[W];
-  if (o_off[W] > out_cap) { *rc_out = fail(AHIP_E_CAP, "output buffer too small"); return true; }
-  std::vector<int32_t> rcs(W, AHIP_OK);
-  std::vector<size_t> got(W, 0);
+  // (ISIZE is not trusted: a total that does not fit the caller's buffer sends the call to the exact path, which reports
+  // the real size)
+  if (o_off[S] > out_cap) return false;
+  std::vector<int32_t> rcs(S, AHIP_OK);
+  std::vector<size_t> got(S, 0);
   for (size_t w = 0; w < W; ++w) {
-    const size_t lo = bounds[w], hi = bounds[w + 1];
-    if (lo >= hi) { g_workers[w]->submit([] {}); continue; }
-    const uint8_t *src = in + ms[lo].begin;
-    const size_t len = ms[hi - 1].end - ms[lo].begin;
-    uint8_t *dst = out + o_off[w];
-    const size_t cap = o_off[w + 1] - o_off[w];
-    int32_t *rcp = &rcs[w];
-    size_t *gp = &got[w];
-    g_workers[w]->submit([=] { *rcp = gzip_decode_host_impl(src, len, verify, 0, dst, cap, gp); });
+    std::vector<size_t> mine;
+    for (size_t q = w; q < S; q += W) if (bounds[q] < bounds[q + 1]) mine.push_back(q);
+    set[w]->submit([&, mine] {
+      for (size_t q : mine) {
+        const size_t lo = bounds[q], hi = bounds[q + 1];
+        rcs[q] = gzip_decode_host_impl(in + ms[lo].begin, ms[hi - 1].end - ms[lo].begin, verify, 0, out + o_off[q], o_off[q + 1] - o_off[q], &got[q]);
+        if (rcs[q] != AHIP_OK) break;
+      }
+    });
   }
-  for (size_t w = 0; w < W; ++w) g_workers[w]->wait();
-  for (size_t w = 0; w < W; ++w)
-    if (rcs[w] != AHIP_OK || got[w] != o_off[w + 1] - o_off[w]) return false;  // lying ISIZE, damaged member, a reference into another shard: exact path
+  for (size_t w = 0; w < W; ++w) set[w]->wait();
+  for (size_t q = 0; q < S; ++q)
+    if (rcs[q] != AHIP_OK || got[q] != o_off[q + 1] - o_off[q]) return false;  // lying ISIZE, damaged member, a reference into another slice: exact path
+  if (out_len) *out_len = o_off[S];
   *rc_out = AHIP_OK;
+  return true;
+}
+// contexts on the current device for the host-pointer pipeline (lazily, once)
+bool ensure_pipe() {
+  if (!g_pipe.empty()) return true;
+  stop_at_exit();
+  int k = 4;
+  if (const char *e = getenv("AHIP_HOST_PIPE")) k = atoi(e);
+  if (k < 2) return false;
+  if (k > 8) k = 8;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  for (int i = 0; i < k; ++i) {
+    g_pipe.emplace_back(new Worker());
+    Worker *w = g_pipe.back().get();
+    w->device = dev;
+    w->th = std::thread([w] { w->loop(); });
+  }
   return true;
 }
 }  // namespace
@@ -1932,6 +1979,7 @@ int32_t ahip_init_devices(uint64_t device_mask) {
     while ((int)devs.size() < k && devs.size() < 16) devs.push_back(devs[0]);
   }
   HIP_TRY(hipSetDevice(devs[0]));  // the calling thread keeps working on the first one
+  stop_at_exit();
   if (devs.size() > 1)
     for (int d : devs) {
       g_workers.emplace_back(new Worker());
@@ -2108,7 +2156,10 @@ int32_t ahip_gzip_decode(const uint8_t *in, size_t in_len, int32_t verify, int32
   int32_t rc = ensure_init();
   if (rc != AHIP_OK) return rc;
   g_last_shards = 1;
-  if (!raw && !g_workers.empty() && gzip_decode_sharded(in, in_len, verify, out, out_cap, out_len, &rc)) { g_last_shards = (int32_t)g_workers.size(); return rc; }
+  if (!raw && !g_workers.empty() && gzip_decode_sharded(g_workers, 1, in, in_len, verify, out, out_cap, out_len, &rc)) { g_last_shards = (int32_t)g_workers.size(); return rc; }
+  // one device: a large stream of BGZF members is cut into slices whose upload / decode / download overlap
+  if (!raw && g_workers.empty() && in_len >= (32u << 20) && ensure_pipe() &&
+      gzip_decode_sharded(g_pipe, 4, in, in_len, verify, out, out_cap, out_len, &rc)) { g_last_shards = (int32_t)g_pipe.size(); return rc; }
   return gzip_decode_host_impl(in, in_len, verify, raw, out, out_cap, out_len);
 }
 

@@ -206,3 +206,26 @@ def test_device_resident_framed_encoders(native_built):
     m = ctypes.c_size_t()
     tiny = torch.zeros(8, dtype=torch.uint8, device="cuda")
     assert L.ahip_gzip_encode_device(d_in.data_ptr(), len(data), 6, 15, 0, tiny.data_ptr(), 8, ctypes.byref(m), None) == -1 and m.value > len(data) // 100
+
+
+def test_host_pointer_pipeline_on_one_device(native_built):
+    """ahip_gzip_decode(host in, host out) on ONE device: a large stream of BGZF members is cut into slices that several
+    contexts of the same device upload, decode and download side by side (PCIe overlapped with the decode); what cannot be
+    cut that way takes the exact path.  Results equal the single-context decode."""
+    import numpy as np
+    import archive_amd
+    from archive_amd import _native as N
+    from tools import corpus
+    L = N.lib()
+    assert L.ahip_init(0) == 0
+    assert L.ahip_init_devices(1) == 0 and L.ahip_device_count() == 1
+    comp, plain = corpus.make_gzip(n_members=1400, want_plain=True)   # 37 MB -> 92 MB
+    assert len(comp) >= (32 << 20)
+    dec = archive_amd.GZipDecoder()
+    out = dec.decode_bytes(bytes(comp))
+    assert dec.last_status == 0 and L.ahip_debug_last_shards() == 4
+    assert np.array_equal(np.frombuffer(out, dtype=np.uint8), plain)
+    # a member without BC in the middle: not partitionable, exact path, same bytes
+    mixed = bytes(comp) + streams.gz_member(streams.text(50000, 3))
+    out2 = dec.decode_bytes(mixed)
+    assert L.ahip_debug_last_shards() == 1 and out2 == bytes(plain) + streams.text(50000, 3)
