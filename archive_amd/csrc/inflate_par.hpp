@@ -1144,8 +1144,8 @@ AHIP_DEVINL void resolve_member(ResLds &P, const u8 *in, const u32 *area, const 
       const bool D = fit && defer_;
       // flushed sources that were not fetched ahead (the window was flushed after the chunk was prepared): fetched
       // now, and waited for inside this branch, so that nothing else waits for the loads of the NEXT chunk
-      const bool late = G && !c.pre;
-      if (__any(late)) {
+      const bool late = G && !c.pre;  // (only after a flush: otherwise `pre` is exactly the classification)
+      if (wrel != c.wrel0 && __any(late)) {
         if (late) {
           const u8 *sp = out_base + wpos + so;
           c.w0 = load_u64_unaligned(sp);
@@ -1282,26 +1282,13 @@ AHIP_DEVINL void resolve_member(ResLds &P, const u8 *in, const u32 *area, const 
       c.wrel0 = wrel;
       c.inbm = q.nin >= 64 ? ~0ull : (1ull << q.nin) - 1;
       c.cend = (i32)lane_bcast((u32)c.ob + c.len, (int)q.nin - 1);
-#ifdef AHIP_RES_UNCOND_LOADS
-      const u8 *sp = c.pre ? out_base + wpos + so : (const u8 *)area;
-      const u8 *sp2 = (c.pre && c.len > 16) ? sp + c.len - 16 : sp;
-      c.w0 = load_u64_unaligned(sp);
-      c.w1 = load_u64_unaligned(sp + 8);
-      c.w2 = load_u64_unaligned(sp2);
-      c.w3 = load_u64_unaligned(sp2 + 8);
-#else
-      c.w0 = c.w1 = c.w2 = c.w3 = 0;
+      c.w0 = c.w1 = c.w2 = c.w3 = 0;  // (also ends the live range of the previous chunk's registers)
       if (c.pre) {
-#ifdef AHIP_ABLATE_SRC  // EXPERIMENT (wrong bytes): every source fetch goes to the member's first 4 KiB -- what do the cache misses cost?
-        const u8 *sp = out_base + ((u32)(wpos + so) & 0xfffu);
-#else
         const u8 *sp = out_base + wpos + so;
-#endif
         c.w0 = load_u64_unaligned(sp);
         c.w1 = load_u64_unaligned(sp + 8);
         if (c.len > 16) { c.w2 = load_u64_unaligned(sp + c.len - 16); c.w3 = load_u64_unaligned(sp + c.len - 8); }
       }
-#endif
       RTICK(r_q1);
       RACC(2, r_q0, r_q1);
       return c;

@@ -273,7 +273,9 @@ def main():
             w = pmc["workload"]
             if (w["members"], w["member_bytes"], w["kind"], w["bc"]) == (args.members, args.member_bytes, args.kind, not args.no_bc):
                 line["roofline"]["traffic"] = round(pmc["traffic_bytes_per_launch"] / 1e9, 2)
-                line["roofline"]["traffic_unit"] = ("GB per decode (rocprofv3 FETCH_SIZE+WRITE_SIZE, calibrated, profiles/%s)" % os.path.basename(latest))
+                line["roofline"]["traffic_unit"] = "GB per decode"
+                line["roofline"]["traffic_source"] = ("NOT measured in this run: read from the committed profile profiles/%s (rocprofv3 --pmc passes over "
+                                                      "this same command, L2 request counters by request size; tools/run_prof.sh)" % os.path.basename(latest))
         except Exception:
             pass
         if strong is not None:

@@ -18,6 +18,7 @@ STAGE = ("inflate_tokenize_kernel", "inflate_resolve_kernel")
 
 
 def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"\(.*$", "", name).strip()
     name = re.sub(r"^void ", "", name)
     return name
@@ -101,6 +102,77 @@ def sq_table(rnd, bench_line):
         f.write("| **VALU wave-instructions per output byte** | " + " | ".join("%.2f" % (mean(k, "SQ_INSTS_VALU") / (65536 * 65536)) for k in ks) + " |\n")
         f.write("\nEvery VALU instruction occupies its SIMD for one quad-cycle (SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU), so the chip issues at most\n"
                 "1024 SIMDs x 2.4 GHz / 4 = 614 G wave-instructions/s: the utilisation row is measured against that.\n")
+
+
+def request_traffic(rnd, bench_line, js):
+    """Memory-side traffic from the L2's request counters by request SIZE (TCC_EA0_RDREQ_{32B,64B,128B}, TCC_EA0_WRREQ /
+    _64B): bytes = sum(size x requests).  Checked on known byte counts (tools/pmc_calib.py: 2 GiB copy, 2 GiB fill, 2^26
+    random 16-byte gathers out of 2 GiB); appended to profiles/<rnd>_pmc_traffic.md and stored in the JSON as the traffic
+    figure of record (no scale factors needed)."""
+    try:
+        paths = {t: one("%s/**/*counter_collection.csv" % t) for t in ("pmc_rq", "pmc_wq", "cal_rq", "cal_wq")}
+    except SystemExit:
+        return
+
+    def table(path):
+        acc = {}
+        for row in csv.DictReader(open(path)):
+            k = short(row["Kernel_Name"])
+            d = acc.setdefault(k, {})
+            s_, n_ = d.get(row["Counter_Name"], (0.0, 0))
+            d[row["Counter_Name"]] = (s_ + float(row["Counter_Value"]), n_ + 1)
+        return {k: {c: v[0] / v[1] for c, v in d.items()} for k, d in acc.items()}
+
+    def rbytes(d):
+        n32, n64, n128 = d.get("TCC_EA0_RDREQ_32B_sum", 0), d.get("TCC_EA0_RDREQ_64B_sum", 0), d.get("TCC_EA0_RDREQ_128B_sum", 0)
+        rest = d.get("TCC_EA0_RDREQ_sum", 0) - n32 - n64 - n128  # (none seen)
+        return 32 * n32 + 64 * n64 + 128 * n128 + 64 * max(0.0, rest)
+
+    def wbytes(d):
+        n64 = d.get("TCC_EA0_WRREQ_64B_sum", 0)
+        return 64 * n64 + 32 * max(0.0, d.get("TCC_EA0_WRREQ_sum", 0) - n64)
+    rq, wq, crq, cwq = (table(paths[t]) for t in ("pmc_rq", "pmc_wq", "cal_rq", "cal_wq"))
+    l2 = {}
+    try:
+        l2 = table(one("pmc_l2/**/*counter_collection.csv"))
+    except SystemExit:
+        pass
+    stage_r = sum(rbytes(d) for k, d in rq.items() if any(s_ in k for s_ in STAGE))
+    stage_w = sum(wbytes(d) for k, d in wq.items() if any(s_ in k for s_ in STAGE))
+    algo = bench_line["roofline"]["algorithmic_bytes"] if bench_line else None
+    js["request_counters"] = {"read_bytes": stage_r, "write_bytes": stage_w,
+                              "kernels": {k: {"read_bytes": rbytes(rq.get(k, {})), "write_bytes": wbytes(wq.get(k, {}))} for k in sorted(set(rq) | set(wq)) if any(s_ in k for s_ in STAGE)}}
+    js["traffic_bytes_per_launch"] = stage_r + stage_w
+    js["note"] = ("traffic_bytes_per_launch = memory-side bytes of inflate_tokenize_kernel + inflate_resolve_kernel per decode from the L2 request "
+                  "counters by request size (TCC_EA0_RDREQ_{32B,64B,128B}_sum x size, TCC_EA0_WRREQ_64B_sum x 64 + the rest x 32; separate --pmc "
+                  "passes), which reproduce the known byte counts of tools/pmc_calib.py (2 GiB copy: reads and writes exact) -- no scale factor. "
+                  "Infinity-Cache hits are included (the counters sit between L2 and the fabric).  FETCH_SIZE / WRITE_SIZE (raw) are kept for comparison.")
+    json.dump(js, open(os.path.join(PROF, "%s_pmc_traffic.json" % rnd), "w"), indent=1)
+    with open(os.path.join(PROF, "%s_pmc_traffic.md" % rnd), "a") as f:
+        f.write("\n## Traffic from the request counters by request size (the figure of record)\n\n"
+                "    rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum ... -- python bench.py --steps 3 --warmup 1 --cpu-seconds 0 --no-extras\n"
+                "    rocprofv3 --kernel-trace --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum ...                                         (same command; and both over tools/pmc_calib.py)\n\n"
+                "FETCH_SIZE is TCC_EA0_RDREQ x 64 B whatever the request size (MI355X_MICROARCH.md); the requests of these kernels are 128-byte ones, "
+                "so bytes = sum over sizes of size x requests.  Calibration on known byte counts:\n\n"
+                "| calibration kernel | what it moves | read bytes (counters) | write bytes (counters) |\n|---|---|---|---|\n")
+        for k in sorted(set(crq) | set(cwq)):
+            what = "2 GiB read + 2 GiB written" if "copy" in k.lower() else ("2 GiB written (16 B per lane)" if "Fill" in k else
+                   ("2^26 x 16 B gathered at random out of 2 GiB (+ 0.5 GiB of indices), 1 GiB written" if "ndex" in k else ""))
+            if rbytes(crq.get(k, {})) + wbytes(cwq.get(k, {})) > 1e8:
+                f.write("| `%s` | %s | %.3f GB | %.3f GB |\n" % (k[:90], what, rbytes(crq.get(k, {})) / 1e9, wbytes(cwq.get(k, {})) / 1e9))
+        f.write("\n| kernel (per decode) | read requests 32 / 64 / 128 B | read bytes | write requests (64 B / all) | write bytes | L2 hit / miss |\n|---|---|---|---|---|---|\n")
+        for k in sorted(set(rq) | set(wq), key=lambda k_: -(rbytes(rq.get(k_, {})) + wbytes(wq.get(k_, {})))):
+            d, w = rq.get(k, {}), wq.get(k, {})
+            if rbytes(d) + wbytes(w) < 1e6:
+                continue
+            h = l2.get(k, {})
+            f.write("| `%s` | %.3g / %.3g / %.3g | %.2f GB | %.3g / %.3g | %.2f GB | %s |\n" % (
+                k[:70], d.get("TCC_EA0_RDREQ_32B_sum", 0), d.get("TCC_EA0_RDREQ_64B_sum", 0), d.get("TCC_EA0_RDREQ_128B_sum", 0), rbytes(d) / 1e9,
+                w.get("TCC_EA0_WRREQ_64B_sum", 0), w.get("TCC_EA0_WRREQ_sum", 0), wbytes(w) / 1e9,
+                ("%.3g / %.3g" % (h.get("TCC_HIT_sum", 0), h.get("TCC_MISS_sum", 0))) if h else ""))
+        if algo:
+            f.write("\nInflate stage per decode: **%.1f GB read + %.1f GB written = %.1f GB** against %.2f GB algorithmic (C + U): %.1fx.\n"
+                    % (stage_r / 1e9, stage_w / 1e9, (stage_r + stage_w) / 1e9, algo / 1e9, (stage_r + stage_w) / algo))
 
 
 def main():
@@ -217,6 +289,7 @@ def main():
                     "%.2f GB algorithmic (C + U): %.2fx.\n" % (
                         stage_f * rs / 1e9, stage_f / 1e9, stage_w * ws / 1e9, stage_w / 1e9,
                         (stage_f * rs + stage_w * ws) / 1e9, algo / 1e9, (stage_f * rs + stage_w * ws) / algo))
+    request_traffic(rnd, bench_line, js)
     sq_table(rnd, bench_line)
     for extra in ("bench_%s.log" % rnd, "pytest_gpu_%s.log" % rnd, "checksum_stats.log"):
         src = os.path.join(OUT, extra)
