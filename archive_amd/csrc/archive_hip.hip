@@ -608,6 +608,7 @@ int32_t plan_build(ahip_gzip_plan *pl, bool force_sizing, hipStream_t st) {
     // been measured the all-members launch (one wave each, all at once) wins unless a member is really long.
     pl->big.clear();
     std::vector<std::pair<u32, MemberResult>> measured;
+    bool nothing_left = false;
     if (K <= (1u << 20) && n >= sm_min_bytes() && !getenv("AHIP_NO_SM")) {
       std::vector<GzHeader> hh(K);
       std::vector<u64> cp(K);
@@ -637,9 +638,13 @@ int32_t plan_build(ahip_gzip_plan *pl, bool force_sizing, hipStream_t st) {
       }
       if (changed)
         HIP_TRY(hipMemcpyAsync(pl->sizing_descs.p, sd.data(), (size_t)K * sizeof(MemberDesc), hipMemcpyHostToDevice, st));
+      nothing_left = true;
+      for (u32 i = 0; i < K; ++i) nothing_left = nothing_left && sd[i].in_off >= n;
     }
+    // (when the long members cover every candidate the launch below sizes nothing: it then must not take the token
+    //  scratch either -- the chunked path has just kept ITS tokens there for the decode proper)
     HIP_TRY(launch_inflate<false>(in, n, pl->sizing_descs.as<MemberDesc>(), K, (u8 *)nullptr,
-                                  pl->sizing_results.as<MemberResult>(), st, nullptr, 0, pl->cand_pos.as<u64>(), &pl->tok_gen));
+                                  pl->sizing_results.as<MemberResult>(), st, nullptr, 0, nothing_left ? nullptr : pl->cand_pos.as<u64>(), &pl->tok_gen));
     for (auto &mr : measured)
       HIP_TRY(hipMemcpyAsync(pl->sizing_results.as<MemberResult>() + mr.first, &mr.second, sizeof(MemberResult), hipMemcpyHostToDevice, st));
     if (!measured.empty()) HIP_TRY(hipStreamSynchronize(st));
@@ -882,6 +887,8 @@ struct SmPlan {  // what the sizing pass learned, kept for the write pass of the
   u64 total_out = 0, end_pos = 0;
   u32 blocks = 0;
   bool valid = false;
+  u64 tok_gen = 0;             // the sizing pass kept its tokens (along the input) as scratch contents number tok_gen (0: it did not)
+  std::vector<u32> chain_cand; // candidate index of every chunk of the chain
 };
 static thread_local SmPlan g_sm;
 
@@ -914,8 +921,18 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
     const u32 n_chunks = (u32)((n - off + cb - 1) / cb);
     if (n_chunks < 4) return AHIP_OK;
     constexpr u32 SPLIT = 4;  // waves searching behind each cut
-    HIP_TRY(dcand.reserve((size_t)n_chunks * SPLIT * 8));
+    HIP_TRY(dcand.reserve((size_t)n_chunks * SPLIT * 8 * 4));  // (x 4: -DAHIP_PROFILE builds leave three cycle counts per workgroup behind the finds)
     hipLaunchKernelGGL(sm_find_kernel, dim3((n_chunks - 1) * SPLIT), dim3(64), 0, st, d_in, n, off, cb, n_chunks, SPLIT, dcand.as<u64>());
+#ifdef AHIP_PROFILE
+    if (dbg) {
+      std::vector<u64> pc((size_t)n_chunks * SPLIT * 4);
+      HIP_TRY(hipMemcpy(pc.data(), dcand.p, pc.size() * 8, hipMemcpyDeviceToHost));
+      const size_t nn = (size_t)n_chunks * SPLIT, wgs = (size_t)(n_chunks - 1) * SPLIT;
+      double a = 0, b = 0, c = 0;
+      for (size_t i = 0; i < wgs; ++i) { a += (double)pc[nn + i]; b += (double)pc[2 * nn + i]; c += (double)pc[3 * nn + i]; }
+      fprintf(stderr, "[ahip] sm find: cycles per workgroup: staging %.0f  first filter %.0f  second filter %.0f\n", a / wgs, b / wgs, c / wgs);
+    }
+#endif
     std::vector<u64> found((size_t)n_chunks * SPLIT);
     HIP_TRY(hipMemcpyAsync(found.data(), dcand.p, (size_t)n_chunks * SPLIT * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -939,8 +956,17 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
     HIP_TRY(hipMemcpyAsync(dcand.p, cand.data(), (size_t)nc * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dchunks.p, cd.data(), (size_t)nc * sizeof(ChunkDesc), hipMemcpyHostToDevice, st));
     const u32 grid = nc < (u32)sm_resident_waves() ? nc : (u32)sm_resident_waves();
+    // the sizing pass keeps its tokens, laid out along the input (12 B of scratch per compressed byte): the write pass
+    // then only resolves them (AHIP_SM_TWO_PASS=1: tokenize again with exact offsets, as the first version did)
+    void *ktp = nullptr, *ksp = nullptr;
+    u64 kept_gen = 0;
+    if (!getenv("AHIP_SM_TWO_PASS") && n <= (4ull << 30)) {
+      if (tokens_reserve(((size_t)n * IN_R + (size_t)nc * IN_PAD + 64) * 4, &ktp) == hipSuccess &&
+          scratch_reserve(((size_t)(n / 32) + (size_t)nc * 64 + 64) * DIR_BYTES, &ksp) == hipSuccess) kept_gen = g_tok_gen;
+      else { ktp = nullptr; ksp = nullptr; }
+    }
     hipLaunchKernelGGL(sm_tokenize_kernel, dim3(grid), dim3(64), 0, st, d_in, n, dchunks.as<ChunkDesc>(), nc, dcand.as<u64>(), nc,
-                       (u32 *)nullptr, (DirEnt *)nullptr, dres.as<MemberResult>());
+                       (u32 *)ktp, (DirEnt *)ksp, dres.as<MemberResult>(), kept_gen ? 1u : 0u);
     std::vector<MemberResult> rs(nc);
     HIP_TRY(hipMemcpyAsync(rs.data(), dres.p, (size_t)nc * sizeof(MemberResult), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -950,8 +976,11 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
     u64 total = 0;
     for (;;) {
       const MemberResult &r = rs[i];
-      g_sm.chain.push_back(ChunkDesc{cand[i], total, r.out_len, (u32)(total < SM_WINDOW ? total : SM_WINDOW), 0});
+      g_sm.chain.push_back(ChunkDesc{cand[i], total, r.out_len, (u32)(total < SM_WINDOW ? total : SM_WINDOW), i});
       g_sm.sized.push_back(r);
+      // the kept tokens serve only if the chunk was sized with the window it really has, and its token area held
+      if (i && total < SM_WINDOW) kept_gen = 0;
+      if (r.blocks & MR_FAR) kept_gen = 0;
       total += r.out_len;
       g_sm.blocks += r.blocks;
       if (r.status == MS_OK) { g_sm.end_pos = r.end_pos; break; }
@@ -964,6 +993,7 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
     g_sm.total_out = total;
     g_sm.d_in = d_in; g_sm.n = n; g_sm.off = off;
     g_sm.valid = true;
+    g_sm.tok_gen = kept_gen;
     if (dbg) fprintf(stderr, "[ahip] sm: %zu chunks on the chain, %llu bytes out (find + sizing + chain: %.2f ms)\n", g_sm.chain.size(),
                      (unsigned long long)total, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
   }
@@ -978,8 +1008,6 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
   const u32 nch = (u32)g_sm.chain.size(), nc = (u32)g_sm.cand.size();
   const u64 total = g_sm.total_out;
   void *tp = nullptr, *sp = nullptr;
-  HIP_TRY(tokens_reserve(((size_t)(total * 3 / 2) + (size_t)nch * 1024 + 64) * 4, &tp));
-  HIP_TRY(scratch_reserve(((size_t)(total / 16) + (size_t)nch * 64 + 64) * DIR_BYTES, &sp));
   HIP_TRY(dsym.reserve((size_t)total * 2 + 64));
   HIP_TRY(dwin.reserve((size_t)nch * SM_WINDOW));
   HIP_TRY(dcand.reserve((size_t)nc * 8));
@@ -988,21 +1016,30 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
   HIP_TRY(hipMemcpyAsync(dcand.p, g_sm.cand.data(), (size_t)nc * 8, hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(dchunks.p, g_sm.chain.data(), (size_t)nch * sizeof(ChunkDesc), hipMemcpyHostToDevice, st));
   const u32 grid = nch < (u32)sm_resident_waves() ? nch : (u32)sm_resident_waves();
-  hipLaunchKernelGGL(sm_tokenize_kernel, dim3(grid), dim3(64), 0, st, d_in, n, dchunks.as<ChunkDesc>(), nch, dcand.as<u64>(), nc,
-                     (u32 *)tp, (DirEnt *)sp, dres.as<MemberResult>());
-  std::vector<MemberResult> rs(nch);
-  HIP_TRY(hipMemcpyAsync(rs.data(), dres.p, (size_t)nch * sizeof(MemberResult), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  HIP_TRY(hipGetLastError());
-  for (u32 i = 0; i < nch; ++i)
-    if (rs[i].status != g_sm.sized[i].status || rs[i].out_len != g_sm.sized[i].out_len || rs[i].end_pos != g_sm.sized[i].end_pos) {
-      // e.g. a back-reference into the void in front of the stream that the permissive sizing pass let through
-      if (dbg) fprintf(stderr, "[ahip] sm: chunk %u differs from its sizing run (status %u vs %u): one-wave path\n", i, rs[i].status, g_sm.sized[i].status);
-      g_sm.valid = false;
-      return AHIP_OK;
-    }
-  hipLaunchKernelGGL(sm_resolve_kernel, dim3(grid), dim3(64), 0, st, d_in, dchunks.as<ChunkDesc>(), nch, dsym.as<u16>(), (const u32 *)tp,
-                     (const DirEnt *)sp, dres.as<MemberResult>());
+  const bool kept = g_sm.tok_gen && g_sm.tok_gen == g_tok_gen;  // the sizing pass's tokens are still in the scratch
+  if (dbg) fprintf(stderr, "[ahip] sm: kept tokens %llu, scratch holds %llu -> %s\n", (unsigned long long)g_sm.tok_gen, (unsigned long long)g_tok_gen, kept ? "one pass" : "tokenize again");
+  if (kept) {
+    tp = g_tokens.p; sp = g_scratch.p;
+    HIP_TRY(hipMemcpyAsync(dres.p, g_sm.sized.data(), (size_t)nch * sizeof(MemberResult), hipMemcpyHostToDevice, st));
+  } else {
+    HIP_TRY(tokens_reserve(((size_t)(total * 3 / 2) + (size_t)nch * 1024 + 64) * 4, &tp));
+    HIP_TRY(scratch_reserve(((size_t)(total / 16) + (size_t)nch * 64 + 64) * DIR_BYTES, &sp));
+    hipLaunchKernelGGL(sm_tokenize_kernel, dim3(grid), dim3(64), 0, st, d_in, n, dchunks.as<ChunkDesc>(), nch, dcand.as<u64>(), nc,
+                       (u32 *)tp, (DirEnt *)sp, dres.as<MemberResult>(), 0u);
+    std::vector<MemberResult> rs(nch);
+    HIP_TRY(hipMemcpyAsync(rs.data(), dres.p, (size_t)nch * sizeof(MemberResult), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    for (u32 i = 0; i < nch; ++i)
+      if (rs[i].status != g_sm.sized[i].status || rs[i].out_len != g_sm.sized[i].out_len || rs[i].end_pos != g_sm.sized[i].end_pos) {
+        // e.g. a back-reference into the void in front of the stream that the permissive sizing pass let through
+        if (dbg) fprintf(stderr, "[ahip] sm: chunk %u differs from its sizing run (status %u vs %u): one-wave path\n", i, rs[i].status, g_sm.sized[i].status);
+        g_sm.valid = false;
+        return AHIP_OK;
+      }
+  }
+  hipLaunchKernelGGL(sm_resolve_kernel, dim3(grid), dim3(64), 0, st, d_in, n, dchunks.as<ChunkDesc>(), nch, dsym.as<u16>(), (const u32 *)tp,
+                     (const DirEnt *)sp, dres.as<MemberResult>(), dcand.as<u64>(), nc, kept ? 1u : 0u);
   {
     static thread_local DevBuf dwsym, dgwin;
     u32 gs = 1;

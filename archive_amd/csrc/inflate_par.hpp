@@ -941,7 +941,7 @@ struct ResLds {
   u8 obuf[WIN_CAP + 64] __attribute__((aligned(16)));  // + alignment offset (<= 15) + a 16-byte read past the last source byte
   u32 pmap[WIN_CAP / 32 + 4];  // one bit per window byte: a deferred match has yet to write it
   uint2 plist[PEND_CAP];       // the window's deferred matches in stream order: {window index | len << 16, distance}
-  u32 rbits[LOOK_TOK / 32 + 2];  // the current look at the directory: bit i = token i of the look is the first of its run
+  u32 rbits[LOOK_TOK / 32 + 4];  // the current look at the directory: bit i = token i of the look is the first of its run
   uint2 rtab[64];              //   run r of the look: {area offset of its token 0 - index of that token in the look, output offset rel. borg}
 };
 
@@ -1232,7 +1232,7 @@ AHIP_DEVINL void resolve_member(ResLds &P, const u8 *in, const u32 *area, const 
     const i32 rb = (i32)((((u64)dv.w << 32) | dv.z) - borg);                     // where its output starts, rel. borg
     // token -> run without a search: a bit per token of the look marks the first token of every run, so the run of token i
     // is the number of marks in [0, i] - 1; what a lane needs of its run comes from a table
-    for (u32 i = lane; i < LOOK_TOK / 32 + 2; i += 64) P.rbits[i] = 0;
+    for (u32 i = lane; i < LOOK_TOK / 32 + 4; i += 64) P.rbits[i] = 0;
     wave_sync();
     if (rmine) {
       P.rtab[lane] = make_uint2(dv.x - ts, (u32)rb);
@@ -1240,6 +1240,7 @@ AHIP_DEVINL void resolve_member(ResLds &P, const u8 *in, const u32 *area, const 
     }
     wave_sync();
     u32 gruns = 0;  // runs that begin in front of the next gathered chunk
+    u32 gb0 = P.rbits[0], gb1 = P.rbits[1];  // the marks of the next gathered chunk, read one chunk ahead
     RTICK(r_l1);
     RACC(0, r_l0, r_l1);
     auto gather = [&](u32 c0) -> Tok {  // (called with c0 = 0, 64, 128, ... in this order)
@@ -1248,7 +1249,9 @@ AHIP_DEVINL void resolve_member(ResLds &P, const u8 *in, const u32 *area, const 
       const u32 idx = c0 + (u32)lane;
       q.inb = idx < total;
       q.nin = total - c0 < 64u ? total - c0 : 64u;
-      const u64 bits = (u64)uniform(P.rbits[c0 >> 5]) | ((u64)uniform(P.rbits[(c0 >> 5) + 1]) << 32);
+      const u64 bits = (u64)uniform(gb0) | ((u64)uniform(gb1) << 32);
+      gb0 = P.rbits[(c0 >> 5) + 2];  // (LOOK_TOK / 32 + 2 words: the read past the last chunk stays inside)
+      gb1 = P.rbits[(c0 >> 5) + 3];
       const u32 r = gruns + (u32)__popcll(bits & ((2ull << lane) - 1)) - 1u;  // (token 0 of the look is marked: never negative)
       gruns += (u32)__popcll(bits);
       q.first = (bits >> lane) & 1;
@@ -1352,12 +1355,24 @@ AHIP_DEVINL void resolve_member_sym(ParLdsT<E> &P, const u8 *in, const u32 *area
       const u32 len = ((t >> 16) - (pw >> 16)) & 0xffffu;
       return (t & REC_LIT) ? (TK_LIT | ((t & 0xffu) << 16)) : ((len << 16) | ((t & 0x7fffu) + 1u));
     };
-    for (u32 j = 0; j < nrun; ++j) {
-      const u32 o_ = lane_bcast(roff, (int)j), c_ = lane_bcast(take, (int)j), t_ = lane_bcast(rT, (int)j), x_ = lane_bcast(dv.x, (int)j);
-      for (u32 u = (u32)lane; u < c_; u += 64) {
-        const u32 t = area[o_ + u];
-        const u32 pw = o_ + u > x_ ? area[o_ + u - 1] : 0u;
-        P.tok[t_ + u] = step_word(t, pw);
+    for (u32 j = 0; j < nrun; j += 4) {  // four runs' loads in flight
+      u32 v[4], pv[4], qd[4];
+#pragma unroll
+      for (u32 q = 0; q < 4; ++q) {
+        const int jj = (int)(j + q < nrun ? j + q : nrun - 1);
+        const u32 o_ = lane_bcast(roff, jj), c_ = j + q < nrun ? lane_bcast(take, jj) : 0u, t_ = lane_bcast(rT, jj), x_ = lane_bcast(dv.x, jj);
+        qd[q] = (u32)lane < c_ ? t_ + (u32)lane : 0xffffffffu;
+        v[q] = (u32)lane < c_ ? area[o_ + (u32)lane] : 0u;
+        pv[q] = (lane == 0 && c_ && o_ > x_) ? area[o_ - 1] : 0u;  // the token in front of the piece (lane 0 only)
+        for (u32 u = 64 + (u32)lane; u < c_; u += 64) {  // a long run (the serial decoder's)
+          const u32 t = area[o_ + u];
+          P.tok[t_ + u] = step_word(t, area[o_ + u - 1]);
+        }
+      }
+#pragma unroll
+      for (u32 q = 0; q < 4; ++q) {
+        const u32 before = lane_prev(v[q]);  // (every lane takes part in the shift)
+        if (qd[q] != 0xffffffffu) P.tok[qd[q]] = step_word(v[q], lane == 0 ? pv[q] : before);
       }
     }
     wave_sync();

@@ -97,6 +97,7 @@ AHIP_DEVINL bool sm_header_plausible(const u8 *in, u64 in_len, u64 q, u8 *tab /*
       kl += nl * (32768u >> val);
       kd += (rep - nl) * (32768u >> val);
       nd += rep - nl;
+      if (kl > 32768u || kd > 32768u) return false;  // over-subscribed already: random bits die here after a few symbols
       if (idx <= 256 && idx + rep > 256) eob = true;
     }
     prev = val;
@@ -109,11 +110,17 @@ AHIP_DEVINL bool sm_header_plausible(const u8 *in, u64 in_len, u64 q, u8 *tab /*
 // (searched up to the next cut), ~0 if there is none.
 // The range behind a cut is searched by `split` waves (equal parts, cand[k * split + part]); the host keeps the
 // first find of each cut.
+// The first filter reads the stream from LDS: a slab of SM_SLAB bytes (+ the 16 bytes a window at its last bit position
+// needs) is staged with coalesced 16-byte loads and scanned 64 bit positions per step; lanes of a step read the same
+// few dwords (broadcasts, no bank conflicts).  With the two unaligned 8-byte global loads per window the first version
+// used, every step waited for memory (~ 7 000 cycles per step: 4.1 of the 10 ms of a 256 MiB member).
+constexpr u32 SM_SLAB = 2048;
 __global__ __launch_bounds__(64) void sm_find_kernel(const u8 *__restrict__ in, u64 in_len, u64 data_start, u64 chunk_bytes,
                                                      u32 n_chunks, u32 split, u64 *__restrict__ cand) {
   __shared__ u8 cl_tab[64][128];
   __shared__ u64 queue[128];
   __shared__ u16 kraft4[4096];  // sum of 128 >> len over four 3-bit code-length fields (len 0 counts nothing)
+  __shared__ u32 slab[(SM_SLAB + 32) / 4];
   const int lane = threadIdx.x;
   const u32 k = blockIdx.x / split + 1, part = blockIdx.x % split;
   if (k >= n_chunks) return;
@@ -128,18 +135,44 @@ __global__ __launch_bounds__(64) void sm_find_kernel(const u8 *__restrict__ in, 
   const u64 below = (1ull << lane) - 1;
   u64 found = ~0ull;
   u32 qn = 0;
+  u64 slab_byte = ~0ull;  // stream byte of slab[0] (a multiple of 4)
+#ifdef AHIP_PROFILE
+  u64 pc_stage = 0, pc_first = 0, pc_second = 0;
+#endif
   for (u64 base = q0; found == ~0ull && (base < q1 || qn); base += 64) {
     const bool scanning = base < q1;
     if (scanning) {
+      // the step's windows need bytes [base / 8, (base + 63 + 17 + 64) / 8]: restage when they leave the slab
+      AHIP_TICK(t_a);
+      if (slab_byte == ~0ull || (base >> 3) < slab_byte || ((base + 63 + 17 + 64) >> 3) + 4 > slab_byte + SM_SLAB + 32) {
+        slab_byte = (base >> 3) & ~3ull;
+        wave_sync();
+        for (u32 o = (u32)lane * 16; o < SM_SLAB + 32; o += 1024) {
+          uint4 v = make_uint4(0u, 0u, 0u, 0u);
+          if (slab_byte + o + 16 <= in_len) v = load_u128_unaligned(in + slab_byte + o);
+          else {
+            u32 w[4] = {0, 0, 0, 0};
+            for (u32 b = 0; b < 16; ++b) if (slab_byte + o + b < in_len) w[b >> 2] |= (u32)in[slab_byte + o + b] << (8 * (b & 3));
+            v = make_uint4(w[0], w[1], w[2], w[3]);
+          }
+          *(uint4 *)((u8 *)slab + o) = v;
+        }
+        wave_sync();
+      }
+      AHIP_TICK(t_b);
       // ---- first filter, 64 positions: BTYPE, HLIT/HDIST range, complete code-length code ----
       const u64 q = base + lane;
       bool ok = q + 3 + 14 + 12 <= in_len * 8 && q < q1;
-      if (ok) {
-        const u64 v = sm_bits64(in, in_len, q);
-        const u32 hlit = (u32)(v >> 3) & 31, hdist = (u32)(v >> 8) & 31, ncl = ((u32)(v >> 13) & 15) + 4;
-        ok = ((v >> 1) & 3) == 2 && hlit <= 29 && hdist <= 29;
+      {
+        const u32 rel = (u32)(q - slab_byte * 8);  // bit offset inside the slab
+        const u32 di = rel >> 5, sh = rel & 31;
+        const u32 d0 = slab[di], d1 = slab[di + 1], d2 = slab[di + 2], d3 = slab[di + 3];
+        const u32 v = __builtin_amdgcn_alignbit(d1, d0, sh);                       // bits [q, q + 32)
+        const u64 x = (u64)__builtin_amdgcn_alignbit(d2, d1, sh) | ((u64)__builtin_amdgcn_alignbit(d3, d2, sh) << 32);  // [q + 32, q + 96)
+        u64 w = ((u64)v >> 17) | (x << 15);                                          // [q + 17, q + 81)
+        const u32 hlit = (v >> 3) & 31, hdist = (v >> 8) & 31, ncl = ((v >> 13) & 15) + 4;
+        ok = ok && ((v >> 1) & 3) == 2 && hlit <= 29 && hdist <= 29;
         // sum of 2^(7 - len) over the transmitted lengths == 2^7 (19 x 3 = 57 bits, five table look-ups)
-        u64 w = sm_bits64(in, in_len, q + 17);
         w &= (1ull << (3 * ncl)) - 1;
         const u32 kraft = kraft4[(u32)w & 4095] + kraft4[(u32)(w >> 12) & 4095] + kraft4[(u32)(w >> 24) & 4095] +
                           kraft4[(u32)(w >> 36) & 4095] + kraft4[(u32)(w >> 48) & 4095];
@@ -149,8 +182,13 @@ __global__ __launch_bounds__(64) void sm_find_kernel(const u8 *__restrict__ in, 
       if (ok) queue[qn + (u32)__popcll(m & below)] = q;
       qn += (u32)__popcll(m);
       wave_sync();
+#ifdef AHIP_PROFILE
+      AHIP_TICK(t_c);
+      pc_stage += t_b - t_a; pc_first += t_c - t_b;
+#endif
     }
     if (qn < 64 && scanning && base + 64 < q1) continue;  // collect a full batch first (or drain at the end)
+    AHIP_TICK(t_d);
     // ---- second filter, one queued position per lane; the sizing pass is the final judge of what it lets through ----
     const u32 nb = qn < 64 ? qn : 64;
     bool pass = false;
@@ -164,17 +202,33 @@ __global__ __launch_bounds__(64) void sm_find_kernel(const u8 *__restrict__ in, 
     if ((u32)lane + nb < qn) queue[lane] = moved;
     qn -= nb;
     wave_sync();
+#ifdef AHIP_PROFILE
+    AHIP_TICK(t_e);
+    pc_second += t_e - t_d;
+#endif
   }
   if (lane == 0) cand[(u64)k * split + part] = found;
+#ifdef AHIP_PROFILE
+  if (lane == 0) { u64 *pc = cand + (u64)n_chunks * split * (1 + blockIdx.x % 1) ; (void)pc; }
+  if (lane == 0) { const u64 n = (u64)n_chunks * split; cand[n + blockIdx.x] = pc_stage; cand[2 * n + blockIdx.x] = pc_first; cand[3 * n + blockIdx.x] = pc_second; }
+#endif
 }
 
-// the tokenizer on chunks (persistent grid like inflate_tokenize_kernel); chunk k's token area / run directory follow
-// tok_layout(out_off, out_limit, k)
+// Token area / run directory of candidate c laid out along the INPUT (tok_layout_in): the sizing pass keeps its tokens
+// there, and the write pass resolves the chunks of the chain straight from them (one tokenizer pass instead of two).
+AHIP_DEVINL void sm_layout_in(const u64 *cand_bits, u32 n_cand, u64 in_len, u32 c, u64 &toff, u32 &col_cap, u64 &doff, u32 &dir_cap) {
+  const u64 p0 = uniform64(cand_bits[c]) >> 3;
+  const u64 p1 = c + 1 < n_cand ? (uniform64(cand_bits[c + 1]) >> 3) + 1 : in_len;
+  tok_layout_in(p0, p1 > p0 ? p1 - p0 : 0, c, toff, col_cap, doff, dir_cap);
+}
+// the tokenizer on chunks (persistent grid like inflate_tokenize_kernel).  lay_in = 0: chunk k's token area / run
+// directory follow tok_layout(out_off, out_limit, k) (exact offsets known); lay_in = 1: a sizing pass over ALL candidates
+// that keeps its tokens, laid out along the input.
 __global__ __launch_bounds__(64) void sm_tokenize_kernel(const u8 *__restrict__ in, u64 in_len,
                                                         const ChunkDesc *__restrict__ chunks, u32 n_chunks,
                                                         const u64 *__restrict__ cand_bits, u32 n_cand,
                                                         u32 *__restrict__ tokens, DirEnt *__restrict__ dir,
-                                                        MemberResult *__restrict__ results) {
+                                                        MemberResult *__restrict__ results, u32 lay_in) {
   __shared__ SmLds lds;
   const int lane = threadIdx.x;
   for (u32 k = blockIdx.x; k < n_chunks; k += gridDim.x) {
@@ -189,7 +243,10 @@ __global__ __launch_bounds__(64) void sm_tokenize_kernel(const u8 *__restrict__ 
     TokSink sk{nullptr, 0, nullptr, 0, 0, ~0u, 0, 0, false};
     if (tokens) {
       u64 toff, doff;
-      tok_layout(d.out_off, d.out_limit, k, toff, sk.col_cap, doff, sk.dir_cap);
+      if (lay_in) { sm_layout_in(cand_bits, n_cand, in_len, k, toff, sk.col_cap, doff, sk.dir_cap); sk.sizing = true; }
+      else tok_layout(d.out_off, d.out_limit, k, toff, sk.col_cap, doff, sk.dir_cap);
+      sk.col_cap = uniform(sk.col_cap);
+      sk.dir_cap = uniform(sk.dir_cap);
       sk.area = tokens + toff;
       sk.dir = dir + doff;
     }
@@ -198,10 +255,11 @@ __global__ __launch_bounds__(64) void sm_tokenize_kernel(const u8 *__restrict__ 
   }
 }
 
-// tokens -> symbols
-__global__ __launch_bounds__(64) void sm_resolve_kernel(const u8 *__restrict__ in, const ChunkDesc *__restrict__ chunks,
+// tokens -> symbols.  lay_in = 1: chunk k's tokens are those the sizing pass kept for candidate chunks[k].pad.
+__global__ __launch_bounds__(64) void sm_resolve_kernel(const u8 *__restrict__ in, u64 in_len, const ChunkDesc *__restrict__ chunks,
                                                        u32 n_chunks, u16 *sym, const u32 *__restrict__ tokens,
-                                                       const DirEnt *__restrict__ dir, const MemberResult *__restrict__ results) {
+                                                       const DirEnt *__restrict__ dir, const MemberResult *__restrict__ results,
+                                                       const u64 *__restrict__ cand_bits, u32 n_cand, u32 lay_in) {
   __shared__ ParLdsT<u16> lds;
   const int lane = threadIdx.x;
   for (u32 k = blockIdx.x; k < n_chunks; k += gridDim.x) {
@@ -209,7 +267,8 @@ __global__ __launch_bounds__(64) void sm_resolve_kernel(const u8 *__restrict__ i
     const u32 ndir = (u32)uniform64(results[k].tok_words);
     u64 toff, doff;
     u32 cc, dc;
-    tok_layout(out_off, out_limit, k, toff, cc, doff, dc);
+    if (lay_in) sm_layout_in(cand_bits, n_cand, in_len, uniform(chunks[k].pad), toff, cc, doff, dc);
+    else tok_layout(out_off, out_limit, k, toff, cc, doff, dc);
     u32 cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     resolve_member_sym<u16>(lds, in, tokens + toff, dir + doff, ndir, sym + out_off, cyc, lane);
   }
