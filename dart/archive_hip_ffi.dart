@@ -9,30 +9,30 @@ import 'dart:typed_data';
 
 import 'package:ffi/ffi.dart';
 
-typedef _DecodeNative = Int32 Function(Pointer<Uint8> input, IntPtr inLen, Int32 verify, Int32 raw,
-    Pointer<Uint8> out, IntPtr outCap, Pointer<IntPtr> outLen);
+typedef _DecodeNative = Int32 Function(Pointer<Uint8> input, Size inLen, Int32 verify, Int32 raw,
+    Pointer<Uint8> out, Size outCap, Pointer<Size> outLen);
 typedef _DecodeDart = int Function(
-    Pointer<Uint8> input, int inLen, int verify, int raw, Pointer<Uint8> out, int outCap, Pointer<IntPtr> outLen);
-typedef _InflateNative = Int32 Function(Pointer<Uint8> input, IntPtr inLen, Pointer<Uint8> out, IntPtr outCap,
-    Pointer<IntPtr> outLen, Pointer<IntPtr> consumed);
+    Pointer<Uint8> input, int inLen, int verify, int raw, Pointer<Uint8> out, int outCap, Pointer<Size> outLen);
+typedef _InflateNative = Int32 Function(Pointer<Uint8> input, Size inLen, Pointer<Uint8> out, Size outCap,
+    Pointer<Size> outLen, Pointer<Size> consumed);
 typedef _InflateDart = int Function(
-    Pointer<Uint8> input, int inLen, Pointer<Uint8> out, int outCap, Pointer<IntPtr> outLen, Pointer<IntPtr> consumed);
-typedef _BoundNative = IntPtr Function(Pointer<Uint8> input, IntPtr inLen);
+    Pointer<Uint8> input, int inLen, Pointer<Uint8> out, int outCap, Pointer<Size> outLen, Pointer<Size> consumed);
+typedef _BoundNative = Size Function(Pointer<Uint8> input, Size inLen);
 typedef _BoundDart = int Function(Pointer<Uint8> input, int inLen);
 
 typedef _BatchNative = Int32 Function(
     Pointer<Uint8> input,
-    IntPtr inLen,
+    Size inLen,
     Uint32 nEntries,
     Pointer<Uint64> inOff,
     Pointer<Uint64> inSize,
     Pointer<Uint64> sizeHint,
     Pointer<Uint8> out,
-    IntPtr outCap,
+    Size outCap,
     Pointer<Uint64> outOff,
     Pointer<Uint64> outLen,
     Pointer<Int32> status,
-    Pointer<IntPtr> outTotal);
+    Pointer<Size> outTotal);
 typedef _BatchDart = int Function(
     Pointer<Uint8> input,
     int inLen,
@@ -45,25 +45,25 @@ typedef _BatchDart = int Function(
     Pointer<Uint64> outOff,
     Pointer<Uint64> outLen,
     Pointer<Int32> status,
-    Pointer<IntPtr> outTotal);
-typedef _DeflateNative = Int32 Function(Pointer<Uint8> input, IntPtr inLen, Int32 level, Int32 windowBits,
-    Pointer<Uint8> out, IntPtr outCap, Pointer<IntPtr> outLen, Pointer<Uint32> crc32);
+    Pointer<Size> outTotal);
+typedef _DeflateNative = Int32 Function(Pointer<Uint8> input, Size inLen, Int32 level, Int32 windowBits,
+    Pointer<Uint8> out, Size outCap, Pointer<Size> outLen, Pointer<Uint32> crc32);
 typedef _DeflateDart = int Function(Pointer<Uint8> input, int inLen, int level, int windowBits, Pointer<Uint8> out,
-    int outCap, Pointer<IntPtr> outLen, Pointer<Uint32> crc32);
-typedef _GzEncodeNative = Int32 Function(Pointer<Uint8> input, IntPtr inLen, Int32 level, Int32 windowBits,
-    Uint32 mtime, Pointer<Uint8> out, IntPtr outCap, Pointer<IntPtr> outLen);
+    int outCap, Pointer<Size> outLen, Pointer<Uint32> crc32);
+typedef _GzEncodeNative = Int32 Function(Pointer<Uint8> input, Size inLen, Int32 level, Int32 windowBits,
+    Uint32 mtime, Pointer<Uint8> out, Size outCap, Pointer<Size> outLen);
 typedef _GzEncodeDart = int Function(Pointer<Uint8> input, int inLen, int level, int windowBits, int mtime,
-    Pointer<Uint8> out, int outCap, Pointer<IntPtr> outLen);
-typedef _ZlEncodeNative = Int32 Function(Pointer<Uint8> input, IntPtr inLen, Int32 level, Int32 windowBits,
-    Pointer<Uint8> out, IntPtr outCap, Pointer<IntPtr> outLen);
+    Pointer<Uint8> out, int outCap, Pointer<Size> outLen);
+typedef _ZlEncodeNative = Int32 Function(Pointer<Uint8> input, Size inLen, Int32 level, Int32 windowBits,
+    Pointer<Uint8> out, Size outCap, Pointer<Size> outLen);
 typedef _ZlEncodeDart = int Function(
-    Pointer<Uint8> input, int inLen, int level, int windowBits, Pointer<Uint8> out, int outCap, Pointer<IntPtr> outLen);
-typedef _BoundSizeNative = IntPtr Function(IntPtr inLen);
+    Pointer<Uint8> input, int inLen, int level, int windowBits, Pointer<Uint8> out, int outCap, Pointer<Size> outLen);
+typedef _BoundSizeNative = Size Function(Size inLen);
 typedef _BoundSizeDart = int Function(int inLen);
 typedef _BzNative = Int32 Function(
-    Pointer<Uint8> input, IntPtr inLen, Int32 verify, Pointer<Uint8> out, IntPtr outCap, Pointer<IntPtr> outLen);
+    Pointer<Uint8> input, Size inLen, Int32 verify, Pointer<Uint8> out, Size outCap, Pointer<Size> outLen);
 typedef _BzDart = int Function(
-    Pointer<Uint8> input, int inLen, int verify, Pointer<Uint8> out, int outCap, Pointer<IntPtr> outLen);
+    Pointer<Uint8> input, int inLen, int verify, Pointer<Uint8> out, int outCap, Pointer<Size> outLen);
 
 /// What `Deflate(bytes, ...)` produced: the stream, the CRC-32 of the input, the input length.
 class DeflateResult {
@@ -110,12 +110,12 @@ class ArchiveHip {
   /// of a gzip stream) or by a guess, and grown once if the library reports the real size (AHIP_E_CAP).  Status
   /// codes are mapped to the reference's behaviour: 0/1 -> bytes (the reference is silent about early stops),
   /// 2 -> RangeError.
-  Uint8List _run(List<int> data, int Function(Pointer<Uint8>, int, Pointer<Uint8>, int, Pointer<IntPtr>) call,
+  Uint8List _run(List<int> data, int Function(Pointer<Uint8>, int, Pointer<Uint8>, int, Pointer<Size>) call,
       {int? sizeHint, bool askBound = false}) {
     final n = data.length;
     final inp = malloc<Uint8>(n == 0 ? 1 : n);
     inp.asTypedList(n).setAll(0, data);
-    final outLen = malloc<IntPtr>();
+    final outLen = malloc<Size>();
     var cap = sizeHint ?? 0;
     if (cap == 0 && askBound) cap = _decodeBound(inp, n);
     if (cap == 0) cap = 4 * n + 64;
@@ -155,7 +155,7 @@ class ArchiveHip {
       _run(data, (i, n, o, c, l) => _zlib(i, n, verify ? 1 : 0, raw ? 1 : 0, o, c, l));
 
   Uint8List inflateRaw(List<int> data, {int? uncompressedSize}) {
-    final consumed = malloc<IntPtr>();
+    final consumed = malloc<Size>();
     try {
       final out =
           _run(data, (i, n, o, c, l) => _inflate(i, n, o, c, l, consumed), sizeHint: uncompressedSize);
@@ -206,7 +206,7 @@ class ArchiveHip {
     final off = malloc<Uint64>(k), sz = malloc<Uint64>(k), hint = malloc<Uint64>(k);
     final oOff = malloc<Uint64>(k), oLen = malloc<Uint64>(k);
     final st = malloc<Int32>(k);
-    final total = malloc<IntPtr>();
+    final total = malloc<Size>();
     var cap = 0;
     for (var i = 0; i < k; ++i) {
       off[i] = offsets[i];

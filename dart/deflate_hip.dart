@@ -53,7 +53,9 @@ class Deflate {
   int _deflate(List<int> bytes) {
     final r = ArchiveHip.instance.deflateRaw(bytes, level: _level, windowBits: _windowBits);
     _output.writeBytes(r.bytes);
-    crc32 = r.crc32;
+    // the reference chains the checksum over every call (deflate.dart:1231 `crc32 = getCrc32(bytes, crc32)`): the
+    // library returns the CRC-32 of this call's bytes alone, so the two are combined over GF(2)
+    crc32 = total == 0 ? r.crc32 : _crc32Combine(crc32, r.crc32, r.total);
     total += r.total;
     return zStreamEnd; // what the reference's _deflate(finish) returns once everything is out (deflate.dart:1305)
   }
@@ -76,4 +78,38 @@ class Deflate {
   int addStream(InputStream buffer) => _deflate(buffer.toUint8List());
 
   int get level => _level;
+
+  /// CRC-32 of A || B from CRC-32(A), CRC-32(B) and len(B): multiplication by x^(8 len) in GF(2)[x] / P
+  /// (square-and-multiply on the 32 x 32 bit matrix of "append one zero bit").
+  static int _crc32Combine(int crcA, int crcB, int lenB) {
+    if (lenB <= 0) return crcA;
+    List<int> times(List<int> mat, List<int> m2) => [for (final v in m2) _gf2Times(mat, v)];
+    var odd = List<int>.filled(32, 0); // one zero bit
+    odd[0] = 0xedb88320;
+    for (var n = 1, row = 1; n < 32; ++n, row <<= 1) {
+      odd[n] = row;
+    }
+    var even = times(odd, odd); // two zero bits
+    odd = times(even, even); // four
+    var len = lenB;
+    var crc = crcA;
+    do {
+      even = times(odd, odd); // first pass: one zero BYTE
+      if (len & 1 != 0) crc = _gf2Times(even, crc);
+      len >>= 1;
+      if (len == 0) break;
+      odd = times(even, even);
+      if (len & 1 != 0) crc = _gf2Times(odd, crc);
+      len >>= 1;
+    } while (len != 0);
+    return (crc ^ crcB) & 0xffffffff;
+  }
+
+  static int _gf2Times(List<int> mat, int vec) {
+    var sum = 0;
+    for (var i = 0; vec != 0; vec >>= 1, ++i) {
+      if (vec & 1 != 0) sum ^= mat[i];
+    }
+    return sum;
+  }
 }
