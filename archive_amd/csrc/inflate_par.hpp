@@ -44,12 +44,6 @@ namespace ahip {
 #ifndef AHIP_EMIT_MIN
 #define AHIP_EMIT_MIN 32
 #endif
-#ifndef AHIP_TOK_CAP
-#define AHIP_TOK_CAP 384
-#endif
-#ifndef AHIP_OB_CAP
-#define AHIP_OB_CAP 1728
-#endif
 constexpr int SUB_BITS = AHIP_SUB_BITS;          // bits per work item ("subsequence") of the tokenizer
 constexpr int SUB_DW = SUB_BITS / 32;
 constexpr int RING_DW = AHIP_RING_DW;            // staged bitstream: a ring of dwords in LDS
@@ -60,8 +54,6 @@ constexpr u32 SPEC_BITS = AHIP_SPEC_BITS;        // a speculative run covers the
 constexpr int STEPS = AHIP_STEPS;                // decode steps between two scheduling points
 constexpr u32 EMIT_MIN = AHIP_EMIT_MIN;          // items retired per emit (<= 64)
 constexpr u32 EPOCH_ITEMS = (1u << 27) / SUB_BITS;  // positions inside an epoch stay below 2^27 + slack
-constexpr int TOK_CAP = AHIP_TOK_CAP;            // token queue entries per resolve batch
-constexpr int OB_CAP = AHIP_OB_CAP;              // output bytes assembled in LDS per resolve batch
 static_assert((RING_DW & (RING_DW - 1)) == 0 && (ITEMS & (ITEMS - 1)) == 0, "rings are powers of two");
 static_assert(SUB_BITS % 128 == 0 && SPEC_BITS <= (u32)SUB_BITS && SUB_BITS + 64 < 4096, "item geometry");
 static_assert(EMIT_MIN >= 1 && EMIT_MIN <= 64 && (u32)ITEMS >= 2 * EMIT_MIN && ITEMS >= 32, "scheduler geometry");
@@ -104,23 +96,7 @@ struct TokLds {
   u32 q[64];        // repair queue of one scheduling point: the starts to decode from
   u32 colpos[64];   // words used in every column of the member's token area (kept here between blocks)
 };
-// LDS of the resolver: token queue, output window, start-slot rows
-// E = u8: bytes.  E = u16: symbols of the chunked single-stream decode -- a byte value, or 0x8000 + j for "byte j
-// of the 32 KiB of output in front of this chunk" (not known yet when the chunk is resolved).
-template <typename E>
-struct ParLdsT {
-  u32 tok[TOK_CAP];
-  E obuf[OB_CAP + 32] __attribute__((aligned(16)));
-  u32 slot[3 * 64];  // two alternating 64-entry start-slot rows + one dump row
-};
-constexpr u32 SYM_MARK = 0x8000;
-// history element at window-relative offset si < 0; opos = elements of this chunk in front of the window
-template <typename E>
-AHIP_DEVINL u32 hist_get(const E *hist, i32 si, u64 opos) {
-  if (sizeof(E) == 1) return hist[si];
-  const i64 a = (i64)opos + si;
-  return a >= 0 ? (u32)hist[si] : (u32)(SYM_MARK + 32768 + a);
-}
+constexpr u32 SYM_MARK = 0x8000;  // 16-bit symbols of the chunked single-stream decode: SYM_MARK + j = "byte j of the 32 KiB in front of this chunk"
 
 // Token store of one member in device memory (tokenizer -> resolver hand-off).
 //   area  64 columns of col_cap words.  Lane l of the flow decoder records the tokens of its runs into column l, one
@@ -227,7 +203,7 @@ AHIP_DEVINL u32 decode_token(LaneBits &d, const WaveLds &L, const u32 *inbuf, u3
   lb_normalize<MASK>(d, inbuf);
   const u32 w2 = lb_peek32(d);  // distance code + extra <= 28
   u32 t = L.dt[w2 & ((1u << D_ROOT) - 1)];
-  if (AHIP_ANY_HINT(is_match && (t & E_LONG))) {
+  if (AHIP_ANY_HINT(t & E_LONG)) {  // (whatever the lane's litlen symbol was: a spurious second-level read is harmless and costs less than asking)
     AHIP_ASM_NOTE("long distance code");
     if (t & E_LONG) t = long_lookup(L.d_sub, t, w2, D_ROOT);
   }
@@ -239,101 +215,6 @@ AHIP_DEVINL u32 decode_token(LaneBits &d, const WaveLds &L, const u32 *inbuf, u3
 }
 
 constexpr u32 LR_EOB = 1, LR_ERR = 2;  // how a run ended before its boundary
-
-// Execute `ntok` queued tokens (nbytes of output) in stream order into the LDS output window.
-//  hist: global address of the window's first output byte (earlier output lies below it).
-//
-// Byte-per-lane formulation -- no per-token loops, no divergence on match length:
-//   pass 1  wave scans turn every token into a key {start offset, literal flag, byte | dist-1}
-//           (the literal/match boundary scan); keys replace the tokens in the queue.
-//   pass 2  64 output bytes at a time.  The (at most 64) tokens that START inside the group drop
-//           their key into a 64-entry slot array at their start offset; a wave prefix-max then
-//           hands every byte lane the key of the token that covers it.  A lane's byte is the
-//           literal, an earlier byte of the window (LDS), a byte of flushed history (HBM/L2), or
-//           the byte of a lower lane of the same group (resolved by pointer doubling over the
-//           LDS crossbar; only runs and very short distances get there).
-//           History loads of group g+1 are issued before group g is finished, so their latency
-//           hides behind LDS work.
-struct GroupFront {
-  u32 val;    // literal byte, or history byte (once the load lands)
-  i32 si;     // source offset inside the window (negative: flushed history)
-  bool act, lit;
-  bool pre;   // byte of a far match already deposited into the window by pass 1
-};
-template <typename E>
-AHIP_DEVINL GroupFront resolve_front(ParLdsT<E> &P, u32 ntok, u32 nbytes, const E *hist, u64 opos, u32 g0, u32 &tcur,
-                                     u32 &carry, int lane) {
-  u32 *slot = P.slot + ((g0 >> 6) & 1) * 64;  // two slot arrays alternate: no write-after-read stall
-  wave_sync();
-  slot[lane] = 0;
-  AHIP_LOCKSTEP();  // every lane's zero lands before any lane's key
-  const u32 kidx = tcur + lane;
-  const u32 k = kidx < ntok ? P.tok[kidx] : 0u;
-  const u32 offk = (k >> 17) & 0x1fff;
-  const bool ing = k != 0 && offk < g0 + 64;  // tokens are sorted by offset, so these form lanes 0..cnt-1
-  (ing ? slot + (offk - g0) : P.slot + 128 + lane)[0] = k;  // lanes without a start write to the dump row (branch-free)
-  const u32 cnt = (u32)__popcll(__ballot(ing));
-  wave_sync();  // other lanes wrote slot[]: without this hipcc forwards this lane's own 0
-  u32 key = slot[lane];
-  key = wave_incl_umax(key);
-  key = key > carry ? key : carry;  // the token that covers the start of the group
-  const u32 last = lane_bcast(k, (int)((cnt - 1) & 63));
-  carry = cnt ? last : carry;
-  tcur += cnt;
-  GroupFront f;
-  const u32 x = g0 + lane;
-  f.act = x < nbytes;
-  f.lit = (key >> 16) & 1;
-  f.pre = !f.lit && ((key >> 15) & 1);
-  f.val = key & 0xff;
-  f.si = f.pre ? (i32)x : (i32)x - (i32)((key & 0x7fff) + 1);
-#ifndef AHIP_ABLATE_FAR
-  if (f.act && !f.lit && f.si < 0) f.val = hist_get(hist, f.si, opos);  // far sources pass 1 did not take (long, or too close to the window)
-#endif
-  return f;
-}
-template <typename E>
-AHIP_DEVINL void resolve_back(ParLdsT<E> &P, const GroupFront &f, u32 g0, E *ob, int lane) {
-  u32 val = f.val;
-  const bool copy = f.act && !f.lit;
-  wave_sync();  // bytes of earlier groups were stored by other lanes
-  if (copy && f.si >= 0 && (f.si < (i32)g0 || f.pre)) val = ob[f.si];  // pre: its own deposited byte (lower lanes may copy from it)
-  const bool dep = copy && !f.pre && f.si >= (i32)g0;
-  if (__any(dep)) {
-    u32 srcl = dep ? (u32)(f.si - (i32)g0) : (u32)lane;
-    bool res = !dep;
-    int guard = 0;  // a chain of lower-lane pointers halves every step: 6 steps always suffice
-    do {
-      const u32 sv = lane_gather(val, srcl);
-      const u32 sr = lane_gather(res ? 1u : 0u, srcl);
-      const u32 ss = lane_gather(srcl, srcl);
-      if (!res) {
-        if (sr) { val = sv; res = true; }
-        else srcl = ss;
-      }
-    } while (__any(!res) && ++guard < 8);
-  }
-  if (f.act && !f.pre) ob[g0 + lane] = (E)val;
-}
-// pass 2 of the resolver: keys are already in the queue (resolve_member builds them)
-template <typename E>
-AHIP_DEVINL void resolve_bytes(ParLdsT<E> &P, u32 ntok, u32 nbytes, const E *hist, u64 opos, u32 A, int lane) {
-  E *ob = P.obuf + A;
-  u32 tcur = 0, carry = 0;
-  if (nbytes == 0 || nbytes > (u32)OB_CAP || ntok > (u32)TOK_CAP) return;  // never spin on corrupt bookkeeping
-  GroupFront cur = resolve_front(P, ntok, nbytes, hist, opos, 0, tcur, carry, lane);
-  u32 g0 = 0;
-  for (; g0 + 64 < nbytes; g0 += 64) {  // front of the next group and back of this one: one straight-line body
-    GroupFront nxt = resolve_front(P, ntok, nbytes, hist, opos, g0 + 64, tcur, carry, lane);
-    resolve_back(P, cur, g0, ob, lane);
-    cur = nxt;
-  }
-  resolve_back(P, cur, g0, ob, lane);
-}
-
-AHIP_DEVINL void flush_window(const ParLdsT<u16> &P, u16 *g, u32 A, u32 n, int lane) {  // symbols: plain copy
-  for (u32 i = lane; i < n; i += 64) g[i] = P.obuf[A + i];
-}
 
 // ------------------------------------------------------------------------------------------
 // Tokenizer side
@@ -719,7 +600,7 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
           }
           if (!spc) {
             const bool lit = (i32)t < 0;
-            const i32 req = lit ? 0 : (i32)(t & 0xffff) - (i32)nbytes;
+            const i32 req = (i32)(t & 0xffff) - (i32)nbytes;  // (a literal has no distance: never positive)
             need = req > need ? req : need;
             nbytes += lit ? 1u : (t >> 16);
             if (ms >> 29) { if (emit) col[rowctr] = rec_word(nbytes, t); rowctr += 1; }
@@ -937,13 +818,44 @@ constexpr u32 WIN_FLUSH = WIN_CAP - AHIP_WIN_KEEP;  // ... and it is flushed onc
 constexpr u32 PEND_CAP = AHIP_PEND_CAP;            // deferred matches per window
 constexpr u32 LOOK_TOK = 4096;                     // tokens per look at the directory (a flow run has at most 4095)
 static_assert(WIN_CAP % 32 == 0 && WIN_CAP <= 32768 && WIN_FLUSH >= 512 && AHIP_WIN_KEEP >= 264 && PEND_CAP >= 128, "window geometry");
-struct ResLds {
-  u8 obuf[WIN_CAP + 64] __attribute__((aligned(16)));  // + alignment offset (<= 15) + a 16-byte read past the last source byte
+// E = u8: bytes.  E = u16: symbols of the chunked single-stream decode (sm_inflate.hpp) -- a byte value, or
+// SYM_MARK + j for "byte j of the 32 KiB of output in front of this chunk", not known yet when the chunk is resolved.
+template <typename E>
+struct ResLdsT {
+  E obuf[WIN_CAP + 64] __attribute__((aligned(16)));  // + alignment offset (< 16 bytes) + a 16-element read past the last source element
   u32 pmap[WIN_CAP / 32 + 4];  // one bit per window byte: a deferred match has yet to write it
   uint2 plist[PEND_CAP];       // the window's deferred matches in stream order: {window index | len << 16, distance}
   u32 rbits[LOOK_TOK / 32 + 4];  // the current look at the directory: bit i = token i of the look is the first of its run
   uint2 rtab[64];              //   run r of the look: {area offset of its token 0 - index of that token in the look, output offset rel. borg}
 };
+using ResLds = ResLdsT<u8>;
+
+// exactly `len` (3..16) SYMBOLS of the 16 in (w0..w3) to dp: two overlapping unaligned stores like deposit16(), in
+// 2-byte units ([0, w) and [2 len - w, 2 len), w = 16 / 8 bytes; three symbols = 4 + 2 bytes)
+AHIP_DEVINL void deposit16_sym(u16 *dp, u32 len, u64 w0, u64 w1, u64 w2, u64 w3) {
+  u8 *bp = (u8 *)dp;
+  const u32 b = 2 * len;
+  if (len >= 8) {
+    const u32 o = b - 16;  // 0, 2, .. 16: first byte of the last 16
+    const bool up = o >= 8;
+    const u64 x0 = up ? w1 : w0, x1 = up ? w2 : w1, x2 = up ? w3 : w2;
+    const u32 sh = 8 * (o & 7);
+    const u64 lo = o == 16 ? w2 : (sh ? (x0 >> sh) | (x1 << (64 - sh)) : x0);
+    const u64 hi = o == 16 ? w3 : (sh ? (x1 >> sh) | (x2 << (64 - sh)) : x1);
+    ((unaligned_u64 *)bp)->v = w0;
+    ((unaligned_u64 *)(bp + 8))->v = w1;
+    ((unaligned_u64 *)(bp + o))->v = lo;
+    ((unaligned_u64 *)(bp + o + 8))->v = hi;
+  } else if (len >= 4) {
+    const u32 sh = 8 * (b - 8);  // 0, 16, 32, 48
+    const u64 tail = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
+    ((unaligned_u64 *)bp)->v = w0;
+    ((unaligned_u64 *)(bp + b - 8))->v = tail;
+  } else {  // three symbols (a match is at least 3 long)
+    ((unaligned_u32 *)bp)->v = (u32)w0;
+    ((unaligned_u16 *)(bp + 4))->v = (u16)(w0 >> 32);
+  }
+}
 
 // One member: token runs (area, dir) -> bytes at out_base.  64 tokens per step, one per lane.
 //   offsets  every lane knows where its token goes without a scan: the run's output offset (directory) + the `end` of
@@ -959,12 +871,16 @@ struct ResLds {
 //            their own source or straddling the window start are copied by the whole wave when they are the first
 //            pending one (everything in front of their destination is final then).  Then the window goes to HBM with
 //            16-byte stores.
-AHIP_DEVINL void resolve_member(ResLds &P, const u8 *in, const u32 *area, const DirEnt *dir, u32 ndir, u8 *out_base, u32 *cyc,
+template <typename E>
+AHIP_DEVINL void resolve_member(ResLdsT<E> &P, const u8 *in, const u32 *area, const DirEnt *dir, u32 ndir, E *out_base, u32 *cyc,
                                 int lane) {
+  constexpr bool MARK = sizeof(E) == 2;
+  constexpr u32 EPV = 16 / sizeof(E);        // elements per 16-byte vector
+  constexpr u32 SIMPLE_MAX = MARK ? 16 : 32;  // longest match the two-piece (bytes) / one-piece (symbols) deposit takes
   u64 wpos = 0;                                   // output offset (member-relative) of the window's first byte
   u32 wfill = 0;                                  // bytes assembled in the window
   u32 npend = 0;                                  // deferred matches of the window
-  u32 A = (u32)((uintptr_t)out_base & 15);        // obuf[A + i] <-> out_base[wpos + i]: LDS and global congruent mod 16
+  u32 A = (u32)(((uintptr_t)out_base / sizeof(E)) & (EPV - 1));  // obuf[A + i] <-> out_base[wpos + i]: LDS and global congruent mod 16 bytes
   for (u32 i = lane; i < WIN_CAP / 32 + 4; i += 64) P.pmap[i] = 0;
   wave_sync();
   RTICK(r_begin);
@@ -986,9 +902,9 @@ AHIP_DEVINL void resolve_member(ResLds &P, const u8 *in, const u32 *area, const 
   };
   // the first pending match, copied by the whole wave: every byte in front of its destination is final
   auto wave_copy = [&](u32 fd, u32 L_, u32 D_) {
-    u8 *const ob = P.obuf + A;
+    E *const ob = P.obuf + A;
     const i32 S_ = (i32)fd - (i32)D_;
-    const u8 *gsrc = out_base + wpos;  // window index i < 0 <-> gsrc[i]
+    const E *gsrc = out_base + wpos;  // window index i < 0 <-> gsrc[i] ...
     const u32 n0 = D_ < L_ ? D_ : L_;  // the part that does not read its own output
 #pragma nounroll
     for (u32 k = (u32)lane; k < n0; k += 64) {
@@ -996,8 +912,10 @@ AHIP_DEVINL void resolve_member(ResLds &P, const u8 *in, const u32 *area, const 
       // (values are selected, not pointers: an LDS / global pointer select trips the gfx950 backend)
       const u32 lv = ob[si >= 0 ? si : 0];
       u32 gv = 0;
-      if (si < 0) gv = gsrc[si];
-      ob[fd + k] = (u8)(si >= 0 ? lv : gv);
+      const i64 ab = (i64)wpos + si;   // ... unless it lies in front of the chunk (symbols only): a marker
+      if (si < 0 && (!MARK || ab >= 0)) gv = gsrc[si];
+      if (MARK && ab < 0) gv = (u32)(SYM_MARK + 32768 + ab);
+      ob[fd + k] = (E)(si >= 0 ? lv : gv);
     }
     wave_sync();
     u32 filled = n0;  // a multiple of D_ from here on: the destination repeats with period D_
@@ -1009,27 +927,62 @@ AHIP_DEVINL void resolve_member(ResLds &P, const u8 *in, const u32 *area, const 
       filled += n;
     }
   };
-  auto store_match = [&](u8 *dp, u32 len, u64 w0, u64 w1, u64 w2, u64 w3) {  // len <= 32: two 16-byte pieces, the second ends at len
-    if (len > 16) {
-      ((unaligned_u64 *)dp)->v = w0;
-      ((unaligned_u64 *)(dp + 8))->v = w1;
-      ((unaligned_u64 *)(dp + len - 16))->v = w2;
-      ((unaligned_u64 *)(dp + len - 8))->v = w3;
+  auto store_match = [&](E *dp, u32 len, u64 w0, u64 w1, u64 w2, u64 w3) {
+    if constexpr (MARK) {
+      deposit16_sym(dp, len, w0, w1, w2, w3);  // len <= 16 symbols: one 32-byte piece
+    } else {  // len <= 32: two 16-byte pieces, the second ends at len
+      if (len > 16) {
+        ((unaligned_u64 *)dp)->v = w0;
+        ((unaligned_u64 *)(dp + 8))->v = w1;
+        ((unaligned_u64 *)(dp + len - 16))->v = w2;
+        ((unaligned_u64 *)(dp + len - 8))->v = w3;
+      }
+      if (len <= 16) deposit16(dp, len, w0, w1);
     }
-    if (len <= 16) deposit16(dp, len, w0, w1);
+  };
+  // 16 (bytes: 16 + the last 16) source elements of a match whose source is flushed output at window index so (< 0);
+  // symbols in front of the chunk are made up: markers count upwards like the bytes they stand for
+  auto fetch = [&](i32 so, u32 len, u64 &w0, u64 &w1, u64 &w2, u64 &w3) {
+    if constexpr (MARK) {
+      const i64 ab = (i64)wpos + so;
+      if (ab < 0) {
+        const u64 m = (u64)(SYM_MARK + 32768 + ab) * 0x0001000100010001ull + 0x0003000200010000ull;  // (fields behind `len` may carry: never stored)
+        w0 = m; w1 = m + 0x0004000400040004ull; w2 = m + 0x0008000800080008ull; w3 = m + 0x000c000c000c000cull;
+      } else {
+        const u8 *sp = (const u8 *)(out_base + wpos + so);
+        w0 = load_u64_unaligned(sp); w1 = load_u64_unaligned(sp + 8); w2 = load_u64_unaligned(sp + 16); w3 = load_u64_unaligned(sp + 24);
+      }
+    } else {
+      const u8 *sp = (const u8 *)(out_base + wpos + so);
+      w0 = load_u64_unaligned(sp);
+      w1 = load_u64_unaligned(sp + 8);
+      if (len > 16) { w2 = load_u64_unaligned(sp + len - 16); w3 = load_u64_unaligned(sp + len - 8); }
+    }
+  };
+  // "deposit now": the source is flushed output and the pieces do it.  The first piece may read past the source (the
+  // deposit ignores what lies behind `len`): with dist >= 16 those elements are still this member's own output --
+  // allocated, just not written yet.  Symbols: the source lies either wholly in the chunk or wholly in front of it.
+  auto deposit_now = [&](bool isM, u32 len, u32 dist, i32 so) -> bool {
+    const i32 span = (!MARK && len > 16) ? (i32)len : 16;
+    bool g = isM && len <= SIMPLE_MAX && dist >= len && so + (i32)len <= 0 && (so + span <= 0 || dist >= 16);
+    if constexpr (MARK) {
+      const i64 ab = (i64)wpos + so;
+      g = g && (ab >= 0 || ab + (i64)len <= 0);
+    }
+    return g;
   };
   auto resolve_pending = [&]() {
     RTICK(r_r0);
-    u8 *const ob = P.obuf + A;
+    E *const ob = P.obuf + A;
     wave_sync();
     for (u32 b0 = 0; b0 < npend; b0 += 64) {
       const bool have = b0 + (u32)lane < npend;
       const uint2 e = P.plist[have ? b0 + lane : 0];
       const u32 wo = e.x & 0xffffu, len = e.x >> 16, dist = e.y;
       const i32 so = (i32)wo - (i32)dist;
-      const bool simple = have && so >= 0 && len <= 32 && dist >= len;
+      const bool simple = have && so >= 0 && len <= SIMPLE_MAX && dist >= len;
       const u32 sa = simple ? (u32)so : 0u;             // (every lane reads somewhere harmless)
-      const u32 sa2 = (simple && len > 16) ? sa + len - 16 : sa;
+      const u32 sa2 = (!MARK && simple && len > 16) ? sa + len - 16 : sa;  // bytes: the piece that ends at len
       const u64 lmask = len >= 32 ? 0xffffffffull : ((1ull << len) - 1);
       bool pl = have;
       u32 guard = 0;
@@ -1038,8 +991,9 @@ AHIP_DEVINL void resolve_member(ResLds &P, const u8 *in, const u32 *area, const 
         if (!pend || ++guard > 80) break;
         // marks over the source, and the source bytes themselves, in one LDS round trip
         const u32 m0 = P.pmap[sa >> 5], m1 = P.pmap[(sa >> 5) + 1];
-        const u64 w0 = ((const unaligned_u64 *)(ob + sa))->v, w1 = ((const unaligned_u64 *)(ob + sa + 8))->v;
-        const u64 w2 = ((const unaligned_u64 *)(ob + sa2))->v, w3 = ((const unaligned_u64 *)(ob + sa2 + 8))->v;
+        const u8 *sb = (const u8 *)(ob + sa), *sb2 = MARK ? sb + 16 : (const u8 *)(ob + sa2);  // symbols: one piece of 32 bytes
+        const u64 w0 = ((const unaligned_u64 *)sb)->v, w1 = ((const unaligned_u64 *)(sb + 8))->v;
+        const u64 w2 = ((const unaligned_u64 *)sb2)->v, w3 = ((const unaligned_u64 *)(sb2 + 8))->v;
         const u64 marks = ((((u64)m1 << 32) | m0) >> (sa & 31)) & lmask;
         const bool act = pl && simple && marks == 0;
         const int f = __builtin_ctzll(pend);
@@ -1070,20 +1024,20 @@ AHIP_DEVINL void resolve_member(ResLds &P, const u8 *in, const u32 *area, const 
     if (npend) resolve_pending();
     RTICK(r_f0);
     wave_sync();
-    u8 *g = out_base + wpos;
-    u32 head = (16 - A) & 15;
+    E *g = out_base + wpos;
+    u32 head = (EPV - A) & (EPV - 1);
     if (head > wfill) head = wfill;
     if ((u32)lane < head) g[lane] = P.obuf[A + lane];
-    const u32 body = (wfill - head) & ~15u;
+    const u32 body = (wfill - head) & ~(EPV - 1);
     const uint4 *src = (const uint4 *)(P.obuf + A + head);
     uint4 *dst = (uint4 *)(g + head);
-    for (u32 i = lane; i < body / 16; i += 64) dst[i] = src[i];
+    for (u32 i = lane; i < body / EPV; i += 64) dst[i] = src[i];
     const u32 tail0 = head + body;
     if (tail0 + lane < wfill) g[tail0 + lane] = P.obuf[A + tail0 + lane];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // later matches read this output back
     wave_sync();
     wpos += wfill;
-    A = (A + wfill) & 15;
+    A = (A + wfill) & (EPV - 1);
     wfill = 0;
     RTICK(r_f1);
     RACC(6, r_f0, r_f1);
@@ -1113,17 +1067,11 @@ AHIP_DEVINL void resolve_member(ResLds &P, const u8 *in, const u32 *area, const 
       const bool lit = (c.t & REC_LIT) != 0;
       const u32 dist = (c.t & 0x7fffu) + 1u;
       const bool isM = c.inb && !lit;
-      const bool simple = c.len <= 32 && dist >= c.len;  // two 16-byte pieces, source and destination apart
       const i32 wo = c.ob - (i32)wrel;  // window index of the destination
       const i32 so = wo - (i32)dist;    // window index of the source (negative: flushed output)
-      // A match is deposited right here when its source is flushed output and two 16-byte pieces do it.  The first
-      // piece may read past the source (the deposit ignores what lies behind `len`): with dist >= 16 those bytes are
-      // still this member's own output -- allocated, just not written yet.  Everything else is deferred to the flush.
+      // A match is deposited right here when deposit_now() says so; everything else is deferred to the flush.
       bool Gc = c.gc;  // as classified when the chunk was prepared ...
-      if (wrel != c.wrel0) {  // ... unless the window has moved since
-        const i32 span = c.len > 16 ? (i32)c.len : 16;
-        Gc = isM && simple && so + (i32)c.len <= 0 && (so + span <= 0 || dist >= 16);
-      }
+      if (wrel != c.wrel0) Gc = deposit_now(isM, c.len, dist, so);  // ... unless the window has moved since
       const bool defer_ = isM && !Gc;
       bool fit = c.inb;
       const bool whole = rem == c.inbm && (u32)(c.cend - (i32)wrel) <= WIN_CAP && npend + 64 <= PEND_CAP;
@@ -1138,8 +1086,8 @@ AHIP_DEVINL void resolve_member(ResLds &P, const u8 *in, const u32 *area, const 
       }
       const u64 fm = __ballot(fit);
       if (!fm) return rem;
-      u8 *const ob = P.obuf + A;
-      if (fit && lit) ob[wo] = (u8)c.t;
+      E *const ob = P.obuf + A;
+      if (fit && lit) ob[wo] = (E)(u8)c.t;
       const bool G = fit && Gc;
       const bool D = fit && defer_;
       // flushed sources that were not fetched ahead (the window was flushed after the chunk was prepared): fetched
@@ -1147,10 +1095,7 @@ AHIP_DEVINL void resolve_member(ResLds &P, const u8 *in, const u32 *area, const 
       const bool late = G && !c.pre;  // (only after a flush: otherwise `pre` is exactly the classification)
       if (wrel != c.wrel0 && __any(late)) {
         if (late) {
-          const u8 *sp = out_base + wpos + so;
-          c.w0 = load_u64_unaligned(sp);
-          c.w1 = load_u64_unaligned(sp + 8);
-          if (c.len > 16) { c.w2 = load_u64_unaligned(sp + c.len - 16); c.w3 = load_u64_unaligned(sp + c.len - 8); }
+          fetch(so, c.len, c.w0, c.w1, c.w2, c.w3);
           c.pre = true;
         }
         AHIP_PIN(c.w0); AHIP_PIN(c.w1); AHIP_PIN(c.w2); AHIP_PIN(c.w3);
@@ -1188,11 +1133,11 @@ AHIP_DEVINL void resolve_member(ResLds &P, const u8 *in, const u32 *area, const 
       if (y & DF_STORED) {  // stored block: input -> output copy, past the window
         if (wfill) flush();
         const u64 src = (u64)uniform(area[x]) | ((u64)uniform(area[x + 1]) << 32);
-        u8 *g = out_base + wpos;
-        for (u32 i = lane; i < cnt; i += 64) g[i] = in[src + i];
+        E *g = out_base + wpos;
+        for (u32 i = lane; i < cnt; i += 64) g[i] = (E)in[src + i];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         wpos += cnt;
-        A = (A + cnt) & 15;
+        A = (A + cnt) & (EPV - 1);
       } else {
         // a run whose `end` fields may wrap: lengths are exact modulo 2^16, offsets from a prefix sum
         u32 carry_end = 0;
@@ -1279,19 +1224,13 @@ AHIP_DEVINL void resolve_member(ResLds &P, const u8 *in, const u32 *area, const 
       const bool lit = (q.t & REC_LIT) != 0;
       const u32 dist = (q.t & 0x7fffu) + 1u;
       const i32 so = c.ob - (i32)wrel - (i32)dist;  // against the window as it is NOW: what is flushed stays flushed
-      const i32 span = c.len > 16 ? (i32)c.len : 16;
-      c.gc = q.inb && !lit && c.len <= 32 && dist >= c.len && so + (i32)c.len <= 0 && (so + span <= 0 || dist >= 16);
+      c.gc = deposit_now(q.inb && !lit, c.len, dist, so);
       c.pre = c.gc;
       c.wrel0 = wrel;
       c.inbm = q.nin >= 64 ? ~0ull : (1ull << q.nin) - 1;
       c.cend = (i32)lane_bcast((u32)c.ob + c.len, (int)q.nin - 1);
       c.w0 = c.w1 = c.w2 = c.w3 = 0;  // (also ends the live range of the previous chunk's registers)
-      if (c.pre) {
-        const u8 *sp = out_base + wpos + so;
-        c.w0 = load_u64_unaligned(sp);
-        c.w1 = load_u64_unaligned(sp + 8);
-        if (c.len > 16) { c.w2 = load_u64_unaligned(sp + c.len - 16); c.w3 = load_u64_unaligned(sp + c.len - 8); }
-      }
+      if (c.pre) fetch(so, c.len, c.w0, c.w1, c.w2, c.w3);
       RTICK(r_q1);
       RACC(2, r_q0, r_q1);
       return c;
@@ -1311,118 +1250,6 @@ AHIP_DEVINL void resolve_member(ResLds &P, const u8 *in, const u32 *area, const 
   if (wfill) flush();
   RTICK(r_end);
   RACC(7, r_begin, r_end);
-}
-
-// ------------------------------------------------------------------------------------------
-// The byte-per-lane resolver (resolve_front / resolve_back / resolve_bytes above), kept for the 16-bit SYMBOLS of the
-// chunked single-stream decode (sm_inflate.hpp): a symbol is a byte value or 0x8000 + j, "byte j of the 32 KiB in
-// front of this chunk".  Tokens are converted from the recorded form (end, payload) to step words while they are
-// gathered into the LDS queue; offsets then come from prefix sums over the lengths, 64 tokens at a time.
-// ------------------------------------------------------------------------------------------
-template <typename E>
-AHIP_DEVINL void resolve_member_sym(ParLdsT<E> &P, const u8 *in, const u32 *area, const DirEnt *dir, u32 ndir, E *out_base, u32 *cyc,
-                                    int lane) {
-  static_assert(sizeof(E) == 2, "symbols only: bytes go through resolve_member()");
-  u32 de = 0, df = 0;  // cursor into the token stream: directory entry, tokens of it already consumed
-  u64 opos = 0;
-  while (de < ndir) {
-    AHIP_TICK(t_0);
-    // ---- gather up to TOK_CAP tokens of the next runs into the queue, a whole wave on one run at a time
-    //      (coalesced); a stored block ends the batch (it is handled at a batch head) ----
-    const u32 ei = de + (u32)lane;
-    const DirEnt dv = ei < ndir ? dir[ei] : make_uint4(0u, 0u, 0u, 0u);
-    const u64 sm = __ballot(ei < ndir && (dv.y & DF_STORED) != 0);
-    const u32 nplain = sm ? (u32)__builtin_ctzll(sm) : 64u;
-    if (nplain == 0) {  // stored block at the head (df == 0): input -> output copy
-      const u32 len = lane_bcast(dv.y, 0) & DF_CNT, x = lane_bcast(dv.x, 0);
-      const u64 src = (u64)uniform(area[x]) | ((u64)uniform(area[x + 1]) << 32);
-      for (u32 i = lane; i < len; i += 64) out_base[opos + i] = (E)in[src + i];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      opos += len;
-      de += 1;
-      continue;
-    }
-    const bool mine = ei < ndir && (u32)lane < nplain;
-    const u32 cnt = mine ? (dv.y & DF_CNT) : 0u;
-    const u32 rcnt = lane == 0 ? cnt - df : cnt, roff = lane == 0 ? dv.x + df : dv.x;
-    u32 rtot;
-    const u32 rT = wave_excl_sum(rcnt, rtot);
-    const u32 take = rT < (u32)TOK_CAP ? (rcnt < (u32)TOK_CAP - rT ? rcnt : (u32)TOK_CAP - rT) : 0u;
-    const u32 nrun = (u32)__popcll(__ballot(take != 0));
-    const u32 want = rtot < (u32)TOK_CAP ? rtot : (u32)TOK_CAP;
-    // recorded token + the one before it in the run -> step word
-    auto step_word = [&](u32 t, u32 pw) -> u32 {
-      const u32 len = ((t >> 16) - (pw >> 16)) & 0xffffu;
-      return (t & REC_LIT) ? (TK_LIT | ((t & 0xffu) << 16)) : ((len << 16) | ((t & 0x7fffu) + 1u));
-    };
-    for (u32 j = 0; j < nrun; j += 4) {  // four runs' loads in flight
-      u32 v[4], pv[4], qd[4];
-#pragma unroll
-      for (u32 q = 0; q < 4; ++q) {
-        const int jj = (int)(j + q < nrun ? j + q : nrun - 1);
-        const u32 o_ = lane_bcast(roff, jj), c_ = j + q < nrun ? lane_bcast(take, jj) : 0u, t_ = lane_bcast(rT, jj), x_ = lane_bcast(dv.x, jj);
-        qd[q] = (u32)lane < c_ ? t_ + (u32)lane : 0xffffffffu;
-        v[q] = (u32)lane < c_ ? area[o_ + (u32)lane] : 0u;
-        pv[q] = (lane == 0 && c_ && o_ > x_) ? area[o_ - 1] : 0u;  // the token in front of the piece (lane 0 only)
-        for (u32 u = 64 + (u32)lane; u < c_; u += 64) {  // a long run (the serial decoder's)
-          const u32 t = area[o_ + u];
-          P.tok[t_ + u] = step_word(t, area[o_ + u - 1]);
-        }
-      }
-#pragma unroll
-      for (u32 q = 0; q < 4; ++q) {
-        const u32 before = lane_prev(v[q]);  // (every lane takes part in the shift)
-        if (qd[q] != 0xffffffffu) P.tok[qd[q]] = step_word(v[q], lane == 0 ? pv[q] : before);
-      }
-    }
-    wave_sync();
-    // cursor += adv tokens
-    auto advance = [&](u32 adv) {
-      const u32 nfull = (u32)__popcll(__ballot(mine && rT + rcnt <= adv));  // runs used up (a prefix)
-      const u32 base = nfull < 64 ? lane_bcast(rT, (int)nfull) : rtot;
-      df = nfull ? adv - base : df + adv;
-      de += nfull;
-    };
-    u32 ntok = want;
-    // ---- pass 1 (keys) with the element cut at OB_CAP ----
-    E *g = out_base + opos;
-    const u32 A = 0u;
-    u32 run = 0, kept = 0;
-    for (u32 c = 0; c < ntok; c += 64) {
-      const u32 idx = c + lane;
-      const bool inb = idx < ntok;
-      const u32 t = inb ? P.tok[idx] : 0u;
-      const bool lit = t >> 31;
-      const u32 len = inb ? (lit ? 1u : (t >> 16)) : 0u;
-      u32 total;
-      const u32 off = run + wave_excl_sum(len, total);
-      const bool fits = inb && off + len <= (u32)OB_CAP;
-      const u32 key = (1u << 30) | (off << 17) | (lit ? (0x10000u | ((t >> 16) & 0xff)) : ((t & 0xffff) - 1));
-      if (fits) P.tok[idx] = key;
-      const u64 fm = __ballot(fits), im = __ballot(inb);
-      if (fm != im) {  // the window is full: cut after the last fitting token
-        const u32 nf = (u32)__popcll(fm);
-        kept = c + nf;
-        run = nf ? lane_bcast(off + len, (int)nf - 1) : run;
-        break;
-      }
-      run += total;
-      kept = c + (u32)__popcll(im);
-    }
-    ntok = kept;
-    wave_sync();
-    AHIP_TICK(t_1);
-    AHIP_ACC(cyc[6], t_0, t_1);
-    const u32 nbytes = run;
-    resolve_bytes(P, ntok, nbytes, (const E *)g, opos, A, lane);
-    wave_sync();
-    AHIP_TICK(t_2);
-    AHIP_ACC(cyc[5], t_1, t_2);
-    flush_window(P, g, A, nbytes, lane);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // later batches read this output back
-    opos += nbytes;
-    advance(ntok);
-  }
 }
 
 }  // namespace ahip

@@ -8,6 +8,7 @@
 #include "../../archive_amd/csrc/inflate_par.hpp"
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <thread>
 #include <vector>
 using namespace ahip;
@@ -36,7 +37,12 @@ static const uint8_t LX[29] = {0,0,0,0,0,0,0,0,1,1,1,1,2,2,2,2,3,3,3,3,4,4,4,4,5
 static const uint16_t DB[30] = {1,2,3,4,5,7,9,13,17,25,33,49,65,97,129,193,257,385,513,769,1025,1537,2049,3073,4097,6145,8193,12289,16385,24577};
 static const uint8_t DX[30] = {0,0,0,0,1,1,2,2,3,3,4,4,5,5,6,6,7,7,8,8,9,9,10,10,11,11,12,12,13,13};
 
-static ResLds P;  // the wave's LDS
+#ifdef EMU_SYM   // 16-bit symbols: the member's first part plays "output in front of the chunk", the rest is resolved as a chunk
+typedef u16 Elem;
+#else
+typedef u8 Elem;
+#endif
+static ResLdsT<Elem> P;  // the wave's LDS
 
 int main(int argc, char **argv) {
   if (argc < 2) return 2;
@@ -45,7 +51,7 @@ int main(int argc, char **argv) {
   fseek(f, 0, SEEK_END); n_ = ftell(f); fseek(f, 0, SEEK_SET);
   std::vector<uint8_t> buf(n_ + 64, 0); if (fread(buf.data(), 1, n_, f) != n_) return 2; in_ = buf.data();
   std::vector<uint8_t> out, ref;
-  size_t pos = 0, members = 0; uint64_t toks_total = 0, stored_recs = 0, runs_total = 0;
+  size_t pos = 0, members = 0; uint64_t toks_total = 0, stored_recs = 0, runs_total = 0, markers_total = 0;
   while (pos + 18 <= n_ && in_[pos] == 0x1f && in_[pos + 1] == 0x8b) {
     int flg = in_[pos + 3]; size_t q = pos + 10;
     if (flg & 4) q += 2 + in_[q] + 256 * in_[q + 1];
@@ -103,6 +109,17 @@ int main(int argc, char **argv) {
     std::vector<uint32_t> area; std::vector<DirEnt> dir;
     size_t t = 0, ri = 0;
     uint64_t opos = 0;
+    uint64_t front = 0;  // bytes of the member in front of the resolved part
+#ifdef EMU_SYM
+    {  // skip whole tokens until about a third of the member (at most 40 000 bytes) lies in front of the chunk
+      const uint64_t want_front = std::min<uint64_t>(40000, (ref.size() - out0) / 3);
+      while (t < tok.size() && front < want_front) {
+        if (ri < rec_at.size() && rec_at[ri] == t) { front += tok[t] & 0xffffu; t += 3; ++ri; continue; }
+        front += (int32_t)tok[t] < 0 ? 1u : (tok[t] >> 16);
+        ++t;
+      }
+    }
+#endif
     while (t < tok.size()) {
       seed = seed * 1664525u + 1013904223u;
       while (ri < rec_at.size() && rec_at[ri] < t) ++ri;
@@ -130,23 +147,29 @@ int main(int argc, char **argv) {
       t = end;
     }
     runs_total += dir.size(); toks_total += tok.size();
-    const size_t produced = ref.size() - out0;
-    out.resize(out0 + produced + 64, 0xEE);
+    const size_t produced = ref.size() - out0 - front;
+    std::vector<Elem> eout(produced + 64, (Elem)0xEE);
     u32 cyc_all[64][8] = {};
     std::vector<std::thread> th;
     for (int l = 0; l < 64; ++l)
-      th.emplace_back([&, l]() { wave_emu::lane = l; resolve_member(P, in_, area.data(), dir.data(), (u32)dir.size(), out.data() + out0, cyc_all[l], l); });
+      th.emplace_back([&, l]() { wave_emu::lane = l; resolve_member<Elem>(P, in_, area.data(), dir.data(), (u32)dir.size(), eout.data(), cyc_all[l], l); });
     for (auto &x : th) x.join();
-    out.resize(out0 + produced);
-    if (memcmp(out.data() + out0, ref.data() + out0, produced)) {
-      size_t i = 0; while (out[out0 + i] == ref[out0 + i]) ++i;
-      printf("MISMATCH in member %zu at byte %zu of %zu (got %02x want %02x)\n", members, i, produced, out[out0 + i], ref[out0 + i]);
-      return 1;
+    const uint8_t *want = ref.data() + out0 + front;
+    for (size_t i = 0; i < produced; ++i) {
+      uint32_t v = eout[i];
+      if (sizeof(Elem) == 2 && v >= SYM_MARK) {  // a marker: byte j of the 32 KiB in front of the chunk
+        const int64_t j = (int64_t)v - SYM_MARK, at = (int64_t)front - 32768 + j;
+        if (at < 0 || at >= (int64_t)front) { printf("MARKER out of range in member %zu at %zu: %x (front %llu)\n", members, i, v, (unsigned long long)front); return 1; }
+        v = ref[out0 + (size_t)at];
+        markers_total++;
+      }
+      if (v != want[i]) { printf("MISMATCH in member %zu at element %zu of %zu (got %02x want %02x)\n", members, i, produced, v, want[i]); return 1; }
     }
     members++;
     pos = (size_t)((p + 7) >> 3) + 8;
   }
-  const char *what = "token-centric resolver";
+  const char *what = sizeof(Elem) == 2 ? "token-centric resolver, 16-bit symbols" : "token-centric resolver";
+  if (sizeof(Elem) == 2) printf("markers checked: %llu\n", (unsigned long long)markers_total);
   printf("resolver emu ok [%s]: %zu members, %zu bytes, %llu token words in %llu runs, %llu stored records\n", what, members, ref.size(),
          (unsigned long long)toks_total, (unsigned long long)runs_total, (unsigned long long)stored_recs);
   return members ? 0 : 7;

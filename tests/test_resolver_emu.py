@@ -4,7 +4,9 @@
 tests/emu/resolver_emu.cc, cut into runs of random length like the tokenizer's directory (stored blocks as directory
 entries of their own, some runs flagged DF_BIG), and the result is compared byte for byte with a sequential LZ77 replay.
 Builds: the production window geometry, a small window (chunks split at the window's end all the time), a large one, and a
-large one with a short list of deferred matches (chunks split where the list is full)."""
+large one with a short list of deferred matches (chunks split where the list is full); and the 16-bit symbol form of the
+chunked single-stream decode: the first part of every member lies "in front of the chunk", what refers to it must come out
+as markers that point at the right bytes."""
 import os
 import random
 import subprocess
@@ -27,7 +29,8 @@ def _binary(variant):
     if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps):
         flags = {"production": [], "small_window": ["-DAHIP_WIN_CAP=1024", "-DAHIP_WIN_KEEP=400"],
                  "big_window": ["-DAHIP_WIN_CAP=8192", "-DAHIP_WIN_KEEP=2048"],
-                 "small_pending": ["-DAHIP_WIN_CAP=8192", "-DAHIP_WIN_KEEP=512", "-DAHIP_PEND_CAP=128"]}[variant]
+                 "small_pending": ["-DAHIP_WIN_CAP=8192", "-DAHIP_WIN_KEEP=512", "-DAHIP_PEND_CAP=128"],
+                 "symbols": ["-DEMU_SYM"], "symbols_small_window": ["-DEMU_SYM", "-DAHIP_WIN_CAP=1024", "-DAHIP_WIN_KEEP=400"]}[variant]
         cmd = ["g++", "-std=c++17", "-O2", "-pthread", "-o", exe, src] + flags
         subprocess.check_call(cmd)
     return exe
@@ -60,7 +63,7 @@ def _corpus():
     return blob, sum(len(p) for p, _ in parts), len(parts)
 
 
-@pytest.mark.parametrize("variant", ["production", "small_window", "big_window", "small_pending"])
+@pytest.mark.parametrize("variant", ["production", "small_window", "big_window", "small_pending", "symbols", "symbols_small_window"])
 def test_resolver_device_code_on_the_cpu(tmp_path, variant):
     exe = _binary(variant)
     blob, total, members = _corpus()
@@ -70,3 +73,5 @@ def test_resolver_device_code_on_the_cpu(tmp_path, variant):
         r = subprocess.run([exe, str(path), str(seed)], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
         assert "resolver emu ok" in r.stdout and "%d members, %d bytes" % (members, total) in r.stdout, r.stdout
+        if variant.startswith("symbols"):
+            assert int(r.stdout.split("markers checked:")[1].split()[0]) > 1000, r.stdout
