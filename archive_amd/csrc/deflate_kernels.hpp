@@ -102,7 +102,7 @@ AHIP_DEVINL void df_match_lens(const u32 *ring, const u32 (&rc)[NW], u32 rp, u32
     const u64 pw = df_rd8(ring, rp + l);
     u64 cw[NW];
 #pragma unroll
-    for (int k = 0; k < NW; ++k) cw[k] = df_rd8(ring, rc[k] + l);  // dead candidates read too: masking them was measured slower
+    for (int k = 0; k < NW; ++k) cw[k] = df_rd8(ring, rc[k] + l);  // dead candidates read too: masking them (per lane, or per candidate with a wave vote) was measured slower
     any = false;
     const u32 room = maxl - l;  // > 0
 #pragma unroll
