@@ -97,14 +97,17 @@ AHIP_DEVINL u32 next_member(u32 *next, int lane) {
   if (lane == 0) k = atomicAdd(next, 1u);
   return uniform(k);  // lane 0's value
 }
-template <bool KEEP>
+// keep != 0: a sizing run that keeps its tokens, laid out along the input (InLayout).  A run-time flag, not a template
+// parameter: as a second instance the same code came out of the register allocator five VGPRs over its budget, and
+// the scratch that cost held the kernel to ~ 7 of its 10 waves per CU (14.4 against 9.6 ms on config 4 without BC).
 __global__ __launch_bounds__(64, AHIP_TOK_MIN_WAVES) void inflate_tokenize_kernel(const u8 *__restrict__ in, u64 in_len,
                                                              const MemberDesc *__restrict__ members, u32 first_member,
                                                              u32 n_members, u32 *__restrict__ tokens, DirEnt *__restrict__ dir,
                                                              u64 group_out0, MemberResult *__restrict__ results,
-                                                             u32 *__restrict__ late, InLayout lay, MemberSel sel) {
+                                                             u32 *__restrict__ late, InLayout lay, MemberSel sel, u32 keep) {
   __shared__ TokKernelLds lds;
   const int lane = threadIdx.x;
+  const bool KEEP = uniform(keep) != 0;
   for (u32 k = next_member(late + 1, lane); k < n_members; k = next_member(late + 1, lane)) {
     const u32 m = member_index(sel, first_member, k);
     MemberDesc d = members[m];
@@ -117,11 +120,17 @@ __global__ __launch_bounds__(64, AHIP_TOK_MIN_WAVES) void inflate_tokenize_kerne
     const u64 lim = uniform64(d.in_end) ? uniform64(d.in_end) : in_len;
     const bool sizing = !tokens || KEEP;
     TokSink sk = KEEP ? candidate_sink(tokens, dir, lay, m)
-                         : member_sink(tokens, dir, sel.ids ? uniform64(sel.rel[k]) : d.out_off - group_out0, d.out_limit, k);
+                      : member_sink(tokens, dir, sel.ids ? uniform64(sel.rel[k]) : d.out_off - group_out0, d.out_limit, k);
     // keep the sink in scalar registers whichever layout made it
     sk.col_cap = uniform(sk.col_cap);
     sk.dir_cap = uniform(sk.dir_cap);
+#ifdef AHIP_MEMBER_CYC
+    const u64 t0 = __builtin_readcyclecounter();
+#endif
     inflate_member<false, true>(lds.w, hdr, &lds.p, in, lim, d, (u8 *)nullptr, sk, results[m], lane);
+#ifdef AHIP_MEMBER_CYC
+    if (lane == 0) results[m].fallbacks = (u32)((__builtin_readcyclecounter() - t0) >> 4);
+#endif
     // rare: inflate_late_kernel finishes these (a sizing run only cares about the ones whose size it does not know yet)
     if (lane == 0 && (sizing ? results[m].status == MS_OVERSUB : member_is_late(results[m]))) atomicAdd(late, 1u);
   }
@@ -367,7 +376,7 @@ hipError_t launch_inflate_group(const u8 *in, u64 n, const MemberDesc *members, 
     if (e != hipSuccess) return e;
     e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (e != hipSuccess) return e;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, inflate_tokenize_kernel<false>, 64, 0);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, inflate_tokenize_kernel, 64, 0);
     if (e != hipSuccess) return e;
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, inflate_resolve_kernel<false>, 64, 0);
     if (e != hipSuccess) return e;
@@ -412,11 +421,11 @@ hipError_t launch_inflate_group(const u8 *in, u64 n, const MemberDesc *members, 
   e = hipMemsetAsync(dlate.p, 0, 64, st);  // [0] late members, [1] / [2] the tokenizer's / resolver's next member
   if (e != hipSuccess) return e;
   if (lay.pos)
-    hipLaunchKernelGGL(inflate_tokenize_kernel<true>, dim3(grid1), dim3(64), 0, st, in, n, members, first, count, (u32 *)tp, (DirEnt *)dp,
-                       out0, res, dlate.as<u32>(), lay, MemberSel{nullptr, nullptr});
+    hipLaunchKernelGGL(inflate_tokenize_kernel, dim3(grid1), dim3(64), 0, st, in, n, members, first, count, (u32 *)tp, (DirEnt *)dp,
+                       out0, res, dlate.as<u32>(), lay, MemberSel{nullptr, nullptr}, 1u);
   else
-    hipLaunchKernelGGL(inflate_tokenize_kernel<false>, dim3(grid1), dim3(64), 0, st, in, n, members, first, count, (u32 *)tp, (DirEnt *)dp,
-                       out0, res, dlate.as<u32>(), lay, MemberSel{nullptr, nullptr});
+    hipLaunchKernelGGL(inflate_tokenize_kernel, dim3(grid1), dim3(64), 0, st, in, n, members, first, count, (u32 *)tp, (DirEnt *)dp,
+                       out0, res, dlate.as<u32>(), lay, MemberSel{nullptr, nullptr}, 0u);
   if (WRITE) {
     const u32 grid2 = count < (u32)res_resident ? count : (u32)res_resident;
     hipLaunchKernelGGL(inflate_resolve_kernel<false>, dim3(grid2), dim3(64), 0, st, in, members, first, count, out,
@@ -468,8 +477,8 @@ hipError_t launch_inflate_listed(const u8 *in, u64 n, const MemberDesc *members,
   if (e != hipSuccess) return e;
   const MemberSel sel{ids, rel};
   const u32 r1 = tok_resident > 0 ? (u32)tok_resident : 2048u, r2 = res_resident > 0 ? (u32)res_resident : 4096u;
-  hipLaunchKernelGGL(inflate_tokenize_kernel<false>, dim3(count < r1 ? count : r1), dim3(64), 0, st, in, n, members, 0u, count,
-                     g_tokens2.as<u32>(), g_scratch2.as<DirEnt>(), (u64)0, res, g_late.as<u32>(), InLayout{nullptr, 0, n}, sel);
+  hipLaunchKernelGGL(inflate_tokenize_kernel, dim3(count < r1 ? count : r1), dim3(64), 0, st, in, n, members, 0u, count,
+                     g_tokens2.as<u32>(), g_scratch2.as<DirEnt>(), (u64)0, res, g_late.as<u32>(), InLayout{nullptr, 0, n}, sel, 0u);
   hipLaunchKernelGGL(inflate_resolve_kernel<false>, dim3(count < r2 ? count : r2), dim3(64), 0, st, in, members, 0u, count, out,
                      (const u32 *)g_tokens2.p, (const DirEnt *)g_scratch2.p, (u64)0, res, InLayout{nullptr, 0, n},
                      (const MemberResult *)nullptr, sel, g_late.as<u32>() + 2);
@@ -648,6 +657,27 @@ int32_t plan_build(ahip_gzip_plan *pl, bool force_sizing, hipStream_t st) {
     for (auto &mr : measured)
       HIP_TRY(hipMemcpyAsync(pl->sizing_results.as<MemberResult>() + mr.first, &mr.second, sizeof(MemberResult), hipMemcpyHostToDevice, st));
     if (!measured.empty()) HIP_TRY(hipStreamSynchronize(st));
+    if (getenv("AHIP_DEBUG_SIZING")) {  // what the candidates turned out to be (and, in -DAHIP_MEMBER_CYC builds, what they cost)
+      std::vector<MemberResult> rr(K);
+      std::vector<u64> cp(K);
+      HIP_TRY(hipMemcpyAsync(rr.data(), pl->sizing_results.p, (size_t)K * sizeof(MemberResult), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(cp.data(), pl->cand_pos.p, (size_t)K * 8, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      u32 hist[16] = {0};
+      std::vector<u32> order(K);
+      for (u32 i = 0; i < K; ++i) { hist[rr[i].status & 15]++; order[i] = i; }
+      std::sort(order.begin(), order.end(), [&](u32 a, u32 b) { return rr[a].fallbacks > rr[b].fallbacks; });
+      fprintf(stderr, "[ahip] sizing: K=%u status histogram", K);
+      for (int q = 0; q < 16; ++q) if (hist[q]) fprintf(stderr, " %d:%u", q, hist[q]);
+      fprintf(stderr, "\n");
+      for (u32 j = 0; j < K && j < 12; ++j) {
+        const MemberResult &r = rr[order[j]];
+        fprintf(stderr, "[ahip]   cand %u at %llu: cyc/16 %u status %u blocks %u(0x%x) out %llu end %llu runs %llu\n", order[j],
+                (unsigned long long)cp[order[j]], r.fallbacks, r.status, r.blocks & 0xffffff, r.blocks >> 24, (unsigned long long)r.out_len,
+                (unsigned long long)r.end_pos, (unsigned long long)r.tok_words);
+      }
+      if (K > 24) { const MemberResult &r = rr[order[K / 2]]; fprintf(stderr, "[ahip]   median cyc/16 %u out %llu\n", r.fallbacks, (unsigned long long)r.out_len); }
+    }
     hipLaunchKernelGGL(gz_apply_sizing, dim3(cdiv(K, 256)), dim3(256), 0, st, pl->hdr.as<GzHeader>(), K,
                        pl->sizing_results.as<MemberResult>(), n);
     pl->sized = true;

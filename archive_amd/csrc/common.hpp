@@ -122,6 +122,13 @@ AHIP_DEVINL void wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// number of set bits of a wave mask below this lane (v_mbcnt: no per-lane 64-bit mask to keep in registers)
+#ifdef AHIP_HOST_EMU
+AHIP_DEVINL u32 wave_rank(u64 mask) { return (u32)__builtin_popcountll(mask & ((1ull << wave_emu::lane) - 1)); }
+#else
+AHIP_DEVINL u32 wave_rank(u64 mask) { return __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u)); }
+#endif
+
 AHIP_DEVINL u32 uniform(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
 AHIP_DEVINL u64 uniform64(u64 v) {
   u32 lo = uniform((u32)v), hi = uniform((u32)(v >> 32));

@@ -115,8 +115,8 @@ struct TokSink {
   u32 scol, spos, srun;  // serial writer: its column (~0u: none yet), next word, first word of the open run
   bool full;
   bool sizing;  // a sizing run that keeps its tokens: a full sink is reported as MR_FAR next to the true status
-  u64 sbase;    // serial writer: output offset (member-relative) of the open run's first byte
-  u32 sbytes;   //   bytes the open run has produced
+  u32 sbytes;   // serial writer: bytes the open run has produced (its first byte's output offset is not kept: the
+                //   callers know where the output stands, out_rel, and the run starts sbytes in front of that)
 };
 // member k of a launch group whose output starts out_rel bytes into the group's output
 AHIP_DEVINL void tok_layout(u64 out_rel, u64 out_limit, u32 k, u64 &tok_off, u32 &col_cap, u64 &dir_off, u32 &dir_cap) {
@@ -222,33 +222,32 @@ constexpr u32 LR_EOB = 1, LR_ERR = 2;  // how a run ended before its boundary
 
 // ---- the serial writer: one lane-uniform token at a time into the free space of the columns ----
 // Its runs are always flagged DF_BIG (they may be of any length; the resolver takes their offsets from a prefix sum).
-AHIP_DEVINL void sink_close(TokSink &k, u32 *colpos, int lane) {  // close the open run, note how far its column is used
+AHIP_DEVINL void sink_close(TokSink &k, u32 *colpos, int lane, u64 out_rel) {  // close the open run (out_rel: output produced so far), note how far its column is used
   if (!k.area || k.scol >= 64) return;
   if (k.spos > k.srun) {
     if (k.ndir < k.dir_cap) {
-      if (lane == 0) k.dir[k.ndir] = make_uint4(k.srun, (k.spos - k.srun) | DF_BIG, (u32)k.sbase, (u32)(k.sbase >> 32));
+      const u64 base = out_rel - k.sbytes;
+      if (lane == 0) k.dir[k.ndir] = make_uint4(k.srun, (k.spos - k.srun) | DF_BIG, (u32)base, (u32)(base >> 32));
       k.ndir++;
     } else k.full = true;
   }
   if (lane == 0) colpos[k.scol] = k.spos - k.scol * k.col_cap;
   wave_sync();
   k.srun = k.spos;
-  k.sbase += k.sbytes;
   k.sbytes = 0;
 }
-// (re)start at output offset `out_rel`: the flow decoder may have used this column meanwhile
-AHIP_DEVINL void sink_open(TokSink &k, const u32 *colpos, u64 out_rel) {
-  k.sbase = out_rel;
+// (re)start: the flow decoder may have used this column meanwhile
+AHIP_DEVINL void sink_open(TokSink &k, const u32 *colpos) {
   k.sbytes = 0;
   if (!k.area || k.scol >= 64) return;
   k.spos = k.scol * k.col_cap + uniform(colpos[k.scol]);
   k.srun = k.spos;
 }
-AHIP_DEVINL bool sink_room(TokSink &k, u32 *colpos, u32 words, int lane) {  // `words` contiguous words
+AHIP_DEVINL bool sink_room(TokSink &k, u32 *colpos, u32 words, int lane, u64 out_rel) {  // `words` contiguous words
   for (;;) {
     if (k.scol < 64 && k.spos + words <= (k.scol + 1) * k.col_cap && k.spos - k.srun < (1u << 22)) return true;
     const bool split = k.scol < 64 && k.spos + words <= (k.scol + 1) * k.col_cap;  // only the run got too long
-    sink_close(k, colpos, lane);
+    sink_close(k, colpos, lane, out_rel);
     if (split) continue;
     k.scol += 1;  // ~0u -> 0
     if (k.scol >= 64) { k.scol = 64; k.full = true; return false; }
@@ -256,10 +255,11 @@ AHIP_DEVINL bool sink_room(TokSink &k, u32 *colpos, u32 words, int lane) {  // `
     k.srun = k.spos;
   }
 }
-// one token: `step_word` as the decode step makes it (literal / match), `adv` the bytes it produces
-AHIP_DEVINL void sink_put(TokSink &k, u32 *colpos, u32 step_word, u32 adv, int lane) {
+// one token: `step_word` as the decode step makes it (literal / match), `adv` the bytes it produces; out_rel = the
+// output offset in FRONT of it
+AHIP_DEVINL void sink_put(TokSink &k, u32 *colpos, u32 step_word, u32 adv, int lane, u64 out_rel) {
   if (!k.area || k.full) return;
-  if (!sink_room(k, colpos, 1, lane)) return;
+  if (!sink_room(k, colpos, 1, lane, out_rel)) return;
   k.sbytes += adv;
   if (lane == 0) k.area[k.spos] = rec_word(k.sbytes, step_word);
   k.spos += 1;
@@ -277,7 +277,7 @@ AHIP_DEVINL u32 huffman_token_emit(WaveLds &L, BitCursor &b, OutCursor &o, TokSi
   if (e & (E_LIT | E_EOB | E_BAD | E_HOLE)) {
     if (e & E_LIT) {
       if (o.pos >= o.limit) return 100 + MS_CAP;
-      sink_put(sink, colpos, e & 0xffff0000u, 1u, lane);  // (0x8000 | byte) << 16
+      sink_put(sink, colpos, e & 0xffff0000u, 1u, lane, o.pos - o.org);  // (0x8000 | byte) << 16
       o.pos += 1;
       b.pos += cl;
       return 0;
@@ -307,13 +307,13 @@ AHIP_DEVINL u32 huffman_token_emit(WaveLds &L, BitCursor &b, OutCursor &o, TokSi
   if ((u64)dist > o.pos) return 100 + MS_FARREF;
   if (o.pos + (u64)len > o.limit) return 100 + MS_CAP;
   if ((u64)dist > o.pos - o.hist) o.far = 1;
-  sink_put(sink, colpos, ((u32)len << 16) | (u32)dist, (u32)len, lane);
+  sink_put(sink, colpos, ((u32)len << 16) | (u32)dist, (u32)len, lane, o.pos - o.org);
   o.pos += (u64)len;
   return 0;
 }
 AHIP_DEVINL u32 huffman_block_emit(WaveLds &L, BitCursor &b, OutCursor &o, TokSink &sink, u32 *colpos, int lane) {
   const u32 ll_max = L.lld.maxlen, d_max = L.dd.maxlen;
-  sink_open(sink, colpos, o.pos - o.org);
+  sink_open(sink, colpos);
   u32 rs;
   for (;;) {
     u32 r;
@@ -323,7 +323,7 @@ AHIP_DEVINL u32 huffman_block_emit(WaveLds &L, BitCursor &b, OutCursor &o, TokSi
     rs = r == 1 ? (u32)MS_OK : r - 100;
     break;
   }
-  sink_close(sink, colpos, lane);
+  sink_close(sink, colpos, lane, o.pos - o.org);
   return rs;
 }
 // _parseUncompressedBlock as a directory entry: a block of >= 3 bytes becomes one DF_STORED entry (two area words hold
@@ -338,24 +338,26 @@ AHIP_DEVINL u32 stored_block_emit(BitCursor &b, OutCursor &o, TokSink &sink, u32
   u64 byte = b.pos >> 3;
   if ((u64)len > b.in_len - byte) return MS_FALSE;
   if (o.pos + (u64)len > o.limit) return MS_CAP;
-  sink_open(sink, colpos, o.pos - o.org);
+  sink_open(sink, colpos);
+  const u64 out_rel = o.pos - o.org;
   if (len >= 3) {
-    if (sink.area && !sink.full && sink_room(sink, colpos, 2, lane)) {
+    if (sink.area && !sink.full && sink_room(sink, colpos, 2, lane, out_rel)) {
       if (sink.ndir < sink.dir_cap) {
         if (lane == 0) {
           sink.area[sink.spos] = (u32)byte;
           sink.area[sink.spos + 1] = (u32)(byte >> 32);
-          sink.dir[sink.ndir] = make_uint4(sink.spos, (u32)len | DF_STORED, (u32)sink.sbase, (u32)(sink.sbase >> 32));
+          sink.dir[sink.ndir] = make_uint4(sink.spos, (u32)len | DF_STORED, (u32)out_rel, (u32)(out_rel >> 32));
         }
         sink.ndir++;
       } else sink.full = true;
       sink.spos += 2;
       sink.srun = sink.spos;  // the two words belong to the entry above, not to a token run
     }
+    sink_close(sink, colpos, lane, out_rel);
   } else {
-    for (int i = 0; i < len; ++i) sink_put(sink, colpos, TK_LIT | ((u32)b.in[byte + i] << 16), 1u, lane);
+    for (int i = 0; i < len; ++i) sink_put(sink, colpos, TK_LIT | ((u32)b.in[byte + i] << 16), 1u, lane, out_rel + (u64)i);
+    sink_close(sink, colpos, lane, out_rel + (u64)len);
   }
-  sink_close(sink, colpos, lane);
   o.pos += (u64)len;
   b.pos += 8ull * (u64)len;
   return MS_OK;
@@ -388,10 +390,9 @@ AHIP_DEVINL u32 stored_block_emit(BitCursor &b, OutCursor &o, TokSink &sink, u32
 // hands the rest of the block to the serial decoder, which restates the reference symbol by symbol.
 AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutCursor &o, TokSink &sink, int lane,
                                        ParStats &st, u64 hint_end_bits) {
-  const bool emit = sink.area != nullptr;
+  bool emit = sink.area != nullptr && !sink.full;
   constexpr u32 SLACK_DW = 4;  // a token may run 48 bits past its item and the reader looks two dwords ahead
   constexpr u32 SUB = SUB_BITS;
-  const u64 lt_mask = (1ull << lane) - 1;
   u32 eguard = 0;
   for (;;) {  // epochs: positions are 32-bit offsets from the epoch origin
     if (++eguard > (1u << 16)) { st.dbg |= 1; break; }
@@ -429,7 +430,7 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
     u32 rowctr = P.colpos[lane];  // words this lane has recorded into its column of the token area
     i32 need = 0;
     LaneBits d{0, 0, 0, 0, 2};
-    u32 *const col = sink.area + (u32)lane * sink.col_cap;
+    const u32 colbase = (u32)lane * sink.col_cap;  // this lane's column of the member's token area (words)
     u32 rot = 0;  // rotates which idle lanes take the recording runs, so that the columns fill evenly
     u32 guard = 0;
     for (;;) {
@@ -496,6 +497,9 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
         const u32 nh = (u32)__popcll(hm);
         const bool bad_cap = (u64)tot_bytes > o.limit - o.pos;         // output window exhausted
         const bool bad_far = __any(mine && (u64)nd > o.pos + B) != 0;  // back-reference before the start of the output
+        // (a sizing run that keeps its tokens only has the room the COMPRESSED size suggests: when that runs out the
+        //  tokens are given up -- the member is tokenized again by the decode proper -- and the flow goes on counting)
+        if (emit && sink.sizing && sink.ndir + nh > sink.dir_cap) { sink.full = true; emit = false; }
         const bool bad_dir = emit && sink.ndir + nh > sink.dir_cap;    // directory full
         if (bad_cap || bad_far || bad_dir) {
           st.fallbacks++;
@@ -508,7 +512,7 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
         if (emit) {
           if (mine && cnt != 0) {
             const u64 ob = o.pos - o.org + B;  // where the run's first byte goes, counted from the member's own first byte
-            sink.dir[sink.ndir + (u32)__popcll(hm & lt_mask)] =
+            sink.dir[sink.ndir + wave_rank(hm)] =
                 make_uint4(cl * sink.col_cap + r0, cnt | (nby > 0xffffu ? DF_BIG : 0u), (u32)ob, (u32)(ob >> 32));
           }
           sink.ndir += nh;
@@ -523,7 +527,10 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
         wave_sync();
       }
       // a recording lane must not run out of column: the serial decoder takes over with what all columns have left
-      if (emit && !finishing && __any(rowctr + (u32)STEPS > sink.col_cap)) { st.fallbacks++; st.dbg |= 32; stop_serial = true; }
+      if (emit && !finishing && __any(rowctr + (u32)STEPS > sink.col_cap)) {
+        if (sink.sizing) { sink.full = true; emit = false; }
+        else { st.fallbacks++; st.dbg |= 32; stop_serial = true; }
+      }
       AHIP_TICK(t_s2);
       AHIP_ACC(st.cyc[4], t_s1, t_s2);
       if (stop_serial || (finishing && retired == V)) break;
@@ -534,7 +541,7 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
         if (im) {
           const u32 nidle = (u32)__popcll(im);
           if (rot >= nidle) rot = 0;
-          u32 rank = (u32)__popcll(im & lt_mask) + rot;
+          u32 rank = wave_rank(im) + rot;
           rank = rank >= nidle ? rank - nidle : rank;
           rot += 7;
           const u32 stage_items = (stage_hi - SLACK_DW) / SUB_DW;  // items whose bits (+ slack) are in the ring
@@ -544,9 +551,11 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
           const u64 rm2 = __ballot(rr);
           const u32 nrr = (u32)__popcll(rm2);
           const u32 na = nrr < nidle ? nrr : nidle;
-          const u32 rr_rank = (u32)__popcll(rm2 & lt_mask);
+          const u32 rr_rank = wave_rank(rm2);
           if (rr && rr_rank < na) { P.q[rr_rank] = pend; P.fa[(pend / SUB) & ITEM_MASK] = 1u << 30; }
-          st.rounds += na;
+#ifdef AHIP_PROFILE
+          st.rounds += na;  // (repairs: a diagnostic)
+#endif
           // (b) runs whose predicted start is known: consecutive items from next_fix
           const u32 sb = next_fix + (u32)lane;
           const bool okb = sb < lim && (P.spec[(sb - 1) & ITEM_MASK] & 0xc000u) == 0xc000u;
@@ -603,7 +612,7 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
             const i32 req = (i32)(t & 0xffff) - (i32)nbytes;  // (a literal has no distance: never positive)
             need = req > need ? req : need;
             nbytes += lit ? 1u : (t >> 16);
-            if (ms >> 29) { if (emit) col[rowctr] = rec_word(nbytes, t); rowctr += 1; }
+            if (ms >> 29) { if (emit) sink.area[colbase + rowctr] = rec_word(nbytes, t); rowctr += 1; }
           }
         }
         ++g;

@@ -232,11 +232,16 @@ AHIP_DEVINL bool build_decode_table(const u8 *lens, int n, u32 *primary, int roo
   }
   wave_sync();
   // symbols -> primary / second-level entries
+  // (the entry of symbol c * 64 + lane depends on the lane alone, and the compiler would compute all of them once per
+  //  kernel and keep them in a dozen VGPRs across the whole decode -- the registers the flow decoder is short of:
+  //  the pin makes them local to this table build)
+  u32 ln = (u32)lane;
+  AHIP_PIN(ln);
 #pragma unroll
   for (int c = 0; c < CHUNKS; ++c) {
     u32 l = mylen[c];
     if (l) {
-      u32 s = c * 64 + lane;
+      u32 s = c * 64 + ln;
       u32 cde = cd.first[l] + myrank[c];
       const u32 e = IS_DIST ? dist_entry(s, l) : litlen_entry(s, l);
       if ((int)l <= root) {
