@@ -47,6 +47,7 @@ struct BzResult {
 };
 
 // ---- B0: magic scan ----
+#ifndef AHIP_HOST_EMU
 __global__ __launch_bounds__(256) void bz_scan_magic(const u8 *__restrict__ in, u64 n, BzCand *cands, u32 *count, u32 cap) {
   const u64 p = (u64)blockIdx.x * 256 + threadIdx.x;  // byte offset
   if (p + 6 > n) return;
@@ -63,6 +64,8 @@ __global__ __launch_bounds__(256) void bz_scan_magic(const u8 *__restrict__ in, 
     }
   }
 }
+
+#endif
 
 // ---- MSB-first bit reader over global memory (Bz2BitReader) ----
 // 64-bit left-aligned buffer refilled 32 bits at a time: one global load per ~4 symbols instead of
@@ -105,6 +108,7 @@ AHIP_DEVINL u32 bz_bits(BzBits &b, u32 nb) {  // nb <= 24
 }
 
 constexpr u32 BZ_FAST_BITS = 10;
+constexpr u32 BZ_RING = 512;
 struct BzLds {
   i32 limit[6][24], base[6][24];
   u16 perm[6][258];
@@ -114,6 +118,7 @@ struct BzLds {
   // fast[t][p]: what the reference's limit/base/perm loop does with the 10-bit pattern p, precomputed:
   // symbol << 5 | length; 0 = no code of <= 10 bits matches (or an invalid index): take the exact loop
   u16 fast[6][1u << BZ_FAST_BITS];
+  u32 ring[BZ_RING];  // the stream ahead of the symbol loop, as big-endian dwords
 };
 
 // Wave-uniform bit reader for the symbol loop: the stream is fetched 64 dwords at a time (one per lane,
@@ -166,29 +171,22 @@ AHIP_DEVINL u32 bzf_bits(BzFast &f, u32 nb, int lane) {  // nb <= 24; the refere
   return v;
 }
 
-// one wave per candidate block
-__global__ __launch_bounds__(64) void bz_decode_block(const u8 *__restrict__ in, u64 n, const BzCand *__restrict__ cands,
-                                                      u32 ncand, u32 block_size100k, u32 *__restrict__ tt_all,
-                                                      u8 *__restrict__ sel_all,
-                                                      BzResult *__restrict__ results) {
-  __shared__ BzLds L;
-  const u32 blk = blockIdx.x, lane = threadIdx.x;
-  if (blk >= ncand) return;
+// one wave per candidate block (a device function: tests/emu/bzip2_emu.cc runs it on the CPU wave emulation)
+AHIP_DEVINL void bz_decode_block_wave(BzLds &L, const u8 *__restrict__ in, u64 n, const BzCand cand, u32 block_size100k,
+                                      u32 *__restrict__ tt, u8 *__restrict__ sel, BzResult &out, const u32 lane) {
   const u32 nblock_max = 100000u * block_size100k;
-  u32 *tt = tt_all + (u64)blk * nblock_max;
-  u8 *sel = sel_all + (u64)blk * BZ_MAX_SELECTORS;
   BzResult R{0, 0, BZ_ST_OK, 0, 0, 0, 0, 0};
   BzBits b{in, n, 0, false, 0, 0, 0};
-  bz_seek(b, cands[blk].bit + 48);
+  bz_seek(b, cand.bit + 48);
   u32 status = BZ_ST_OK;
   u32 nblock = 0, orig_ptr = 0;
-  if (cands[blk].kind != 0) {  // end-of-stream marker: just the combined CRC
+  if (cand.kind != 0) {  // end-of-stream marker: just the combined CRC
     u32 c = bz_bits(b, 16);
     c = (c << 16) | bz_bits(b, 16);
     R.stored_crc = c;
     R.end_bit = b.bit;
     R.status = b.fault ? BZ_ST_RANGE : BZ_ST_OK;
-    if (lane == 0) results[blk] = R;
+    out = R;
     return;
   }
   {
@@ -252,6 +250,8 @@ __global__ __launch_bounds__(64) void bz_decode_block(const u8 *__restrict__ in,
       if (b.fault) { status = BZ_ST_RANGE; break; }
       if (bad) { status = BZ_ST_FALSE; break; }
     }
+    // (the reference's tables are fresh, zero-filled arrays for every block: a damaged code can index perm past its symbols)
+    for (u32 i = lane; i < 6 * 258; i += 64) (&L.perm[0][0])[i] = 0;
     wave_sync();
     // _hbCreateDecodeTables, one lane (tiny)
     if (lane == 0) {
@@ -292,102 +292,157 @@ __global__ __launch_bounds__(64) void bz_decode_block(const u8 *__restrict__ in,
       }
     }
     wave_sync();
-    // MTF list and seqToUnseq in registers: lane l holds entries 4l .. 4l+3 (byte j = entry 4l + j)
-    u32 mtf = (4u * lane) | ((4u * lane + 1) << 8) | ((4u * lane + 2) << 16) | ((4u * lane + 3) << 24);
-    const u32 s2u = L.seq2unseq[4 * lane] | ((u32)L.seq2unseq[4 * lane + 1] << 8) | ((u32)L.seq2unseq[4 * lane + 2] << 16) |
-                    ((u32)L.seq2unseq[4 * lane + 3] << 24);
-    BzFast f;
-    bzf_init(f, in, n, b.bit, lane);
-    // selectors: 64 at a time, one per lane
-    u32 selv = sel[lane < nsel ? lane : 0];
+    // ---- the symbol loop ----
+    // Serial by nature (a code's position is the end of the one before, the list is updated by every symbol), but
+    // not one LDS round trip per symbol: the 128 bit positions from the current one are looked up at once (lane l:
+    // positions l and l + 64, ten bits each, against the current group's table), and the chain through them --
+    // position -> its entry -> the next position -- runs on scalar registers with v_readlane; a window ends after
+    // 128 bits or with the group of 50 symbols (the next one has another table).  Codes longer than ten bits and
+    // the last bits of the input take the reference's bit-by-bit loop, read from global memory.
+    // The MTF list lives in four registers, entry 64 j + lane in m[j], already mapped through seqToUnseq (the
+    // reference maps on output: the same bytes); an index below 64 -- almost always -- costs a v_readlane and a
+    // wave_shr DPP move under a lane mask.
+    u32 m0 = lane < num_in_use ? L.seq2unseq[lane] : 0u, m1 = lane + 64 < num_in_use ? L.seq2unseq[lane + 64] : 0u;
+    u32 m2 = lane + 128 < num_in_use ? L.seq2unseq[lane + 128] : 0u, m3 = lane + 192 < num_in_use ? L.seq2unseq[lane + 192] : 0u;
+    const u64 nbits = n * 8;
+    u64 bit = b.bit;
+    auto stream_word = [&](u64 idx) -> u32 {  // dword idx of the stream as a big-endian value, zeros behind the end
+      const u64 off = idx * 4;
+      if (off + 4 <= n) return __builtin_bswap32(*(const u32 *)(in + off));  // `in` is device-allocated: aligned
+      u32 w = 0;
+      for (int k = 0; k < 4; ++k) w = (w << 8) | (off + k < n ? in[off + k] : 0u);
+      return w;
+    };
+    constexpr u32 RM = BZ_RING - 1;
+    u64 ring_hi = bit >> 5;  // dwords [ring_hi - BZ_RING, ring_hi) are in the ring; `nxt` is the batch after
+    L.ring[(u32)(ring_hi + lane) & RM] = stream_word(ring_hi + lane);
+    L.ring[(u32)(ring_hi + 64 + lane) & RM] = stream_word(ring_hi + 64 + lane);
+    ring_hi += 128;
+    u32 nxt = stream_word(ring_hi + lane);
+    auto peek_global = [&](u64 at, u32 nb) -> u32 {  // 1 <= nb <= 24 bits at `at`, all inside the input
+      const u64 by = at >> 3;
+      u32 w = 0;
+      for (int k = 0; k < 4; ++k) w = (w << 8) | (by + k < n ? (u32)in[by + k] : 0u);
+      return uniform((w << ((u32)at & 7)) >> (32 - nb));
+    };
+    u32 selv = sel[lane < nsel ? lane : 0];  // selectors: 64 at a time, one per lane
     const u32 eob = num_in_use + 1;
     i32 group_no = -1;
     u32 group_pos = 0, gsel = 0;
-    i32 gmin = 0;
-    auto get_mtf_val = [&]() -> i32 {
+    u32 pend = 0;        // tt[] stores are gathered 64 at a time: lane k keeps the byte for index 64 j + k
+    u32 es = 0, N = 0;   // the zero run being read (N = 0: none)
+    u32 stop = 0;  // 1 end of block, 2 bad data (false), 3 read past the end (RangeError)
+    auto put_run = [&](u32 v, u32 cnt) {
+      while (cnt) {
+        const u32 off = nblock & 63, take = cnt < 64 - off ? cnt : 64 - off;
+        if ((u32)lane - off < take) pend = v;
+        nblock += take; cnt -= take;
+        if ((nblock & 63) == 0) tt[nblock - 64 + lane] = pend;
+      }
+    };
+    auto mtf_take = [&](u32 nn) -> u32 {  // entry nn (< 256) moves to the front
+      if (nn < 64) {
+        const u32 v = lane_bcast(m0, (int)nn);
+        const u32 sh = lane_prev(m0);
+        if ((u32)lane <= nn) m0 = sh;
+        m0 = lane == 0 ? v : m0;
+        return v;
+      }
+      const u32 q = nn >> 6, r = nn & 63;
+      const u32 v = q == 1 ? lane_bcast(m1, (int)r) : (q == 2 ? lane_bcast(m2, (int)r) : lane_bcast(m3, (int)r));
+      const u32 c1 = lane_bcast(m0, 63), c2 = lane_bcast(m1, 63), c3 = lane_bcast(m2, 63);
+      const u32 u0 = lane_prev(m0), u1 = lane_prev(m1), u2 = lane_prev(m2), u3 = lane_prev(m3);
+      const u32 s0 = lane == 0 ? v : u0;
+      const u32 s1 = lane == 0 ? c1 : u1;
+      const u32 s2 = lane == 0 ? c2 : u2;
+      const u32 s3 = lane == 0 ? c3 : u3;
+      const bool low = (u32)lane <= r;
+      m0 = s0;
+      if (q == 1) { if (low) m1 = s1; }
+      else if (q == 2) { m1 = s1; if (low) m2 = s2; }
+      else { m1 = s1; m2 = s2; if (low) m3 = s3; }
+      return v;
+    };
+    while (stop == 0) {
       if (group_pos == 0) {
         group_no++;
-        if (group_no >= (i32)nsel) return -1;
+        if (group_no >= (i32)nsel) { stop = 2; break; }
         group_pos = 50;
         if (group_no && (group_no & 63) == 0) selv = sel[(u32)group_no + lane < nsel ? (u32)group_no + lane : 0];
         gsel = lane_bcast(selv, group_no & 63);
-        gmin = (i32)uniform((u32)L.min_len[gsel]);
       }
-      group_pos--;
-      bzf_refill(f, lane);
-      const u32 e = uniform(L.fast[gsel][(u32)(f.buf >> (64 - BZ_FAST_BITS))]);
-      const u32 el = e & 31;
-      if (e != 0 && f.bit + el <= f.nbits) {
-        f.buf <<= el; f.cnt -= el; f.bit += el;
-        return (i32)(e >> 5);
+      while ((bit >> 5) + 6 > ring_hi) {
+        L.ring[(u32)(ring_hi + lane) & RM] = nxt;
+        ring_hi += 64;
+        nxt = stream_word(ring_hi + lane);
       }
-      // the reference loop, bit by bit (long codes, invalid indices, end of input)
-      i32 zn = gmin;
-      i32 zvec = (i32)bzf_bits(f, (u32)zn, lane);
+      wave_sync();
+      u32 ent0, ent1;
+      {
+        const u32 bo = ((u32)bit & 31) + (u32)lane, a = (u32)(bit >> 5) + (bo >> 5), sft = bo & 31;
+        const u32 w0 = L.ring[a & RM], w1 = L.ring[(a + 1) & RM], w2 = L.ring[(a + 2) & RM], w3 = L.ring[(a + 3) & RM];
+        const u32 p0 = (u32)(((((u64)w0 << 32) | w1) << sft) >> (64 - BZ_FAST_BITS));
+        const u32 p1 = (u32)(((((u64)w2 << 32) | w3) << sft) >> (64 - BZ_FAST_BITS));
+        ent0 = L.fast[gsel][p0];
+        ent1 = L.fast[gsel][p1];
+        if (bit + (u32)lane + (ent0 & 31) > nbits) ent0 = 0;
+        if (bit + (u32)lane + 64 + (ent1 & 31) > nbits) ent1 = 0;
+      }
+      u32 p = 0, budget = group_pos;
       for (;;) {
-        if (zn > 20) return -1;
-        if (zvec <= (i32)uniform((u32)L.limit[gsel][zn])) break;
-        zn++;
-        zvec = (zvec << 1) | (i32)bzf_bits(f, 1, lane);
-      }
-      const i32 idx = zvec - (i32)uniform((u32)L.base[gsel][zn]);
-      if (idx < 0 || idx >= 258) return -1;
-      return (i32)uniform(L.perm[gsel][idx]);
-    };
-    // tt[] stores are gathered 64 at a time (lane k keeps the symbol for index 64j + k)
-    u32 pend = 0, pend_lo = 0;
-    auto flush_partial = [&]() {
-      const u32 idx = (nblock & ~63u) + lane;
-      if (idx >= pend_lo && idx < nblock) tt[idx] = pend;
-      pend_lo = nblock;
-    };
-    i32 next_sym = get_mtf_val();
-    bool bad = next_sym < 0;
-    while (!bad && !f.fault && (u32)next_sym != eob) {
-      if (next_sym == 0 || next_sym == 1) {
-        i32 es = -1, N = 1;
-        do {
-          if (N >= 2 * 1024 * 1024) { bad = true; break; }
-          es += (next_sym == 0) ? N : 2 * N;
+        const u32 e = p < 64 ? lane_bcast(ent0, (int)p) : lane_bcast(ent1, (int)(p - 64));
+        u32 sym;
+        if (e != 0) { sym = e >> 5; p += e & 31; }
+        else {  // the reference loop, bit by bit (long codes, invalid indices, end of input)
+          const u64 at = bit + p;
+          i32 zn = (i32)uniform((u32)L.min_len[gsel]);
+          if (at + (u32)zn > nbits) { stop = 3; break; }
+          i32 zvec = (i32)peek_global(at, (u32)zn);
+          bool ok = true;
+          for (;;) {
+            if (zn > 20) { ok = false; break; }
+            if (zvec <= (i32)uniform((u32)L.limit[gsel][zn])) break;
+            if (at + (u32)zn + 1 > nbits) { stop = 3; break; }
+            zvec = (zvec << 1) | (i32)peek_global(at + (u32)zn, 1);
+            zn++;
+          }
+          if (stop) break;
+          const i32 idx = ok ? zvec - (i32)uniform((u32)L.base[gsel][zn]) : -1;
+          if (idx < 0 || idx >= 258) { stop = 2; break; }
+          sym = uniform(L.perm[gsel][idx]);
+          p += (u32)zn;
+        }
+        budget--;
+        if (sym <= 1) {  // RUNA / RUNB: one more binary digit of the run of front bytes
+          if (N == 0) { N = 1; es = 0; }
+          if (N >= 2 * 1024 * 1024) { stop = 2; break; }
+          es += (sym + 1) * N;
           N *= 2;
-          next_sym = get_mtf_val();
-        } while (next_sym == 0 || next_sym == 1);
-        if (bad) break;
-        es++;
-        const u32 front = lane_bcast(mtf, 0) & 0xff;
-        const u32 ucv = (lane_bcast(s2u, (int)(front >> 2)) >> (8 * (front & 3))) & 0xff;
-        if (nblock + (u32)es > nblock_max) { bad = true; break; }
-        flush_partial();
-        for (u32 k = lane; k < (u32)es; k += 64) tt[nblock + k] = ucv;
-        nblock += (u32)es;
-        pend_lo = nblock;
-        if (next_sym < 0) { bad = true; break; }
-        continue;
+        } else {
+          if (N) {
+            if (nblock + es > nblock_max) { stop = 2; break; }
+            put_run(lane_bcast(m0, 0), es);
+            N = 0;
+          }
+          if (sym == eob) { stop = 1; break; }
+          if (nblock >= nblock_max) { stop = 2; break; }
+          const u32 v = mtf_take(sym - 1);
+          if ((u32)lane == (nblock & 63)) pend = v;
+          nblock++;
+          if ((nblock & 63) == 0) tt[nblock - 64 + lane] = pend;
+        }
+        if (p >= 128 || budget == 0) break;
       }
-      if (nblock >= nblock_max) { bad = true; break; }
-      const u32 nn = (u32)next_sym - 1;
-      next_sym = get_mtf_val();  // independent of the list update below: its table read overlaps it
-      // move to front, in registers
-      const u32 q = nn >> 2, r = nn & 3;
-      const u32 v = (lane_bcast(mtf, (int)q) >> (8 * r)) & 0xff;
-      const u32 up = lane_prev(mtf) >> 24;
-      const u32 shifted = (mtf << 8) | (lane == 0 ? v : up);
-      const u32 mask = r == 3 ? 0xffffffffu : ((1u << (8 * (r + 1))) - 1);
-      if ((u32)lane < q) mtf = shifted;
-      else if ((u32)lane == q) mtf = (shifted & mask) | (mtf & ~mask);
-      const u32 ucv = (lane_bcast(s2u, (int)(v >> 2)) >> (8 * (v & 3))) & 0xff;
-      if ((u32)lane == (nblock & 63)) pend = ucv;
-      nblock++;
-      if ((nblock & 63) == 0) {
-        const u32 idx = nblock - 64 + lane;
-        if (idx >= pend_lo) tt[idx] = pend;
-        pend_lo = nblock;
-      }
-      if (next_sym < 0) bad = true;
+      bit += p;
+      group_pos = budget;
     }
-    flush_partial();
-    b.bit = f.bit;
-    b.fault = f.fault;
+    {
+      const u32 idx = (nblock & ~63u) + lane;
+      if (idx < nblock) tt[idx] = pend;
+    }
+    b.bit = bit;
+    b.fault = stop == 3;
+    const bool bad = stop == 2;
     if (b.fault) { status = BZ_ST_RANGE; break; }
     if (bad) { status = BZ_ST_FALSE; break; }
     if (orig_ptr >= nblock) { status = BZ_ST_FALSE; break; }
@@ -399,6 +454,19 @@ __global__ __launch_bounds__(64) void bz_decode_block(const u8 *__restrict__ in,
   R.end_bit = b.bit;
   R.crc = 0;
   R.pad_orig_ptr = orig_ptr;
+  out = R;
+}
+
+#ifndef AHIP_HOST_EMU
+__global__ __launch_bounds__(64) void bz_decode_block(const u8 *__restrict__ in, u64 n, const BzCand *__restrict__ cands,
+                                                      u32 ncand, u32 block_size100k, u32 *__restrict__ tt_all,
+                                                      u8 *__restrict__ sel_all, BzResult *__restrict__ results) {
+  __shared__ BzLds L;
+  const u32 blk = blockIdx.x, lane = threadIdx.x;
+  if (blk >= ncand) return;
+  BzResult R;
+  bz_decode_block_wave(L, in, n, cands[blk], block_size100k, tt_all + (u64)blk * (100000u * block_size100k),
+                       sel_all + (u64)blk * BZ_MAX_SELECTORS, R, lane);
   if (lane == 0) results[blk] = R;
 }
 
@@ -752,5 +820,7 @@ __global__ __launch_bounds__(256) void bz_rle_expand(u32 block_size100k, const B
   if (t == 0) term ^= gf_mulmod(0xffffffffu, gf_xpow8(total, crc_tab + 256));  // the 0xffffffff initial value
   if (term) atomicXor(&results[blk].crc, term);
 }
+
+#endif  // AHIP_HOST_EMU
 
 }  // namespace ahip

@@ -1,0 +1,83 @@
+// bzip2_emu.cc -- phase 1 of the bzip2 block decoder (bz_decode_block_wave: header, selectors, code lengths, tables and
+// the windowed Huffman + MTF symbol loop) executed on the CPU by 64 threads as the 64 lanes of a wave
+// (tests/emu/wave_emu.hpp).  The later phases are separate kernels on the device; here the host finishes the block the
+// plain way (T^-1, pointer chase, run-length undo) so that the bytes can be compared.  Test infrastructure only.
+//
+//   g++ -std=c++17 -O2 -pthread -o bzip2_emu tests/emu/bzip2_emu.cc
+//   bzip2_emu <file.bz2> <expected plain bytes>
+#define AHIP_HOST_EMU 1
+#include "../../archive_amd/csrc/bzip2_kernels.hpp"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+using namespace ahip;
+
+static BzLds LDS;
+
+static std::vector<uint8_t> slurp(const char *path) {
+  FILE *f = fopen(path, "rb"); if (!f) { perror(path); exit(2); }
+  fseek(f, 0, SEEK_END); size_t n = ftell(f); fseek(f, 0, SEEK_SET);
+  std::vector<uint8_t> b(n); if (n && fread(b.data(), 1, n, f) != n) exit(2); fclose(f);
+  return b;
+}
+template <class F> static void wave(F f) {
+  std::vector<std::thread> th;
+  for (int l = 0; l < 64; ++l) th.emplace_back([=]() { wave_emu::lane = l; f(l); });
+  for (auto &x : th) x.join();
+}
+static uint64_t bits48(const std::vector<uint8_t> &d, uint64_t bit) {
+  uint64_t v = 0;
+  for (int k = 0; k < 48; ++k) { const uint64_t b = bit + k; v = (v << 1) | ((d[b >> 3] >> (7 - (b & 7))) & 1); }
+  return v;
+}
+int main(int argc, char **argv) {
+  if (argc < 3) return 2;
+  std::vector<uint8_t> comp = slurp(argv[1]), want = slurp(argv[2]);
+  const size_t n = comp.size();
+  if (n < 14 || comp[0] != 'B' || comp[1] != 'Z' || comp[2] != 'h') { printf("not a bzip2 stream\n"); return 2; }
+  const uint32_t level = comp[3] - '0';
+  // device buffers are allocated: 4-byte aligned, readable a little past the end
+  uint8_t *in = (uint8_t *)aligned_alloc(64, (n + 127) & ~(size_t)63);
+  memset(in, 0, (n + 127) & ~(size_t)63);
+  memcpy(in, comp.data(), n);
+  std::vector<uint32_t> tt((size_t)100000 * level + 64);
+  std::vector<uint8_t> sel(BZ_MAX_SELECTORS + 64), out;
+  uint64_t bit = 32;
+  size_t blocks = 0;
+  for (;;) {
+    if (bit + 48 > n * 8) { printf("ran off the stream at bit %llu\n", (unsigned long long)bit); return 1; }
+    const uint64_t magic = bits48(comp, bit);
+    if (magic == 0x177245385090ull) break;
+    if (magic != 0x314159265359ull) { printf("no block magic at bit %llu\n", (unsigned long long)bit); return 1; }
+    BzResult R{};
+    const BzCand c{bit, 0, 0};
+    wave([&](int lane) { BzResult r; bz_decode_block_wave(LDS, in, n, c, level, tt.data(), sel.data(), r, (u32)lane); if (lane == 0) R = r; });
+    if (R.status != BZ_ST_OK) { printf("block %zu: status %u\n", blocks, R.status); return 1; }
+    const uint32_t nb = R.nblock;
+    // T^-1 and the walk, as bzip2_decoder.dart:406-439 / :610-727 do them
+    uint32_t cf[257] = {0};
+    for (uint32_t i = 0; i < nb; ++i) { if (tt[i] > 255) { printf("block %zu: tt[%u] = %x is no byte\n", blocks, i, tt[i]); return 1; } cf[(tt[i] & 0xff) + 1]++; }
+    for (int i = 1; i <= 256; ++i) cf[i] += cf[i - 1];
+    for (uint32_t i = 0; i < nb; ++i) { const uint32_t ch = tt[i] & 0xff; tt[cf[ch]++] |= i << 8; }
+    uint32_t tpos = tt[R.pad_orig_ptr] >> 8, run = 0, prev = 256;
+    for (uint32_t k = 0; k < nb; ++k) {
+      tpos = tt[tpos];
+      const uint8_t ch = tpos & 0xff;
+      tpos >>= 8;
+      if (run == 4) { for (uint32_t r = 0; r < ch; ++r) out.push_back((uint8_t)prev); run = 0; prev = 256; continue; }
+      out.push_back(ch);
+      if (ch == prev) run++; else { run = 1; prev = ch; }
+    }
+    bit = R.end_bit;
+    ++blocks;
+  }
+  if (out.size() != want.size() || memcmp(out.data(), want.data(), out.size())) {
+    size_t i = 0; while (i < out.size() && i < want.size() && out[i] == want[i]) ++i;
+    printf("MISMATCH at byte %zu (sizes %zu / %zu)\n", i, out.size(), want.size());
+    return 1;
+  }
+  printf("bzip2 emu ok: %zu blocks, %zu bytes\n", blocks, out.size());
+  return 0;
+}
