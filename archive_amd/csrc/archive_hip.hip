@@ -1292,12 +1292,19 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
   // block at level 9), following the chain of blocks exactly like decodeStream between them: a block ends where
   // the next magic starts.  A batch's blocks are placed and expanded before the next batch is decoded; nothing
   // behind the point where the chain stops is ever touched.
-  const u64 per_block = nblock_max * 5 + wstride * (sizeof(BzWalk) + 4) + BZ_SPANS * sizeof(BzSpan) + BZ_MAX_SELECTORS + sizeof(BzResult) + 64;
+  const u64 per_block = nblock_max * 5 + (u64)BZ_SYM_CAP * 2 + BZ_CHUNKS * 530 + wstride * (sizeof(BzWalk) + 4) + BZ_SPANS * sizeof(BzSpan) + BZ_MAX_SELECTORS + sizeof(BzResult) + 64;
   u64 batch_mem = 6ull << 30;
   if (const char *e = getenv("AHIP_BZ_BATCH_BYTES")) { if (atoll(e) > 0) batch_mem = (u64)atoll(e); }
   u32 batch = (u32)std::min<u64>(ncand, std::max<u64>(4, batch_mem / per_block));
   HIP_TRY(dtt.reserve((size_t)batch * nblock_max * 4));
   HIP_TRY(dsel.reserve((size_t)batch * BZ_MAX_SELECTORS));
+  static thread_local DevBuf dsyms, dlist0, dchunks, dperms, dlists, dchoff;
+  HIP_TRY(dsyms.reserve((size_t)batch * BZ_SYM_CAP * 2));
+  HIP_TRY(dlist0.reserve((size_t)batch * 256));
+  HIP_TRY(dchunks.reserve((size_t)batch * BZ_CHUNKS * sizeof(BzChunk)));
+  HIP_TRY(dperms.reserve((size_t)batch * BZ_CHUNKS * 256));
+  HIP_TRY(dlists.reserve((size_t)batch * BZ_CHUNKS * 256));
+  HIP_TRY(dchoff.reserve((size_t)batch * BZ_CHUNKS * 4));
   HIP_TRY(dpre.reserve((size_t)batch * nblock_max));
   HIP_TRY(dwalk.reserve((size_t)batch * wstride * sizeof(BzWalk)));
   HIP_TRY(drank.reserve((size_t)batch * wstride * 4));
@@ -1334,8 +1341,15 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
     if (next >= c0 + batch) continue;  // the chain has already stepped over this whole batch (false magics inside data)
     const u32 nb = (u32)std::min<size_t>(batch, ncand - c0);
     const BzCand *dc = dcand.as<BzCand>() + c0;
-    hipLaunchKernelGGL(bz_decode_block, dim3(nb), dim3(64), 0, st, d_in, (u64)in_len, dc, nb, (u32)level, dtt.as<u32>(), dsel.as<u8>(),
+    // phase 1: the Huffman side of every block (one wave each) -> symbol streams; what the symbols mean by chunks
+    hipLaunchKernelGGL(bz_decode_block, dim3(nb), dim3(64), 0, st, d_in, (u64)in_len, dc, nb, dsyms.as<u16>(), dlist0.as<u8>(), dsel.as<u8>(),
                        dres.as<BzResult>());
+    hipLaunchKernelGGL(bz_mtf_chunks<false>, dim3(BZ_CHUNKS / 4, nb), dim3(256), 0, st, dsyms.as<u16>(), dres.as<BzResult>(), (u32)level,
+                       dchunks.as<BzChunk>(), dperms.as<u8>(), dlists.as<u8>(), dchoff.as<u32>(), dtt.as<u32>());
+    hipLaunchKernelGGL(bz_mtf_scan, dim3(nb), dim3(64), 0, st, dres.as<BzResult>(), dc, nb, (u32)level, dchunks.as<BzChunk>(), dperms.as<u8>(),
+                       dlist0.as<u8>(), dlists.as<u8>(), dchoff.as<u32>());
+    hipLaunchKernelGGL(bz_mtf_chunks<true>, dim3(BZ_CHUNKS / 4, nb), dim3(256), 0, st, dsyms.as<u16>(), dres.as<BzResult>(), (u32)level,
+                       dchunks.as<BzChunk>(), dperms.as<u8>(), dlists.as<u8>(), dchoff.as<u32>(), dtt.as<u32>());
     hipLaunchKernelGGL(bz_tinv_scatter, dim3(nb), dim3(1024), 0, st, dtt.as<u32>(), (u32)level, dc, dres.as<BzResult>());
     hipLaunchKernelGGL(bz_walk<false>, dim3(wgrid, nb), dim3(256), 0, st, dtt.as<u32>(), (u32)level, dc, dres.as<BzResult>(),
                        dwalk.as<BzWalk>(), drank.as<u32>(), dpre.as<u8>());

@@ -43,7 +43,7 @@ struct BzResult {
   u64 end_bit;   // bit position just after the block
   u64 out_len;
   u32 status, crc, stored_crc, nblock;
-  u32 pad_orig_ptr, pad;  // origPtr (phases 2-4 need it)
+  u32 pad_orig_ptr, nsyms;  // origPtr (phases 2-4 need it); symbols the Huffman pass recorded
 };
 
 // ---- B0: magic scan ----
@@ -109,6 +109,9 @@ AHIP_DEVINL u32 bz_bits(BzBits &b, u32 nb) {  // nb <= 24
 
 constexpr u32 BZ_FAST_BITS = 10;
 constexpr u32 BZ_RING = 512;
+constexpr u32 BZ_SYM_CAP = BZ_MAX_SELECTORS * 50 + 128;  // symbols of a block: 50 per selector
+constexpr u32 BZ_CHUNKS = 64;                          // MTF chunks per block
+constexpr u32 BZ_MISS = 0xff;                          // length field of a fast-table entry that has no code
 struct BzLds {
   i32 limit[6][24], base[6][24];
   u16 perm[6][258];
@@ -116,8 +119,8 @@ struct BzLds {
   i32 min_len[6];
   u8 seq2unseq[256];
   // fast[t][p]: what the reference's limit/base/perm loop does with the 10-bit pattern p, precomputed:
-  // symbol << 5 | length; 0 = no code of <= 10 bits matches (or an invalid index): take the exact loop
-  u16 fast[6][1u << BZ_FAST_BITS];
+  // symbol << 8 | length; length BZ_MISS = no code of <= 10 bits matches (or an invalid index): take the exact loop
+  u32 fast[6][1u << BZ_FAST_BITS];
   u32 ring[BZ_RING];  // the stream ahead of the symbol loop, as big-endian dwords
 };
 
@@ -172,14 +175,16 @@ AHIP_DEVINL u32 bzf_bits(BzFast &f, u32 nb, int lane) {  // nb <= 24; the refere
 }
 
 // one wave per candidate block (a device function: tests/emu/bzip2_emu.cc runs it on the CPU wave emulation)
-AHIP_DEVINL void bz_decode_block_wave(BzLds &L, const u8 *__restrict__ in, u64 n, const BzCand cand, u32 block_size100k,
-                                      u32 *__restrict__ tt, u8 *__restrict__ sel, BzResult &out, const u32 lane) {
-  const u32 nblock_max = 100000u * block_size100k;
+// syms: room for BZ_SYM_CAP symbols; list0: the block's initial MTF list (256 bytes, seqToUnseq applied)
+AHIP_DEVINL void bz_decode_block_wave(BzLds &L, const u8 *__restrict__ in, u64 n, const BzCand cand,
+                                      u16 *__restrict__ syms, u8 *__restrict__ list0, u8 *__restrict__ sel, BzResult &out,
+                                      const u32 lane) {
   BzResult R{0, 0, BZ_ST_OK, 0, 0, 0, 0, 0};
+  u32 nsyms = 0;
   BzBits b{in, n, 0, false, 0, 0, 0};
   bz_seek(b, cand.bit + 48);
   u32 status = BZ_ST_OK;
-  u32 nblock = 0, orig_ptr = 0;
+  u32 orig_ptr = 0;
   if (cand.kind != 0) {  // end-of-stream marker: just the combined CRC
     u32 c = bz_bits(b, 16);
     c = (c << 16) | bz_bits(b, 16);
@@ -279,31 +284,29 @@ AHIP_DEVINL void bz_decode_block_wave(BzLds &L, const u8 *__restrict__ in, u64 n
     for (u32 t = 0; t < ngroups; ++t) {
       const i32 minl = L.min_len[t];
       for (u32 pat = lane; pat < (1u << BZ_FAST_BITS); pat += 64) {
-        u32 e = 0;
+        u32 e = BZ_MISS;
         for (i32 zn = minl; zn <= (i32)BZ_FAST_BITS; ++zn) {
           const i32 zvec = (i32)(pat >> (BZ_FAST_BITS - zn));
           if (zvec <= L.limit[t][zn]) {
             const i32 idx = zvec - L.base[t][zn];
-            if (idx >= 0 && idx < 258) e = ((u32)L.perm[t][idx] << 5) | (u32)zn;
+            if (idx >= 0 && idx < 258) e = ((u32)L.perm[t][idx] << 8) | (u32)zn;
             break;  // an index out of range is the reference's error: the exact loop reports it
           }
         }
-        L.fast[t][pat] = (u16)e;
+        L.fast[t][pat] = e;
       }
     }
     wave_sync();
     // ---- the symbol loop ----
-    // Serial by nature (a code's position is the end of the one before, the list is updated by every symbol), but
-    // not one LDS round trip per symbol: the 128 bit positions from the current one are looked up at once (lane l:
-    // positions l and l + 64, ten bits each, against the current group's table), and the chain through them --
-    // position -> its entry -> the next position -- runs on scalar registers with v_readlane; a window ends after
-    // 128 bits or with the group of 50 symbols (the next one has another table).  Codes longer than ten bits and
-    // the last bits of the input take the reference's bit-by-bit loop, read from global memory.
-    // The MTF list lives in four registers, entry 64 j + lane in m[j], already mapped through seqToUnseq (the
-    // reference maps on output: the same bytes); an index below 64 -- almost always -- costs a v_readlane and a
-    // wave_shr DPP move under a lane mask.
-    u32 m0 = lane < num_in_use ? L.seq2unseq[lane] : 0u, m1 = lane + 64 < num_in_use ? L.seq2unseq[lane + 64] : 0u;
-    u32 m2 = lane + 128 < num_in_use ? L.seq2unseq[lane + 128] : 0u, m3 = lane + 192 < num_in_use ? L.seq2unseq[lane + 192] : 0u;
+    // Only the Huffman side is serial here: a code's position is the end of the one before.  The 128 bit positions
+    // from the current one are looked up at once (lane l: positions l and l + 64, ten bits each, against the current
+    // group's table), and the chain through them -- position -> its entry -> the next position -- runs on scalar
+    // registers (v_readlane, a bit set in a mask, an add: the loop below is all a symbol costs on the serial path).
+    // The positions the chain visited are the symbols: they are cut at the end of the group of 50 (the next group
+    // has another table) or at the end-of-block symbol and stored, compacted, as 16-bit values.  What the symbols
+    // MEAN -- the move-to-front list, the zero runs -- is left to bz_mtf_*: chunks of the symbol stream, in parallel.
+    // Codes longer than ten bits and the last bits of the input take the reference's bit-by-bit loop.
+    for (u32 i = lane; i < 256; i += 64) list0[i] = i < num_in_use ? L.seq2unseq[i] : (u8)0;
     const u64 nbits = n * 8;
     u64 bit = b.bit;
     auto stream_word = [&](u64 idx) -> u32 {  // dword idx of the stream as a big-endian value, zeros behind the end
@@ -329,40 +332,7 @@ AHIP_DEVINL void bz_decode_block_wave(BzLds &L, const u8 *__restrict__ in, u64 n
     const u32 eob = num_in_use + 1;
     i32 group_no = -1;
     u32 group_pos = 0, gsel = 0;
-    u32 pend = 0;        // tt[] stores are gathered 64 at a time: lane k keeps the byte for index 64 j + k
-    u32 es = 0, N = 0;   // the zero run being read (N = 0: none)
     u32 stop = 0;  // 1 end of block, 2 bad data (false), 3 read past the end (RangeError)
-    auto put_run = [&](u32 v, u32 cnt) {
-      while (cnt) {
-        const u32 off = nblock & 63, take = cnt < 64 - off ? cnt : 64 - off;
-        if ((u32)lane - off < take) pend = v;
-        nblock += take; cnt -= take;
-        if ((nblock & 63) == 0) tt[nblock - 64 + lane] = pend;
-      }
-    };
-    auto mtf_take = [&](u32 nn) -> u32 {  // entry nn (< 256) moves to the front
-      if (nn < 64) {
-        const u32 v = lane_bcast(m0, (int)nn);
-        const u32 sh = lane_prev(m0);
-        if ((u32)lane <= nn) m0 = sh;
-        m0 = lane == 0 ? v : m0;
-        return v;
-      }
-      const u32 q = nn >> 6, r = nn & 63;
-      const u32 v = q == 1 ? lane_bcast(m1, (int)r) : (q == 2 ? lane_bcast(m2, (int)r) : lane_bcast(m3, (int)r));
-      const u32 c1 = lane_bcast(m0, 63), c2 = lane_bcast(m1, 63), c3 = lane_bcast(m2, 63);
-      const u32 u0 = lane_prev(m0), u1 = lane_prev(m1), u2 = lane_prev(m2), u3 = lane_prev(m3);
-      const u32 s0 = lane == 0 ? v : u0;
-      const u32 s1 = lane == 0 ? c1 : u1;
-      const u32 s2 = lane == 0 ? c2 : u2;
-      const u32 s3 = lane == 0 ? c3 : u3;
-      const bool low = (u32)lane <= r;
-      m0 = s0;
-      if (q == 1) { if (low) m1 = s1; }
-      else if (q == 2) { m1 = s1; if (low) m2 = s2; }
-      else { m1 = s1; m2 = s2; if (low) m3 = s3; }
-      return v;
-    };
     while (stop == 0) {
       if (group_pos == 0) {
         group_no++;
@@ -385,89 +355,267 @@ AHIP_DEVINL void bz_decode_block_wave(BzLds &L, const u8 *__restrict__ in, u64 n
         const u32 p1 = (u32)(((((u64)w2 << 32) | w3) << sft) >> (64 - BZ_FAST_BITS));
         ent0 = L.fast[gsel][p0];
         ent1 = L.fast[gsel][p1];
-        if (bit + (u32)lane + (ent0 & 31) > nbits) ent0 = 0;
-        if (bit + (u32)lane + 64 + (ent1 & 31) > nbits) ent1 = 0;
+        if (bit + (u32)lane + (ent0 & 0xff) > nbits) ent0 = BZ_MISS;
+        if (bit + (u32)lane + 64 + (ent1 & 0xff) > nbits) ent1 = BZ_MISS;
       }
-      u32 p = 0, budget = group_pos;
-      for (;;) {
-        const u32 e = p < 64 ? lane_bcast(ent0, (int)p) : lane_bcast(ent1, (int)(p - 64));
-        u32 sym;
-        if (e != 0) { sym = e >> 5; p += e & 31; }
-        else {  // the reference loop, bit by bit (long codes, invalid indices, end of input)
-          const u64 at = bit + p;
-          i32 zn = (i32)uniform((u32)L.min_len[gsel]);
-          if (at + (u32)zn > nbits) { stop = 3; break; }
-          i32 zvec = (i32)peek_global(at, (u32)zn);
-          bool ok = true;
-          for (;;) {
-            if (zn > 20) { ok = false; break; }
-            if (zvec <= (i32)uniform((u32)L.limit[gsel][zn])) break;
-            if (at + (u32)zn + 1 > nbits) { stop = 3; break; }
-            zvec = (zvec << 1) | (i32)peek_global(at + (u32)zn, 1);
-            zn++;
-          }
-          if (stop) break;
-          const i32 idx = ok ? zvec - (i32)uniform((u32)L.base[gsel][zn]) : -1;
-          if (idx < 0 || idx >= 258) { stop = 2; break; }
-          sym = uniform(L.perm[gsel][idx]);
-          p += (u32)zn;
+      // the chain: a missing entry adds 255 and so ends it
+      u32 p = 0;
+      u64 mlo = 0, mhi = 0;
+      while (p < 64) { const u32 e = lane_bcast(ent0, (int)p); mlo |= 1ull << p; p += e & 0xff; }
+      while (p < 128) { const u32 e = lane_bcast(ent1, (int)(p - 64)); mhi |= 1ull << (p - 64); p += e & 0xff; }
+      bool miss = p >= 255;  // the last position visited has no entry
+      if (miss) {
+        if (mhi) { const u32 q = 63u - (u32)__builtin_clzll(mhi); mhi &= ~(1ull << q); p = 64 + q; }
+        else { const u32 q = 63u - (u32)__builtin_clzll(mlo); mlo &= ~(1ull << q); p = q; }
+      }
+      const bool my0 = (mlo >> lane) & 1, my1 = (mhi >> lane) & 1;
+      // the end-of-block symbol ends everything; what the chain found behind it is not there
+      const u64 e0 = __ballot(my0 && (ent0 >> 8) == eob), e1 = __ballot(my1 && (ent1 >> 8) == eob);
+      if (e0 | e1) {
+        if (e0) { const u32 q = (u32)__builtin_ctzll(e0); mlo &= (2ull << q) - 1; mhi = 0; p = q + (lane_bcast(ent0, (int)q) & 0xff); }
+        else { const u32 q = (u32)__builtin_ctzll(e1); mhi &= (2ull << q) - 1; p = 64 + q + (lane_bcast(ent1, (int)q) & 0xff); }
+        miss = false;
+        stop = 1;
+      }
+      // ... and so does the end of the group: the (group_pos + 1)-th symbol belongs to the next table
+      const u32 c0 = (u32)__popcll(mlo), c1 = (u32)__popcll(mhi);
+      u32 take = c0 + c1;
+      if (take + (miss ? 1u : 0u) > group_pos) {
+        const u64 my_lo = (mlo >> lane) & 1, my_hi = (mhi >> lane) & 1;
+        const u64 k0 = __ballot(my_lo && wave_rank(mlo) == group_pos), k1 = __ballot(my_hi && c0 + wave_rank(mhi) == group_pos);
+        if (k0) { const u32 q = (u32)__builtin_ctzll(k0); mlo &= (1ull << q) - 1; mhi = 0; p = q; }
+        else if (k1) { const u32 q = (u32)__builtin_ctzll(k1); mhi &= (1ull << q) - 1; p = 64 + q; }
+        // (neither: the symbols fill the group exactly and the missing one is the next group's -- p already points at it)
+        take = group_pos;
+        miss = false;
+        stop = 0;
+      }
+      {
+        const bool s0 = (mlo >> lane) & 1, s1 = (mhi >> lane) & 1;
+        if (s0) syms[nsyms + wave_rank(mlo)] = (u16)(ent0 >> 8);
+        if (s1) syms[nsyms + (u32)__popcll(mlo) + wave_rank(mhi)] = (u16)(ent1 >> 8);
+      }
+      if (stop == 1) take -= 1;  // the end-of-block symbol is not recorded
+      nsyms += take;
+      group_pos -= (stop == 1) ? take + 1 : take;
+      if (miss) {  // the reference loop, bit by bit (long codes, invalid indices, end of input)
+        const u64 at = bit + p;
+        i32 zn = (i32)uniform((u32)L.min_len[gsel]);
+        if (at + (u32)zn > nbits) { stop = 3; break; }
+        i32 zvec = (i32)peek_global(at, (u32)zn);
+        bool ok = true;
+        for (;;) {
+          if (zn > 20) { ok = false; break; }
+          if (zvec <= (i32)uniform((u32)L.limit[gsel][zn])) break;
+          if (at + (u32)zn + 1 > nbits) { stop = 3; break; }
+          zvec = (zvec << 1) | (i32)peek_global(at + (u32)zn, 1);
+          zn++;
         }
-        budget--;
-        if (sym <= 1) {  // RUNA / RUNB: one more binary digit of the run of front bytes
-          if (N == 0) { N = 1; es = 0; }
-          if (N >= 2 * 1024 * 1024) { stop = 2; break; }
-          es += (sym + 1) * N;
-          N *= 2;
-        } else {
-          if (N) {
-            if (nblock + es > nblock_max) { stop = 2; break; }
-            put_run(lane_bcast(m0, 0), es);
-            N = 0;
-          }
-          if (sym == eob) { stop = 1; break; }
-          if (nblock >= nblock_max) { stop = 2; break; }
-          const u32 v = mtf_take(sym - 1);
-          if ((u32)lane == (nblock & 63)) pend = v;
-          nblock++;
-          if ((nblock & 63) == 0) tt[nblock - 64 + lane] = pend;
-        }
-        if (p >= 128 || budget == 0) break;
+        if (stop) break;
+        const i32 idx = ok ? zvec - (i32)uniform((u32)L.base[gsel][zn]) : -1;
+        if (idx < 0 || idx >= 258) { stop = 2; break; }
+        const u32 sym = uniform(L.perm[gsel][idx]);
+        p += (u32)zn;
+        group_pos--;
+        if (sym == eob) stop = 1;
+        else { if (lane == 0) syms[nsyms] = (u16)sym; nsyms++; }
       }
       bit += p;
-      group_pos = budget;
-    }
-    {
-      const u32 idx = (nblock & ~63u) + lane;
-      if (idx < nblock) tt[idx] = pend;
     }
     b.bit = bit;
     b.fault = stop == 3;
     const bool bad = stop == 2;
     if (b.fault) { status = BZ_ST_RANGE; break; }
     if (bad) { status = BZ_ST_FALSE; break; }
-    if (orig_ptr >= nblock) { status = BZ_ST_FALSE; break; }
   } while (0);
 
-  // phases 2-4 are separate launches
+  // what the symbols mean, and everything behind that, are separate launches (bz_mtf_scan sets nblock and the final status)
   R.status = status;
-  R.nblock = nblock;
+  R.nblock = 0;
+  R.nsyms = nsyms;
   R.end_bit = b.bit;
   R.crc = 0;
   R.pad_orig_ptr = orig_ptr;
   out = R;
 }
 
+// ---- the symbol stream's meaning: move-to-front list and zero runs (bzip2_decoder.dart:267-388), by chunks ----
+// The list after a stretch of symbols is a permutation of the list before it, whatever that was: every chunk first runs
+// its symbols over the identity (pass 0: the permutation, and how many bytes the chunk makes), one wave per block
+// chains the permutations (bz_mtf_scan: every chunk's true list and output offset, the block's size and verdict), and
+// the chunks run again with the bytes (pass 1: tt[]).  A chunk starts where the even split says, moved behind the
+// digits of a zero run that began before it: runs are never cut.
+struct BzChunk { u32 count, bad; };
+
+AHIP_DEVINL u32 bz_chunk_start(const u16 *__restrict__ syms, u32 nsyms, u32 c) {
+  const u32 per = (nsyms + BZ_CHUNKS - 1) / BZ_CHUNKS;
+  const u64 nominal = (u64)c * per;
+  if (nominal >= nsyms) return nsyms;
+  u32 st = (u32)nominal;
+  if (st > 0 && syms[st - 1] <= 1)
+    for (u32 k = 0; k < 32 && st < nsyms && syms[st] <= 1; ++k) ++st;  // (more than 21 digits: the run's owner reports it)
+  return st;
+}
+
+// list: 256 bytes the chunk starts from (pass 1) / nullptr = the identity (pass 0, result to perm_out)
+template <bool WRITE>
+AHIP_DEVINL void bz_mtf_chunk_wave(const u16 *__restrict__ syms, u32 nsyms, u32 c, u32 limit, const u8 *__restrict__ list,
+                                   u32 out_off, u32 *__restrict__ tt, u8 *__restrict__ perm_out, BzChunk &res, const u32 lane) {
+  const u32 s0 = uniform(bz_chunk_start(syms, nsyms, c)), s1 = uniform(c + 1 < BZ_CHUNKS ? bz_chunk_start(syms, nsyms, c + 1) : nsyms);
+  u32 m0, m1, m2, m3;  // the list: entry 64 j + lane in m[j]
+  if (WRITE) { m0 = list[lane]; m1 = list[lane + 64]; m2 = list[lane + 128]; m3 = list[lane + 192]; }
+  else { m0 = lane; m1 = lane + 64; m2 = lane + 128; m3 = lane + 192; }
+  auto mtf_take = [&](u32 nn) -> u32 {  // entry nn (< 256) moves to the front
+    if (nn < 64) {
+      const u32 v = lane_bcast(m0, (int)nn);
+      const u32 sh = lane_prev(m0);
+      if (lane <= nn) m0 = sh;
+      m0 = lane == 0 ? v : m0;
+      return v;
+    }
+    const u32 q = nn >> 6, r = nn & 63;
+    const u32 v = q == 1 ? lane_bcast(m1, (int)r) : (q == 2 ? lane_bcast(m2, (int)r) : lane_bcast(m3, (int)r));
+    const u32 c1 = lane_bcast(m0, 63), c2 = lane_bcast(m1, 63), c3 = lane_bcast(m2, 63);
+    const u32 u0 = lane_prev(m0), u1 = lane_prev(m1), u2 = lane_prev(m2), u3 = lane_prev(m3);
+    const u32 t0 = lane == 0 ? v : u0, t1 = lane == 0 ? c1 : u1, t2 = lane == 0 ? c2 : u2, t3 = lane == 0 ? c3 : u3;
+    const bool low = lane <= r;
+    m0 = t0;
+    if (q == 1) { if (low) m1 = t1; }
+    else if (q == 2) { m1 = t1; if (low) m2 = t2; }
+    else { m1 = t1; m2 = t2; if (low) m3 = t3; }
+    return v;
+  };
+  u32 cnt = 0;   // bytes made so far
+  u32 pend = 0;  // tt[] stores are gathered 64 at a time: lane k keeps the byte for index 64 j + k
+  auto flush_full = [&](u32 end_idx) {  // end_idx: a multiple of 64 just reached
+    const u32 i = end_idx - 64 + lane;
+    if (i >= out_off) tt[i] = pend;
+  };
+  auto put_run = [&](u32 v, u32 k) {
+    while (k) {
+      const u32 idx = out_off + cnt, off = idx & 63, take = k < 64 - off ? k : 64 - off;
+      if (lane - off < take) pend = v;
+      cnt += take; k -= take;
+      if (((idx + take) & 63) == 0) flush_full(idx + take);
+    }
+  };
+  u32 r0 = 0, es = 0, bad = 0;  // the zero run being read: digits so far, value so far
+  for (u32 base = s0; base < s1 && !bad; base += 64) {
+    const u32 here = s1 - base < 64 ? s1 - base : 64;
+    const u32 v = lane < here ? (u32)syms[base + lane] : 0xffffu;
+    const u64 dm = __ballot(v <= 1), bm = __ballot(v == 1);
+    u32 k = 0;
+    while (k < here) {
+      if ((dm >> k) & 1) {  // RUNA / RUNB digits: the whole stretch at once
+        const u64 rest = ~(dm >> k);
+        const u32 r = rest ? (u32)__builtin_ctzll(rest) : 64u;
+        if (r0 + r > 21) { bad = 1; break; }  // the 22nd digit finds N >= 2M
+        const u32 B = (u32)(bm >> k) & ((1u << r) - 1);
+        es += (((1u << r) - 1) + B) << r0;
+        r0 += r;
+        k += r;
+        continue;
+      }
+      if (r0) {
+        if (cnt + es > limit) { bad = 1; break; }
+        if (WRITE) put_run(lane_bcast(m0, 0), es); else cnt += es;
+        r0 = 0; es = 0;
+      }
+      if (cnt >= limit) { bad = 1; break; }
+      const u32 sym = lane_bcast(v, (int)k);
+      const u32 byte = mtf_take(sym - 1);
+      if (WRITE) {
+        const u32 idx = out_off + cnt;
+        if (lane == (idx & 63)) pend = byte;
+        if (((idx + 1) & 63) == 0) flush_full(idx + 1);
+      }
+      cnt++;
+      k++;
+    }
+  }
+  if (r0 && !bad) {  // a run ends with its chunk
+    if (cnt + es > limit) bad = 1;
+    else if (WRITE) put_run(lane_bcast(m0, 0), es);
+    else cnt += es;
+  }
+  if (WRITE) {
+    const u32 end = out_off + cnt, i = (end & ~63u) + lane;
+    if (i >= out_off && i < end) tt[i] = pend;
+  } else {
+    perm_out[lane] = (u8)m0; perm_out[lane + 64] = (u8)m1; perm_out[lane + 128] = (u8)m2; perm_out[lane + 192] = (u8)m3;
+  }
+  res.count = cnt;
+  res.bad = bad;
+}
+
+// one wave per block: chunk offsets and lists, the block's size and verdict
+struct BzScanLds { u8 cur[256], nxt[256]; };
+AHIP_DEVINL void bz_mtf_scan_wave(BzScanLds &S, BzResult &R, u32 nblock_max, const BzChunk *__restrict__ chunks,
+                                  const u8 *__restrict__ perms, const u8 *__restrict__ list0, u8 *__restrict__ lists,
+                                  u32 *__restrict__ offs, const u32 lane) {
+  if (R.nsyms == 0 && R.status != BZ_ST_OK) return;  // nothing was decoded (header trouble, end-of-stream marker)
+  for (u32 i = lane; i < 256; i += 64) S.cur[i] = list0[i];
+  wave_sync();
+  u64 running = 0;
+  u32 bad = 0;
+  for (u32 c = 0; c < BZ_CHUNKS; ++c) {
+    for (u32 i = lane; i < 256; i += 64) lists[c * 256 + i] = S.cur[i];
+    if (lane == 0) offs[c] = running > 0xffffffffull ? 0xffffffffu : (u32)running;
+    bad |= uniform(chunks[c].bad);
+    running += uniform(chunks[c].count);
+    for (u32 i = lane; i < 256; i += 64) S.nxt[i] = S.cur[perms[c * 256 + i]];
+    wave_sync();
+    for (u32 i = lane; i < 256; i += 64) S.cur[i] = S.nxt[i];
+    wave_sync();
+  }
+  // every error of the list / run side comes before the one the Huffman side stopped at, and reads as `false`
+  u32 status = R.status;
+  if (bad || running > nblock_max) status = BZ_ST_FALSE;
+  if (status == BZ_ST_OK && R.pad_orig_ptr >= running) status = BZ_ST_FALSE;
+  R.status = status;
+  R.nblock = status == BZ_ST_OK ? (u32)running : 0u;
+}
+
 #ifndef AHIP_HOST_EMU
 __global__ __launch_bounds__(64) void bz_decode_block(const u8 *__restrict__ in, u64 n, const BzCand *__restrict__ cands,
-                                                      u32 ncand, u32 block_size100k, u32 *__restrict__ tt_all,
+                                                      u32 ncand, u16 *__restrict__ syms_all, u8 *__restrict__ list0_all,
                                                       u8 *__restrict__ sel_all, BzResult *__restrict__ results) {
   __shared__ BzLds L;
   const u32 blk = blockIdx.x, lane = threadIdx.x;
   if (blk >= ncand) return;
   BzResult R;
-  bz_decode_block_wave(L, in, n, cands[blk], block_size100k, tt_all + (u64)blk * (100000u * block_size100k),
+  bz_decode_block_wave(L, in, n, cands[blk], syms_all + (u64)blk * BZ_SYM_CAP, list0_all + (u64)blk * 256,
                        sel_all + (u64)blk * BZ_MAX_SELECTORS, R, lane);
   if (lane == 0) results[blk] = R;
+}
+// grid (BZ_CHUNKS / 4, blocks), 256 threads: one wave per chunk
+template <bool WRITE>
+__global__ __launch_bounds__(256) void bz_mtf_chunks(const u16 *__restrict__ syms_all, const BzResult *__restrict__ results,
+                                                     u32 block_size100k, BzChunk *__restrict__ chunks_all, u8 *__restrict__ perms_all,
+                                                     const u8 *__restrict__ lists_all, const u32 *__restrict__ offs_all,
+                                                     u32 *__restrict__ tt_all) {
+  const u32 blk = blockIdx.y, c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const u32 nblock_max = 100000u * block_size100k;
+  const BzResult &R = results[blk];
+  if (WRITE && R.status != BZ_ST_OK) return;
+  BzChunk res;
+  bz_mtf_chunk_wave<WRITE>(syms_all + (u64)blk * BZ_SYM_CAP, R.nsyms, c, nblock_max,
+                           WRITE ? lists_all + ((u64)blk * BZ_CHUNKS + c) * 256 : nullptr,
+                           WRITE ? offs_all[(u64)blk * BZ_CHUNKS + c] : 0u, tt_all + (u64)blk * nblock_max,
+                           perms_all + ((u64)blk * BZ_CHUNKS + c) * 256, res, lane);
+  if (!WRITE && lane == 0) chunks_all[(u64)blk * BZ_CHUNKS + c] = res;
+}
+__global__ __launch_bounds__(64) void bz_mtf_scan(BzResult *__restrict__ results, const BzCand *__restrict__ cands, u32 ncand,
+                                                  u32 block_size100k, const BzChunk *__restrict__ chunks_all, const u8 *__restrict__ perms_all,
+                                                  const u8 *__restrict__ list0_all, u8 *__restrict__ lists_all,
+                                                  u32 *__restrict__ offs_all) {
+  __shared__ BzScanLds S;
+  const u32 blk = blockIdx.x, lane = threadIdx.x;
+  if (blk >= ncand || cands[blk].kind != 0) return;
+  BzResult R = results[blk];
+  bz_mtf_scan_wave(S, R, 100000u * block_size100k, chunks_all + (u64)blk * BZ_CHUNKS, perms_all + (u64)blk * BZ_CHUNKS * 256,
+                   list0_all + (u64)blk * 256, lists_all + (u64)blk * BZ_CHUNKS * 256, offs_all + (u64)blk * BZ_CHUNKS, lane);
+  if (lane == 0) { results[blk].status = R.status; results[blk].nblock = R.nblock; }
 }
 
 // ---- phase 2 (own launch): T^-1 ----

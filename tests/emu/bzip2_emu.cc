@@ -1,7 +1,9 @@
-// bzip2_emu.cc -- phase 1 of the bzip2 block decoder (bz_decode_block_wave: header, selectors, code lengths, tables and
-// the windowed Huffman + MTF symbol loop) executed on the CPU by 64 threads as the 64 lanes of a wave
-// (tests/emu/wave_emu.hpp).  The later phases are separate kernels on the device; here the host finishes the block the
-// plain way (T^-1, pointer chase, run-length undo) so that the bytes can be compared.  Test infrastructure only.
+// bzip2_emu.cc -- phase 1 of the bzip2 block decoder executed on the CPU by 64 threads as the 64 lanes of a wave
+// (tests/emu/wave_emu.hpp): bz_decode_block_wave (header, selectors, code lengths, tables, the windowed Huffman chain ->
+// symbol stream), then the chunked move-to-front side glued the way archive_hip.hip launches it (bz_mtf_chunk_wave<false>
+// per chunk, bz_mtf_scan_wave, bz_mtf_chunk_wave<true> per chunk).  The later phases are separate kernels on the device;
+// here the host finishes the block the plain way (T^-1, pointer chase, run-length undo) so that the bytes can be
+// compared.  Test infrastructure only.
 //
 //   g++ -std=c++17 -O2 -pthread -o bzip2_emu tests/emu/bzip2_emu.cc
 //   bzip2_emu <file.bz2> <expected plain bytes>
@@ -15,6 +17,7 @@
 using namespace ahip;
 
 static BzLds LDS;
+static BzScanLds SLDS;
 
 static std::vector<uint8_t> slurp(const char *path) {
   FILE *f = fopen(path, "rb"); if (!f) { perror(path); exit(2); }
@@ -42,8 +45,11 @@ int main(int argc, char **argv) {
   uint8_t *in = (uint8_t *)aligned_alloc(64, (n + 127) & ~(size_t)63);
   memset(in, 0, (n + 127) & ~(size_t)63);
   memcpy(in, comp.data(), n);
-  std::vector<uint32_t> tt((size_t)100000 * level + 64);
-  std::vector<uint8_t> sel(BZ_MAX_SELECTORS + 64), out;
+  std::vector<uint32_t> tt((size_t)100000 * level + 64, 0xdead0000u);
+  std::vector<uint8_t> sel(BZ_MAX_SELECTORS + 64), out, list0(256), perms(BZ_CHUNKS * 256), lists(BZ_CHUNKS * 256);
+  std::vector<uint16_t> syms(BZ_SYM_CAP);
+  std::vector<BzChunk> chunks(BZ_CHUNKS);
+  std::vector<uint32_t> offs(BZ_CHUNKS);
   uint64_t bit = 32;
   size_t blocks = 0;
   for (;;) {
@@ -53,8 +59,15 @@ int main(int argc, char **argv) {
     if (magic != 0x314159265359ull) { printf("no block magic at bit %llu\n", (unsigned long long)bit); return 1; }
     BzResult R{};
     const BzCand c{bit, 0, 0};
-    wave([&](int lane) { BzResult r; bz_decode_block_wave(LDS, in, n, c, level, tt.data(), sel.data(), r, (u32)lane); if (lane == 0) R = r; });
+    wave([&](int lane) { BzResult r; bz_decode_block_wave(LDS, in, n, c, syms.data(), list0.data(), sel.data(), r, (u32)lane); if (lane == 0) R = r; });
+    if (R.status != BZ_ST_OK) { printf("block %zu: Huffman side status %u\n", blocks, R.status); return 1; }
+    const uint32_t nmax = 100000u * level;
+    for (uint32_t k = 0; k < BZ_CHUNKS; ++k)
+      wave([&](int lane) { BzChunk r; bz_mtf_chunk_wave<false>(syms.data(), R.nsyms, k, nmax, nullptr, 0, tt.data(), perms.data() + k * 256, r, (u32)lane); if (lane == 0) chunks[k] = r; });
+    wave([&](int lane) { BzResult r = R; bz_mtf_scan_wave(SLDS, r, nmax, chunks.data(), perms.data(), list0.data(), lists.data(), offs.data(), (u32)lane); wave_emu::barrier(); if (lane == 0) R = r; });
     if (R.status != BZ_ST_OK) { printf("block %zu: status %u\n", blocks, R.status); return 1; }
+    for (uint32_t k = 0; k < BZ_CHUNKS; ++k)
+      wave([&](int lane) { BzChunk r; bz_mtf_chunk_wave<true>(syms.data(), R.nsyms, k, nmax, lists.data() + k * 256, offs[k], tt.data(), perms.data() + k * 256, r, (u32)lane); });
     const uint32_t nb = R.nblock;
     // T^-1 and the walk, as bzip2_decoder.dart:406-439 / :610-727 do them
     uint32_t cf[257] = {0};
