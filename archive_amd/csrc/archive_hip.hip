@@ -1427,6 +1427,15 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
     }
   }
   HIP_TRY(hipStreamSynchronize(st));
+#ifdef AHIP_BZ_PROFILE
+  {
+    unsigned long long pr[8] = {0}, zero[8] = {0};
+    HIP_TRY(hipMemcpyFromSymbol(pr, HIP_SYMBOL(bz_prof), sizeof(pr)));
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(bz_prof), zero, sizeof(zero)));
+    fprintf(stderr, "[ahip] bzip2 Huffman pass, cycles summed over blocks: header %llu tables %llu | window setup %llu chain %llu cuts+stores %llu | windows %llu symbols %llu\n",
+            pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6]);
+  }
+#endif
   if (over_cap) { if (out_len) *out_len = total; return fail(AHIP_E_CAP, "output buffer too small"); }
   if (saw_eos && verify && eos_stored != combined && verdict == AHIP_OK) verdict = AHIP_FALSE;
   if (out_len) *out_len = crc_stop ? keep : total;

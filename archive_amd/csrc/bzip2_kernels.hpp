@@ -111,16 +111,30 @@ constexpr u32 BZ_FAST_BITS = 10;
 constexpr u32 BZ_RING = 512;
 constexpr u32 BZ_SYM_CAP = BZ_MAX_SELECTORS * 50 + 128;  // symbols of a block: 50 per selector
 constexpr u32 BZ_CHUNKS = 64;                          // MTF chunks per block
-constexpr u32 BZ_MISS = 0xff;                          // length field of a fast-table entry that has no code
+constexpr u32 BZ_MISS_ENT = 1u | (1u << 9) | (1u << 18) | (1u << 31);  // chain entry without a code: the exact loop decides there (bit 31)
+constexpr u32 BZ_WIN = 256;                            // bit positions looked up per window (4 per lane)
+#ifdef AHIP_BZ_PROFILE
+__device__ unsigned long long bz_prof[8];  // cycles: 0 header+selectors+lengths 1 tables 2 window setup 3 chain 4 cuts+stores 5 windows 6 symbols
+#define BZ_TICK(v) const u64 v = __builtin_readcyclecounter()
+#define BZ_ACC(i, a, b) prof[i] += (b) - (a)
+#else
+#define BZ_TICK(v) do { } while (0)
+#define BZ_ACC(i, a, b) do { } while (0)
+#endif
 struct BzLds {
   i32 limit[6][24], base[6][24];
   u16 perm[6][258];
   u8 len[6][258];
   i32 min_len[6];
   u8 seq2unseq[256];
-  // fast[t][p]: what the reference's limit/base/perm loop does with the 10-bit pattern p, precomputed:
-  // symbol << 8 | length; length BZ_MISS = no code of <= 10 bits matches (or an invalid index): take the exact loop
-  u32 fast[6][1u << BZ_FAST_BITS];
+  // What the reference's limit/base/perm loop does with the 10-bit pattern p, precomputed:
+  //   chain[t][p]  bits 0-8 the bits ALL the codes take that lie completely inside the pattern, bits 9-17 the bits the
+  //                first one takes, bits 18-27 a mask of the offsets those codes start at (bit 0 always);
+  //                BZ_MISS_ENT = not even one code of <= 10 bits, an invalid index, or the end-of-block symbol: the
+  //                exact loop decides there (an entry never continues across such a code either);
+  //   sym[t][p]    the first code's symbol.
+  u32 chain[6][1u << BZ_FAST_BITS];
+  u16 sym[6][1u << BZ_FAST_BITS];
   u32 ring[BZ_RING];  // the stream ahead of the symbol loop, as big-endian dwords
 };
 
@@ -181,6 +195,10 @@ AHIP_DEVINL void bz_decode_block_wave(BzLds &L, const u8 *__restrict__ in, u64 n
                                       const u32 lane) {
   BzResult R{0, 0, BZ_ST_OK, 0, 0, 0, 0, 0};
   u32 nsyms = 0;
+#ifdef AHIP_BZ_PROFILE
+  u64 prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  BZ_TICK(t_begin);
   BzBits b{in, n, 0, false, 0, 0, 0};
   bz_seek(b, cand.bit + 48);
   u32 status = BZ_ST_OK;
@@ -258,6 +276,8 @@ AHIP_DEVINL void bz_decode_block_wave(BzLds &L, const u8 *__restrict__ in, u64 n
     // (the reference's tables are fresh, zero-filled arrays for every block: a damaged code can index perm past its symbols)
     for (u32 i = lane; i < 6 * 258; i += 64) (&L.perm[0][0])[i] = 0;
     wave_sync();
+    BZ_TICK(t_hdr);
+    BZ_ACC(0, t_begin, t_hdr);
     // _hbCreateDecodeTables, one lane (tiny)
     if (lane == 0) {
       for (u32 t = 0; t < ngroups; ++t) {
@@ -280,31 +300,43 @@ AHIP_DEVINL void bz_decode_block_wave(BzLds &L, const u8 *__restrict__ in, u64 n
       }
     }
     wave_sync();
-    // fast tables: run the reference's decode loop on every 10-bit pattern once
+    // fast tables: run the reference's decode loop on every 10-bit pattern once -- and again on what is left of the
+    // pattern behind each code, as long as whole codes fit
     for (u32 t = 0; t < ngroups; ++t) {
       const i32 minl = L.min_len[t];
       for (u32 pat = lane; pat < (1u << BZ_FAST_BITS); pat += 64) {
-        u32 e = BZ_MISS;
-        for (i32 zn = minl; zn <= (i32)BZ_FAST_BITS; ++zn) {
-          const i32 zvec = (i32)(pat >> (BZ_FAST_BITS - zn));
-          if (zvec <= L.limit[t][zn]) {
-            const i32 idx = zvec - L.base[t][zn];
-            if (idx >= 0 && idx < 258) e = ((u32)L.perm[t][idx] << 8) | (u32)zn;
-            break;  // an index out of range is the reference's error: the exact loop reports it
+        u32 used = 0, len1 = 0, starts = 0, sym1 = 0;
+        for (;;) {
+          i32 found = 0, fsym = 0;
+          for (i32 zn = minl; used + (u32)zn <= BZ_FAST_BITS; ++zn) {
+            const i32 zvec = (i32)(((pat << used) & ((1u << BZ_FAST_BITS) - 1)) >> (BZ_FAST_BITS - zn));
+            if (zvec <= L.limit[t][zn]) {
+              const i32 idx = zvec - L.base[t][zn];
+              if (idx >= 0 && idx < 258) { found = zn; fsym = L.perm[t][idx]; }
+              break;  // an index out of range is the reference's error: the exact loop reports it
+            }
           }
+          if (!found || (u32)fsym == num_in_use + 1) break;  // (the end-of-block symbol goes through the exact loop)
+          starts |= 1u << used;
+          if (used == 0) { len1 = (u32)found; sym1 = (u32)fsym; }
+          used += (u32)found;
         }
-        L.fast[t][pat] = e;
+        L.chain[t][pat] = used ? (used | (len1 << 9) | (starts << 18)) : BZ_MISS_ENT;
+        L.sym[t][pat] = (u16)sym1;
       }
     }
     wave_sync();
+    BZ_TICK(t_tab);
+    BZ_ACC(1, t_hdr, t_tab);
     // ---- the symbol loop ----
-    // Only the Huffman side is serial here: a code's position is the end of the one before.  The 128 bit positions
-    // from the current one are looked up at once (lane l: positions l and l + 64, ten bits each, against the current
-    // group's table), and the chain through them -- position -> its entry -> the next position -- runs on scalar
-    // registers (v_readlane, a bit set in a mask, an add: the loop below is all a symbol costs on the serial path).
-    // The positions the chain visited are the symbols: they are cut at the end of the group of 50 (the next group
-    // has another table) or at the end-of-block symbol and stored, compacted, as 16-bit values.  What the symbols
-    // MEAN -- the move-to-front list, the zero runs -- is left to bz_mtf_*: chunks of the symbol stream, in parallel.
+    // Only the Huffman side is serial here: a code's position is the end of the one before.  The 256 bit positions
+    // from the current one are looked up at once (lane l: positions l, l + 64, l + 128, l + 192, ten bits each,
+    // against the current group's table), and the chain through them -- position -> its entry -> the position
+    // behind the codes the entry covers -- runs on scalar registers: a v_readlane, the entry's start mask shifted
+    // into a 64-bit mask, an add (the loops below are all that is serial, about three instructions a symbol).
+    // The marked positions are the symbols: they are cut at the end of the group of 50 (the next group has another
+    // table) or at the end-of-block symbol and stored, compacted, as 16-bit values.  What the symbols MEAN -- the
+    // move-to-front list, the zero runs -- is left to bz_mtf_*: chunks of the symbol stream, in parallel.
     // Codes longer than ten bits and the last bits of the input take the reference's bit-by-bit loop.
     for (u32 i = lane; i < 256; i += 64) list0[i] = i < num_in_use ? L.seq2unseq[i] : (u8)0;
     const u64 nbits = n * 8;
@@ -341,63 +373,114 @@ AHIP_DEVINL void bz_decode_block_wave(BzLds &L, const u8 *__restrict__ in, u64 n
         if (group_no && (group_no & 63) == 0) selv = sel[(u32)group_no + lane < nsel ? (u32)group_no + lane : 0];
         gsel = lane_bcast(selv, group_no & 63);
       }
-      while ((bit >> 5) + 6 > ring_hi) {
+      BZ_TICK(t_w0);
+      while ((bit >> 5) + 10 > ring_hi) {
         L.ring[(u32)(ring_hi + lane) & RM] = nxt;
         ring_hi += 64;
         nxt = stream_word(ring_hi + lane);
       }
       wave_sync();
-      u32 ent0, ent1;
+      u32 elen[4], epat[4], symv[4];
+      u64 missm[4];
       {
-        const u32 bo = ((u32)bit & 31) + (u32)lane, a = (u32)(bit >> 5) + (bo >> 5), sft = bo & 31;
-        const u32 w0 = L.ring[a & RM], w1 = L.ring[(a + 1) & RM], w2 = L.ring[(a + 2) & RM], w3 = L.ring[(a + 3) & RM];
-        const u32 p0 = (u32)(((((u64)w0 << 32) | w1) << sft) >> (64 - BZ_FAST_BITS));
-        const u32 p1 = (u32)(((((u64)w2 << 32) | w3) << sft) >> (64 - BZ_FAST_BITS));
-        ent0 = L.fast[gsel][p0];
-        ent1 = L.fast[gsel][p1];
-        if (bit + (u32)lane + (ent0 & 0xff) > nbits) ent0 = BZ_MISS;
-        if (bit + (u32)lane + 64 + (ent1 & 0xff) > nbits) ent1 = BZ_MISS;
+        const u32 bo = ((u32)bit & 31) + lane, a = (u32)(bit >> 5) + (bo >> 5), sft = bo & 31;
+        const bool near_end = bit + BZ_WIN + 32 > nbits;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const u32 w0 = L.ring[(a + 2 * r) & RM], w1 = L.ring[(a + 2 * r + 1) & RM];
+          const u32 pt = (u32)(((((u64)w0 << 32) | w1) << sft) >> (64 - BZ_FAST_BITS));
+          const u32 e = L.chain[gsel][pt];
+          symv[r] = L.sym[gsel][pt];
+          const u32 l1 = (e >> 9) & 511;
+          bool ms = (e >> 31) != 0;
+          // the last ten positions of a register step one code at a time (a start mask must not reach into the
+          // next register's positions); so do the last bits of the input, where no code may end behind it
+          const bool single = lane >= 54 || near_end;
+          if (near_end && bit + lane + 64 * r + l1 > nbits) ms = true;
+          elen[r] = single ? l1 : (e & 511);
+          epat[r] = single ? 1u : ((e >> 18) & 1023);
+          missm[r] = __ballot(ms);
+        }
       }
-      // the chain: a missing entry adds 255 and so ends it
-      u32 p = 0;
-      u64 mlo = 0, mhi = 0;
-      while (p < 64) { const u32 e = lane_bcast(ent0, (int)p); mlo |= 1ull << p; p += e & 0xff; }
-      while (p < 128) { const u32 e = lane_bcast(ent1, (int)(p - 64)); mhi |= 1ull << (p - 64); p += e & 0xff; }
-      bool miss = p >= 255;  // the last position visited has no entry
-      if (miss) {
-        if (mhi) { const u32 q = 63u - (u32)__builtin_clzll(mhi); mhi &= ~(1ull << q); p = 64 + q; }
-        else { const u32 q = 63u - (u32)__builtin_clzll(mlo); mlo &= ~(1ull << q); p = q; }
+      BZ_TICK(t_w1);
+      BZ_ACC(2, t_w0, t_w1);
+      // The chain.  A step: the entry at the current position -- its start mask into the visited mask, its length
+      // onto the position.  An entry without a code steps on by one bit (what follows is rubbish, found out and cut
+      // below).  Below position 44 of a register two steps need no check in between (2 x 10 bits stay inside).
+      u32 p = 0, seen = 0;
+      u64 m[4] = {0, 0, 0, 0};
+      bool more = true;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (more) {
+          u32 o = p - 64 * r;
+          u64 mm = 0;
+          while (o < 44) {
+            const u32 l0 = lane_bcast(elen[r], (int)o), p0 = lane_bcast(epat[r], (int)o);
+            mm |= (u64)p0 << o; o += l0;
+            const u32 l1 = lane_bcast(elen[r], (int)o), p1 = lane_bcast(epat[r], (int)o);
+            mm |= (u64)p1 << o; o += l1;
+          }
+          while (o < 64) { const u32 l0 = lane_bcast(elen[r], (int)o), p0 = lane_bcast(epat[r], (int)o); mm |= (u64)p0 << o; o += l0; }
+          m[r] = mm;
+          p = o + 64 * r;
+          seen += (u32)__popcll(mm);
+          if (seen > group_pos) more = false;  // the group ends inside what has been seen: the rest would be cut anyway
+        }
       }
-      const bool my0 = (mlo >> lane) & 1, my1 = (mhi >> lane) & 1;
-      // the end-of-block symbol ends everything; what the chain found behind it is not there
-      const u64 e0 = __ballot(my0 && (ent0 >> 8) == eob), e1 = __ballot(my1 && (ent1 >> 8) == eob);
-      if (e0 | e1) {
-        if (e0) { const u32 q = (u32)__builtin_ctzll(e0); mlo &= (2ull << q) - 1; mhi = 0; p = q + (lane_bcast(ent0, (int)q) & 0xff); }
-        else { const u32 q = (u32)__builtin_ctzll(e1); mhi &= (2ull << q) - 1; p = 64 + q + (lane_bcast(ent1, (int)q) & 0xff); }
-        miss = false;
-        stop = 1;
+      BZ_TICK(t_w2);
+      BZ_ACC(3, t_w1, t_w2);
+      // a visited position without a code: it and everything behind it is not there; the exact loop takes over at it
+      bool miss = false;
+      if ((m[0] & missm[0]) | (m[1] & missm[1]) | (m[2] & missm[2]) | (m[3] & missm[3])) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (miss) m[r] = 0;
+          else if (m[r] & missm[r]) {
+            const u32 q = (u32)__builtin_ctzll(m[r] & missm[r]);
+            m[r] &= (1ull << q) - 1;
+            p = 64 * r + q;
+            miss = true;
+          }
+        }
       }
-      // ... and so does the end of the group: the (group_pos + 1)-th symbol belongs to the next table
-      const u32 c0 = (u32)__popcll(mlo), c1 = (u32)__popcll(mhi);
-      u32 take = c0 + c1;
+      // the group ends with its 50th symbol: the next one belongs to the next table
+      const u32 c0 = (u32)__popcll(m[0]), c1 = (u32)__popcll(m[1]), c2 = (u32)__popcll(m[2]), c3 = (u32)__popcll(m[3]);
+      u32 take = c0 + c1 + c2 + c3;
       if (take + (miss ? 1u : 0u) > group_pos) {
-        const u64 my_lo = (mlo >> lane) & 1, my_hi = (mhi >> lane) & 1;
-        const u64 k0 = __ballot(my_lo && wave_rank(mlo) == group_pos), k1 = __ballot(my_hi && c0 + wave_rank(mhi) == group_pos);
-        if (k0) { const u32 q = (u32)__builtin_ctzll(k0); mlo &= (1ull << q) - 1; mhi = 0; p = q; }
-        else if (k1) { const u32 q = (u32)__builtin_ctzll(k1); mhi &= (1ull << q) - 1; p = 64 + q; }
-        // (neither: the symbols fill the group exactly and the missing one is the next group's -- p already points at it)
+        if (take > group_pos) {  // the symbol of rank group_pos is the first one that is not this group's
+          const u32 rr = group_pos < c0 ? 0u : (group_pos < c0 + c1 ? 1u : (group_pos < c0 + c1 + c2 ? 2u : 3u));
+          const u32 k = group_pos - (rr == 0 ? 0u : (rr == 1 ? c0 : (rr == 2 ? c0 + c1 : c0 + c1 + c2)));
+          const u64 mm = rr == 0 ? m[0] : (rr == 1 ? m[1] : (rr == 2 ? m[2] : m[3]));
+          const u32 q = (u32)__builtin_ctzll(__ballot(((mm >> lane) & 1) && wave_rank(mm) == k));
+          const u64 keep = (1ull << q) - 1;
+          if (rr == 0) { m[0] &= keep; m[1] = 0; m[2] = 0; m[3] = 0; }
+          else if (rr == 1) { m[1] &= keep; m[2] = 0; m[3] = 0; }
+          else if (rr == 2) { m[2] &= keep; m[3] = 0; }
+          else m[3] &= keep;
+          p = 64 * rr + q;
+        }
+        // (take == group_pos: the marked ones fill the group exactly and the position without a code is the next group's)
         take = group_pos;
         miss = false;
-        stop = 0;
       }
       {
-        const bool s0 = (mlo >> lane) & 1, s1 = (mhi >> lane) & 1;
-        if (s0) syms[nsyms + wave_rank(mlo)] = (u16)(ent0 >> 8);
-        if (s1) syms[nsyms + (u32)__popcll(mlo) + wave_rank(mhi)] = (u16)(ent1 >> 8);
+        u32 below = nsyms;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (m[r]) {
+            if ((m[r] >> lane) & 1) syms[below + wave_rank(m[r])] = (u16)symv[r];
+            below += (u32)__popcll(m[r]);
+          }
+        }
       }
-      if (stop == 1) take -= 1;  // the end-of-block symbol is not recorded
+      BZ_TICK(t_w3);
+      BZ_ACC(4, t_w2, t_w3);
+#ifdef AHIP_BZ_PROFILE
+      prof[5] += 1;
+#endif
       nsyms += take;
-      group_pos -= (stop == 1) ? take + 1 : take;
+      group_pos -= take;
       if (miss) {  // the reference loop, bit by bit (long codes, invalid indices, end of input)
         const u64 at = bit + p;
         i32 zn = (i32)uniform((u32)L.min_len[gsel]);
@@ -430,6 +513,10 @@ AHIP_DEVINL void bz_decode_block_wave(BzLds &L, const u8 *__restrict__ in, u64 n
   } while (0);
 
   // what the symbols mean, and everything behind that, are separate launches (bz_mtf_scan sets nblock and the final status)
+#ifdef AHIP_BZ_PROFILE
+  prof[6] = nsyms;
+  if (lane == 0) for (int k = 0; k < 7; ++k) atomicAdd(&bz_prof[k], prof[k]);
+#endif
   R.status = status;
   R.nblock = 0;
   R.nsyms = nsyms;
