@@ -1250,6 +1250,7 @@ uint32_t ahip_adler32(const uint8_t *data, size_t len, uint32_t adler) {
   return (uint32_t)((s2 << 16) | s1);
 }
 
+static bool bz_parallel_huffman() { static const bool v = getenv("AHIP_BZ_SERIAL_HUFFMAN") == nullptr; return v; }
 // bzip2 on device memory.  `in` = the first bytes of the stream on the host (header checks), d_in = the whole
 // stream on the device, d_out = device output of out_cap bytes.
 static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, int32_t verify, u8 *d_out, size_t out_cap,
@@ -1292,13 +1293,17 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
   // block at level 9), following the chain of blocks exactly like decodeStream between them: a block ends where
   // the next magic starts.  A batch's blocks are placed and expanded before the next batch is decoded; nothing
   // behind the point where the chain stops is ever touched.
-  const u64 per_block = nblock_max * 5 + (u64)BZ_SYM_CAP * 2 + BZ_CHUNKS * 530 + wstride * (sizeof(BzWalk) + 4) + BZ_SPANS * sizeof(BzSpan) + BZ_MAX_SELECTORS + sizeof(BzResult) + 64;
+  const u64 per_block = nblock_max * 5 + (u64)BZ_SYM_CAP * 2 + BZ_CHUNKS * 530 + sizeof(BzTables) + BZ_MAX_SELECTORS * 4 + wstride * (sizeof(BzWalk) + 4) + BZ_SPANS * sizeof(BzSpan) + BZ_MAX_SELECTORS + sizeof(BzResult) + 64;
   u64 batch_mem = 6ull << 30;
   if (const char *e = getenv("AHIP_BZ_BATCH_BYTES")) { if (atoll(e) > 0) batch_mem = (u64)atoll(e); }
-  u32 batch = (u32)std::min<u64>(ncand, std::max<u64>(4, batch_mem / per_block));
+  const u64 j50_per_block = bz_parallel_huffman() ? (u64)in_len * 8 / std::max<u32>(1, ncand) * 12 : 0;  // 6 tables x 2 bytes per bit
+  u32 batch = (u32)std::min<u64>(ncand, std::max<u64>(4, batch_mem / (per_block + j50_per_block)));
   HIP_TRY(dtt.reserve((size_t)batch * nblock_max * 4));
   HIP_TRY(dsel.reserve((size_t)batch * BZ_MAX_SELECTORS));
-  static thread_local DevBuf dsyms, dlist0, dchunks, dperms, dlists, dchoff;
+  static thread_local DevBuf dsyms, dlist0, dchunks, dperms, dlists, dchoff, dtab, dj50, dgstart, dgcount;
+  HIP_TRY(dtab.reserve((size_t)batch * sizeof(BzTables)));
+  HIP_TRY(dgstart.reserve((size_t)batch * BZ_MAX_SELECTORS * 4));
+  HIP_TRY(dgcount.reserve((size_t)batch * 4));
   HIP_TRY(dsyms.reserve((size_t)batch * BZ_SYM_CAP * 2));
   HIP_TRY(dlist0.reserve((size_t)batch * 256));
   HIP_TRY(dchunks.reserve((size_t)batch * BZ_CHUNKS * sizeof(BzChunk)));
@@ -1342,8 +1347,28 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
     const u32 nb = (u32)std::min<size_t>(batch, ncand - c0);
     const BzCand *dc = dcand.as<BzCand>() + c0;
     // phase 1: the Huffman side of every block (one wave each) -> symbol streams; what the symbols mean by chunks
-    hipLaunchKernelGGL(bz_decode_block, dim3(nb), dim3(64), 0, st, d_in, (u64)in_len, dc, nb, dsyms.as<u16>(), dlist0.as<u8>(), dsel.as<u8>(),
-                       dres.as<BzResult>());
+    if (bz_parallel_huffman()) {
+      // headers and tables (one wave per block), the 50-code jump from every bit position (tiles, any number of workgroups),
+      // the walk over the groups (one workgroup per block), the groups (one thread each); what is irregular, serially
+      const u64 bit0 = cands[c0].bit, bit1 = c0 + nb < ncand ? cands[c0 + nb].bit : (u64)in_len * 8;
+      const u64 tstride = bit1 - bit0 + 64;
+      u64 widest = 0;
+      for (u32 i = 0; i < nb; ++i) widest = std::max<u64>(widest, (c0 + i + 1 < ncand ? cands[c0 + i + 1].bit : (u64)in_len * 8) - cands[c0 + i].bit);
+      HIP_TRY(dj50.reserve((size_t)tstride * 6 * 2));
+      hipLaunchKernelGGL(bz_header, dim3(nb), dim3(64), 0, st, d_in, (u64)in_len, dc, nb, dtab.as<BzTables>(), dlist0.as<u8>(), dsel.as<u8>(),
+                         dres.as<BzResult>());
+      hipLaunchKernelGGL(bz_jump_tiles, dim3((u32)cdiv(widest, BZ_TW) + 1, nb), dim3(512), 0, st, d_in, (u64)in_len, dcand.as<BzCand>(), ncand,
+                         (u32)c0, dtab.as<BzTables>(), dj50.as<u16>(), bit0, tstride);
+      hipLaunchKernelGGL(bz_group_starts, dim3(nb), dim3(256), 0, st, d_in, (u64)in_len, dcand.as<BzCand>(), ncand, (u32)c0, dtab.as<BzTables>(),
+                         dsel.as<u8>(), dj50.as<u16>(), bit0, tstride, dgstart.as<u32>(), dgcount.as<u32>(), dres.as<BzResult>());
+      hipLaunchKernelGGL(bz_decode_groups, dim3(cdiv(BZ_MAX_SELECTORS, 256), nb), dim3(256), 0, st, d_in, (u64)in_len, dtab.as<BzTables>(),
+                         dsel.as<u8>(), dgstart.as<u32>(), dgcount.as<u32>(), dsyms.as<u16>(), dres.as<BzResult>());
+      hipLaunchKernelGGL(bz_decode_block, dim3(nb), dim3(64), 0, st, d_in, (u64)in_len, dc, nb, dsyms.as<u16>(), dlist0.as<u8>(), dsel.as<u8>(),
+                         dres.as<BzResult>(), 1u);
+    } else {
+      hipLaunchKernelGGL(bz_decode_block, dim3(nb), dim3(64), 0, st, d_in, (u64)in_len, dc, nb, dsyms.as<u16>(), dlist0.as<u8>(), dsel.as<u8>(),
+                         dres.as<BzResult>(), 0u);
+    }
     hipLaunchKernelGGL(bz_mtf_chunks<false>, dim3(BZ_CHUNKS / 4, nb), dim3(256), 0, st, dsyms.as<u16>(), dres.as<BzResult>(), (u32)level,
                        dchunks.as<BzChunk>(), dperms.as<u8>(), dlists.as<u8>(), dchoff.as<u32>(), dtt.as<u32>());
     hipLaunchKernelGGL(bz_mtf_scan, dim3(nb), dim3(64), 0, st, dres.as<BzResult>(), dc, nb, (u32)level, dchunks.as<BzChunk>(), dperms.as<u8>(),

@@ -35,6 +35,7 @@ namespace ahip {
 
 constexpr u32 BZ_MAX_SELECTORS = 18002;
 constexpr u32 BZ_ST_OK = 0, BZ_ST_FALSE = 1, BZ_ST_RANGE = 2, BZ_ST_OVERFLOW = 16, BZ_ST_UNSUPPORTED = 17, BZ_ST_SERIAL = 18;
+constexpr u32 BZ_ST_HUFF_SERIAL = 19;  // between kernels only: the position-parallel Huffman pass hands the block to the serial one
 constexpr u32 BZ_G = 128;      // splitter stride of the list ranking
 constexpr u32 BZ_SPANS = 1024;  // run-length spans per block
 
@@ -121,6 +122,16 @@ __device__ unsigned long long bz_prof[8];  // cycles: 0 header+selectors+lengths
 #define BZ_TICK(v) do { } while (0)
 #define BZ_ACC(i, a, b) do { } while (0)
 #endif
+// What bz_header leaves in global memory for the position-parallel Huffman pass (bz_jump_tile / bz_walk_groups /
+// bz_decode_groups below): the reference's limit / base / perm tables and the first-code table.
+struct BzTables {
+  i32 limit[6][24], base[6][24];
+  u16 perm[6][258];
+  i32 min_len[6];
+  u16 e16[6][1u << BZ_FAST_BITS];  // first code of the 10-bit pattern: symbol << 5 | length; 0 = the exact loop decides
+  u32 ngroups, nsel, eob, pad;
+  u64 sym_bit;                     // where the block's symbol stream starts
+};
 struct BzLds {
   i32 limit[6][24], base[6][24];
   u16 perm[6][258];
@@ -190,9 +201,10 @@ AHIP_DEVINL u32 bzf_bits(BzFast &f, u32 nb, int lane) {  // nb <= 24; the refere
 
 // one wave per candidate block (a device function: tests/emu/bzip2_emu.cc runs it on the CPU wave emulation)
 // syms: room for BZ_SYM_CAP symbols; list0: the block's initial MTF list (256 bytes, seqToUnseq applied)
+// exp != nullptr: stop in front of the symbol stream and leave the tables there (BzTables)
 AHIP_DEVINL void bz_decode_block_wave(BzLds &L, const u8 *__restrict__ in, u64 n, const BzCand cand,
                                       u16 *__restrict__ syms, u8 *__restrict__ list0, u8 *__restrict__ sel, BzResult &out,
-                                      const u32 lane) {
+                                      const u32 lane, BzTables *__restrict__ exp = nullptr) {
   BzResult R{0, 0, BZ_ST_OK, 0, 0, 0, 0, 0};
   u32 nsyms = 0;
 #ifdef AHIP_BZ_PROFILE
@@ -328,6 +340,18 @@ AHIP_DEVINL void bz_decode_block_wave(BzLds &L, const u8 *__restrict__ in, u64 n
     wave_sync();
     BZ_TICK(t_tab);
     BZ_ACC(1, t_hdr, t_tab);
+    for (u32 i = lane; i < 256; i += 64) list0[i] = i < num_in_use ? L.seq2unseq[i] : (u8)0;
+    if (exp) {
+      for (u32 i = lane; i < 6 * 24; i += 64) { (&exp->limit[0][0])[i] = (&L.limit[0][0])[i]; (&exp->base[0][0])[i] = (&L.base[0][0])[i]; }
+      for (u32 i = lane; i < 6 * 258; i += 64) (&exp->perm[0][0])[i] = (&L.perm[0][0])[i];
+      for (u32 i = lane; i < 6 * (1u << BZ_FAST_BITS); i += 64) {
+        const u32 e = (&L.chain[0][0])[i];
+        (&exp->e16[0][0])[i] = (i >> BZ_FAST_BITS) < ngroups && !(e >> 31) ? (u16)(((u32)(&L.sym[0][0])[i] << 5) | ((e >> 9) & 31)) : (u16)0;
+      }
+      if (lane < 6) exp->min_len[lane] = L.min_len[lane];
+      if (lane == 0) { exp->ngroups = ngroups; exp->nsel = nsel; exp->eob = num_in_use + 1; exp->pad = 0; exp->sym_bit = b.bit; }
+      break;
+    }
     // ---- the symbol loop ----
     // Only the Huffman side is serial here: a code's position is the end of the one before.  The 256 bit positions
     // from the current one are looked up at once (lane l: positions l, l + 64, l + 128, l + 192, ten bits each,
@@ -338,7 +362,6 @@ AHIP_DEVINL void bz_decode_block_wave(BzLds &L, const u8 *__restrict__ in, u64 n
     // table) or at the end-of-block symbol and stored, compacted, as 16-bit values.  What the symbols MEAN -- the
     // move-to-front list, the zero runs -- is left to bz_mtf_*: chunks of the symbol stream, in parallel.
     // Codes longer than ten bits and the last bits of the input take the reference's bit-by-bit loop.
-    for (u32 i = lane; i < 256; i += 64) list0[i] = i < num_in_use ? L.seq2unseq[i] : (u8)0;
     const u64 nbits = n * 8;
     u64 bit = b.bit;
     auto stream_word = [&](u64 idx) -> u32 {  // dword idx of the stream as a big-endian value, zeros behind the end
@@ -526,6 +549,237 @@ AHIP_DEVINL void bz_decode_block_wave(BzLds &L, const u8 *__restrict__ in, u64 n
   out = R;
 }
 
+// ---- the Huffman side, position-parallel ----
+// bz_decode_block_wave above walks a block's codes one after the other: a code's position is the end of the one before
+// it, and one wave spends ~45 cycles on each of the ~500 000 codes of a block.  Here the dependence is broken up:
+//   bz_jump_tile     for EVERY bit position of the block (tiles of 4096, any number of workgroups) and every one of
+//                    its coding tables: where does a decoder stand 50 codes after starting here?  The code length at
+//                    every position is one table lookup; the 2-, 4-, ... 32-code jumps follow by doubling
+//                    (J2k[i] = Jk[i] + Jk[i + Jk[i]], in LDS), J50 = J32 . J16 . J2.  A jump that would pass the
+//                    end-of-block symbol, an invalid code or the end of the input is marked instead.
+//   bz_walk_groups   one workgroup per block follows the groups: start of group g + 1 = start of g + J50[selector
+//                    of g][start of g] -- one LDS lookup per 50 codes -- until it stands on a mark.
+//   bz_decode_groups every group decodes its 50 codes from its start, one thread each; the marked group is decoded the
+//                    same way and finds the end-of-block symbol (or the error) exactly where the reference does.
+// The symbol stream that results is what bz_decode_block_wave writes; anything irregular (a mark with nothing behind it:
+// a block running into its successor's bits) is handed to that function (BZ_ST_HUFF_SERIAL).
+constexpr u32 BZ_TW = 4096, BZ_TOV = 1024, BZ_TN = BZ_TW + BZ_TOV;  // tile: positions written / overlap / computed
+constexpr u16 BZ_TERM = 0xffff;
+#ifdef AHIP_HOST_EMU
+#define BZ_BLOCK_SYNC() do { } while (0)  /* the emulation runs these functions with one thread */
+#else
+#define BZ_BLOCK_SYNC() __syncthreads()
+#endif
+struct BzTileLds {
+  u16 x[4][BZ_TN];
+  u32 bits[BZ_TN / 32 + 4];  // the tile's stream as big-endian dwords, from the dword its first bit lies in
+  i32 limit[6][24], base[6][24];
+  u16 perm[6][258];
+  i32 min_len[6];
+  u16 e16[6][1u << BZ_FAST_BITS];
+};
+AHIP_DEVINL u32 bz_stream_word(const u8 *__restrict__ in, u64 n, u64 idx) {  // dword idx as a big-endian value, zeros behind the end
+  const u64 off = idx * 4;
+  if (off + 4 <= n) return __builtin_bswap32(*(const u32 *)(in + off));  // `in` is device-allocated: aligned
+  u32 w = 0;
+  for (int k = 0; k < 4; ++k) w = (w << 8) | (off + k < n ? in[off + k] : 0u);
+  return w;
+}
+// The length of the code at a position whose next 32 bits are w32 (table t), the way the reference finds it; 0 = no
+// code there: none of <= 20 bits, an invalid index, the end-of-block symbol (sym_out says which when asked).
+template <class TB>
+AHIP_DEVINL u32 bz_code_at(const TB &T, u32 t, u32 w32, u32 eob, u32 &sym_out) {
+  const u32 e = T.e16[t][w32 >> (32 - BZ_FAST_BITS)];
+  if (e) { sym_out = e >> 5; return e & 31; }
+  i32 zn = T.min_len[t];
+  for (;;) {
+    if (zn > 20) { sym_out = 0xffffu; return 0; }
+    const i32 zvec = (i32)(w32 >> (32 - zn));
+    if (zvec <= T.limit[t][zn]) {
+      const i32 idx = zvec - T.base[t][zn];
+      if (idx < 0 || idx >= 258) { sym_out = 0xffffu; return 0; }
+      sym_out = T.perm[t][idx];
+      return sym_out == eob ? 0u : (u32)zn;
+    }
+    zn++;
+  }
+}
+// One tile: positions [tile_bit, tile_bit + BZ_TW) of the block whose tables are T; `lim` = the first bit that is not
+// the block's any more (the next block's magic, or the end of the input).  j50[t * tstride + i] for position tile_bit + i.
+AHIP_DEVINL void bz_jump_tile(BzTileLds &S, const u8 *__restrict__ in, u64 n, const BzTables *__restrict__ T, u64 tile_bit,
+                              u64 lim, u16 *__restrict__ j50, u64 tstride, const u32 tid, const u32 nthreads) {
+  const u32 ngroups = T->ngroups, eob = T->eob;
+  for (u32 i = tid; i < 6 * 24; i += nthreads) { (&S.limit[0][0])[i] = (&T->limit[0][0])[i]; (&S.base[0][0])[i] = (&T->base[0][0])[i]; }
+  for (u32 i = tid; i < 6 * 258; i += nthreads) (&S.perm[0][0])[i] = (&T->perm[0][0])[i];
+  for (u32 i = tid; i < 6 * (1u << BZ_FAST_BITS) / 2; i += nthreads) ((u32 *)&S.e16[0][0])[i] = ((const u32 *)&T->e16[0][0])[i];
+  for (u32 i = tid; i < 6; i += nthreads) S.min_len[i] = T->min_len[i];
+  const u64 d0 = tile_bit >> 5;
+  const u32 sft0 = (u32)tile_bit & 31;
+  for (u32 i = tid; i < BZ_TN / 32 + 4; i += nthreads) S.bits[i] = bz_stream_word(in, n, d0 + i);
+  BZ_BLOCK_SYNC();
+  const u64 nbits = n * 8;
+  auto dbl = [&](const u16 *src, u16 *dst) {
+    for (u32 i = tid; i < BZ_TN; i += nthreads) {
+      const u32 a = src[i];
+      u32 r = BZ_TERM;
+      if (a != BZ_TERM && i + a < BZ_TN) { const u32 b = src[i + a]; if (b != BZ_TERM) r = a + b; }
+      dst[i] = (u16)r;
+    }
+    BZ_BLOCK_SYNC();
+  };
+  for (u32 t = 0; t < ngroups; ++t) {
+    for (u32 i = tid; i < BZ_TN; i += nthreads) {
+      const u64 at = tile_bit + i;
+      u32 r = BZ_TERM;
+      if (at < lim) {
+        const u32 bo = sft0 + i;
+        const u32 w32 = (u32)(((((u64)S.bits[bo >> 5] << 32) | S.bits[(bo >> 5) + 1]) << (bo & 31)) >> 32);
+        u32 sym;
+        const u32 len = bz_code_at(S, t, w32, eob, sym);
+        if (len && at + len <= nbits) r = len;
+      }
+      S.x[0][i] = (u16)r;
+    }
+    BZ_BLOCK_SYNC();
+    dbl(S.x[0], S.x[1]);  // J2 (kept)
+    dbl(S.x[1], S.x[2]);  // J4
+    dbl(S.x[2], S.x[0]);  // J8
+    dbl(S.x[0], S.x[2]);  // J16 (kept)
+    dbl(S.x[2], S.x[3]);  // J32 (kept)
+    for (u32 i = tid; i < BZ_TW; i += nthreads) {
+      if (tile_bit + i >= lim) break;
+      u32 r = BZ_TERM;
+      const u32 a = S.x[3][i];
+      if (a != BZ_TERM) {
+        const u32 b = S.x[2][i + a];
+        if (b != BZ_TERM) { const u32 c = S.x[1][i + a + b]; if (c != BZ_TERM) r = a + b + c; }
+      }
+      j50[t * tstride + i] = (u16)r;
+    }
+    BZ_BLOCK_SYNC();
+  }
+}
+
+// One workgroup per block: the starts of its groups (bits from sym_bit).  jt = LDS room for 6 x BZ_TW jumps.
+// Returns (thread 0) the number of groups that have a start: the last of them is the one standing on a mark, or -- no
+// mark within nsel groups -- there is none and the block is `false` (the reference runs out of selectors).
+struct alignas(16) BzWalkLds { u16 jt[6][BZ_TW + 8]; u8 sel[BZ_MAX_SELECTORS + 14]; u32 pos_lo, pos_hi, g, done; };
+AHIP_DEVINL void bz_walk_groups(BzWalkLds &S, const BzTables *__restrict__ T, const u8 *__restrict__ sel, u64 lim,
+                                const u16 *__restrict__ j50, u64 j50_bit0, u64 tstride, u32 *__restrict__ gstart,
+                                u32 &found, u32 &marked, const u32 tid, const u32 nthreads) {  // marked: see below
+  const u32 ngroups = T->ngroups, nsel = T->nsel;
+  const u64 sym_bit = T->sym_bit;
+  for (u32 i = tid; i < nsel; i += nthreads) S.sel[i] = sel[i];
+  if (tid == 0) { S.pos_lo = (u32)sym_bit; S.pos_hi = (u32)(sym_bit >> 32); S.g = 0; S.done = 0; }
+  BZ_BLOCK_SYNC();
+  // a tile's jumps: 6 rows of BZ_TW 16-bit values, fetched 8 at a time; the NEXT tile's are requested before the walk
+  // through this one and stored behind it (a jump is < 1024 bits: the walk never skips a tile)
+  constexpr u32 VEC = 8, PER_ROW = BZ_TW / VEC, MAX_SLOTS = 12;  // 6 * 512 vectors over >= 256 threads
+  uint4 hold[MAX_SLOTS];
+  auto request = [&](u64 base) {  // tile at `base` -> registers
+#pragma unroll
+    for (u32 k = 0; k < MAX_SLOTS; ++k) {
+      const u32 v = tid + k * nthreads;
+      hold[k] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+      if (v < 6 * PER_ROW && base < lim) {
+        const u32 t = v / PER_ROW, i = (v % PER_ROW) * VEC;
+        if (t < ngroups && base + i + VEC <= lim) hold[k] = load_u128_unaligned((const u8 *)(j50 + t * tstride + (base - j50_bit0) + i));
+        else if (t < ngroups && base + i < lim) {
+          u16 tmp[VEC];
+          for (u32 q = 0; q < VEC; ++q) tmp[q] = base + i + q < lim ? j50[t * tstride + (base - j50_bit0) + i + q] : BZ_TERM;
+          hold[k] = make_uint4(tmp[0] | (u32)tmp[1] << 16, tmp[2] | (u32)tmp[3] << 16, tmp[4] | (u32)tmp[5] << 16, tmp[6] | (u32)tmp[7] << 16);
+        }
+      }
+    }
+  };
+  auto deposit = [&]() {  // registers -> LDS
+#pragma unroll
+    for (u32 k = 0; k < MAX_SLOTS; ++k) {
+      const u32 v = tid + k * nthreads;
+      if (v < 6 * PER_ROW) { const u32 t = v / PER_ROW, i = (v % PER_ROW) * VEC; *(uint4 *)&S.jt[t][i] = hold[k]; }
+    }
+  };
+  u64 base = sym_bit;
+  if (nthreads * MAX_SLOTS >= 6 * PER_ROW) request(base);
+  for (;;) {
+    const u64 pos = ((u64)S.pos_hi << 32) | S.pos_lo;
+    if (S.done || pos >= lim) break;
+    BZ_BLOCK_SYNC();
+    if (nthreads * MAX_SLOTS >= 6 * PER_ROW) { deposit(); request(base + BZ_TW); }
+    else {  // (few threads -- the CPU emulation: plain copies)
+      for (u32 t = 0; t < ngroups; ++t)
+        for (u32 i = tid; i < BZ_TW; i += nthreads) S.jt[t][i] = base + i < lim ? j50[t * tstride + (base - j50_bit0) + i] : BZ_TERM;
+    }
+    BZ_BLOCK_SYNC();
+    if (tid == 0) {
+      u64 q = pos;
+      u32 g = S.g, done = 0;
+      while (q < base + BZ_TW) {
+        if (g >= nsel) { done = 2; break; }  // out of selectors
+        gstart[g] = (u32)(q - sym_bit);
+        const u32 j = S.jt[S.sel[g]][(u32)(q - base)];
+        ++g;
+        if (j == BZ_TERM) { done = 1; break; }
+        q += j;
+      }
+      S.pos_lo = (u32)q; S.pos_hi = (u32)(q >> 32); S.g = g; S.done = done;
+    }
+    base += BZ_TW;
+    BZ_BLOCK_SYNC();
+  }
+  found = S.g;
+  marked = S.done == 1 ? 1u : (S.done == 2 ? 0u : 2u);  // 1 a marked group ends the walk, 0 out of selectors, 2 irregular
+}
+struct BzGroupLds {
+  i32 limit[6][24], base[6][24];
+  u16 perm[6][258];
+  i32 min_len[6];
+  u16 e16[6][1u << BZ_FAST_BITS];
+};
+
+// Group g of a block (one thread): its <= 50 codes from gstart[g] into syms[50 g ...].  The marked group (last = true)
+// stops where the reference stops and reports how: its symbols before that, the bit behind the end-of-block symbol.
+struct BzGroupEnd { u32 status, nsyms; u64 end_bit; };
+template <class TB>
+AHIP_DEVINL void bz_decode_group(const TB &T, u32 eob, const u8 *__restrict__ in, u64 n, u64 sym_bit, u32 g, u32 start, u32 t,
+                                 bool last, u16 *__restrict__ syms, BzGroupEnd &end) {
+  const u64 nbits = n * 8;
+  u64 pos = sym_bit + start;
+  u32 k = 0;
+  u32 status = BZ_ST_HUFF_SERIAL;  // (a marked group that turns out to have nothing in it: left to the serial decoder)
+  for (; k < 50; ++k) {
+    const u64 by = pos >> 3;
+    u64 w = 0;
+    if (by + 8 <= n) w = __builtin_bswap64(load_u64_unaligned(in + by));
+    else for (int q = 0; q < 8; ++q) w = (w << 8) | (by + q < n ? (u64)in[by + q] : 0ull);
+    const u32 w32 = (u32)((w << ((u32)pos & 7)) >> 32);
+    u32 sym;
+    u32 len = bz_code_at(T, t, w32, eob, sym);
+    if (len && pos + len > nbits) len = 0;
+    if (!len) {
+      if (!last) break;  // (cannot happen: the jump over this group was not marked)
+      // the reference's bit-by-bit loop: where exactly does it stop?
+      i32 zn = T.min_len[t];
+      if (pos + (u32)zn > nbits) { status = BZ_ST_RANGE; break; }
+      bool ok = true, fault = false;
+      for (;;) {
+        if (zn > 20) { ok = false; break; }
+        if ((i32)(w32 >> (32 - zn)) <= T.limit[t][zn]) break;
+        if (pos + (u32)zn + 1 > nbits) { fault = true; break; }
+        zn++;
+      }
+      if (fault) { status = BZ_ST_RANGE; break; }
+      const i32 idx = ok ? (i32)(w32 >> (32 - zn)) - T.base[t][zn] : -1;
+      if (idx < 0 || idx >= 258) { status = BZ_ST_FALSE; break; }
+      if ((u32)T.perm[t][idx] == eob) { status = BZ_ST_OK; pos += (u32)zn; break; }
+      break;  // (cannot happen: a code after all)
+    }
+    syms[(u64)g * 50 + k] = (u16)sym;
+    pos += len;
+  }
+  if (last) { end.status = status; end.nsyms = g * 50 + k; end.end_bit = pos; }
+}
+
 // ---- the symbol stream's meaning: move-to-front list and zero runs (bzip2_decoder.dart:267-388), by chunks ----
 // The list after a stretch of symbols is a permutation of the list before it, whatever that was: every chunk first runs
 // its symbols over the identity (pass 0: the permutation, and how many bytes the chunk makes), one wave per block
@@ -664,16 +918,85 @@ AHIP_DEVINL void bz_mtf_scan_wave(BzScanLds &S, BzResult &R, u32 nblock_max, con
 }
 
 #ifndef AHIP_HOST_EMU
+// only_serial: just the blocks the position-parallel pass handed back (BZ_ST_HUFF_SERIAL)
 __global__ __launch_bounds__(64) void bz_decode_block(const u8 *__restrict__ in, u64 n, const BzCand *__restrict__ cands,
                                                       u32 ncand, u16 *__restrict__ syms_all, u8 *__restrict__ list0_all,
-                                                      u8 *__restrict__ sel_all, BzResult *__restrict__ results) {
+                                                      u8 *__restrict__ sel_all, BzResult *__restrict__ results, u32 only_serial) {
   __shared__ BzLds L;
   const u32 blk = blockIdx.x, lane = threadIdx.x;
   if (blk >= ncand) return;
+  if (only_serial && results[blk].status != BZ_ST_HUFF_SERIAL) return;
   BzResult R;
   bz_decode_block_wave(L, in, n, cands[blk], syms_all + (u64)blk * BZ_SYM_CAP, list0_all + (u64)blk * 256,
                        sel_all + (u64)blk * BZ_MAX_SELECTORS, R, lane);
   if (lane == 0) results[blk] = R;
+}
+// bz_header: the block headers and tables for the position-parallel pass (one wave per candidate)
+__global__ __launch_bounds__(64) void bz_header(const u8 *__restrict__ in, u64 n, const BzCand *__restrict__ cands, u32 ncand,
+                                                BzTables *__restrict__ tables, u8 *__restrict__ list0_all,
+                                                u8 *__restrict__ sel_all, BzResult *__restrict__ results) {
+  __shared__ BzLds L;
+  const u32 blk = blockIdx.x, lane = threadIdx.x;
+  if (blk >= ncand) return;
+  BzResult R;
+  bz_decode_block_wave(L, in, n, cands[blk], (u16 *)nullptr, list0_all + (u64)blk * 256, sel_all + (u64)blk * BZ_MAX_SELECTORS, R, lane,
+                       tables + blk);
+  if (lane == 0) {
+    results[blk] = R;
+    if (R.status != BZ_ST_OK || cands[blk].kind != 0) tables[blk].ngroups = 0;  // nothing to decode
+  }
+}
+// grid (tiles, blocks).  cands_all / ncand_all: the whole sorted candidate list (a block's bits end at the next candidate)
+__global__ __launch_bounds__(512) void bz_jump_tiles(const u8 *__restrict__ in, u64 n, const BzCand *__restrict__ cands_all,
+                                                     u32 ncand_all, u32 first, const BzTables *__restrict__ tables,
+                                                     u16 *__restrict__ j50, u64 j50_bit0, u64 tstride) {
+  __shared__ BzTileLds S;
+  const u32 blk = blockIdx.y;
+  const BzTables *T = tables + blk;
+  if (T->ngroups == 0) return;
+  const u64 lim = first + blk + 1 < ncand_all ? cands_all[first + blk + 1].bit : n * 8;
+  const u64 tile_bit = T->sym_bit + (u64)blockIdx.x * BZ_TW;
+  if (tile_bit >= lim) return;
+  bz_jump_tile(S, in, n, T, tile_bit, lim, j50 + (tile_bit - j50_bit0), tstride, threadIdx.x, blockDim.x);
+}
+__global__ __launch_bounds__(256) void bz_group_starts(const u8 *__restrict__ in, u64 n, const BzCand *__restrict__ cands_all, u32 ncand_all,
+                                               u32 first, const BzTables *__restrict__ tables, const u8 *__restrict__ sel_all,
+                                               const u16 *__restrict__ j50, u64 j50_bit0, u64 tstride, u32 *__restrict__ gstart_all,
+                                               u32 *__restrict__ gcount, BzResult *__restrict__ results) {
+  __shared__ BzWalkLds S;
+  const u32 blk = blockIdx.x;
+  const BzTables *T = tables + blk;
+  if (T->ngroups == 0) { if (threadIdx.x == 0) gcount[blk] = 0; return; }
+  const u64 lim = first + blk + 1 < ncand_all ? cands_all[first + blk + 1].bit : n * 8;
+  u32 found = 0, marked = 0;
+  bz_walk_groups(S, T, sel_all + (u64)blk * BZ_MAX_SELECTORS, lim, j50, j50_bit0, tstride, gstart_all + (u64)blk * BZ_MAX_SELECTORS,
+                 found, marked, threadIdx.x, blockDim.x);
+  if (threadIdx.x == 0) {
+    gcount[blk] = marked == 1 ? found : 0u;
+    if (marked != 1) { results[blk].status = marked == 0 ? BZ_ST_FALSE : BZ_ST_HUFF_SERIAL; results[blk].nsyms = 0; }
+  }
+}
+// grid (ceil(BZ_MAX_SELECTORS / 256), blocks): one thread per group
+__global__ __launch_bounds__(256) void bz_decode_groups(const u8 *__restrict__ in, u64 n, const BzTables *__restrict__ tables,
+                                                        const u8 *__restrict__ sel_all, const u32 *__restrict__ gstart_all,
+                                                        const u32 *__restrict__ gcount, u16 *__restrict__ syms_all,
+                                                        BzResult *__restrict__ results) {
+  __shared__ BzGroupLds S;
+  const u32 blk = blockIdx.y, found = gcount[blk];
+  if (blockIdx.x * 256 >= found) return;
+  const BzTables *T = tables + blk;
+  for (u32 i = threadIdx.x; i < 6 * 24; i += 256) { (&S.limit[0][0])[i] = (&T->limit[0][0])[i]; (&S.base[0][0])[i] = (&T->base[0][0])[i]; }
+  for (u32 i = threadIdx.x; i < 6 * 258; i += 256) (&S.perm[0][0])[i] = (&T->perm[0][0])[i];
+  for (u32 i = threadIdx.x; i < 6 * (1u << BZ_FAST_BITS) / 2; i += 256) ((u32 *)&S.e16[0][0])[i] = ((const u32 *)&T->e16[0][0])[i];
+  if (threadIdx.x < 6) S.min_len[threadIdx.x] = T->min_len[threadIdx.x];
+  __syncthreads();
+  const u32 g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= found) return;
+  BzGroupEnd end;
+  const bool last = g + 1 == found;
+  bz_decode_group(S, T->eob, in, n, T->sym_bit, g, gstart_all[(u64)blk * BZ_MAX_SELECTORS + g], sel_all[(u64)blk * BZ_MAX_SELECTORS + g],
+                  last, syms_all + (u64)blk * BZ_SYM_CAP, end);
+  if (last) { results[blk].status = end.status; results[blk].nsyms = end.nsyms; results[blk].end_bit = end.end_bit; }
 }
 // grid (BZ_CHUNKS / 4, blocks), 256 threads: one wave per chunk
 template <bool WRITE>

@@ -61,6 +61,35 @@ int main(int argc, char **argv) {
     const BzCand c{bit, 0, 0};
     wave([&](int lane) { BzResult r; bz_decode_block_wave(LDS, in, n, c, syms.data(), list0.data(), sel.data(), r, (u32)lane); if (lane == 0) R = r; });
     if (R.status != BZ_ST_OK) { printf("block %zu: Huffman side status %u\n", blocks, R.status); return 1; }
+    {
+      // the position-parallel Huffman pass (bz_header's tables, bz_jump_tile for every tile, bz_walk_groups, bz_decode_group
+      // for every group; these functions have no cross-lane operations and run here with one thread) must leave the
+      // same symbol stream, end position and verdict
+      static BzTables T;
+      static BzTileLds TL;
+      static BzWalkLds WL;
+      BzResult H{};
+      std::vector<uint8_t> sel2(BZ_MAX_SELECTORS + 64), list2(256);
+      wave([&](int lane) { BzResult r; bz_decode_block_wave(LDS, in, n, c, (u16 *)nullptr, list2.data(), sel2.data(), r, (u32)lane, &T); if (lane == 0) H = r; });
+      if (H.status != BZ_ST_OK || T.sym_bit != H.end_bit) { printf("block %zu: header pass status %u\n", blocks, H.status); return 1; }
+      const uint64_t lim = n * 8, bit0 = bit;  // (one block at a time here: its bits end with the input)
+      const uint64_t tstride = lim - bit0 + 64;
+      std::vector<uint16_t> j50((size_t)tstride * 6, 0xabcd), syms2(BZ_SYM_CAP, 0xeeee);
+      for (uint64_t tb = T.sym_bit; tb < lim; tb += BZ_TW) bz_jump_tile(TL, in, n, &T, tb, lim, j50.data() + (tb - bit0), tstride, 0, 1);
+      std::vector<uint32_t> gstart(BZ_MAX_SELECTORS);
+      uint32_t found = 0, marked = 0;
+      bz_walk_groups(WL, &T, sel2.data(), lim, j50.data(), bit0, tstride, gstart.data(), found, marked, 0, 1);
+      if (marked != 1 || found == 0) { printf("block %zu: walk found %u groups, marked %u\n", blocks, found, marked); return 1; }
+      BzGroupEnd end{};
+      for (uint32_t g = 0; g < found; ++g) bz_decode_group(T, T.eob, in, n, T.sym_bit, g, gstart[g], sel2[g], g + 1 == found, syms2.data(), end);
+      if (end.status != R.status || end.nsyms != R.nsyms || end.end_bit != R.end_bit || memcmp(syms2.data(), syms.data(), (size_t)R.nsyms * 2) ||
+          memcmp(sel2.data(), sel.data(), T.nsel) || memcmp(list2.data(), list0.data(), 256)) {
+        size_t i = 0; while (i < R.nsyms && syms2[i] == syms[i]) ++i;
+        printf("block %zu: position-parallel pass differs: status %u/%u nsyms %u/%u end %llu/%llu first differing symbol %zu\n", blocks, end.status, R.status,
+               end.nsyms, R.nsyms, (unsigned long long)end.end_bit, (unsigned long long)R.end_bit, i);
+        return 1;
+      }
+    }
     const uint32_t nmax = 100000u * level;
     for (uint32_t k = 0; k < BZ_CHUNKS; ++k)
       wave([&](int lane) { BzChunk r; bz_mtf_chunk_wave<false>(syms.data(), R.nsyms, k, nmax, nullptr, 0, tt.data(), perms.data() + k * 256, r, (u32)lane); if (lane == 0) chunks[k] = r; });
