@@ -571,7 +571,7 @@ constexpr u16 BZ_TERM = 0xffff;
 #define BZ_BLOCK_SYNC() __syncthreads()
 #endif
 struct BzTileLds {
-  u16 x[4][BZ_TN];
+  u16 x[4][BZ_TN + 2];
   u32 bits[BZ_TN / 32 + 4];  // the tile's stream as big-endian dwords, from the dword its first bit lies in
   i32 limit[6][24], base[6][24];
   u16 perm[6][258];
@@ -618,12 +618,15 @@ AHIP_DEVINL void bz_jump_tile(BzTileLds &S, const u8 *__restrict__ in, u64 n, co
   for (u32 i = tid; i < BZ_TN / 32 + 4; i += nthreads) S.bits[i] = bz_stream_word(in, n, d0 + i);
   BZ_BLOCK_SYNC();
   const u64 nbits = n * 8;
+  // (a mark is the largest value: a sum with one in it saturates to it; x[.][BZ_TN] stays a mark, and every index is
+  //  clamped to it -- no branches)
+  for (u32 i = tid; i < 4; i += nthreads) S.x[i][BZ_TN] = BZ_TERM;
   auto dbl = [&](const u16 *src, u16 *dst) {
     for (u32 i = tid; i < BZ_TN; i += nthreads) {
       const u32 a = src[i];
-      u32 r = BZ_TERM;
-      if (a != BZ_TERM && i + a < BZ_TN) { const u32 b = src[i + a]; if (b != BZ_TERM) r = a + b; }
-      dst[i] = (u16)r;
+      const u32 j = i + a < BZ_TN ? i + a : BZ_TN;
+      const u32 r = a + src[j];
+      dst[i] = (u16)(r < BZ_TERM ? r : BZ_TERM);
     }
     BZ_BLOCK_SYNC();
   };
@@ -648,13 +651,12 @@ AHIP_DEVINL void bz_jump_tile(BzTileLds &S, const u8 *__restrict__ in, u64 n, co
     dbl(S.x[2], S.x[3]);  // J32 (kept)
     for (u32 i = tid; i < BZ_TW; i += nthreads) {
       if (tile_bit + i >= lim) break;
-      u32 r = BZ_TERM;
       const u32 a = S.x[3][i];
-      if (a != BZ_TERM) {
-        const u32 b = S.x[2][i + a];
-        if (b != BZ_TERM) { const u32 c = S.x[1][i + a + b]; if (c != BZ_TERM) r = a + b + c; }
-      }
-      j50[t * tstride + i] = (u16)r;
+      const u32 j = i + a < BZ_TN ? i + a : BZ_TN;
+      const u32 ab = a + S.x[2][j];
+      const u32 k = i + ab < BZ_TN ? i + ab : BZ_TN;
+      const u32 r = ab + S.x[1][k];
+      j50[t * tstride + i] = (u16)(r < BZ_TERM ? r : BZ_TERM);
     }
     BZ_BLOCK_SYNC();
   }
@@ -712,16 +714,20 @@ AHIP_DEVINL void bz_walk_groups(BzWalkLds &S, const BzTables *__restrict__ T, co
     }
     BZ_BLOCK_SYNC();
     if (tid == 0) {
-      u64 q = pos;
+      u32 o = (u32)(pos - base);  // position inside the tile
+      const u32 rel = (u32)(base - sym_bit);
       u32 g = S.g, done = 0;
-      while (q < base + BZ_TW) {
+      u32 sg = g < nsel ? S.sel[g] : 0u;
+      while (o < BZ_TW) {
         if (g >= nsel) { done = 2; break; }  // out of selectors
-        gstart[g] = (u32)(q - sym_bit);
-        const u32 j = S.jt[S.sel[g]][(u32)(q - base)];
+        const u32 j = S.jt[sg][o];
+        sg = S.sel[g + 1];  // (room for one past the end) -- independent of the jump just requested
+        gstart[g] = rel + o;
         ++g;
         if (j == BZ_TERM) { done = 1; break; }
-        q += j;
+        o += j;
       }
+      const u64 q = base + o;
       S.pos_lo = (u32)q; S.pos_hi = (u32)(q >> 32); S.g = g; S.done = done;
     }
     base += BZ_TW;
@@ -809,9 +815,9 @@ AHIP_DEVINL void bz_mtf_chunk_wave(const u16 *__restrict__ syms, u32 nsyms, u32 
   auto mtf_take = [&](u32 nn) -> u32 {  // entry nn (< 256) moves to the front
     if (nn < 64) {
       const u32 v = lane_bcast(m0, (int)nn);
-      const u32 sh = lane_prev(m0);
-      if (lane <= nn) m0 = sh;
-      m0 = lane == 0 ? v : m0;
+      u32 sh = lane_prev(m0);
+      sh = lane == 0 ? v : sh;
+      m0 = lane <= nn ? sh : m0;
       return v;
     }
     const u32 q = nn >> 6, r = nn & 63;
@@ -862,16 +868,22 @@ AHIP_DEVINL void bz_mtf_chunk_wave(const u16 *__restrict__ syms, u32 nsyms, u32 
         if (WRITE) put_run(lane_bcast(m0, 0), es); else cnt += es;
         r0 = 0; es = 0;
       }
-      if (cnt >= limit) { bad = 1; break; }
-      const u32 sym = lane_bcast(v, (int)k);
-      const u32 byte = mtf_take(sym - 1);
-      if (WRITE) {
-        const u32 idx = out_off + cnt;
-        if (lane == (idx & 63)) pend = byte;
-        if (((idx + 1) & 63) == 0) flush_full(idx + 1);
+      // list symbols up to the next digit (or the end of the batch), in pieces that stay inside one 64-entry line of tt[]
+      const u64 nd = dm >> k;
+      u32 len = nd ? (u32)__builtin_ctzll(nd) : 64u;
+      len = len < here - k ? len : here - k;
+      if (cnt + len > limit) { bad = 1; break; }  // (some symbol of the stretch finds nblock >= nblockMAX)
+      while (len) {
+        const u32 idx = out_off + cnt, off = idx & 63;
+        const u32 piece = WRITE ? (len < 64 - off ? len : 64 - off) : len;
+        for (u32 q = 0; q < piece; ++q) {
+          const u32 sym = lane_bcast(v, (int)(k + q));
+          const u32 byte = mtf_take(sym - 1);
+          if (WRITE) { if (lane == off + q) pend = byte; }
+        }
+        cnt += piece; k += piece; len -= piece;
+        if (WRITE && ((idx + piece) & 63) == 0) flush_full(idx + piece);
       }
-      cnt++;
-      k++;
     }
   }
   if (r0 && !bad) {  // a run ends with its chunk
