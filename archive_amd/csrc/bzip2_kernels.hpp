@@ -250,19 +250,29 @@ AHIP_DEVINL void bz_decode_block_wave(BzLds &L, const u8 *__restrict__ in, u64 n
     const u32 nsel = bz_bits(b, 15);
     if (nsel < 1) { status = BZ_ST_FALSE; break; }
     if (nsel > BZ_MAX_SELECTORS) { status = BZ_ST_RANGE; break; }  // Dart: store past the Uint8List
+    // selectors and code lengths: ~30 000 bits read a few at a time -- from the stream held in registers (64 dwords a
+    // lane-load, the next batch in flight), not one global load per 32 bits
+    BzFast f;
+    bzf_init(f, in, n, b.bit, lane);
     {
       u32 pos = 0x543210;  // MTF list of group numbers, 4 bits each
       bool bad = false;
       for (u32 i = 0; i < nsel; ++i) {
-        u32 j = 0;
-        while (bz_bits(b, 1)) { if (++j >= ngroups) { bad = true; break; } }
-        if (bad || b.fault) break;
+        bzf_refill(f, lane);
+        const u32 top = (u32)(f.buf >> 32);
+        const u32 j = top == 0xffffffffu ? 32u : (u32)__builtin_clz(~top);  // the unary number: ones up to a zero
+        if (j >= ngroups) {  // the reference reads them one by one: the ngroups-th one is the error -- if the input lasts that long
+          if (f.bit + ngroups > f.nbits) f.fault = true; else bad = true;
+          break;
+        }
+        if (f.bit + j + 1 > f.nbits) { f.fault = true; break; }
+        f.buf <<= j + 1; f.cnt -= j + 1; f.bit += j + 1;
         const u32 v = (pos >> (4 * j)) & 15;
         const u32 low = pos & ((1u << (4 * j)) - 1);
         pos = (pos & ~((1u << (4 * (j + 1))) - 1)) | (low << 4) | v;
         if (lane == 0) sel[i] = (u8)v;
       }
-      if (b.fault) { status = BZ_ST_RANGE; break; }
+      if (f.fault) { status = BZ_ST_RANGE; break; }
       if (bad) { status = BZ_ST_FALSE; break; }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // lane 0's selector stores -> every lane's loads
       wave_sync();
@@ -270,21 +280,22 @@ AHIP_DEVINL void bz_decode_block_wave(BzLds &L, const u8 *__restrict__ in, u64 n
     {
       bool bad = false;
       for (u32 t = 0; t < ngroups && !bad; ++t) {
-        i32 c = (i32)bz_bits(b, 5);
+        i32 c = (i32)bzf_bits(f, 5, lane);
         for (u32 i = 0; i < alpha; ++i) {
           for (;;) {
             if (c < 1 || c > 20) { bad = true; break; }
-            if (!bz_bits(b, 1)) break;
-            if (!bz_bits(b, 1)) c++; else c--;
-            if (b.fault) { bad = true; break; }
+            if (!bzf_bits(f, 1, lane)) break;
+            if (!bzf_bits(f, 1, lane)) c++; else c--;
+            if (f.fault) { bad = true; break; }
           }
           if (bad) break;
           if (lane == 0) L.len[t][i] = (u8)c;
         }
       }
-      if (b.fault) { status = BZ_ST_RANGE; break; }
+      if (f.fault) { status = BZ_ST_RANGE; break; }
       if (bad) { status = BZ_ST_FALSE; break; }
     }
+    b.bit = f.bit;
     // (the reference's tables are fresh, zero-filled arrays for every block: a damaged code can index perm past its symbols)
     for (u32 i = lane; i < 6 * 258; i += 64) (&L.perm[0][0])[i] = 0;
     wave_sync();
