@@ -390,12 +390,13 @@ AHIP_DEVINL u32 stored_block_emit(BitCursor &b, OutCursor &o, TokSink &sink, u32
 // hands the rest of the block to the serial decoder, which restates the reference symbol by symbol.
 AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutCursor &o, TokSink &sink, int lane,
                                        ParStats &st, u64 hint_end_bits) {
-  bool emit = sink.area != nullptr && !sink.full;
   constexpr u32 SLACK_DW = 4;  // a token may run 48 bits past its item and the reader looks two dwords ahead
   constexpr u32 SUB = SUB_BITS;
   u32 eguard = 0;
   for (;;) {  // epochs: positions are 32-bit offsets from the epoch origin
     if (++eguard > (1u << 16)) { st.dbg |= 1; break; }
+    const bool emit = sink.area != nullptr && !sink.full;  // (fixed for the epoch: the decode loop below is compiled for either case)
+    bool give_up_tokens = false;
     const u64 gbyte = (b.pos >> 3) & ~3ull;
     if (gbyte + (u64)(2 * SUB_DW + SLACK_DW) * 4 > b.in_len) break;  // too close to the end: checked serial path
     const u64 avail_dw = (b.in_len - gbyte) >> 2;
@@ -498,9 +499,10 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
         const bool bad_cap = (u64)tot_bytes > o.limit - o.pos;         // output window exhausted
         const bool bad_far = __any(mine && (u64)nd > o.pos + B) != 0;  // back-reference before the start of the output
         // (a sizing run that keeps its tokens only has the room the COMPRESSED size suggests: when that runs out the
-        //  tokens are given up -- the member is tokenized again by the decode proper -- and the flow goes on counting)
-        if (emit && sink.sizing && sink.ndir + nh > sink.dir_cap) { sink.full = true; emit = false; }
+        //  tokens are given up -- the member is tokenized again by the decode proper -- and the flow starts a new
+        //  epoch that only counts)
         const bool bad_dir = emit && sink.ndir + nh > sink.dir_cap;    // directory full
+        if (bad_dir && sink.sizing) { sink.full = true; give_up_tokens = true; stop_serial = true; break; }
         if (bad_cap || bad_far || bad_dir) {
           st.fallbacks++;
           st.dbg |= bad_cap ? 4u : 0u; st.dbg |= bad_far ? 8u : 0u; st.dbg |= bad_dir ? 16u : 0u;
@@ -528,7 +530,7 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
       }
       // a recording lane must not run out of column: the serial decoder takes over with what all columns have left
       if (emit && !finishing && __any(rowctr + (u32)STEPS > sink.col_cap)) {
-        if (sink.sizing) { sink.full = true; emit = false; }
+        if (sink.sizing) { sink.full = true; give_up_tokens = true; stop_serial = true; }
         else { st.fallbacks++; st.dbg |= 32; stop_serial = true; }
       }
       AHIP_TICK(t_s2);
@@ -647,6 +649,7 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
 #ifdef AHIP_PROFILE
     st.partial += g;  // decode steps of the wave
 #endif
+    if (give_up_tokens) continue;  // a new epoch from the last retired item, counting only
     if (stop_serial) { if (!(st.dbg & 2)) { /* counted at the site */ } break; }
     if (block_done) return MS_OK;
     // the epoch is used up (V == n_items): go on from the new origin
