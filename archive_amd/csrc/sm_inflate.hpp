@@ -110,110 +110,125 @@ AHIP_DEVINL bool sm_header_plausible(const u8 *in, u64 in_len, u64 q, u8 *tab /*
 // (searched up to the next cut), ~0 if there is none.
 // The range behind a cut is searched by `split` waves (equal parts, cand[k * split + part]); the host keeps the
 // first find of each cut.
-// The first filter reads the stream from LDS: a slab of SM_SLAB bytes (+ the 16 bytes a window at its last bit position
-// needs) is staged with coalesced 16-byte loads and scanned 64 bit positions per step; lanes of a step read the same
-// few dwords (broadcasts, no bank conflicts).  With the two unaligned 8-byte global loads per window the first version
-// used, every step waited for memory (~ 7 000 cycles per step: 4.1 of the 10 ms of a 256 MiB member).
-constexpr u32 SM_SLAB = 2048;
-__global__ __launch_bounds__(64) void sm_find_kernel(const u8 *__restrict__ in, u64 in_len, u64 data_start, u64 chunk_bytes,
-                                                     u32 n_chunks, u32 split, u64 *__restrict__ cand) {
-  __shared__ u8 cl_tab[64][128];
-  __shared__ u64 queue[128];
-  __shared__ u16 kraft4[4096];  // sum of 128 >> len over four 3-bit code-length fields (len 0 counts nothing)
-  __shared__ u32 slab[(SM_SLAB + 32) / 4];
-  const int lane = threadIdx.x;
-  const u32 k = blockIdx.x / split + 1, part = blockIdx.x % split;
-  if (k >= n_chunks) return;
+// The stream is read from LDS: a slab of SM_SLAB bytes (+ what a window at its last bit position needs) is staged
+// with coalesced 16-byte loads.  Three filters, each on what the one before lets through:
+//   0  bit-parallel, 2 048 positions a step (every lane a dword = 32 positions): BTYPE == 2 and HLIT, HDIST <= 29 are
+//      a dozen shifts and ANDs on the dword and its successor -- 22 % of random positions pass; they are compacted
+//      into a list (in stream order);
+//   1  one listed position per lane: the code-length code is complete (Kraft sum of the 3-bit lengths == 1: five
+//      look-ups in a table of four fields each) -- about one in 300;
+//   2  sm_header_plausible, one per lane, 64 at a time.
+// (Round 3's first version ran filter 1 on all 64 positions of a step: 3.5 of the 7.6 ms of a 256 MiB member.)
+constexpr u32 SM_SLAB = 2048, SM_STEP = 2048;  // bytes per slab; bit positions per filter-0 step
+// one wave (a device function: tests/emu/sm_find_emu.cc runs it on the CPU wave emulation)
+struct SmFindLds {
+  u8 cl_tab[64][128];
+  u64 queue[128];
+  u16 kraft4[4096];  // sum of 128 >> len over four 3-bit code-length fields (len 0 counts nothing)
+  u32 slab[(SM_SLAB + 64) / 4];
+  u16 list[SM_STEP];  // filter 0's survivors: bit offsets inside the slab
+};
+AHIP_DEVINL u64 sm_find_wave(SmFindLds &S, const u8 *__restrict__ in, u64 in_len, u64 q0, u64 q1, const int lane) {
   for (u32 i = lane; i < 4096; i += 64) {
     u32 t = 0;
     for (u32 f = 0; f < 4; ++f) { const u32 l = (i >> (3 * f)) & 7; t += l ? (128u >> l) : 0u; }
-    kraft4[i] = (u16)t;
+    S.kraft4[i] = (u16)t;
   }
   wave_sync();
-  const u64 part_bits = chunk_bytes * 8 / split;
-  const u64 q0 = (data_start + (u64)k * chunk_bytes) * 8 + part * part_bits, q1 = q0 + part_bits;
   const u64 below = (1ull << lane) - 1;
+  const u64 end_bits = in_len * 8;
   u64 found = ~0ull;
   u32 qn = 0;
   u64 slab_byte = ~0ull;  // stream byte of slab[0] (a multiple of 4)
-#ifdef AHIP_PROFILE
-  u64 pc_stage = 0, pc_first = 0, pc_second = 0;
-#endif
-  for (u64 base = q0; found == ~0ull && (base < q1 || qn); base += 64) {
-    const bool scanning = base < q1;
-    if (scanning) {
-      // the step's windows need bytes [base / 8, (base + 63 + 17 + 64) / 8]: restage when they leave the slab
-      AHIP_TICK(t_a);
-      if (slab_byte == ~0ull || (base >> 3) < slab_byte || ((base + 63 + 17 + 64) >> 3) + 4 > slab_byte + SM_SLAB + 32) {
-        slab_byte = (base >> 3) & ~3ull;
-        wave_sync();
-        for (u32 o = (u32)lane * 16; o < SM_SLAB + 32; o += 1024) {
-          uint4 v = make_uint4(0u, 0u, 0u, 0u);
-          if (slab_byte + o + 16 <= in_len) v = load_u128_unaligned(in + slab_byte + o);
-          else {
-            u32 w[4] = {0, 0, 0, 0};
-            for (u32 b = 0; b < 16; ++b) if (slab_byte + o + b < in_len) w[b >> 2] |= (u32)in[slab_byte + o + b] << (8 * (b & 3));
-            v = make_uint4(w[0], w[1], w[2], w[3]);
-          }
-          *(uint4 *)((u8 *)slab + o) = v;
-        }
-        wave_sync();
-      }
-      AHIP_TICK(t_b);
-      // ---- first filter, 64 positions: BTYPE, HLIT/HDIST range, complete code-length code ----
-      const u64 q = base + lane;
-      bool ok = q + 3 + 14 + 12 <= in_len * 8 && q < q1;
-      {
-        const u32 rel = (u32)(q - slab_byte * 8);  // bit offset inside the slab
-        const u32 di = rel >> 5, sh = rel & 31;
-        const u32 d0 = slab[di], d1 = slab[di + 1], d2 = slab[di + 2], d3 = slab[di + 3];
-        const u32 v = __builtin_amdgcn_alignbit(d1, d0, sh);                       // bits [q, q + 32)
-        const u64 x = (u64)__builtin_amdgcn_alignbit(d2, d1, sh) | ((u64)__builtin_amdgcn_alignbit(d3, d2, sh) << 32);  // [q + 32, q + 96)
-        u64 w = ((u64)v >> 17) | (x << 15);                                          // [q + 17, q + 81)
-        const u32 hlit = (v >> 3) & 31, hdist = (v >> 8) & 31, ncl = ((v >> 13) & 15) + 4;
-        ok = ok && ((v >> 1) & 3) == 2 && hlit <= 29 && hdist <= 29;
-        // sum of 2^(7 - len) over the transmitted lengths == 2^7 (19 x 3 = 57 bits, five table look-ups)
-        w &= (1ull << (3 * ncl)) - 1;
-        const u32 kraft = kraft4[(u32)w & 4095] + kraft4[(u32)(w >> 12) & 4095] + kraft4[(u32)(w >> 24) & 4095] +
-                          kraft4[(u32)(w >> 36) & 4095] + kraft4[(u32)(w >> 48) & 4095];
-        ok = ok && kraft == 128;
-      }
-      const u64 m = __ballot(ok);
-      if (ok) queue[qn + (u32)__popcll(m & below)] = q;
-      qn += (u32)__popcll(m);
-      wave_sync();
-#ifdef AHIP_PROFILE
-      AHIP_TICK(t_c);
-      pc_stage += t_b - t_a; pc_first += t_c - t_b;
-#endif
-    }
-    if (qn < 64 && scanning && base + 64 < q1) continue;  // collect a full batch first (or drain at the end)
-    AHIP_TICK(t_d);
-    // ---- second filter, one queued position per lane; the sizing pass is the final judge of what it lets through ----
+  auto second = [&]() {  // sm_header_plausible on the first <= 64 queued positions; lowest position first
     const u32 nb = qn < 64 ? qn : 64;
     bool pass = false;
-    if ((u32)lane < nb) pass = sm_header_plausible(in, in_len, queue[lane], cl_tab[lane]);
+    if ((u32)lane < nb) pass = sm_header_plausible(in, in_len, S.queue[lane], S.cl_tab[lane]);
     const u64 pm = __ballot(pass);
-    if (pm) found = queue[__ffsll((long long)pm) - 1];  // lowest position first
-    // drop the batch
+    if (pm) found = S.queue[__builtin_ctzll(pm)];
     wave_sync();
-    const u64 moved = (u32)lane + nb < qn ? queue[lane + nb] : 0;
+    const u64 moved = (u32)lane + nb < qn ? S.queue[lane + nb] : 0;
     wave_sync();
-    if ((u32)lane + nb < qn) queue[lane] = moved;
+    if ((u32)lane + nb < qn) S.queue[lane] = moved;
     qn -= nb;
     wave_sync();
-#ifdef AHIP_PROFILE
-    AHIP_TICK(t_e);
-    pc_second += t_e - t_d;
-#endif
+  };
+  for (u64 base = q0 & ~31ull; found == ~0ull && base < q1; base += SM_STEP) {
+    // the step's windows need bytes [base / 8, (base + SM_STEP - 1 + 17 + 64) / 8]: restage when they leave the slab
+    if (slab_byte == ~0ull || ((base + SM_STEP - 1 + 17 + 64) >> 3) + 4 > slab_byte + SM_SLAB + 64) {
+      slab_byte = (base >> 3) & ~3ull;
+      wave_sync();
+      for (u32 o = (u32)lane * 16; o < SM_SLAB + 64; o += 1024) {
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (slab_byte + o + 16 <= in_len) v = load_u128_unaligned(in + slab_byte + o);
+        else {
+          u32 w[4] = {0, 0, 0, 0};
+          for (u32 b = 0; b < 16; ++b) if (slab_byte + o + b < in_len) w[b >> 2] |= (u32)in[slab_byte + o + b] << (8 * (b & 3));
+          v = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        *(uint4 *)((u8 *)S.slab + o) = v;
+      }
+      wave_sync();
+    }
+    // ---- filter 0: this lane's dword, positions wq .. wq + 31 ----
+    const u32 wi = (u32)((base - slab_byte * 8) >> 5) + (u32)lane;  // dword of the slab
+    const u64 wq = base + 32ull * lane;
+    const u64 v = (u64)S.slab[wi] | ((u64)S.slab[wi + 1] << 32);
+    u32 m = (u32)(~(v >> 1) & (v >> 2));                                   // BTYPE == 2: bit 1 clear, bit 2 set
+    m &= ~(u32)((v >> 4) & (v >> 5) & (v >> 6) & (v >> 7));                // HLIT <= 29: not 1111x
+    m &= ~(u32)((v >> 9) & (v >> 10) & (v >> 11) & (v >> 12));             // HDIST <= 29
+    // inside [q0, q1) and with the 29 bits a header needs at least
+    if (wq < q0) m &= q0 - wq >= 32 ? 0u : ~0u << (u32)(q0 - wq);
+    const u64 lastp1 = end_bits >= 29 ? end_bits - 28 : 0, hi = q1 < lastp1 ? q1 : lastp1;  // first position not to test
+    if (wq + 32 > hi) m &= wq >= hi ? 0u : ~0u >> (32 - (u32)(hi - wq));
+    u32 total;
+    u32 at = wave_excl_sum((u32)__builtin_popcount(m), total);
+    const u32 rel0 = wi * 32;
+    for (u32 mm = m; mm; mm &= mm - 1) S.list[at++] = (u16)(rel0 + (u32)__builtin_ctz(mm));
+    wave_sync();
+    // ---- filter 1, 64 listed positions at a time: a complete code-length code ----
+    for (u32 b0 = 0; b0 < total && found == ~0ull; b0 += 64) {
+      bool ok = b0 + (u32)lane < total;
+      u32 rel = 0;
+      if (ok) {
+        rel = S.list[b0 + lane];
+        const u32 di = rel >> 5, sh = rel & 31;
+        const u32 d0 = S.slab[di], d1 = S.slab[di + 1], d2 = S.slab[di + 2], d3 = S.slab[di + 3];
+        const u32 x0 = __builtin_amdgcn_alignbit(d1, d0, sh);                       // bits [q, q + 32)
+        const u64 x = (u64)__builtin_amdgcn_alignbit(d2, d1, sh) | ((u64)__builtin_amdgcn_alignbit(d3, d2, sh) << 32);  // [q + 32, q + 96)
+        u64 w = ((u64)x0 >> 17) | (x << 15);                                          // [q + 17, q + 81)
+        const u32 ncl = ((x0 >> 13) & 15) + 4;
+        // sum of 2^(7 - len) over the transmitted lengths == 2^7 (19 x 3 = 57 bits, five table look-ups)
+        w &= (1ull << (3 * ncl)) - 1;
+        const u32 kraft = S.kraft4[(u32)w & 4095] + S.kraft4[(u32)(w >> 12) & 4095] + S.kraft4[(u32)(w >> 24) & 4095] +
+                          S.kraft4[(u32)(w >> 36) & 4095] + S.kraft4[(u32)(w >> 48) & 4095];
+        ok = kraft == 128;
+      }
+      const u64 pm = __ballot(ok);
+      if (ok) S.queue[qn + (u32)__popcll(pm & below)] = slab_byte * 8 + rel;
+      qn += (u32)__popcll(pm);
+      wave_sync();
+      if (qn >= 64) second();
+    }
   }
-  if (lane == 0) cand[(u64)k * split + part] = found;
-#ifdef AHIP_PROFILE
-  if (lane == 0) { u64 *pc = cand + (u64)n_chunks * split * (1 + blockIdx.x % 1) ; (void)pc; }
-  if (lane == 0) { const u64 n = (u64)n_chunks * split; cand[n + blockIdx.x] = pc_stage; cand[2 * n + blockIdx.x] = pc_first; cand[3 * n + blockIdx.x] = pc_second; }
-#endif
+  while (qn && found == ~0ull) second();
+  return found;
 }
+#ifndef AHIP_HOST_EMU
+__global__ __launch_bounds__(64) void sm_find_kernel(const u8 *__restrict__ in, u64 in_len, u64 data_start, u64 chunk_bytes,
+                                                     u32 n_chunks, u32 split, u64 *__restrict__ cand) {
+  __shared__ SmFindLds S;
+  const int lane = threadIdx.x;
+  const u32 k = blockIdx.x / split + 1, part = blockIdx.x % split;
+  if (k >= n_chunks) return;
+  const u64 part_bits = chunk_bytes * 8 / split;
+  const u64 q0 = (data_start + (u64)k * chunk_bytes) * 8 + part * part_bits;
+  const u64 found = sm_find_wave(S, in, in_len, q0, q0 + part_bits, lane);
+  if (lane == 0) cand[(u64)k * split + part] = found;
+}
+#endif
 
+#ifndef AHIP_HOST_EMU  // (the emulation only runs the block finder of this file)
 // Token area / run directory of candidate c laid out along the INPUT (tok_layout_in): the sizing pass keeps its tokens
 // there, and the write pass resolves the chunks of the chain straight from them (one tokenizer pass instead of two).
 AHIP_DEVINL void sm_layout_in(const u64 *cand_bits, u32 n_cand, u64 in_len, u32 c, u64 &toff, u32 &col_cap, u64 &doff, u32 &dir_cap) {
@@ -354,5 +369,7 @@ __global__ __launch_bounds__(256) void sm_translate_kernel(const ChunkDesc *__re
     out[off + i] = s < SYM_MARK ? (u8)s : w[s - SYM_MARK];
   }
 }
+
+#endif  // AHIP_HOST_EMU
 
 }  // namespace ahip
