@@ -1294,7 +1294,7 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
   // the next magic starts.  A batch's blocks are placed and expanded before the next batch is decoded; nothing
   // behind the point where the chain stops is ever touched.
   const u64 per_block = nblock_max * 5 + (u64)BZ_SYM_CAP * 2 + BZ_CHUNKS * 530 + sizeof(BzTables) + BZ_MAX_SELECTORS * 4 + wstride * (sizeof(BzWalk) + 4) + BZ_SPANS * sizeof(BzSpan) + BZ_MAX_SELECTORS + sizeof(BzResult) + 64;
-  u64 batch_mem = 6ull << 30;
+  u64 batch_mem = 24ull << 30;  // (of 288 GB: every batch costs one latency-bound header + walk + rank round)
   if (const char *e = getenv("AHIP_BZ_BATCH_BYTES")) { if (atoll(e) > 0) batch_mem = (u64)atoll(e); }
   const u64 j50_per_block = bz_parallel_huffman() ? (u64)in_len * 8 / std::max<u32>(1, ncand) * 12 : 0;  // 6 tables x 2 bytes per bit
   u32 batch = (u32)std::min<u64>(ncand, std::max<u64>(4, batch_mem / (per_block + j50_per_block)));

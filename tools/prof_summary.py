@@ -181,6 +181,8 @@ def main():
     side_profile(rnd, "df", "Deflate level 6, 1 GiB log text (config 3)", "python tests/perf/deflate_stats.py 1024")
     side_profile(rnd, "sm", "Inflate of ONE 256 MiB gzip member of wiki-like text (config 2a)", "python tools/sm_check.py 256 wiki")
     side_profile(rnd, "bz", "BZip2 decode, 384 MiB of wiki-like text in 900k blocks (config 5)", "python tests/perf/bzip2_stats.py 384")
+    side_profile(rnd, "bz64", "BZip2 decode, 64 blocks of 900k (55 MiB of wiki-like text; config 5 as bench.py quotes it)", "python tests/perf/bzip2_stats.py 55")
+    side_profile(rnd, "nobc", "config 4 WITHOUT the BGZF BC subfield (index + sizing run that keeps its tokens + resolve)", "python bench.py --no-bc --no-extras --cpu-seconds 0 --steps 5 --warmup 1")
 
     # ---- kernel-trace stats
     stats_csv = one("prof_%s/**/*kernel_stats.csv" % rnd)
