@@ -127,7 +127,8 @@ template <u32 DF_HASH_BITS, u32 DF_WAYS, u32 LA = 0, u32 LB = 0, u32 SUB = 256>
 __global__ __launch_bounds__(SUB) void deflate_match_kernel(const u8 *__restrict__ in, DeflateParams P,
                                                             u32 *__restrict__ match) {
   constexpr u32 DF_SUB = SUB;
-  static_assert(SUB % 64 == 0 && DF_AHEAD % SUB == 0 && DF_AHEAD >= 2 * SUB, "step geometry");
+  constexpr u32 AHEAD = SUB > 512 ? 2 * SUB : DF_AHEAD;  // bytes staged in front of the step
+  static_assert(SUB % 64 == 0 && AHEAD % SUB == 0 && AHEAD >= 2 * SUB && DF_CHUNK + AHEAD + SUB <= DF_RING, "step geometry");
   __shared__ u16 tbl[(1u << DF_HASH_BITS) * DF_WAYS];
   __shared__ u16 tblA[LA ? (1u << LA) : 1u];
   __shared__ u16 tblB[LB ? (1u << LB) : 1u];
@@ -158,13 +159,13 @@ __global__ __launch_bounds__(SUB) void deflate_match_kernel(const u8 *__restrict
     if (r < DF_MIRROR) ring[(DF_RING + r) >> 2] = v;
   };
   auto stage = [&](u32 q) { put(q, fetch(q)); };
-  for (u32 q = 4 * tid; q < DF_AHEAD; q += 4 * SUB) stage(q);  // [0, DF_AHEAD)
+  for (u32 q = 4 * tid; q < AHEAD; q += 4 * SUB) stage(q);  // [0, AHEAD)
   __syncthreads();
   // History before the chunk is only inserted.  Consecutive steps write different ways, so up to four are
   // done as one (same table as step by step, a quarter of the barriers).
   u32 base = 0;
   for (; base + MERGE * DF_SUB <= dict; base += MERGE * DF_SUB) {
-    if (tid < MERGE * (SUB / 4)) stage(base + DF_AHEAD + 4 * tid);
+    if (tid < MERGE * (SUB / 4)) stage(base + AHEAD + 4 * tid);
     __syncthreads();  // the last position's 4 bytes reach into what was just staged
 #pragma unroll
     for (u32 k = 0; k < MERGE; ++k) {
@@ -182,14 +183,14 @@ __global__ __launch_bounds__(SUB) void deflate_match_kernel(const u8 *__restrict
   u32 pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   AHIP_TICK(t_dict);
-  // window prefetch: wave 0 loads the 256 bytes at base + DF_AHEAD during one step and stores them into the
+  // window prefetch: wave 0 loads the SUB bytes at base + AHEAD during one step and stores them into the
   // ring at the top of the next, so the load's latency is never waited for
-  u32 pf = tid < SUB / 4 ? fetch(base + DF_AHEAD + 4 * tid) : 0u;
+  u32 pf = tid < SUB / 4 ? fetch(base + AHEAD + 4 * tid) : 0u;
   for (; base < wlen; base += DF_SUB) {
     AHIP_TICK(t0);
     if (tid < SUB / 4) {  // nobody reads these slots during this step
-      put(base + DF_AHEAD + 4 * tid, pf);
-      pf = fetch(base + DF_SUB + DF_AHEAD + 4 * tid);
+      put(base + AHEAD + 4 * tid, pf);
+      pf = fetch(base + DF_SUB + AHEAD + 4 * tid);
     }
     const u32 p = base + tid;
     const bool has4 = p + 4 <= wlen;
