@@ -97,17 +97,18 @@ AHIP_DEVINL u32 next_member(u32 *next, int lane) {
   if (lane == 0) k = atomicAdd(next, 1u);
   return uniform(k);  // lane 0's value
 }
-// keep != 0: a sizing run that keeps its tokens, laid out along the input (InLayout).  A run-time flag, not a template
-// parameter: as a second instance the same code came out of the register allocator five VGPRs over its budget, and
-// the scratch that cost held the kernel to ~ 7 of its 10 waves per CU (14.4 against 9.6 ms on config 4 without BC).
+// KEEP: a sizing run that keeps its tokens, laid out along the input (InLayout).  (Two instances of the same code: the
+// second one used to come out of the register allocator five VGPRs over its budget -- the per-lane constants of the
+// table build, hoisted out of the member loop; they are pinned inside it now, build_decode_table -- and as ONE kernel
+// with a run-time flag the common instance was 0.7 % slower.)
+template <bool KEEP>
 __global__ __launch_bounds__(64, AHIP_TOK_MIN_WAVES) void inflate_tokenize_kernel(const u8 *__restrict__ in, u64 in_len,
                                                              const MemberDesc *__restrict__ members, u32 first_member,
                                                              u32 n_members, u32 *__restrict__ tokens, DirEnt *__restrict__ dir,
                                                              u64 group_out0, MemberResult *__restrict__ results,
-                                                             u32 *__restrict__ late, InLayout lay, MemberSel sel, u32 keep) {
+                                                             u32 *__restrict__ late, InLayout lay, MemberSel sel) {
   __shared__ TokKernelLds lds;
   const int lane = threadIdx.x;
-  const bool KEEP = uniform(keep) != 0;
   for (u32 k = next_member(late + 1, lane); k < n_members; k = next_member(late + 1, lane)) {
     const u32 m = member_index(sel, first_member, k);
     MemberDesc d = members[m];
@@ -376,7 +377,7 @@ hipError_t launch_inflate_group(const u8 *in, u64 n, const MemberDesc *members, 
     if (e != hipSuccess) return e;
     e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (e != hipSuccess) return e;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, inflate_tokenize_kernel, 64, 0);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, inflate_tokenize_kernel<false>, 64, 0);
     if (e != hipSuccess) return e;
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, inflate_resolve_kernel<false>, 64, 0);
     if (e != hipSuccess) return e;
@@ -421,11 +422,11 @@ hipError_t launch_inflate_group(const u8 *in, u64 n, const MemberDesc *members, 
   e = hipMemsetAsync(dlate.p, 0, 64, st);  // [0] late members, [1] / [2] the tokenizer's / resolver's next member
   if (e != hipSuccess) return e;
   if (lay.pos)
-    hipLaunchKernelGGL(inflate_tokenize_kernel, dim3(grid1), dim3(64), 0, st, in, n, members, first, count, (u32 *)tp, (DirEnt *)dp,
-                       out0, res, dlate.as<u32>(), lay, MemberSel{nullptr, nullptr}, 1u);
+    hipLaunchKernelGGL(inflate_tokenize_kernel<true>, dim3(grid1), dim3(64), 0, st, in, n, members, first, count, (u32 *)tp, (DirEnt *)dp,
+                       out0, res, dlate.as<u32>(), lay, MemberSel{nullptr, nullptr});
   else
-    hipLaunchKernelGGL(inflate_tokenize_kernel, dim3(grid1), dim3(64), 0, st, in, n, members, first, count, (u32 *)tp, (DirEnt *)dp,
-                       out0, res, dlate.as<u32>(), lay, MemberSel{nullptr, nullptr}, 0u);
+    hipLaunchKernelGGL(inflate_tokenize_kernel<false>, dim3(grid1), dim3(64), 0, st, in, n, members, first, count, (u32 *)tp, (DirEnt *)dp,
+                       out0, res, dlate.as<u32>(), lay, MemberSel{nullptr, nullptr});
   if (WRITE) {
     const u32 grid2 = count < (u32)res_resident ? count : (u32)res_resident;
     hipLaunchKernelGGL(inflate_resolve_kernel<false>, dim3(grid2), dim3(64), 0, st, in, members, first, count, out,
@@ -477,8 +478,8 @@ hipError_t launch_inflate_listed(const u8 *in, u64 n, const MemberDesc *members,
   if (e != hipSuccess) return e;
   const MemberSel sel{ids, rel};
   const u32 r1 = tok_resident > 0 ? (u32)tok_resident : 2048u, r2 = res_resident > 0 ? (u32)res_resident : 4096u;
-  hipLaunchKernelGGL(inflate_tokenize_kernel, dim3(count < r1 ? count : r1), dim3(64), 0, st, in, n, members, 0u, count,
-                     g_tokens2.as<u32>(), g_scratch2.as<DirEnt>(), (u64)0, res, g_late.as<u32>(), InLayout{nullptr, 0, n}, sel, 0u);
+  hipLaunchKernelGGL(inflate_tokenize_kernel<false>, dim3(count < r1 ? count : r1), dim3(64), 0, st, in, n, members, 0u, count,
+                     g_tokens2.as<u32>(), g_scratch2.as<DirEnt>(), (u64)0, res, g_late.as<u32>(), InLayout{nullptr, 0, n}, sel);
   hipLaunchKernelGGL(inflate_resolve_kernel<false>, dim3(count < r2 ? count : r2), dim3(64), 0, st, in, members, 0u, count, out,
                      (const u32 *)g_tokens2.p, (const DirEnt *)g_scratch2.p, (u64)0, res, InLayout{nullptr, 0, n},
                      (const MemberResult *)nullptr, sel, g_late.as<u32>() + 2);

@@ -431,7 +431,7 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
     u32 rowctr = P.colpos[lane];  // words this lane has recorded into its column of the token area
     i32 need = 0;
     LaneBits d{0, 0, 0, 0, 2};
-    const u32 colbase = (u32)lane * sink.col_cap;  // this lane's column of the member's token area (words)
+    u32 *const col = sink.area + (u32)lane * sink.col_cap;  // this lane's column of the member's token area
     u32 rot = 0;  // rotates which idle lanes take the recording runs, so that the columns fill evenly
     u32 guard = 0;
     for (;;) {
@@ -614,7 +614,7 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
             const i32 req = (i32)(t & 0xffff) - (i32)nbytes;  // (a literal has no distance: never positive)
             need = req > need ? req : need;
             nbytes += lit ? 1u : (t >> 16);
-            if (ms >> 29) { if (emit) sink.area[colbase + rowctr] = rec_word(nbytes, t); rowctr += 1; }
+            if (ms >> 29) { if (emit) col[rowctr] = rec_word(nbytes, t); rowctr += 1; }
           }
         }
         ++g;
