@@ -1251,7 +1251,7 @@ uint32_t ahip_adler32(const uint8_t *data, size_t len, uint32_t adler) {
   return (uint32_t)((s2 << 16) | s1);
 }
 
-static bool bz_parallel_huffman() { static const bool v = getenv("AHIP_BZ_SERIAL_HUFFMAN") == nullptr; return v; }
+static bool bz_parallel_huffman() { return getenv("AHIP_BZ_SERIAL_HUFFMAN") == nullptr; }  // (read per call: the tests switch it)
 // bzip2 on device memory.  `in` = the first bytes of the stream on the host (header checks), d_in = the whole
 // stream on the device, d_out = device output of out_cap bytes.
 static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, int32_t verify, u8 *d_out, size_t out_cap,

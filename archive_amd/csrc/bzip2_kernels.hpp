@@ -260,6 +260,17 @@ AHIP_DEVINL void bz_decode_block_wave(BzLds &L, const u8 *__restrict__ in, u64 n
       for (u32 i = 0; i < nsel; ++i) {
         bzf_refill(f, lane);
         const u32 top = (u32)(f.buf >> 32);
+        if (!(top >> 31)) {  // zero bits: that many selectors in a row take the table at the front of the list
+          u32 z = top ? (u32)__builtin_clz(top) : 32u;
+          z = z < nsel - i ? z : nsel - i;
+          if (f.bit + z > f.nbits) z = (u32)(f.nbits - f.bit);  // (what is left of the input; the next read is the RangeError)
+          if (z) {
+            if (lane < z) sel[i + lane] = (u8)(pos & 15);
+            f.buf <<= z; f.cnt -= z; f.bit += z;
+            i += z - 1;
+            continue;
+          }
+        }
         const u32 j = top == 0xffffffffu ? 32u : (u32)__builtin_clz(~top);  // the unary number: ones up to a zero
         if (j >= ngroups) {  // the reference reads them one by one: the ngroups-th one is the error -- if the input lasts that long
           if (f.bit + ngroups > f.nbits) f.fault = true; else bad = true;
@@ -582,7 +593,7 @@ constexpr u16 BZ_TERM = 0xffff;
 #define BZ_BLOCK_SYNC() __syncthreads()
 #endif
 struct BzTileLds {
-  u16 x[4][BZ_TN + 2];
+  u16 x[3][BZ_TN + 2];
   u32 bits[BZ_TN / 32 + 4];  // the tile's stream as big-endian dwords, from the dword its first bit lies in
   i32 limit[6][24], base[6][24];
   u16 perm[6][258];
@@ -631,7 +642,7 @@ AHIP_DEVINL void bz_jump_tile(BzTileLds &S, const u8 *__restrict__ in, u64 n, co
   const u64 nbits = n * 8;
   // (a mark is the largest value: a sum with one in it saturates to it; x[.][BZ_TN] stays a mark, and every index is
   //  clamped to it -- no branches)
-  for (u32 i = tid; i < 4; i += nthreads) S.x[i][BZ_TN] = BZ_TERM;
+  for (u32 i = tid; i < 3; i += nthreads) S.x[i][BZ_TN] = BZ_TERM;
   auto dbl = [&](const u16 *src, u16 *dst) {
     for (u32 i = tid; i < BZ_TN; i += nthreads) {
       const u32 a = src[i];
@@ -659,10 +670,10 @@ AHIP_DEVINL void bz_jump_tile(BzTileLds &S, const u8 *__restrict__ in, u64 n, co
     dbl(S.x[1], S.x[2]);  // J4
     dbl(S.x[2], S.x[0]);  // J8
     dbl(S.x[0], S.x[2]);  // J16 (kept)
-    dbl(S.x[2], S.x[3]);  // J32 (kept)
+    dbl(S.x[2], S.x[0]);  // J32 (kept; J8 is not needed any more)
     for (u32 i = tid; i < BZ_TW; i += nthreads) {
       if (tile_bit + i >= lim) break;
-      const u32 a = S.x[3][i];
+      const u32 a = S.x[0][i];
       const u32 j = i + a < BZ_TN ? i + a : BZ_TN;
       const u32 ab = a + S.x[2][j];
       const u32 k = i + ab < BZ_TN ? i + ab : BZ_TN;

@@ -66,7 +66,12 @@ def test_oracle_malformed():
 
 
 @pytest.mark.gpu
-def test_gpu_matches_oracle(native_built):
+@pytest.mark.parametrize("huffman_pass", ["position_parallel", "serial_wave"])
+def test_gpu_matches_oracle(native_built, monkeypatch, huffman_pass):
+    """Both forms of the Huffman pass: bz_jump_tiles / bz_group_starts / bz_decode_groups (the default), and the serial
+    wave bz_decode_block that irregular blocks fall back to (AHIP_BZ_SERIAL_HUFFMAN=1 sends every block there)."""
+    if huffman_pass == "serial_wave":
+        monkeypatch.setenv("AHIP_BZ_SERIAL_HUFFMAN", "1")
     import archive_amd
     from archive_amd import _native as N
     from archive_amd import errors
