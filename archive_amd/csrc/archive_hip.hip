@@ -2068,7 +2068,7 @@ bool ensure_pipe() {
   int k = 4;
   if (const char *e = getenv("AHIP_HOST_PIPE")) k = atoi(e);
   if (k < 2) return false;
-  if (k > 8) k = 8;
+  if (k > 16) k = 16;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return false;
   for (int i = 0; i < k; ++i) {
