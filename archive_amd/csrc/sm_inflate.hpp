@@ -121,10 +121,13 @@ AHIP_DEVINL bool sm_header_plausible(const u8 *in, u64 in_len, u64 q, u8 *tab /*
 // (Round 3's first version ran filter 1 on all 64 positions of a step: 3.5 of the 7.6 ms of a 256 MiB member.)
 constexpr u32 SM_SLAB = 2048, SM_STEP = 2048;  // bytes per slab; bit positions per filter-0 step
 // one wave (a device function: tests/emu/sm_find_emu.cc runs it on the CPU wave emulation)
+// (15 KB a wave: ten waves per CU.  With 64 second-filter tables and 16-bit Kraft sums it was 23 KB -- six waves --
+//  and the kernel is latency-bound.)
+constexpr u32 SM_SECOND = 32;  // candidates the second filter takes at a time (a 128-byte table each)
 struct SmFindLds {
-  u8 cl_tab[64][128];
+  u8 cl_tab[SM_SECOND][128];
   u64 queue[128];
-  u16 kraft4[4096];  // sum of 128 >> len over four 3-bit code-length fields (len 0 counts nothing)
+  u8 kraft4[4096];  // sum of 128 >> len over four 3-bit code-length fields (len 0 counts nothing), saturated at 255
   u32 slab[(SM_SLAB + 64) / 4];
   u16 list[SM_STEP];  // filter 0's survivors: bit offsets inside the slab
 };
@@ -132,7 +135,7 @@ AHIP_DEVINL u64 sm_find_wave(SmFindLds &S, const u8 *__restrict__ in, u64 in_len
   for (u32 i = lane; i < 4096; i += 64) {
     u32 t = 0;
     for (u32 f = 0; f < 4; ++f) { const u32 l = (i >> (3 * f)) & 7; t += l ? (128u >> l) : 0u; }
-    S.kraft4[i] = (u16)t;
+    S.kraft4[i] = (u8)(t < 255 ? t : 255);  // (256 = four 1-bit codes: over the mark like everything above 128)
   }
   wave_sync();
   const u64 below = (1ull << lane) - 1;
@@ -140,16 +143,17 @@ AHIP_DEVINL u64 sm_find_wave(SmFindLds &S, const u8 *__restrict__ in, u64 in_len
   u64 found = ~0ull;
   u32 qn = 0;
   u64 slab_byte = ~0ull;  // stream byte of slab[0] (a multiple of 4)
-  auto second = [&]() {  // sm_header_plausible on the first <= 64 queued positions; lowest position first
-    const u32 nb = qn < 64 ? qn : 64;
+  auto second = [&]() {  // sm_header_plausible on the first <= SM_SECOND queued positions; lowest position first
+    const u32 nb = qn < SM_SECOND ? qn : SM_SECOND;
     bool pass = false;
     if ((u32)lane < nb) pass = sm_header_plausible(in, in_len, S.queue[lane], S.cl_tab[lane]);
     const u64 pm = __ballot(pass);
     if (pm) found = S.queue[__builtin_ctzll(pm)];
     wave_sync();
-    const u64 moved = (u32)lane + nb < qn ? S.queue[lane + nb] : 0;
+    const u64 m0 = (u32)lane + nb < qn ? S.queue[lane + nb] : 0, m1 = (u32)lane + 64 + nb < qn ? S.queue[lane + 64 + nb] : 0;
     wave_sync();
-    if ((u32)lane + nb < qn) S.queue[lane] = moved;
+    if ((u32)lane + nb < qn) S.queue[lane] = m0;
+    if ((u32)lane + 64 + nb < qn) S.queue[lane + 64] = m1;
     qn -= nb;
     wave_sync();
   };
@@ -200,7 +204,7 @@ AHIP_DEVINL u64 sm_find_wave(SmFindLds &S, const u8 *__restrict__ in, u64 in_len
         const u32 ncl = ((x0 >> 13) & 15) + 4;
         // sum of 2^(7 - len) over the transmitted lengths == 2^7 (19 x 3 = 57 bits, five table look-ups)
         w &= (1ull << (3 * ncl)) - 1;
-        const u32 kraft = S.kraft4[(u32)w & 4095] + S.kraft4[(u32)(w >> 12) & 4095] + S.kraft4[(u32)(w >> 24) & 4095] +
+        const u32 kraft = (u32)S.kraft4[(u32)w & 4095] + S.kraft4[(u32)(w >> 12) & 4095] + S.kraft4[(u32)(w >> 24) & 4095] +
                           S.kraft4[(u32)(w >> 36) & 4095] + S.kraft4[(u32)(w >> 48) & 4095];
         ok = kraft == 128;
       }
@@ -208,7 +212,7 @@ AHIP_DEVINL u64 sm_find_wave(SmFindLds &S, const u8 *__restrict__ in, u64 in_len
       if (ok) S.queue[qn + (u32)__popcll(pm & below)] = slab_byte * 8 + rel;
       qn += (u32)__popcll(pm);
       wave_sync();
-      if (qn >= 64) second();
+      while (qn >= 64 && found == ~0ull) second();
     }
   }
   while (qn && found == ~0ull) second();
