@@ -1,14 +1,19 @@
-// bzip2_kernels.hpp -- bzip2 block decoder on gfx950 (first correct version, block-parallel).
+// bzip2_kernels.hpp -- bzip2 block decoder on gfx950: blocks in parallel, and every phase inside a block in parallel.
 //
 // Reference: /root/reference/lib/src/codecs/bzip2_decoder.dart (libbzip2's decompress.c in Dart).
 // The reference walks blocks one after another; blocks are independent once their bit positions are
 // known, so:
 //   B0 bz_scan_magic   every bit position of the stream is tested for the 48-bit block magic
 //                      0x314159265359 / end-of-stream magic 0x177245385090 (_readBlockType :90-111).
-//   B1 bz_decode_block one wave64 per candidate block:
-//        phase 1  header, selectors, code lengths, limit/base/perm tables (:114-246, :774-813) and the
-//                 Huffman + MTF + RUNA/RUNB loop into tt[] (:267-388) -- serial by nature, executed
-//                 wave-uniformly with tables in LDS;
+//   B1 per candidate block:
+//        phase 1  header, selectors, code lengths, limit/base/perm tables (:114-246, :774-813): bz_header, one wave;
+//                 the Huffman codes (:267-388, the part that reads bits): bz_jump_tiles (where a decoder stands 50
+//                 codes after any bit position, by doubling), bz_group_starts (one look-up per group of 50 codes),
+//                 bz_decode_groups (a thread per group) -> a stream of 16-bit symbols; irregular blocks through
+//                 bz_decode_block, one serial wave (256 positions looked up per step, the chain on scalar registers);
+//                 what the symbols mean -- move-to-front list, RUNA/RUNB zero runs -- into tt[]: bz_mtf_chunks
+//                 (64 chunks per block: the list after a chunk is a permutation of the list before it) twice, with
+//                 bz_mtf_scan chaining the permutations in between;
 //        phase 2  T^-1 (:406-439) as a stable counting sort over 16 waves (bz_tinv_scatter) -- same
 //                 result as the reference's serial loop;
 //        phase 3  inverse BWT (:610-727).  The pointer chase tt[t] -> t is one cycle through the block;
