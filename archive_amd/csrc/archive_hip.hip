@@ -542,7 +542,7 @@ struct ahip_gzip_plan {
   u32 K = 0;           // candidates
   bool cands_ready = false;  // cand_pos / hdr hold this stream's candidates (a rebuild with sizes from the data keeps them)
   ChainSummary sum{};
-  DevBuf tile_counts, tile_offsets, cand_pos, hdr, scratch_u32, members, expect_status, results, sizing_descs,
+  DevBuf tile_counts, tile_offsets, tile_slots, cand_pos, hdr, scratch_u32, members, expect_status, results, sizing_descs,
       sizing_results, dsum, drun, retok_ids, retok_rel;
   bool ran = false;
   hipStream_t run_stream = nullptr;  // the stream the last ahip_gzip_plan_run was enqueued on
@@ -550,7 +550,7 @@ struct ahip_gzip_plan {
   struct Big { u32 cand, member; u64 in_off, out_off, out_len; };
   std::vector<Big> big;           // long members decoded by many waves each (sm_inflate), outside the member launch
   ~ahip_gzip_plan() {
-    for (DevBuf *b : {&tile_counts, &tile_offsets, &cand_pos, &hdr, &scratch_u32, &members, &expect_status, &results,
+    for (DevBuf *b : {&tile_counts, &tile_offsets, &tile_slots, &cand_pos, &hdr, &scratch_u32, &members, &expect_status, &results,
                       &sizing_descs, &sizing_results, &dsum, &drun, &retok_ids, &retok_rel})
       b->release();
   }
@@ -586,7 +586,8 @@ int32_t plan_build(ahip_gzip_plan *pl, bool force_sizing, hipStream_t st) {
     HIP_TRY(pl->tile_counts.reserve((size_t)tiles * 4 + 4));
     HIP_TRY(pl->tile_offsets.reserve((size_t)tiles * 4 + 4));
     u32 *d_total = pl->tile_offsets.as<u32>() + tiles;
-    hipLaunchKernelGGL(gz_count_candidates, dim3(tiles), dim3(256), 0, st, in, start, n, pl->tile_counts.as<u32>());
+    HIP_TRY(pl->tile_slots.reserve((size_t)tiles * TILE_SLOTS * 2 + 16));
+    hipLaunchKernelGGL(gz_count_candidates, dim3(tiles), dim3(256), 0, st, in, start, n, pl->tile_counts.as<u32>(), pl->tile_slots.as<u16>());
     hipLaunchKernelGGL(scan_exclusive_u32, dim3(1), dim3(1024), 0, st, pl->tile_counts.as<u32>(),
                        pl->tile_offsets.as<u32>(), (u64)tiles, d_total);
     K = 0;
@@ -599,8 +600,8 @@ int32_t plan_build(ahip_gzip_plan *pl, bool force_sizing, hipStream_t st) {
     }
     HIP_TRY(pl->cand_pos.reserve((size_t)K * 8));
     HIP_TRY(pl->hdr.reserve((size_t)K * sizeof(GzHeader)));
-    hipLaunchKernelGGL(gz_write_candidates, dim3(tiles), dim3(256), 0, st, in, start, n, pl->tile_counts.as<u32>(),
-                       pl->tile_offsets.as<u32>(), pl->cand_pos.as<u64>());
+    hipLaunchKernelGGL(gz_write_candidates, dim3(tiles + (tiles + 255) / 256), dim3(256), 0, st, in, start, n, pl->tile_counts.as<u32>(),
+                       pl->tile_offsets.as<u32>(), pl->cand_pos.as<u64>(), pl->tile_slots.as<u16>(), tiles);
     hipLaunchKernelGGL(gz_parse_headers, dim3(cdiv(K, 256)), dim3(256), 0, st, in, n, pl->cand_pos.as<u64>(), K,
                        pl->hdr.as<GzHeader>(), pl->dsum.as<ChainSummary>());
     pl->cands_ready = true;

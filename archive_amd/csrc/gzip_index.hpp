@@ -87,16 +87,39 @@ AHIP_DEVINL u32 block_reduce_add_256(u32 v, u32 *sm) {
   return t;
 }
 
-__global__ __launch_bounds__(256) void gz_count_candidates(const u8 *in, u64 start, u64 n, u32 *tile_counts) {
+// tile_slots: the offsets (inside the tile) of a tile's candidates when it has at most TILE_SLOTS of them -- nearly
+// every tile: members are tens of KiB apart -- so that gz_write_candidates does not have to read the input again.
+constexpr u32 TILE_SLOTS = 4;
+__global__ __launch_bounds__(256) void gz_count_candidates(const u8 *in, u64 start, u64 n, u32 *tile_counts, u16 *tile_slots) {
   __shared__ u32 sm[4];
+  __shared__ u32 nslot;
+  __shared__ u32 slot[TILE_SLOTS];
+  if (threadIdx.x == 0) nslot = 0;
+  __syncthreads();
   u32 c = 0;
 #pragma unroll
   for (u32 r = 0; r < TILE_BYTES / 4096; ++r) {
-    u64 base = start + (u64)blockIdx.x * TILE_BYTES + r * 4096 + threadIdx.x * 16;
-    c += __popc(candidate_mask16(in, n, base));
+    const u32 rel = r * 4096 + threadIdx.x * 16;
+    u32 mask = candidate_mask16(in, n, start + (u64)blockIdx.x * TILE_BYTES + rel);
+    c += __popc(mask);
+    while (mask) {  // (rare: one thread in ten thousand)
+      const u32 k = (u32)__ffs(mask) - 1;
+      mask &= mask - 1;
+      const u32 i = atomicAdd(&nslot, 1u);
+      if (i < TILE_SLOTS) slot[i] = rel + k;
+    }
   }
-  u32 t = block_reduce_add_256(c, sm);
-  if (threadIdx.x == 0) tile_counts[blockIdx.x] = t;
+  u32 t = block_reduce_add_256(c, sm);  // (its barriers also order the slot writes)
+  if (threadIdx.x == 0) {
+    tile_counts[blockIdx.x] = t;
+    if (t && t <= TILE_SLOTS) {  // in position order
+      u32 v[TILE_SLOTS];
+      for (u32 i = 0; i < TILE_SLOTS; ++i) v[i] = i < t ? slot[i] : 0xffffffffu;
+      for (u32 i = 1; i < TILE_SLOTS; ++i)
+        for (u32 j = i; j > 0 && v[j - 1] > v[j]; --j) { const u32 x = v[j]; v[j] = v[j - 1]; v[j - 1] = x; }
+      for (u32 i = 0; i < t; ++i) tile_slots[(u64)blockIdx.x * TILE_SLOTS + i] = (u16)v[i];
+    }
+  }
 }
 
 // Exclusive scan of `num` u32 values by ONE workgroup of 1024 threads; total to *total.
@@ -124,14 +147,28 @@ __global__ __launch_bounds__(1024) void scan_exclusive_u32(const u32 *in, u32 *o
   if (threadIdx.x == 0) *total = carry_s;
 }
 
+// 256 tiles per workgroup when their candidates are in the slots; a tile with more than TILE_SLOTS is scanned again
+// by a workgroup of its own (grid: tiles / 256 + tiles workgroups, the first ones serve the slots)
 __global__ __launch_bounds__(256) void gz_write_candidates(const u8 *in, u64 start, u64 n, const u32 *tile_counts,
-                                                           const u32 *tile_offsets, u64 *cand_pos) {
-  if (tile_counts[blockIdx.x] == 0) return;  // uniform per block
+                                                           const u32 *tile_offsets, u64 *cand_pos, const u16 *tile_slots,
+                                                           u32 tiles) {
+  const u32 slot_wgs = (tiles + 255) / 256;
+  if (blockIdx.x < slot_wgs) {
+    const u32 tile = blockIdx.x * 256 + threadIdx.x;
+    if (tile >= tiles) return;
+    const u32 c = tile_counts[tile];
+    if (c == 0 || c > TILE_SLOTS) return;
+    const u32 off = tile_offsets[tile];
+    for (u32 i = 0; i < c; ++i) cand_pos[off + i] = start + (u64)tile * TILE_BYTES + tile_slots[(u64)tile * TILE_SLOTS + i];
+    return;
+  }
+  const u32 bx = blockIdx.x - slot_wgs;  // the tile this workgroup scans again if it has to
+  if (tile_counts[bx] <= TILE_SLOTS) return;  // uniform per block
   __shared__ u32 wsum[4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  u32 tile_off = tile_offsets[blockIdx.x];
+  u32 tile_off = tile_offsets[bx];
   for (u32 r = 0; r < TILE_BYTES / 4096; ++r) {  // sub-tiles in position order
-    u64 base = start + (u64)blockIdx.x * TILE_BYTES + r * 4096 + threadIdx.x * 16;
+    u64 base = start + (u64)bx * TILE_BYTES + r * 4096 + threadIdx.x * 16;
     u32 mask = candidate_mask16(in, n, base);
     u32 c = __popc(mask), x = c;
     for (int o = 1; o < 64; o <<= 1) { u32 y = __shfl_up(x, o); if (lane >= o) x += y; }
