@@ -60,7 +60,8 @@ int main(int argc, char **argv) {
     BzResult R{};
     const BzCand c{bit, 0, 0};
     wave([&](int lane) { BzResult r; bz_decode_block_wave(LDS, in, n, c, syms.data(), list0.data(), sel.data(), r, (u32)lane); if (lane == 0) R = r; });
-    if (R.status != BZ_ST_OK) { printf("block %zu: Huffman side status %u\n", blocks, R.status); return 1; }
+    const bool damaged_ok = argc > 3 && !strcmp(argv[3], "agree");  // damaged input: only ask that both forms of the pass agree
+    if (R.status != BZ_ST_OK && !damaged_ok) { printf("block %zu: Huffman side status %u\n", blocks, R.status); return 1; }
     {
       // the position-parallel Huffman pass (bz_header's tables, bz_jump_tile for every tile, bz_walk_groups, bz_decode_group
       // for every group; these functions have no cross-lane operations and run here with one thread) must leave the
@@ -71,7 +72,11 @@ int main(int argc, char **argv) {
       BzResult H{};
       std::vector<uint8_t> sel2(BZ_MAX_SELECTORS + 64), list2(256);
       wave([&](int lane) { BzResult r; bz_decode_block_wave(LDS, in, n, c, (u16 *)nullptr, list2.data(), sel2.data(), r, (u32)lane, &T); if (lane == 0) H = r; });
-      if (H.status != BZ_ST_OK || T.sym_bit != H.end_bit) { printf("block %zu: header pass status %u\n", blocks, H.status); return 1; }
+      if (H.status != BZ_ST_OK) {  // header trouble: the serial wave must have stopped the same way, before any symbol
+        if (damaged_ok && H.status == R.status && R.nsyms == 0) { printf("bzip2 emu agree: block %zu header status %u\n", blocks, H.status); return 0; }
+        printf("block %zu: header pass status %u, serial wave %u\n", blocks, H.status, R.status); return 1;
+      }
+      if (T.sym_bit != H.end_bit) { printf("block %zu: header pass end\n", blocks); return 1; }
       const uint64_t lim = n * 8, bit0 = bit;  // (one block at a time here: its bits end with the input)
       const uint64_t tstride = lim - bit0 + 64;
       std::vector<uint16_t> j50((size_t)tstride * 6, 0xabcd), syms2(BZ_SYM_CAP, 0xeeee);
@@ -79,9 +84,19 @@ int main(int argc, char **argv) {
       std::vector<uint32_t> gstart(BZ_MAX_SELECTORS);
       uint32_t found = 0, marked = 0;
       bz_walk_groups(WL, &T, sel2.data(), lim, j50.data(), bit0, tstride, gstart.data(), found, marked, 0, 1);
-      if (marked != 1 || found == 0) { printf("block %zu: walk found %u groups, marked %u\n", blocks, found, marked); return 1; }
       BzGroupEnd end{};
-      for (uint32_t g = 0; g < found; ++g) bz_decode_group(T, T.eob, in, n, T.sym_bit, g, gstart[g], sel2[g], g + 1 == found, syms2.data(), end);
+      if (marked == 0) { end.status = BZ_ST_FALSE; end.nsyms = R.nsyms; end.end_bit = R.end_bit; }  // out of selectors: `false`, whatever was decoded
+      else if (marked == 2 && damaged_ok) { printf("bzip2 emu agree: block %zu handed to the serial wave by the walk (it ran into the end of the block's bits)\n", blocks); return 0; }
+      else if (marked != 1 || found == 0) { printf("block %zu: walk found %u groups, marked %u\n", blocks, found, marked); return 1; }
+      else for (uint32_t g = 0; g < found; ++g) bz_decode_group(T, T.eob, in, n, T.sym_bit, g, gstart[g], sel2[g], g + 1 == found, syms2.data(), end);
+      if (end.status == BZ_ST_HUFF_SERIAL) { printf("bzip2 emu agree: block %zu handed to the serial wave\n", blocks); return 0; }
+      if (damaged_ok && R.status != BZ_ST_OK) {
+        // an error: the verdict must be the same; the symbols in front of it too (the list side reads them and may fail first)
+        const bool same = end.status == R.status && (marked == 0 || (end.nsyms == R.nsyms && !memcmp(syms2.data(), syms.data(), (size_t)R.nsyms * 2)));
+        printf(same ? "bzip2 emu agree: block %zu status %u after %u symbols\n" : "block %zu: verdicts differ (%u)\n", blocks, R.status, R.nsyms);
+        if (!same) printf("  position-parallel: status %u nsyms %u; serial wave: status %u nsyms %u\n", end.status, end.nsyms, R.status, R.nsyms);
+        return same ? 0 : 1;
+      }
       if (end.status != R.status || end.nsyms != R.nsyms || end.end_bit != R.end_bit || memcmp(syms2.data(), syms.data(), (size_t)R.nsyms * 2) ||
           memcmp(sel2.data(), sel.data(), T.nsel) || memcmp(list2.data(), list0.data(), 256)) {
         size_t i = 0; while (i < R.nsyms && syms2[i] == syms[i]) ++i;
@@ -94,7 +109,10 @@ int main(int argc, char **argv) {
     for (uint32_t k = 0; k < BZ_CHUNKS; ++k)
       wave([&](int lane) { BzChunk r; bz_mtf_chunk_wave<false>(syms.data(), R.nsyms, k, nmax, nullptr, 0, tt.data(), perms.data() + k * 256, r, (u32)lane); if (lane == 0) chunks[k] = r; });
     wave([&](int lane) { BzResult r = R; bz_mtf_scan_wave(SLDS, r, nmax, chunks.data(), perms.data(), list0.data(), lists.data(), offs.data(), (u32)lane); wave_emu::barrier(); if (lane == 0) R = r; });
-    if (R.status != BZ_ST_OK) { printf("block %zu: status %u\n", blocks, R.status); return 1; }
+    if (R.status != BZ_ST_OK) {
+      if (damaged_ok) { printf("bzip2 emu agree: block %zu, the list side says status %u\n", blocks, R.status); return 0; }
+      printf("block %zu: status %u\n", blocks, R.status); return 1;
+    }
     for (uint32_t k = 0; k < BZ_CHUNKS; ++k)
       wave([&](int lane) { BzChunk r; bz_mtf_chunk_wave<true>(syms.data(), R.nsyms, k, nmax, lists.data() + k * 256, offs[k], tt.data(), perms.data() + k * 256, r, (u32)lane); });
     const uint32_t nb = R.nblock;
@@ -115,6 +133,7 @@ int main(int argc, char **argv) {
     bit = R.end_bit;
     ++blocks;
   }
+  if (argc > 3 && !strcmp(argv[3], "agree")) { printf("bzip2 emu agree: %zu blocks decoded by both forms of the pass alike (%zu bytes)\n", blocks, out.size()); return 0; }
   if (out.size() != want.size() || memcmp(out.data(), want.data(), out.size())) {
     size_t i = 0; while (i < out.size() && i < want.size() && out[i] == want[i]) ++i;
     printf("MISMATCH at byte %zu (sizes %zu / %zu)\n", i, out.size(), want.size());

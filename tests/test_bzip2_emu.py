@@ -56,3 +56,27 @@ def test_symbol_loop_on_the_wave_emulation(emu, tmp_path, name):
     b.write_bytes(data)
     r = subprocess.run([emu, str(a), str(b)], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "bzip2 emu ok" in r.stdout and "%d bytes" % len(data) in r.stdout, r.stdout + r.stderr
+
+
+def test_damaged_streams_get_the_same_verdict_from_both_forms_of_the_huffman_pass(emu, tmp_path):
+    """Bit flips and truncations: the position-parallel pass (jump tiles, walk, groups) and the serial wave must stop at
+    the same symbol with the same status -- or both decode the (then wrong) data alike."""
+    rnd = random.Random(9)
+    data, level = _cases()["text"]
+    comp = bz2.compress(data, level)
+    plain = tmp_path / "plain.bin"
+    plain.write_bytes(data)
+    seen = set()
+    for t in range(36):
+        b = bytearray(comp)
+        if t % 3:
+            pos = rnd.randrange(10 * 8, len(b) * 8 - 80)
+            b[pos >> 3] ^= 1 << (pos & 7)
+        else:
+            b = b[:rnd.randrange(20, len(b) - 1)]
+        p = tmp_path / "d.bz2"
+        p.write_bytes(bytes(b))
+        r = subprocess.run([emu, str(p), str(plain), "agree"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "bzip2 emu agree" in r.stdout, (t, r.stdout + r.stderr)
+        seen.add(r.stdout.split(":")[1].strip().split(" ")[0] if ":" in r.stdout else "")
+    assert len(seen) >= 2  # (errors and clean decodes both occurred)
