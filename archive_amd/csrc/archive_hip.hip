@@ -339,8 +339,8 @@ struct DevBuf;
 hipError_t scratch_reserve(size_t bytes, void **p);
 hipError_t tokens_reserve(size_t bytes, void **p);
 
-// Largest output (bytes) decoded per tokenize/resolve launch pair: its token streams take 4x that.
-// Output bytes decoded per tokenize/resolve launch pair (the token scratch is 4 B per output byte).
+// Output bytes decoded per tokenize/resolve launch pair.  The token scratch takes 6 B per output byte (1.5 words) and
+// the run directory 1 B (a 16-byte entry per 16 bytes): a 6 GiB group holds about 42 GiB of scratch.
 // AHIP_GROUP_OUT_MAX (bytes) shrinks it so that tests can drive the multi-group path with small streams.
 static u64 group_out_max() {
   static u64 v = 0;
@@ -395,12 +395,17 @@ hipError_t launch_inflate_group(const u8 *in, u64 n, const MemberDesc *members, 
   if (e != hipSuccess) return e;
   InLayout lay{nullptr, 0, n};
   if (!WRITE && lay_pos && first == 0 && !getenv("AHIP_NO_TOKEN_REUSE") && n <= (4ull << 30)) {
+    // (12 B per input byte: when the device cannot spare that, the sizing run simply does not keep its tokens -- it needs
+    //  none itself -- and the decode proper tokenizes again)
     e = tokens_reserve(((size_t)n * IN_R + (size_t)count * IN_PAD + 64) * 4, &tp);
-    if (e != hipSuccess) return e;
-    e = scratch_reserve(((size_t)(n / 32) + (size_t)count * 64 + 64) * DIR_BYTES, &dp);
-    if (e != hipSuccess) return e;
-    lay = InLayout{lay_pos, count, n};
-    if (gen_out) *gen_out = g_tok_gen;
+    if (e == hipSuccess) e = scratch_reserve(((size_t)(n / 32) + (size_t)count * 64 + 64) * DIR_BYTES, &dp);
+    if (e == hipSuccess) {
+      lay = InLayout{lay_pos, count, n};
+      if (gen_out) *gen_out = g_tok_gen;
+    } else {
+      (void)hipGetLastError();
+      tp = nullptr; dp = nullptr;
+    }
   }
   if (WRITE) {
     // 1.5 token words + 1/16 directory entry per output byte, plus a fixed allowance per member (tok_layout)
