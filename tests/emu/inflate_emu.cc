@@ -55,6 +55,22 @@ int main(int argc, char **argv) {
     sk.area = area.data(); sk.dir = dir.data();
     MemberResult res{};
     HeaderLds &hdr = *(HeaderLds *)((u8 *)TL.p.inbuf + 1024);  // as in inflate_tokenize_kernel
+    if (getenv("EMU_SIZING_SMALL")) {
+      // a sizing run that keeps its tokens in an area far too small (a false candidate right behind the member's start
+      // cuts it down to this on the device): it must give the tokens up, go on at full speed, and still report the
+      // member's true size and end -- flagged MR_FAR so that the decode proper tokenizes it again
+      sk.sizing = true; sk.col_cap = 8; sk.dir_cap = 63;
+      d.out_limit = ~0ull;
+      wave([&](int lane) { inflate_member<false, true>(TL.w, hdr, &TL.p, comp.data(), n, d, (u8 *)nullptr, sk, res, lane); });
+      const uint64_t want_len = auto_sizes ? 0 : sizes[k];
+      if (res.status != MS_OK || (!auto_sizes && res.out_len != want_len)) { printf("member %zu (sizing, small area): status %u out_len %llu (want %llu)\n", k, res.status, (unsigned long long)res.out_len, (unsigned long long)want_len); return 1; }
+      if (res.blocks & MR_FAR) late++;
+      if (res.fallbacks) fallbacks += res.fallbacks;
+      out_off += res.out_len;
+      pos = (size_t)res.end_pos + 8;
+      ++k;
+      continue;
+    }
     wave([&](int lane) { inflate_member<false, true>(TL.w, hdr, &TL.p, comp.data(), n, d, (u8 *)nullptr, sk, res, lane); });
     if (res.status != MS_OK || (auto_sizes ? res.out_len > limit : res.out_len != limit)) { printf("member %zu: tokenizer status %u out_len %llu (want %llu) blocks %x\n", k, res.status, (unsigned long long)res.out_len, (unsigned long long)limit, res.blocks); return 1; }
     flow_windows += res.windows; fallbacks += res.fallbacks; runs += res.tok_words;
@@ -69,6 +85,12 @@ int main(int argc, char **argv) {
     out_off += got_len;
     pos = (size_t)res.end_pos + 8;
     ++k;
+  }
+  if (getenv("EMU_SIZING_SMALL")) {
+    if (out_off != want.size()) { printf("sized %llu of %zu bytes in %zu members\n", (unsigned long long)out_off, want.size(), k); return 1; }
+    printf("inflate emu sizing ok: %zu members, %llu bytes; %llu gave their tokens up; hand-overs to the serial emitter %llu\n", k, (unsigned long long)out_off,
+           (unsigned long long)late, (unsigned long long)fallbacks);
+    return 0;
   }
   if (out_off != want.size()) { printf("decoded %llu of %zu bytes in %zu members\n", (unsigned long long)out_off, want.size(), k); return 1; }
   printf("inflate emu ok: %zu members, %llu bytes; flow epochs %llu, fallbacks to the serial emitter %llu, directory runs %llu, members reaching into earlier ones %llu\n", k, (unsigned long long)out_off,

@@ -74,3 +74,20 @@ def test_back_references_into_earlier_members_on_the_cpu(tmp_path):
         r = subprocess.run([exe, str(tmp_path / "q.gz"), str(tmp_path / "q.bin"), str(tmp_path / "q.sz")], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "inflate emu ok" in r.stdout, (i, r.stdout + r.stderr)
         assert "members reaching into earlier ones 0" not in r.stdout, r.stdout
+
+
+def test_sizing_run_that_runs_out_of_token_room_on_the_cpu(tmp_path):
+    """A sizing run that keeps its tokens in an area cut short (on the device: by a false `1f 8b 08` right behind the
+    member's start) gives the tokens up and goes on counting with the flow decoder; it used to hand the rest of the
+    member to the symbol-by-symbol emitter, 26 x slower, and 36 such members set the kernel's tail on config 4 without BC."""
+    exe = _binary("production")
+    parts = [p for p in _parts() if len(p[0]) > 1000]
+    (tmp_path / "m.gz").write_bytes(b"".join(streams.gz_member(p, level=lv) for p, lv in parts))
+    (tmp_path / "m.bin").write_bytes(b"".join(p for p, _ in parts))
+    (tmp_path / "m.sz").write_text(" ".join(str(len(p)) for p, _ in parts))
+    env = dict(os.environ, EMU_SIZING_SMALL="1")
+    r = subprocess.run([exe, str(tmp_path / "m.gz"), str(tmp_path / "m.bin"), str(tmp_path / "m.sz")], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "inflate emu sizing ok: %d members" % len(parts) in r.stdout, r.stdout + r.stderr
+    gave_up = int(r.stdout.split("bytes;")[1].split()[0])
+    assert gave_up >= len(parts) - 2, r.stdout  # (nearly) every member is larger than the area
+    assert "hand-overs to the serial emitter 0" in r.stdout, r.stdout  # ... and none of them fell back to the slow path
