@@ -1354,11 +1354,13 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
     const u32 nb = (u32)std::min<size_t>(batch, ncand - c0);
     const BzCand *dc = dcand.as<BzCand>() + c0;
     // phase 1: the Huffman side of every block (one wave each) -> symbol streams; what the symbols mean by chunks
-    if (bz_parallel_huffman()) {
+    const u64 bit0 = cands[c0].bit, bit1 = c0 + nb < ncand ? cands[c0 + nb].bit : (u64)in_len * 8;
+    const u64 tstride = bit1 - bit0 + 64;
+    // (12 bytes of jumps per bit of the batch: a batch whose few candidates lie gigabytes apart -- not a bzip2 stream --
+    //  is left to the serial wave, which needs none)
+    if (bz_parallel_huffman() && tstride * 12 <= std::max<u64>(batch_mem, 4ull << 30)) {
       // headers and tables (one wave per block), the 50-code jump from every bit position (tiles, any number of workgroups),
       // the walk over the groups (one workgroup per block), the groups (one thread each); what is irregular, serially
-      const u64 bit0 = cands[c0].bit, bit1 = c0 + nb < ncand ? cands[c0 + nb].bit : (u64)in_len * 8;
-      const u64 tstride = bit1 - bit0 + 64;
       u64 widest = 0;
       for (u32 i = 0; i < nb; ++i) widest = std::max<u64>(widest, (c0 + i + 1 < ncand ? cands[c0 + i + 1].bit : (u64)in_len * 8) - cands[c0 + i].bit);
       HIP_TRY(dj50.reserve((size_t)tstride * 6 * 2));
