@@ -50,6 +50,9 @@ constexpr int WAVES_PER_BLOCK = 1;
 struct TokKernelLds {
   WaveLds w;
   TokLds p;
+#ifdef AHIP_TOK_LDS_PAD  // dev: fewer resident waves, to measure what residency is worth
+  u32 pad[AHIP_TOK_LDS_PAD / 4];
+#endif
 };
 
 // Persistent workgroups: the grid is sized to what the runtime says is resident at once; members are handed out by a
@@ -147,6 +150,10 @@ __global__ __launch_bounds__(64, AHIP_RES_MIN_WAVES) void inflate_resolve_kernel
                                                             const MemberResult *__restrict__ sized, MemberSel sel,
                                                             u32 *__restrict__ next) {
   __shared__ ResLds lds;
+#ifdef AHIP_RES_LDS_PAD  // dev: fewer resident waves, to measure what residency is worth
+  __shared__ u32 res_pad[AHIP_RES_LDS_PAD / 4];
+  if (n_members == 0xffffffffu) res_pad[threadIdx.x] = 1;  // (keeps the array allocated)
+#endif
   const int lane = threadIdx.x;
   for (u32 k = next_member(next, lane); k < n_members; k = next_member(next, lane)) {
     const u32 m = member_index(sel, first_member, k);
@@ -426,17 +433,33 @@ hipError_t launch_inflate_group(const u8 *in, u64 n, const MemberDesc *members, 
   if (e != hipSuccess) return e;
   e = hipMemsetAsync(dlate.p, 0, 64, st);  // [0] late members, [1] / [2] the tokenizer's / resolver's next member
   if (e != hipSuccess) return e;
+  // AHIP_KTIME=1 (dev): HIP events around the two kernels, printed per launch (the call then synchronises)
+  static thread_local hipEvent_t kt[3] = {nullptr, nullptr, nullptr};
+  const bool ktime = getenv("AHIP_KTIME") != nullptr;
+  if (ktime) {
+    for (auto &ev : kt) if (!ev) (void)hipEventCreate(&ev);
+    (void)hipEventRecord(kt[0], st);
+  }
   if (lay.pos)
     hipLaunchKernelGGL(inflate_tokenize_kernel<true>, dim3(grid1), dim3(64), 0, st, in, n, members, first, count, (u32 *)tp, (DirEnt *)dp,
                        out0, res, dlate.as<u32>(), lay, MemberSel{nullptr, nullptr});
   else
     hipLaunchKernelGGL(inflate_tokenize_kernel<false>, dim3(grid1), dim3(64), 0, st, in, n, members, first, count, (u32 *)tp, (DirEnt *)dp,
                        out0, res, dlate.as<u32>(), lay, MemberSel{nullptr, nullptr});
+  if (ktime) (void)hipEventRecord(kt[1], st);
   if (WRITE) {
     const u32 grid2 = count < (u32)res_resident ? count : (u32)res_resident;
     hipLaunchKernelGGL(inflate_resolve_kernel<false>, dim3(grid2), dim3(64), 0, st, in, members, first, count, out,
                        (const u32 *)tp, (const DirEnt *)dp, out0, res, InLayout{nullptr, 0, n}, (const MemberResult *)nullptr,
                        MemberSel{nullptr, nullptr}, dlate.as<u32>() + 2);
+  }
+  if (ktime) {
+    (void)hipEventRecord(kt[2], st);
+    (void)hipEventSynchronize(kt[2]);
+    float a = 0, b = 0;
+    (void)hipEventElapsedTime(&a, kt[0], kt[1]);
+    (void)hipEventElapsedTime(&b, kt[1], kt[2]);
+    fprintf(stderr, "[ahip] ktime members %u: tokenize %.3f ms, resolve %.3f ms\n", count, a, b);
   }
   hipLaunchKernelGGL(inflate_late_kernel<WRITE>, dim3(WRITE ? 1u : SIZING_LATE_WGS), dim3(64), 0, st, in, n, members, first, count, out, (const u32 *)tp,
                      (const DirEnt *)dp, out0, res, dlate.as<u32>(), dexact.as<u32>(), MemberSel{nullptr, nullptr});
@@ -548,7 +571,7 @@ struct ahip_gzip_plan {
   bool cands_ready = false;  // cand_pos / hdr hold this stream's candidates (a rebuild with sizes from the data keeps them)
   ChainSummary sum{};
   DevBuf tile_counts, tile_offsets, tile_slots, cand_pos, hdr, scratch_u32, members, expect_status, results, sizing_descs,
-      sizing_results, dsum, drun, retok_ids, retok_rel;
+      sizing_results, dsum, drun, retok_ids, retok_rel, chain_aux;
   bool ran = false;
   hipStream_t run_stream = nullptr;  // the stream the last ahip_gzip_plan_run was enqueued on
   std::vector<u64> host_out_off;  // M + 1 entries: output offset of every member, then the total
@@ -556,7 +579,7 @@ struct ahip_gzip_plan {
   std::vector<Big> big;           // long members decoded by many waves each (sm_inflate), outside the member launch
   ~ahip_gzip_plan() {
     for (DevBuf *b : {&tile_counts, &tile_offsets, &tile_slots, &cand_pos, &hdr, &scratch_u32, &members, &expect_status, &results,
-                      &sizing_descs, &sizing_results, &dsum, &drun, &retok_ids, &retok_rel})
+                      &sizing_descs, &sizing_results, &dsum, &drun, &retok_ids, &retok_rel, &chain_aux})
       b->release();
   }
 };
@@ -695,9 +718,23 @@ int32_t plan_build(ahip_gzip_plan *pl, bool force_sizing, hipStream_t st) {
   HIP_TRY(pl->members.reserve((size_t)K * sizeof(MemberDesc)));
   HIP_TRY(pl->expect_status.reserve((size_t)K * 4));
   u32 *s = pl->scratch_u32.as<u32>();
-  hipLaunchKernelGGL(gz_chain, dim3(1), dim3(1024), 0, st, pl->cand_pos.as<u64>(), pl->hdr.as<GzHeader>(), K, start, n,
-                     s, s + (K + 1), s + 2 * (size_t)(K + 1), s + 3 * (size_t)(K + 1), pl->members.as<MemberDesc>(),
-                     pl->expect_status.as<u32>(), pl->dsum.as<ChainSummary>(), pl->retok_ids.as<u32>(), RETOK_CAP);
+  {
+    // the chain (gzip_index.hpp): successors by all workgroups, the exceptions by one, sums and the member list by all
+    const u32 parts = cdiv(K, 1024);
+    HIP_TRY(pl->chain_aux.reserve(16 + (size_t)EXC_CAP * sizeof(ChainExc) + (size_t)parts * sizeof(ChainPart)));
+    u32 *n_exc = pl->chain_aux.as<u32>();
+    ChainExc *exc = (ChainExc *)(pl->chain_aux.as<u8>() + 16);
+    ChainPart *part = (ChainPart *)(pl->chain_aux.as<u8>() + 16 + (size_t)EXC_CAP * sizeof(ChainExc));
+    u32 *nxt = s, *jmp = s + (K + 1), *jmp2 = s + 2 * (size_t)(K + 1), *reach = s + 3 * (size_t)(K + 1);
+    HIP_TRY(hipMemsetAsync(n_exc, 0, 16, st));
+    hipLaunchKernelGGL(gz_link, dim3(cdiv((u64)K + 1, 256)), dim3(256), 0, st, pl->cand_pos.as<u64>(), pl->hdr.as<GzHeader>(), K, n, nxt, reach,
+                       exc, n_exc);
+    hipLaunchKernelGGL(gz_chain_fix, dim3(1), dim3(1024), 0, st, pl->cand_pos.as<u64>(), K, start, nxt, jmp, jmp2, reach, exc, n_exc);
+    hipLaunchKernelGGL(gz_chain_sums, dim3(parts), dim3(1024), 0, st, pl->cand_pos.as<u64>(), pl->hdr.as<GzHeader>(), K, reach, part);
+    hipLaunchKernelGGL(gz_chain_emit, dim3(parts), dim3(1024), 0, st, pl->cand_pos.as<u64>(), pl->hdr.as<GzHeader>(), K, start, nxt, reach,
+                       part, pl->members.as<MemberDesc>(), pl->expect_status.as<u32>(), pl->dsum.as<ChainSummary>(),
+                       pl->retok_ids.as<u32>(), RETOK_CAP);
+  }
   HIP_TRY(hipMemcpyAsync(&pl->sum, pl->dsum.p, sizeof(ChainSummary), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipGetLastError());

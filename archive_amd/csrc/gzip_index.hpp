@@ -19,7 +19,7 @@
 
 namespace ahip {
 
-constexpr u32 TILE_BYTES = 16384;  // 256 threads x 4 x 16 bytes
+constexpr u32 TILE_BYTES = 65536;  // 256 threads x 16 x 16 bytes (fewer tiles: the scan over their counts is one workgroup)
 constexpr u64 POS_UNKNOWN = ~0ull;
 
 constexpr u32 HF_BC = 1;     // size known from the BC subfield
@@ -89,7 +89,7 @@ AHIP_DEVINL u32 block_reduce_add_256(u32 v, u32 *sm) {
 
 // tile_slots: the offsets (inside the tile) of a tile's candidates when it has at most TILE_SLOTS of them -- nearly
 // every tile: members are tens of KiB apart -- so that gz_write_candidates does not have to read the input again.
-constexpr u32 TILE_SLOTS = 4;
+constexpr u32 TILE_SLOTS = 8;
 __global__ __launch_bounds__(256) void gz_count_candidates(const u8 *in, u64 start, u64 n, u32 *tile_counts, u16 *tile_slots) {
   __shared__ u32 sm[4];
   __shared__ u32 nslot;
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void gz_count_candidates(const u8 *in, u64 sta
     const u32 rel = r * 4096 + threadIdx.x * 16;
     u32 mask = candidate_mask16(in, n, start + (u64)blockIdx.x * TILE_BYTES + rel);
     c += __popc(mask);
-    while (mask) {  // (rare: one thread in ten thousand)
+    while (mask) {  // (rare: one thread in a hundred thousand)
       const u32 k = (u32)__ffs(mask) - 1;
       mask &= mask - 1;
       const u32 i = atomicAdd(&nslot, 1u);
@@ -186,7 +186,14 @@ __global__ __launch_bounds__(256) void gz_write_candidates(const u8 *in, u64 sta
   }
 }
 
-// _GZipDecoder._readHeader for one candidate (signature and CM already matched)
+// _GZipDecoder._readHeader for one candidate (signature and CM already matched).
+// Fast path: the first 32 bytes of the header in four registers -- a BGZF header is 18 bytes, a plain one 10 -- so the
+// flags, XLEN and the subfields cost ONE round trip to memory instead of one per field; FNAME / FCOMMENT (a scan for a
+// zero byte) or a longer FEXTRA take the byte-wise path, which is the same parse.
+AHIP_DEVINL u32 hdr_byte(const u64 (&w)[4], u32 k) {  // k < 32
+  const u64 a = k < 16 ? (k < 8 ? w[0] : w[1]) : (k < 24 ? w[2] : w[3]);
+  return (u32)(a >> (8 * (k & 7))) & 0xffu;
+}
 __global__ __launch_bounds__(256) void gz_parse_headers(const u8 *in, u64 n, const u64 *cand_pos, u32 K,
                                                         GzHeader *hdr, ChainSummary *sum) {
   u32 i = blockIdx.x * 256 + threadIdx.x;
@@ -197,34 +204,70 @@ __global__ __launch_bounds__(256) void gz_parse_headers(const u8 *in, u64 n, con
   bool range = false;
   u64 q = p + 3;
   u32 flags = 0;
-  if (q < n) flags = in[q]; else range = true;
-  q = p + 10;  // flags, mtime(4), xfl, os
-  if (q > n) range = true;
   u64 bc_next = POS_UNKNOWN;
-  if (!range && (flags & 0x04)) {
-    if (q + 2 > n) range = true;
-    else {
-      u32 xlen = in[q] | ((u32)in[q + 1] << 8);
-      q += 2;
-      u64 xend = q + xlen;
-      if (xend > n) xend = n;  // readBytes clamps
-      // look for SI1='B' SI2='C' SLEN=2 (BGZF); the reference skips the whole field
-      u64 s = q;
-      while (s + 4 <= xend) {
-        u32 slen = in[s + 2] | ((u32)in[s + 3] << 8);
-        if (in[s] == 66 && in[s + 1] == 67 && slen == 2 && s + 6 <= xend) {
-          u32 bsize = in[s + 4] | ((u32)in[s + 5] << 8);
-          bc_next = p + bsize + 1;
-          break;
+  bool parsed = false;
+  if (p + 32 <= n) {
+    u64 w[4];
+    w[0] = load_u64_unaligned(in + p); w[1] = load_u64_unaligned(in + p + 8);
+    w[2] = load_u64_unaligned(in + p + 16); w[3] = load_u64_unaligned(in + p + 24);
+    flags = hdr_byte(w, 3);
+    u32 r = 10;  // offset of the next field
+    bool ok = (flags & 0x18) == 0;
+    if (ok && (flags & 0x04)) {
+      const u32 xlen = hdr_byte(w, 10) | (hdr_byte(w, 11) << 8);
+      r = 12;
+      const u32 xend = r + xlen;
+      ok = xend <= 30;  // (+ 2 bytes of FHCRC at most: all of it inside the 32 bytes)
+      if (ok) {
+        u32 sp = r;
+        while (sp + 4 <= xend) {
+          const u32 slen = hdr_byte(w, sp + 2) | (hdr_byte(w, sp + 3) << 8);
+          if (hdr_byte(w, sp) == 66 && hdr_byte(w, sp + 1) == 67 && slen == 2 && sp + 6 <= xend) {
+            bc_next = p + (hdr_byte(w, sp + 4) | (hdr_byte(w, sp + 5) << 8)) + 1;
+            break;
+          }
+          sp += 4 + slen;
         }
-        s += 4 + slen;
+        r = xend;
       }
-      q = xend;
+    }
+    if (ok) {
+      if (flags & 0x02) r += 2;
+      q = p + r;
+      parsed = true;
     }
   }
-  if (!range && (flags & 0x08)) { while (q < n) { if (in[q++] == 0) break; } }
-  if (!range && (flags & 0x10)) { while (q < n) { if (in[q++] == 0) break; } }
-  if (!range && (flags & 0x02)) { if (q + 2 > n) range = true; else q += 2; }
+  if (!parsed) {
+    bc_next = POS_UNKNOWN;
+    q = p + 3;
+    if (q < n) flags = in[q]; else range = true;
+    q = p + 10;  // flags, mtime(4), xfl, os
+    if (q > n) range = true;
+    if (!range && (flags & 0x04)) {
+      if (q + 2 > n) range = true;
+      else {
+        u32 xlen = in[q] | ((u32)in[q + 1] << 8);
+        q += 2;
+        u64 xend = q + xlen;
+        if (xend > n) xend = n;  // readBytes clamps
+        // look for SI1='B' SI2='C' SLEN=2 (BGZF); the reference skips the whole field
+        u64 s = q;
+        while (s + 4 <= xend) {
+          u32 slen = in[s + 2] | ((u32)in[s + 3] << 8);
+          if (in[s] == 66 && in[s + 1] == 67 && slen == 2 && s + 6 <= xend) {
+            u32 bsize = in[s + 4] | ((u32)in[s + 5] << 8);
+            bc_next = p + bsize + 1;
+            break;
+          }
+          s += 4 + slen;
+        }
+        q = xend;
+      }
+    }
+    if (!range && (flags & 0x08)) { while (q < n) { if (in[q++] == 0) break; } }
+    if (!range && (flags & 0x10)) { while (q < n) { if (in[q++] == 0) break; } }
+    if (!range && (flags & 0x02)) { if (q + 2 > n) range = true; else q += 2; }
+  }
   h.payload_off = q;
   if (range) {
     h.flags |= HF_RANGE;
@@ -268,84 +311,89 @@ __global__ __launch_bounds__(256) void gz_apply_sizing(GzHeader *hdr, u32 K, con
   hdr[i] = h;
 }
 
-// Member chain from `start`, ONE workgroup of 1024 threads.
-//   nxt/jmp/jmp2/reach: scratch arrays of K+1 u32.
-__global__ __launch_bounds__(1024) void gz_chain(const u64 *cand_pos, const GzHeader *hdr, u32 K, u64 start, u64 n,
-                                                 u32 *nxt, u32 *jmp, u32 *jmp2, u32 *reach, MemberDesc *members,
-                                                 u32 *expect_status, ChainSummary *sum, u32 *retok_ids, u32 retok_cap) {
+// Member chain from `start`: the orbit of candidate 0 under `next`.  Four small kernels, only the second of which is a
+// single workgroup (and it only touches the exceptions):
+//   gz_link        every candidate's successor index nxt[i] (the next candidate in position order, nearly always; a
+//                  binary search otherwise); reach[i] = 1; candidates with nxt[i] != i + 1 are appended to a list
+//   gz_chain_fix   the chain runs through consecutive candidates except where a false magic inside compressed data
+//                  (about one per 16 MiB) or garbage interrupts it: sort the exceptions, let one thread hop between
+//                  them, clear reach[] over what the hops skip.  More exceptions than the list holds (adversarial
+//                  input): pointer doubling over all candidates, as before.
+//   gz_chain_sums  per 1024 candidates: members, output bytes, compressed bytes on the chain
+//   gz_chain_emit  ordered member list + output offsets (the workgroup's prefix = the sums in front of it)
+constexpr u32 EXC_CAP = 3072, EXC_SORT = 4096;  // listed exceptions; the power of two their sort pads to
+struct ChainExc { u32 idx, nxt; };
+__global__ __launch_bounds__(256) void gz_link(const u64 *cand_pos, const GzHeader *hdr, u32 K, u64 n, u32 *nxt, u32 *reach,
+                                               ChainExc *exc, u32 *n_exc) {
+  const u32 i = blockIdx.x * 256 + threadIdx.x;
+  if (i > K) return;
+  if (i == K) { nxt[K] = K; reach[K] = 0; return; }
+  const u64 np = hdr[i].next_pos;
+  u32 j = K;
+  if (!(hdr[i].flags & HF_RANGE) && np < n) {
+    if (i + 1 < K && cand_pos[i + 1] == np) j = i + 1;
+    else {
+      u32 lo = i + 1, hi = K;  // candidates are sorted; next_pos > pos
+      while (lo < hi) { u32 mid = (lo + hi) >> 1; if (cand_pos[mid] < np) lo = mid + 1; else hi = mid; }
+      if (lo < K && cand_pos[lo] == np) j = lo;
+    }
+  }
+  nxt[i] = j;
+  reach[i] = 1;
+  if (j != i + 1) {  // (the last candidate of a clean stream is one: its successor is K)
+    const u32 slot = atomicAdd(n_exc, 1u);
+    if (slot < EXC_CAP) exc[slot] = ChainExc{i, j};
+  }
+}
+__global__ __launch_bounds__(1024) void gz_chain_fix(const u64 *cand_pos, u32 K, u64 start, const u32 *nxt, u32 *jmp, u32 *jmp2,
+                                                     u32 *reach, const ChainExc *exc, const u32 *n_exc_p) {
   const u32 tid = threadIdx.x;
-  __shared__ u64 wsum_a[16], wsum_b[16], wsum_c[16];
-  __shared__ u64 carry_a, carry_b, carry_c;
   const bool first_ok = K > 0 && cand_pos[0] == start;
-  // A: successor index of every candidate (the next candidate in position order, nearly always)
-  for (u32 i = tid; i < K; i += 1024) {
-    u64 np = hdr[i].next_pos;
-    u32 j = K;
-    if (!(hdr[i].flags & HF_RANGE) && np < n) {
-      if (i + 1 < K && cand_pos[i + 1] == np) j = i + 1;
-      else {
-        u32 lo = i + 1, hi = K;  // candidates are sorted; next_pos > pos
-        while (lo < hi) { u32 mid = (lo + hi) >> 1; if (cand_pos[mid] < np) lo = mid + 1; else hi = mid; }
-        if (lo < K && cand_pos[lo] == np) j = lo;
-      }
-    }
-    nxt[i] = j;
-    reach[i] = 0;
+  const u32 n_exc = *n_exc_p;
+  if (!first_ok) {  // nothing is on the chain
+    for (u32 i = tid; i < K; i += 1024) reach[i] = 0;
+    return;
   }
-  if (tid == 0) { nxt[K] = K; reach[K] = 0; }
-  __syncthreads();
-  // B: reachability from candidate 0.  The chain runs through consecutive candidates except where a
-  // false magic inside compressed data (about one per 16 MiB) or garbage interrupts it, so: list the
-  // exceptions (nxt[i] != i+1) in index order in LDS, let one thread hop between them, and mark the
-  // runs in between with all threads.  Pointer doubling remains for adversarial inputs.
-  constexpr u32 EXC_CAP = 3072;
-  __shared__ u32 exc_idx[EXC_CAP], exc_nxt[EXC_CAP];
-  __shared__ u32 run_lo[EXC_CAP + 1], run_hi[EXC_CAP + 1];
-  __shared__ u32 cnt_scan[1024];
-  __shared__ u32 n_exc, n_runs;
-  const u32 chunk = (K + 1023) / 1024;
-  const u32 c0 = tid * chunk < K ? tid * chunk : K, c1 = c0 + chunk < K ? c0 + chunk : K;
-  u32 mine = 0;
-  for (u32 i = c0; i < c1; ++i) mine += nxt[i] != i + 1;
-  cnt_scan[tid] = mine;
-  __syncthreads();
-  for (u32 o = 1; o < 1024; o <<= 1) {  // inclusive scan of the per-thread counts
-    u32 v = tid >= o ? cnt_scan[tid - o] : 0;
-    __syncthreads();
-    cnt_scan[tid] += v;
-    __syncthreads();
-  }
-  if (tid == 1023) n_exc = cnt_scan[1023];
-  __syncthreads();
-  const bool listed = n_exc <= EXC_CAP;
-  if (listed) {
-    u32 slot = cnt_scan[tid] - mine;
-    for (u32 i = c0; i < c1; ++i) {
-      u32 j = nxt[i];
-      if (j != i + 1) { exc_idx[slot] = i; exc_nxt[slot] = j; ++slot; }
+  if (n_exc <= EXC_CAP) {
+    __shared__ u32 e_idx[EXC_SORT], e_nxt[EXC_SORT];
+    __shared__ u32 skip_lo[EXC_CAP + 1], skip_hi[EXC_CAP + 1];  // candidates [lo, hi) the chain jumps over
+    __shared__ u32 n_skip;
+    u32 P = 1;
+    while (P < n_exc) P <<= 1;
+    for (u32 k = tid; k < P; k += 1024) {
+      const bool have = k < n_exc;
+      e_idx[k] = have ? exc[k].idx : 0xffffffffu;
+      e_nxt[k] = have ? exc[k].nxt : 0u;
     }
     __syncthreads();
-    if (tid == 0) {
-      u32 r = 0;
-      if (first_ok) {
-        u32 i = 0, p = 0;
-        const u32 E = n_exc;
-        for (;;) {
-          while (p < E && exc_idx[p] < i) ++p;
-          if (p == E) { run_lo[r] = i; run_hi[r] = K - 1; ++r; break; }  // consecutive to the last candidate
-          run_lo[r] = i; run_hi[r] = exc_idx[p]; ++r;
-          i = exc_nxt[p];
-          if (i >= K) break;
+    for (u32 size = 2; size <= P; size <<= 1)  // bitonic sort by candidate index (the list was appended in no order)
+      for (u32 stride = size >> 1; stride > 0; stride >>= 1) {
+        for (u32 k = tid; k < P / 2; k += 1024) {
+          const u32 a = ((k & ~(stride - 1)) << 1) | (k & (stride - 1)), b = a | stride;
+          const bool up = (a & size) == 0;
+          const u32 ia = e_idx[a], ib = e_idx[b];
+          if ((ia > ib) == up) { e_idx[a] = ib; e_idx[b] = ia; const u32 t = e_nxt[a]; e_nxt[a] = e_nxt[b]; e_nxt[b] = t; }
         }
+        __syncthreads();
       }
-      n_runs = r;
+    if (tid == 0) {
+      u32 r = 0, i = 0, p = 0;
+      for (;;) {  // at candidate i, on the chain
+        while (p < n_exc && e_idx[p] < i) ++p;
+        if (p == n_exc) break;  // consecutive to the last candidate (whose successor K is itself an exception: not reached here)
+        const u32 at = e_idx[p], to = e_nxt[p];
+        // the chain runs i .. at, then jumps to `to` (K: it ends) over (at, to)
+        skip_lo[r] = at + 1; skip_hi[r] = to < K ? to : K; ++r;
+        if (to >= K) break;
+        i = to;
+      }
+      n_skip = r;
     }
     __syncthreads();
-    for (u32 r = 0; r < n_runs; ++r)
-      for (u32 i = run_lo[r] + tid; i <= run_hi[r]; i += 1024) reach[i] = 1;
-    __syncthreads();
+    for (u32 r = 0; r < n_skip; ++r)
+      for (u32 i = skip_lo[r] + tid; i < skip_hi[r]; i += 1024) reach[i] = 0;
   } else {
-    for (u32 i = tid; i <= K; i += 1024) { jmp[i] = nxt[i]; if (i == 0 && first_ok) reach[0] = 1; }
+    for (u32 i = tid; i <= K; i += 1024) { jmp[i] = nxt[i]; reach[i] = (i == 0) ? 1u : 0u; }
     if (tid == 0) jmp2[K] = K;
     __syncthreads();
     u32 *ja = jmp, *jb = jmp2;
@@ -359,58 +407,78 @@ __global__ __launch_bounds__(1024) void gz_chain(const u64 *cand_pos, const GzHe
       u32 *t = ja; ja = jb; jb = t;
     }
   }
-  // C: ordered member list + output offsets (exclusive scans over the reach flags)
-  if (tid == 0) { carry_a = 0; carry_b = 0; carry_c = 0; }
-  __syncthreads();
-  const int lane = tid & 63, w = tid >> 6;
-  u64 tail = start;
-  u32 range_err = 0;
-  for (u32 base = 0; base < K; base += 1024) {
-    u32 i = base + tid;
-    bool on = i < K && reach[i];
-    GzHeader h;
-    if (on) h = hdr[i];
-    u64 a = on ? 1 : 0, b = on ? h.size : 0, c = on ? (h.next_pos - cand_pos[i]) : 0;
-    u64 xa = a, xb = b, xc = c;
-    for (int o = 1; o < 64; o <<= 1) {
-      u64 ya = __shfl_up(xa, o), yb = __shfl_up(xb, o), yc = __shfl_up(xc, o);
-      if (lane >= o) { xa += ya; xb += yb; xc += yc; }
-    }
-    if (lane == 63) { wsum_a[w] = xa; wsum_b[w] = xb; wsum_c[w] = xc; }
-    __syncthreads();
-    u64 oa = carry_a, ob = carry_b, oc = carry_c;
-    for (int k = 0; k < w; ++k) { oa += wsum_a[k]; ob += wsum_b[k]; oc += wsum_c[k]; }
-    if (on) {
-      u64 m = oa + xa - a;
-      MemberDesc d;
-      d.in_off = h.payload_off;
-      d.out_off = ob + xb - b;
-      d.out_limit = h.size;
-      d.expect_end = (h.flags & HF_RANGE) ? POS_UNKNOWN : h.next_pos - 8;
-      d.in_end = 0;
-      d.hist = d.out_off < 32768 ? (u32)d.out_off : 32768u;  // every member appends to the same OutputStream (q8)
-      d.pad = i;  // its candidate: where a sizing run left its tokens
-      members[m] = d;
-      expect_status[m] = h.status;
-      if (h.flags & HF_RETOK) {  // listed (in no particular order) for the launch that tokenizes them again
-        const u32 slot = atomicAdd(&sum->retok, 1u);
-        if (slot < retok_cap) retok_ids[slot] = (u32)m;
-      }
-      if (nxt[i] == K) {  // last member of the chain
-        sum->tail_pos = h.next_pos;
-        if (!(h.flags & (HF_BC | HF_SIZED | HF_RANGE))) sum->stopped_unknown = 1;
-      }
-      if (h.flags & HF_RANGE) atomicOr(&sum->range_error, 1u);
-    }
-    __syncthreads();
-    if (tid == 1023) { carry_a = oa + xa; carry_b = ob + xb; carry_c = oc + xc; }
-    __syncthreads();
+}
+struct ChainPart { u64 members, out_bytes, in_bytes; };
+AHIP_DEVINL void block_scan3_1024(u64 &xa, u64 &xb, u64 &xc, u64 &ta, u64 &tb, u64 &tc, u64 (*ws)[16]) {  // inclusive scans; t* = totals
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int o = 1; o < 64; o <<= 1) {
+    u64 ya = __shfl_up(xa, o), yb = __shfl_up(xb, o), yc = __shfl_up(xc, o);
+    if (lane >= o) { xa += ya; xb += yb; xc += yc; }
   }
-  (void)tail; (void)range_err;
-  if (tid == 0) {
-    sum->members = carry_a;
-    sum->total_out = carry_b;
-    sum->payload_bytes = carry_c;
+  if (lane == 63) { ws[0][w] = xa; ws[1][w] = xb; ws[2][w] = xc; }
+  __syncthreads();
+  u64 oa = 0, ob = 0, oc = 0;
+  ta = tb = tc = 0;
+  for (int k = 0; k < 16; ++k) {
+    if (k < w) { oa += ws[0][k]; ob += ws[1][k]; oc += ws[2][k]; }
+    ta += ws[0][k]; tb += ws[1][k]; tc += ws[2][k];
+  }
+  xa += oa; xb += ob; xc += oc;
+  __syncthreads();
+}
+__global__ __launch_bounds__(1024) void gz_chain_sums(const u64 *cand_pos, const GzHeader *hdr, u32 K, const u32 *reach,
+                                                      ChainPart *part) {
+  __shared__ u64 ws[3][16];
+  const u32 i = blockIdx.x * 1024 + threadIdx.x;
+  const bool on = i < K && reach[i];
+  u64 xa = on ? 1 : 0, xb = on ? hdr[i].size : 0, xc = on ? (hdr[i].next_pos - cand_pos[i]) : 0;
+  u64 ta, tb, tc;
+  block_scan3_1024(xa, xb, xc, ta, tb, tc, ws);
+  if (threadIdx.x == 0) part[blockIdx.x] = ChainPart{ta, tb, tc};
+}
+__global__ __launch_bounds__(1024) void gz_chain_emit(const u64 *cand_pos, const GzHeader *hdr, u32 K, u64 start, const u32 *nxt,
+                                                      const u32 *reach, const ChainPart *part, MemberDesc *members,
+                                                      u32 *expect_status, ChainSummary *sum, u32 *retok_ids, u32 retok_cap) {
+  __shared__ u64 ws[3][16];
+  const u32 tid = threadIdx.x;
+  // what the workgroups in front of this one hold
+  u64 pa = 0, pb = 0, pc = 0;
+  for (u32 k = tid; k < blockIdx.x; k += 1024) { pa += part[k].members; pb += part[k].out_bytes; pc += part[k].in_bytes; }
+  { u64 ta, tb, tc; block_scan3_1024(pa, pb, pc, ta, tb, tc, ws); pa = ta; pb = tb; pc = tc; }
+  const u32 i = blockIdx.x * 1024 + tid;
+  const bool on = i < K && reach[i];
+  GzHeader h{};
+  if (on) h = hdr[i];
+  const u64 a = on ? 1 : 0, b = on ? h.size : 0, c = on ? (h.next_pos - cand_pos[i]) : 0;
+  u64 xa = a, xb = b, xc = c, ta, tb, tc;
+  block_scan3_1024(xa, xb, xc, ta, tb, tc, ws);
+  if (on) {
+    const u64 m = pa + xa - a;
+    MemberDesc d;
+    d.in_off = h.payload_off;
+    d.out_off = pb + xb - b;
+    d.out_limit = h.size;
+    d.expect_end = (h.flags & HF_RANGE) ? POS_UNKNOWN : h.next_pos - 8;
+    d.in_end = 0;
+    d.hist = d.out_off < 32768 ? (u32)d.out_off : 32768u;  // every member appends to the same OutputStream (q8)
+    d.pad = i;  // its candidate: where a sizing run left its tokens
+    members[m] = d;
+    expect_status[m] = h.status;
+    if (h.flags & HF_RETOK) {  // listed (in no particular order) for the launch that tokenizes them again
+      const u32 slot = atomicAdd(&sum->retok, 1u);
+      if (slot < retok_cap) retok_ids[slot] = (u32)m;
+    }
+    if (nxt[i] == K) {  // last member of the chain
+      sum->tail_pos = h.next_pos;
+      if (!(h.flags & (HF_BC | HF_SIZED | HF_RANGE))) sum->stopped_unknown = 1;
+    }
+    if (h.flags & HF_RANGE) atomicOr(&sum->range_error, 1u);
+  }
+  if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+    const bool first_ok = K > 0 && cand_pos[0] == start;
+    sum->members = pa + ta;
+    sum->total_out = pb + tb;
+    sum->payload_bytes = pc + tc;
     sum->first_is_gzip = first_ok ? 1u : 0u;
     if (!first_ok) sum->tail_pos = start;
   }
