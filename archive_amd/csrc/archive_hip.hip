@@ -104,8 +104,13 @@ AHIP_DEVINL u32 next_member(u32 *next, int lane) {
 // second one used to come out of the register allocator five VGPRs over its budget -- the per-lane constants of the
 // table build, hoisted out of the member loop; they are pinned inside it now, build_decode_table -- and as ONE kernel
 // with a run-time flag the common instance was 0.7 % slower.)
+#ifdef AHIP_TOK_VGPR  // dev: a hard register budget (the launch bound is capped by what LDS admits)
+#define AHIP_TOK_ATTR __attribute__((amdgpu_num_vgpr(AHIP_TOK_VGPR)))
+#else
+#define AHIP_TOK_ATTR
+#endif
 template <bool KEEP>
-__global__ __launch_bounds__(64, AHIP_TOK_MIN_WAVES) void inflate_tokenize_kernel(const u8 *__restrict__ in, u64 in_len,
+__global__ __launch_bounds__(64, AHIP_TOK_MIN_WAVES) AHIP_TOK_ATTR void inflate_tokenize_kernel(const u8 *__restrict__ in, u64 in_len,
                                                              const MemberDesc *__restrict__ members, u32 first_member,
                                                              u32 n_members, u32 *__restrict__ tokens, DirEnt *__restrict__ dir,
                                                              u64 group_out0, MemberResult *__restrict__ results,
@@ -288,9 +293,19 @@ int32_t fail(int32_t code, const std::string &msg) {
 struct DevBlock { void *p; size_t cap; };
 thread_local std::vector<DevBlock> g_pool;  // one per host thread: a thread works on ONE device (see Worker below)
 
+// A worker thread (one device context, see Worker below) frees what its thread_local buffers still hold when it ends;
+// the main thread's are left to the process exit (the HIP runtime may be gone by the time its TLS objects are destroyed).
+thread_local bool tl_free_bufs_at_exit = false;
 struct DevBuf {
   void *p = nullptr;
   size_t cap = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() {
+    if (p && tl_free_bufs_at_exit) (void)hipFree(p);
+    p = nullptr; cap = 0;
+  }
   hipError_t reserve(size_t n) {
     if (n <= cap) return hipSuccess;
     release();
@@ -1208,7 +1223,8 @@ int32_t zlib_stream_device(const u8 *host_in, const u8 *d_in, u64 n, u64 pos, bo
         if (committed) HIP_TRY(hipMemcpyAsync(nb.p, outbuf.p, committed, hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));
         outbuf.release();
-        outbuf = nb;
+        outbuf.p = nb.p; outbuf.cap = nb.cap;  // (moved, not copied: a DevBuf owns its block)
+        nb.p = nullptr; nb.cap = 0;
       }
       MemberResult r2{};
       rc = inflate_one(d_in, n, pos, outbuf.as<u8>() + committed, r.out_len, true, &r2, st);
@@ -1339,27 +1355,47 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
   // behind the point where the chain stops is ever touched.
   const u64 per_block = nblock_max * 5 + (u64)BZ_SYM_CAP * 2 + BZ_CHUNKS * 530 + sizeof(BzTables) + BZ_MAX_SELECTORS * 4 + wstride * (sizeof(BzWalk) + 4) + BZ_SPANS * sizeof(BzSpan) + BZ_MAX_SELECTORS + sizeof(BzResult) + 64;
   u64 batch_mem = 24ull << 30;  // (of 288 GB: every batch costs one latency-bound header + walk + rank round)
+  {
+    // ... but never more than half of what the device has free right now (other contexts, a caller's own tensors)
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) batch_mem = std::min<u64>(batch_mem, std::max<u64>(free_b / 2, 256ull << 20));
+    else (void)hipGetLastError();
+  }
   if (const char *e = getenv("AHIP_BZ_BATCH_BYTES")) { if (atoll(e) > 0) batch_mem = (u64)atoll(e); }
   const u64 j50_per_block = bz_parallel_huffman() ? (u64)in_len * 8 / std::max<u32>(1, ncand) * 12 : 0;  // 6 tables x 2 bytes per bit
   u32 batch = (u32)std::min<u64>(ncand, std::max<u64>(4, batch_mem / (per_block + j50_per_block)));
-  HIP_TRY(dtt.reserve((size_t)batch * nblock_max * 4));
-  HIP_TRY(dsel.reserve((size_t)batch * BZ_MAX_SELECTORS));
   static thread_local DevBuf dsyms, dlist0, dchunks, dperms, dlists, dchoff, dtab, dj50, dgstart, dgcount;
-  HIP_TRY(dtab.reserve((size_t)batch * sizeof(BzTables)));
-  HIP_TRY(dgstart.reserve((size_t)batch * BZ_MAX_SELECTORS * 4));
-  HIP_TRY(dgcount.reserve((size_t)batch * 4));
-  HIP_TRY(dsyms.reserve((size_t)batch * BZ_SYM_CAP * 2));
-  HIP_TRY(dlist0.reserve((size_t)batch * 256));
-  HIP_TRY(dchunks.reserve((size_t)batch * BZ_CHUNKS * sizeof(BzChunk)));
-  HIP_TRY(dperms.reserve((size_t)batch * BZ_CHUNKS * 256));
-  HIP_TRY(dlists.reserve((size_t)batch * BZ_CHUNKS * 256));
-  HIP_TRY(dchoff.reserve((size_t)batch * BZ_CHUNKS * 4));
-  HIP_TRY(dpre.reserve((size_t)batch * nblock_max));
-  HIP_TRY(dwalk.reserve((size_t)batch * wstride * sizeof(BzWalk)));
-  HIP_TRY(drank.reserve((size_t)batch * wstride * 4));
-  HIP_TRY(dspans.reserve((size_t)batch * BZ_SPANS * sizeof(BzSpan)));
-  HIP_TRY(dres.reserve((size_t)batch * sizeof(BzResult)));
-  HIP_TRY(doff.reserve((size_t)batch * 8));
+  // the work memory of one batch; a device that cannot spare it gets smaller batches, not an error
+  auto reserve_batch = [&](u32 b) -> hipError_t {
+    hipError_t e;
+#define BZ_RES(buf, bytes) do { e = (buf).reserve((size_t)(bytes)); if (e != hipSuccess) return e; } while (0)
+    BZ_RES(dtt, (size_t)b * nblock_max * 4);
+    BZ_RES(dsel, (size_t)b * BZ_MAX_SELECTORS);
+    BZ_RES(dtab, (size_t)b * sizeof(BzTables));
+    BZ_RES(dgstart, (size_t)b * BZ_MAX_SELECTORS * 4);
+    BZ_RES(dgcount, (size_t)b * 4);
+    BZ_RES(dsyms, (size_t)b * BZ_SYM_CAP * 2);
+    BZ_RES(dlist0, (size_t)b * 256);
+    BZ_RES(dchunks, (size_t)b * BZ_CHUNKS * sizeof(BzChunk));
+    BZ_RES(dperms, (size_t)b * BZ_CHUNKS * 256);
+    BZ_RES(dlists, (size_t)b * BZ_CHUNKS * 256);
+    BZ_RES(dchoff, (size_t)b * BZ_CHUNKS * 4);
+    BZ_RES(dpre, (size_t)b * nblock_max);
+    BZ_RES(dwalk, (size_t)b * wstride * sizeof(BzWalk));
+    BZ_RES(drank, (size_t)b * wstride * 4);
+    BZ_RES(dspans, (size_t)b * BZ_SPANS * sizeof(BzSpan));
+    BZ_RES(dres, (size_t)b * sizeof(BzResult));
+    BZ_RES(doff, (size_t)b * 8);
+#undef BZ_RES
+    return hipSuccess;
+  };
+  for (;;) {
+    const hipError_t e = reserve_batch(batch);
+    if (e == hipSuccess) break;
+    (void)hipGetLastError();
+    if (batch <= 1) return fail(AHIP_E_DEVICE, std::string("bzip2 work memory: ") + hipGetErrorString(e));
+    batch = (batch + 1) / 2;
+  }
   {
     u32 table[256 + 64];
     for (u32 i = 0; i < 256; ++i) {
@@ -1395,12 +1431,14 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
     const u64 tstride = bit1 - bit0 + 64;
     // (12 bytes of jumps per bit of the batch: a batch whose few candidates lie gigabytes apart -- not a bzip2 stream --
     //  is left to the serial wave, which needs none)
-    if (bz_parallel_huffman() && tstride * 12 <= std::max<u64>(batch_mem, 4ull << 30)) {
+    // (12 bytes of jumps per bit; when even that allocation fails the serial wave, which needs none, does the batch)
+    bool jumps = bz_parallel_huffman() && tstride * 12 <= std::max<u64>(batch_mem, 4ull << 30);
+    if (jumps && dj50.reserve((size_t)tstride * 6 * 2) != hipSuccess) { (void)hipGetLastError(); jumps = false; }
+    if (jumps) {
       // headers and tables (one wave per block), the 50-code jump from every bit position (tiles, any number of workgroups),
       // the walk over the groups (one workgroup per block), the groups (one thread each); what is irregular, serially
       u64 widest = 0;
       for (u32 i = 0; i < nb; ++i) widest = std::max<u64>(widest, (c0 + i + 1 < ncand ? cands[c0 + i + 1].bit : (u64)in_len * 8) - cands[c0 + i].bit);
-      HIP_TRY(dj50.reserve((size_t)tstride * 6 * 2));
       hipLaunchKernelGGL(bz_header, dim3(nb), dim3(64), 0, st, d_in, (u64)in_len, dc, nb, dtab.as<BzTables>(), dlist0.as<u8>(), dsel.as<u8>(),
                          dres.as<BzResult>());
       hipLaunchKernelGGL(bz_jump_tiles, dim3((u32)cdiv(widest, BZ_TW) + 1, nb), dim3(512), 0, st, d_in, (u64)in_len, dcand.as<BzCand>(), ncand,
@@ -1680,19 +1718,25 @@ static int32_t deflate_host_impl(const uint8_t *in, size_t in_len, int32_t level
   if (out_len) *out_len = 0;
   if (crc32) *crc32 = 0;
   if (adler32) *adler32 = 1;
-  if (window_bits < 9 || window_bits > 15 || level < 0 || level > 9) return AHIP_OK;  // reference: silent no-op
+  // the reference's Deflate fails silently on invalid parameters (deflate.dart:105-115): no output, its crc32 stays 0.
+  // The zlib encoder computes the Adler-32 of the input BEFORE it calls Deflate.stream (_zlib_encoder_web.dart:62-72),
+  // so that trailer is the real checksum even then.
+  const bool noop = window_bits < 9 || window_bits > 15 || level < 0 || level > 9;
+  if (noop && !adler32) return AHIP_OK;
   int32_t rc = ensure_init();
   if (rc != AHIP_OK) return rc;
   static thread_local DevBuf din, dout;
   HIP_TRY(din.reserve(in_len + 16));
-  const size_t bound = ahip_deflate_bound(in_len);
-  HIP_TRY(dout.reserve(bound));
   if (in_len) HIP_TRY(hipMemcpy(din.p, in, in_len, hipMemcpyHostToDevice));
   size_t produced = 0;
-  rc = deflate_device_impl(din.as<u8>(), in_len, level, window_bits, dout.as<u8>(), bound, &produced, nullptr);
-  if (rc != AHIP_OK) return rc;
-  if (out_len) *out_len = produced;
-  if (crc32) { rc = crc32_device_impl(din.as<u8>(), in_len, 0, crc32, nullptr); if (rc != AHIP_OK) return rc; }
+  if (!noop) {
+    const size_t bound = ahip_deflate_bound(in_len);
+    HIP_TRY(dout.reserve(bound));
+    rc = deflate_device_impl(din.as<u8>(), in_len, level, window_bits, dout.as<u8>(), bound, &produced, nullptr);
+    if (rc != AHIP_OK) return rc;
+    if (out_len) *out_len = produced;
+    if (crc32) { rc = crc32_device_impl(din.as<u8>(), in_len, 0, crc32, nullptr); if (rc != AHIP_OK) return rc; }
+  }
   if (adler32) { rc = adler32_device_impl(din.as<u8>(), in_len, 1, adler32, nullptr); if (rc != AHIP_OK) return rc; }
   if (produced > out_cap) return fail(AHIP_E_CAP, "output buffer too small");
   if (produced) HIP_TRY(hipMemcpy(out, dout.p, produced, hipMemcpyDeviceToHost));
@@ -1775,8 +1819,10 @@ static int32_t framed_encode_device(const void *d_in, size_t in_len, int32_t lev
     if (out_len) *out_len = clen + head_len + tail_len;
     if (rc != AHIP_OK) return rc;
   }
+  // gzip: the CRC-32 is the Deflate object's (0 when it refused its parameters); zlib: the Adler-32 is computed over the
+  // input before Deflate.stream is called, whatever Deflate then does (_zlib_encoder_web.dart:62-72)
   uint32_t ck = gzip ? 0u : 1u;
-  if (!(window_bits < 9 || window_bits > 15 || level < 0 || level > 9)) {
+  if (!gzip || !(window_bits < 9 || window_bits > 15 || level < 0 || level > 9)) {
     rc = gzip ? crc32_device_impl((const u8 *)d_in, in_len, 0, &ck, st) : adler32_device_impl((const u8 *)d_in, in_len, 1, &ck, st);
     if (rc != AHIP_OK) return rc;
   }
@@ -1985,6 +2031,7 @@ struct Worker {
   bool has_job = false, done = false, quit = false;
   void loop() {
     (void)hipSetDevice(device);
+    tl_free_bufs_at_exit = true;  // din / dout / token scratch / ... of this context go back to the device when the thread ends
     // its own non-blocking stream: copies and kernels of different contexts overlap (H2D of one slice, decode of
     // another, D2H of a third) instead of queueing on the legacy default stream
     hipStream_t own = nullptr;

@@ -33,7 +33,7 @@ namespace ahip {
 #define AHIP_SUB_BITS 512
 #endif
 #ifndef AHIP_RING_DW
-#define AHIP_RING_DW 2048
+#define AHIP_RING_DW 1536
 #endif
 #ifndef AHIP_SPEC_BITS
 #define AHIP_SPEC_BITS 256
@@ -42,21 +42,33 @@ namespace ahip {
 #define AHIP_STEPS 12
 #endif
 #ifndef AHIP_EMIT_MIN
-#define AHIP_EMIT_MIN 32
+#define AHIP_EMIT_MIN 8
 #endif
 constexpr int SUB_BITS = AHIP_SUB_BITS;          // bits per work item ("subsequence") of the tokenizer
 constexpr int SUB_DW = SUB_BITS / 32;
-constexpr int RING_DW = AHIP_RING_DW;            // staged bitstream: a ring of dwords in LDS
-constexpr u32 RING_MASK = RING_DW - 1;
-constexpr int ITEMS = RING_DW / SUB_DW;          // items the ring holds
-constexpr u32 ITEM_MASK = ITEMS - 1;
+// The staged bitstream is a ring of RING_DW dwords in LDS -- NOT a power of two: the tokenizer's time is inversely
+// proportional to the waves resident on a CU (measured: 13.9 / 10.6 / 9.6 ms with 6 / 8 / 9 of them) and LDS is what
+// limits them, so the ring is as small as the flow allows (96 items; 64 starve the lanes).  Its first RING_MIRROR dwords
+// are kept a second time behind its end: a work unit reads at most that far past its first dword, so the lane readers
+// never wrap an index (no mask in the decode step at all) -- only the scheduler does, once per unit.
+constexpr int RING_DW = AHIP_RING_DW;
+constexpr int ITEMS = RING_DW / SUB_DW;          // items the ring (and the scoreboard) holds
+constexpr int RING_MIRROR = SUB_DW + 8;          // dwords 0 .. RING_MIRROR-1 again at RING_DW ..
+#ifndef AHIP_STAGE_UNIT
+#define AHIP_STAGE_UNIT 128
+#endif
+constexpr u32 STAGE_UNIT = AHIP_STAGE_UNIT;      // dwords per staging unit (<= 256: 16 bytes a lane)
 constexpr u32 SPEC_BITS = AHIP_SPEC_BITS;        // a speculative run covers the last SPEC_BITS of its item
 constexpr int STEPS = AHIP_STEPS;                // decode steps between two scheduling points
 constexpr u32 EMIT_MIN = AHIP_EMIT_MIN;          // items retired per emit (<= 64)
 constexpr u32 EPOCH_ITEMS = (1u << 27) / SUB_BITS;  // positions inside an epoch stay below 2^27 + slack
-static_assert((RING_DW & (RING_DW - 1)) == 0 && (ITEMS & (ITEMS - 1)) == 0, "rings are powers of two");
+static_assert(RING_DW % SUB_DW == 0 && RING_DW % 4 == 0 && RING_MIRROR % 4 == 0 && ITEMS >= 64, "ring geometry");
+static_assert(STAGE_UNIT >= 64 && STAGE_UNIT <= 256 && STAGE_UNIT % 4 == 0 && RING_DW % STAGE_UNIT == 0 && (u32)RING_MIRROR <= STAGE_UNIT, "staging geometry");
 static_assert(SUB_BITS % 128 == 0 && SPEC_BITS <= (u32)SUB_BITS && SUB_BITS + 64 < 4096, "item geometry");
 static_assert(EMIT_MIN >= 1 && EMIT_MIN <= 64 && (u32)ITEMS >= 2 * EMIT_MIN && ITEMS >= 32, "scheduler geometry");
+// x in [0, 2 N) -> x mod N
+AHIP_DEVINL u32 wrap_ring(u32 x) { return x >= (u32)RING_DW ? x - (u32)RING_DW : x; }
+AHIP_DEVINL u32 wrap_item(u32 x) { return x >= (u32)ITEMS ? x - (u32)ITEMS : x; }
 
 // ---- the token store: what the tokenizer hands to the resolver ----
 // The decode step works on a STEP WORD: literal (0x8000 | byte) << 16 (negative), match len << 16 | dist
@@ -86,16 +98,20 @@ constexpr u32 DIR_BYTES = 16;
 
 // LDS of the tokenizer (next to WaveLds): the staged bitstream ring and the per-item scoreboard
 struct TokLds {
-  u32 inbuf[RING_DW] __attribute__((aligned(16)));
+  u32 inbuf[RING_DW + RING_MIRROR] __attribute__((aligned(16)));
   u32 fa[ITEMS];    // decode run of item s: state<<30 | flags<<28 | lane<<22 | (start - s*SUB)<<12 | (end - s*SUB)
   u32 fb[ITEMS];    //   where its first token sits in the recording lane's column (words)
   u32 fc[ITEMS];    //   bytes | tokens<<20
   u16 need[ITEMS];  //   max over its matches of (distance - bytes of the item in front of the match): the "source
                     //   before the start of the output" check
   u16 spec[ITEMS];  // speculative run of item s: 0x8000 done | 0x4000 usable | (end - (s+1)*SUB)
-  u32 q[64];        // repair queue of one scheduling point: the starts to decode from
-  u32 colpos[64];   // words used in every column of the member's token area (kept here between blocks)
+  u16 q[64];        // repair queue of one scheduling point: the starts to decode from, counted from the window's first item
 };
+// (The words used in every column of the member's token area are per-lane data: they live in a register of the owning
+//  lane -- `colreg`, handed through the emitters by reference -- and the serial writer reads / writes another lane's with
+//  v_readlane / a select.)
+AHIP_DEVINL u32 col_get(u32 colreg, u32 c) { return lane_bcast(colreg, (int)c); }  // c wave-uniform
+AHIP_DEVINL void col_set(u32 &colreg, u32 c, u32 v, int lane) { colreg = (u32)lane == c ? v : colreg; }
 constexpr u32 SYM_MARK = 0x8000;  // 16-bit symbols of the chunked single-stream decode: SYM_MARK + j = "byte j of the 32 KiB in front of this chunk"
 
 // Token store of one member in device memory (tokenizer -> resolver hand-off).
@@ -154,41 +170,39 @@ AHIP_DEVINL void tok_layout_in(u64 pos, u64 span, u32 k, u64 &tok_off, u32 &col_
 
 struct ParStats { u32 windows, rounds, fallbacks, partial; u32 cyc[8]; u32 dbg; };
 
-// Per-lane LSB-first bit reader over the LDS window.  The stream continues at bit `sh` of the
-// 64-bit pair (hi:lo); `nextw` is the dword after `hi`, always already requested from LDS, so a
-// refill never waits on the critical path.  v_alignbit_b32 extracts 32 stream bits in one op.
-// MASK: the staged bitstream is a ring of MASK + 1 dwords (ptr keeps counting; ~0u = a plain buffer).
-struct LaneBits { u32 lo, hi, nextw, sh, ptr; };
-template <u32 MASK>
-AHIP_DEVINL void lb_init(LaneBits &d, const u32 *inbuf, u32 p) {
-  u32 w = p >> 5;
-  d.lo = inbuf[w & MASK];
-  d.hi = inbuf[(w + 1) & MASK];
-  d.nextw = inbuf[(w + 2) & MASK];
-  d.ptr = w + 2;
+// Per-lane LSB-first bit reader over the staged ring.  The stream continues at bit `sh` of the 64-bit pair (hi:lo);
+// `nextw` is the dword after `hi`, always already requested from LDS, so a refill never waits on the critical path.
+// v_alignbit_b32 extracts 32 stream bits in one op.  `ptr` is the RING index of nextw and just counts up: a unit starts
+// below RING_DW and ends inside the mirror at the latest.  `off` turns ring coordinates back into the stream position.
+struct LaneBits { u32 lo, hi, nextw, sh, ptr, off; };
+// p: bit position (epoch coordinates); rw: ring index of the dword that holds it (< RING_DW)
+AHIP_DEVINL void lb_init(LaneBits &d, const u32 *inbuf, u32 p, u32 rw) {
+  d.lo = inbuf[rw];
+  d.hi = inbuf[rw + 1];
+  d.nextw = inbuf[rw + 2];
+  d.ptr = rw + 2;
   d.sh = p & 31;
+  d.off = (p & ~31u) - (rw + 2) * 32;
 }
 // bring sh below 32 (branch-free) and re-request the look-ahead dword
-template <u32 MASK>
 AHIP_DEVINL void lb_normalize(LaneBits &d, const u32 *inbuf) {
   const bool adv = d.sh >= 32;
   d.lo = adv ? d.hi : d.lo;
   d.hi = adv ? d.nextw : d.hi;
   d.ptr += adv ? 1u : 0u;
   d.sh &= 31;
-  d.nextw = inbuf[d.ptr & MASK];
+  d.nextw = inbuf[d.ptr];
 }
 AHIP_DEVINL u32 lb_peek32(const LaneBits &d) { return __builtin_amdgcn_alignbit(d.hi, d.lo, d.sh); }
-AHIP_DEVINL u32 lb_pos(const LaneBits &d) { return (d.ptr - 2) * 32 + d.sh; }
+AHIP_DEVINL u32 lb_pos(const LaneBits &d) { return d.ptr * 32 + d.sh + d.off; }
 
 // One token at the lane's cursor, straight-line: every lane runs the litlen AND the distance half (a 64-lane step
 // almost always contains a match anyway); selects pick the result.  The only branches skip the long-code
 // resolution when no lane needs it.  Returns the token -- literal (0x8000 | byte) << 16, match len << 16 | dist --
 // or, for anything else (end of block, bad litlen / distance symbol, unfilled entry), a word that is not negative
 // and has a zero distance field; `e` then says which.
-template <u32 MASK>
 AHIP_DEVINL u32 decode_token(LaneBits &d, const WaveLds &L, const u32 *inbuf, u32 &e) {
-  lb_normalize<MASK>(d, inbuf);
+  lb_normalize(d, inbuf);
   const u32 w = lb_peek32(d);  // 32 valid bits; litlen code + extra <= 20
   e = L.ll[w & ((1u << LL_ROOT) - 1)];
   if (AHIP_ANY_HINT(e & E_LONG)) {
@@ -200,7 +214,7 @@ AHIP_DEVINL u32 decode_token(LaneBits &d, const WaveLds &L, const u32 *inbuf, u3
   const u32 lenv = (e >> 16) + __builtin_amdgcn_ubfe(w, cl, xb);
   const bool is_match = (e & (E_LIT | E_EOB | E_BAD | E_HOLE)) == 0;
   d.sh += cl + xb;
-  lb_normalize<MASK>(d, inbuf);
+  lb_normalize(d, inbuf);
   const u32 w2 = lb_peek32(d);  // distance code + extra <= 28
   u32 t = L.dt[w2 & ((1u << D_ROOT) - 1)];
   if (AHIP_ANY_HINT(t & E_LONG)) {  // (whatever the lane's litlen symbol was: a spurious second-level read is harmless and costs less than asking)
@@ -222,7 +236,7 @@ constexpr u32 LR_EOB = 1, LR_ERR = 2;  // how a run ended before its boundary
 
 // ---- the serial writer: one lane-uniform token at a time into the free space of the columns ----
 // Its runs are always flagged DF_BIG (they may be of any length; the resolver takes their offsets from a prefix sum).
-AHIP_DEVINL void sink_close(TokSink &k, u32 *colpos, int lane, u64 out_rel) {  // close the open run (out_rel: output produced so far), note how far its column is used
+AHIP_DEVINL void sink_close(TokSink &k, u32 &colreg, int lane, u64 out_rel) {  // close the open run (out_rel: output produced so far), note how far its column is used
   if (!k.area || k.scol >= 64) return;
   if (k.spos > k.srun) {
     if (k.ndir < k.dir_cap) {
@@ -231,35 +245,34 @@ AHIP_DEVINL void sink_close(TokSink &k, u32 *colpos, int lane, u64 out_rel) {  /
       k.ndir++;
     } else k.full = true;
   }
-  if (lane == 0) colpos[k.scol] = k.spos - k.scol * k.col_cap;
-  wave_sync();
+  col_set(colreg, k.scol, k.spos - k.scol * k.col_cap, lane);
   k.srun = k.spos;
   k.sbytes = 0;
 }
 // (re)start: the flow decoder may have used this column meanwhile
-AHIP_DEVINL void sink_open(TokSink &k, const u32 *colpos) {
+AHIP_DEVINL void sink_open(TokSink &k, u32 colreg) {
   k.sbytes = 0;
   if (!k.area || k.scol >= 64) return;
-  k.spos = k.scol * k.col_cap + uniform(colpos[k.scol]);
+  k.spos = k.scol * k.col_cap + col_get(colreg, k.scol);
   k.srun = k.spos;
 }
-AHIP_DEVINL bool sink_room(TokSink &k, u32 *colpos, u32 words, int lane, u64 out_rel) {  // `words` contiguous words
+AHIP_DEVINL bool sink_room(TokSink &k, u32 &colreg, u32 words, int lane, u64 out_rel) {  // `words` contiguous words
   for (;;) {
     if (k.scol < 64 && k.spos + words <= (k.scol + 1) * k.col_cap && k.spos - k.srun < (1u << 22)) return true;
     const bool split = k.scol < 64 && k.spos + words <= (k.scol + 1) * k.col_cap;  // only the run got too long
-    sink_close(k, colpos, lane, out_rel);
+    sink_close(k, colreg, lane, out_rel);
     if (split) continue;
     k.scol += 1;  // ~0u -> 0
     if (k.scol >= 64) { k.scol = 64; k.full = true; return false; }
-    k.spos = k.scol * k.col_cap + uniform(colpos[k.scol]);
+    k.spos = k.scol * k.col_cap + col_get(colreg, k.scol);
     k.srun = k.spos;
   }
 }
 // one token: `step_word` as the decode step makes it (literal / match), `adv` the bytes it produces; out_rel = the
 // output offset in FRONT of it
-AHIP_DEVINL void sink_put(TokSink &k, u32 *colpos, u32 step_word, u32 adv, int lane, u64 out_rel) {
+AHIP_DEVINL void sink_put(TokSink &k, u32 &colreg, u32 step_word, u32 adv, int lane, u64 out_rel) {
   if (!k.area || k.full) return;
-  if (!sink_room(k, colpos, 1, lane, out_rel)) return;
+  if (!sink_room(k, colreg, 1, lane, out_rel)) return;
   k.sbytes += adv;
   if (lane == 0) k.area[k.spos] = rec_word(k.sbytes, step_word);
   k.spos += 1;
@@ -268,7 +281,7 @@ AHIP_DEVINL void sink_put(TokSink &k, u32 *colpos, u32 step_word, u32 adv, int l
 // Serial decode of one Huffman block that EMITS tokens instead of writing bytes: the checked path
 // for everything irregular (same decisions, in the same order, as huffman_token<WRITE, CAREFUL>).
 template <bool CAREFUL>
-AHIP_DEVINL u32 huffman_token_emit(WaveLds &L, BitCursor &b, OutCursor &o, TokSink &sink, u32 *colpos, u32 ll_max, u32 d_max, int lane) {
+AHIP_DEVINL u32 huffman_token_emit(WaveLds &L, BitCursor &b, OutCursor &o, TokSink &sink, u32 &colreg, u32 ll_max, u32 d_max, int lane) {
   if (CAREFUL && b.pos + ll_max > b.total_bits) return 100 + MS_FALSE_EOS;
   u64 w = peek_bits(b);
   u32 e = uniform(L.ll[(u32)w & ((1u << LL_ROOT) - 1)]);
@@ -277,7 +290,7 @@ AHIP_DEVINL u32 huffman_token_emit(WaveLds &L, BitCursor &b, OutCursor &o, TokSi
   if (e & (E_LIT | E_EOB | E_BAD | E_HOLE)) {
     if (e & E_LIT) {
       if (o.pos >= o.limit) return 100 + MS_CAP;
-      sink_put(sink, colpos, e & 0xffff0000u, 1u, lane, o.pos - o.org);  // (0x8000 | byte) << 16
+      sink_put(sink, colreg, e & 0xffff0000u, 1u, lane, o.pos - o.org);  // (0x8000 | byte) << 16
       o.pos += 1;
       b.pos += cl;
       return 0;
@@ -307,28 +320,28 @@ AHIP_DEVINL u32 huffman_token_emit(WaveLds &L, BitCursor &b, OutCursor &o, TokSi
   if ((u64)dist > o.pos) return 100 + MS_FARREF;
   if (o.pos + (u64)len > o.limit) return 100 + MS_CAP;
   if ((u64)dist > o.pos - o.hist) o.far = 1;
-  sink_put(sink, colpos, ((u32)len << 16) | (u32)dist, (u32)len, lane, o.pos - o.org);
+  sink_put(sink, colreg, ((u32)len << 16) | (u32)dist, (u32)len, lane, o.pos - o.org);
   o.pos += (u64)len;
   return 0;
 }
-AHIP_DEVINL u32 huffman_block_emit(WaveLds &L, BitCursor &b, OutCursor &o, TokSink &sink, u32 *colpos, int lane) {
+AHIP_DEVINL u32 huffman_block_emit(WaveLds &L, BitCursor &b, OutCursor &o, TokSink &sink, u32 &colreg, int lane) {
   const u32 ll_max = L.lld.maxlen, d_max = L.dd.maxlen;
-  sink_open(sink, colpos);
+  sink_open(sink, colreg);
   u32 rs;
   for (;;) {
     u32 r;
-    if ((b.pos >> 3) + 16 <= b.in_len) r = huffman_token_emit<false>(L, b, o, sink, colpos, ll_max, d_max, lane);
-    else r = huffman_token_emit<true>(L, b, o, sink, colpos, ll_max, d_max, lane);
+    if ((b.pos >> 3) + 16 <= b.in_len) r = huffman_token_emit<false>(L, b, o, sink, colreg, ll_max, d_max, lane);
+    else r = huffman_token_emit<true>(L, b, o, sink, colreg, ll_max, d_max, lane);
     if (r == 0) continue;
     rs = r == 1 ? (u32)MS_OK : r - 100;
     break;
   }
-  sink_close(sink, colpos, lane, o.pos - o.org);
+  sink_close(sink, colreg, lane, o.pos - o.org);
   return rs;
 }
 // _parseUncompressedBlock as a directory entry: a block of >= 3 bytes becomes one DF_STORED entry (two area words hold
 // its input offset); shorter ones are literals
-AHIP_DEVINL u32 stored_block_emit(BitCursor &b, OutCursor &o, TokSink &sink, u32 *colpos, int lane) {
+AHIP_DEVINL u32 stored_block_emit(BitCursor &b, OutCursor &o, TokSink &sink, u32 &colreg, int lane) {
   b.pos = (b.pos + 7) & ~7ull;
   b.blen = 0;
   int len = read_bits(b, 16);
@@ -338,10 +351,10 @@ AHIP_DEVINL u32 stored_block_emit(BitCursor &b, OutCursor &o, TokSink &sink, u32
   u64 byte = b.pos >> 3;
   if ((u64)len > b.in_len - byte) return MS_FALSE;
   if (o.pos + (u64)len > o.limit) return MS_CAP;
-  sink_open(sink, colpos);
+  sink_open(sink, colreg);
   const u64 out_rel = o.pos - o.org;
   if (len >= 3) {
-    if (sink.area && !sink.full && sink_room(sink, colpos, 2, lane, out_rel)) {
+    if (sink.area && !sink.full && sink_room(sink, colreg, 2, lane, out_rel)) {
       if (sink.ndir < sink.dir_cap) {
         if (lane == 0) {
           sink.area[sink.spos] = (u32)byte;
@@ -353,10 +366,10 @@ AHIP_DEVINL u32 stored_block_emit(BitCursor &b, OutCursor &o, TokSink &sink, u32
       sink.spos += 2;
       sink.srun = sink.spos;  // the two words belong to the entry above, not to a token run
     }
-    sink_close(sink, colpos, lane, out_rel);
+    sink_close(sink, colreg, lane, out_rel);
   } else {
-    for (int i = 0; i < len; ++i) sink_put(sink, colpos, TK_LIT | ((u32)b.in[byte + i] << 16), 1u, lane, out_rel + (u64)i);
-    sink_close(sink, colpos, lane, out_rel + (u64)len);
+    for (int i = 0; i < len; ++i) sink_put(sink, colreg, TK_LIT | ((u32)b.in[byte + i] << 16), 1u, lane, out_rel + (u64)i);
+    sink_close(sink, colreg, lane, out_rel + (u64)len);
   }
   o.pos += (u64)len;
   b.pos += 8ull * (u64)len;
@@ -388,7 +401,7 @@ AHIP_DEVINL u32 stored_block_emit(BitCursor &b, OutCursor &o, TokSink &sink, u32
 // Anything irregular on the true path -- bad symbol, back-reference before the start of the output, output
 // window exhausted, a full column, input too close to its end -- stops the flow at the last retired item and
 // hands the rest of the block to the serial decoder, which restates the reference symbol by symbol.
-AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutCursor &o, TokSink &sink, int lane,
+AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutCursor &o, TokSink &sink, u32 &colreg, int lane,
                                        ParStats &st, u64 hint_end_bits) {
   constexpr u32 SLACK_DW = 4;  // a token may run 48 bits past its item and the reader looks two dwords ahead
   constexpr u32 SUB = SUB_BITS;
@@ -411,11 +424,32 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
     AHIP_TICK(t_a);
     for (u32 i = lane; i < (u32)ITEMS; i += 64) { P.fa[i] = 0; P.spec[i] = 0; }
     const u32 total_dw = n_items * SUB_DW + SLACK_DW;
-    u32 stage_hi = 0;  // dwords staged so far (multiple of 4)
-    auto stage_to = [&](u32 target) {
-      for (u32 w = stage_hi + (u32)lane * 4; w < target; w += 256)
-        *(uint4 *)(P.inbuf + (w & RING_MASK)) = load_u128_unaligned(b.in + gbyte + 4 * (u64)w);
-      stage_hi = target;
+    // The ring is filled in UNITS of STAGE_UNIT dwords (16 bytes a lane), and the unit that will be wanted next is always
+    // already on its way into registers (`pf`): a retire step that frees a unit's worth of slots stores data that was
+    // requested a whole retire step earlier instead of waiting ~ 2 us for a fresh load (the retire phase was 8.6 % of the
+    // tokenizer's time, nearly all of it this wait).
+    u32 stage_hi = 0;  // dwords staged so far (whole units, or total_dw)
+    uint4 pf = make_uint4(0u, 0u, 0u, 0u);
+    u32 pf_at = ~0u;   // the unit `pf` holds (its first dword)
+    auto load_unit = [&](u32 base) -> uint4 {
+      const u32 w = base + (u32)lane * 4;
+      return (u32)lane * 4 < STAGE_UNIT && w < total_dw ? load_u128_unaligned(b.in + gbyte + 4 * (u64)w) : make_uint4(0u, 0u, 0u, 0u);
+    };
+    auto stage_to = [&](u32 limit) {  // whole units that end at or below `limit` (the stream's last one may be short)
+      while (stage_hi < total_dw) {
+        const u32 end = stage_hi + STAGE_UNIT < total_dw ? stage_hi + STAGE_UNIT : total_dw;
+        if (end > limit) break;
+        const uint4 v = pf_at == stage_hi ? pf : load_unit(stage_hi);
+        const u32 w = stage_hi + (u32)lane * 4;
+        if ((u32)lane * 4 < STAGE_UNIT && w < total_dw) {
+          const u32 rw = stage_hi % (u32)RING_DW + (u32)lane * 4;  // (RING_DW is a multiple of the unit: no unit straddles the ring's end)
+          *(uint4 *)(P.inbuf + rw) = v;
+          if (rw < (u32)RING_MIRROR) *(uint4 *)(P.inbuf + RING_DW + rw) = v;  // the head of the ring, again behind its end
+        }
+        stage_hi = end;
+        pf_at = ~0u;
+      }
+      if (pf_at != stage_hi && stage_hi < total_dw) { pf = load_unit(stage_hi); pf_at = stage_hi; }  // the next unit: on its way
     };
     stage_to(total_dw < (u32)RING_DW ? total_dw : (u32)RING_DW);
     wave_sync();
@@ -427,10 +461,10 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
     u32 next_spec = 0, next_fix = 1, V = 0, tV = t0, retired = 0, t_ret = t0, g = 0;
     bool block_done = false, stop_serial = false;
     // lane state: ms = mode<<28 | item (mode 0 idle, 1 SPEC, 2 RUN)
-    u32 ms = 0, bound = 0, start = 0, endp = 0, fl = 0, nbytes = 0, row0 = 0;
-    u32 rowctr = P.colpos[lane];  // words this lane has recorded into its column of the token area
+    u32 ms = 0, bound = 0, start = 0, endp = 0, fl = 0, nbytes = 0, row0 = 0, myslot = 0;  // myslot: scoreboard slot of the lane's item
+    u32 rowctr = colreg;  // words this lane has recorded into its column of the token area
     i32 need = 0;
-    LaneBits d{0, 0, 0, 0, 2};
+    LaneBits d{0, 0, 0, 0, 2, 0};
     u32 *const col = sink.area + (u32)lane * sink.col_cap;  // this lane's column of the member's token area
     u32 rot = 0;  // rotates which idle lanes take the recording runs, so that the columns fill evenly
     u32 guard = 0;
@@ -439,7 +473,7 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
         st.dbg |= 2;
 #ifdef AHIP_FLOW_DEBUG
         st.cyc[0] = V; st.cyc[1] = retired; st.cyc[2] = next_fix; st.cyc[3] = next_spec; st.cyc[4] = g; st.cyc[5] = n_items;
-        st.cyc[6] = uniform(P.fa[V & ITEM_MASK]); st.cyc[7] = (block_done ? 1u : 0u) | (u32)__popcll(__ballot((ms >> 28) != 0)) << 8 | stage_hi << 16;
+        st.cyc[6] = uniform(P.fa[V % (u32)ITEMS]); st.cyc[7] = (block_done ? 1u : 0u) | (u32)__popcll(__ballot((ms >> 28) != 0)) << 8 | stage_hi << 16;
 #endif
         stop_serial = true;
         break;
@@ -454,8 +488,9 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
       u32 pend = 0;   //   and where it starts
       if (!block_done && !stop_serial) {
         const u32 wi = V + (u32)lane;
+        const u32 wslot = wrap_item(V % (u32)ITEMS + (u32)lane);  // (V is wave-uniform: the division is scalar)
         const bool win = wi < n_items && wi < retired + (u32)ITEMS;
-        const u32 wa = win ? P.fa[wi & ITEM_MASK] : (1u << 30);
+        const u32 wa = win ? P.fa[wslot] : (1u << 30);
         const u32 wstate = wa >> 30, wfl = (wa >> 28) & 3u;
         const u32 wend = wi * SUB + (wa & 0xfffu), wstart = wi * SUB + ((wa >> 12) & 0x3ffu);
         const u32 wkey = (wstate == 2 && wfl == 0) ? wend : ~0u;  // usable end of a finished run
@@ -487,10 +522,11 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
         const u32 nb = V - retired < 64 ? V - retired : 64u;
         const bool mine = (u32)lane < nb;
         const u32 s = retired + (u32)lane;
-        const u32 a = mine ? P.fa[s & ITEM_MASK] : 0u;
-        const u32 r0 = mine ? P.fb[s & ITEM_MASK] : 0u;
-        const u32 c = mine ? P.fc[s & ITEM_MASK] : 0u;
-        const u32 nd = mine ? (u32)P.need[s & ITEM_MASK] : 0u;
+        const u32 sslot = wrap_item(retired % (u32)ITEMS + (u32)lane);
+        const u32 a = mine ? P.fa[sslot] : 0u;
+        const u32 r0 = mine ? P.fb[sslot] : 0u;
+        const u32 c = mine ? P.fc[sslot] : 0u;
+        const u32 nd = mine ? (u32)P.need[sslot] : 0u;
         const u32 cnt = c >> 20, nby = c & 0xfffffu, cl = (a >> 22) & 63u;
         u32 tot_bytes;
         const u32 B = wave_excl_sum(nby, tot_bytes);
@@ -521,7 +557,7 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
         }
         o.pos += tot_bytes;
         t_ret = lane_bcast(s * SUB + (a & 0xfffu), (int)nb - 1);
-        if (mine) { P.fa[s & ITEM_MASK] = 0; P.spec[s & ITEM_MASK] = 0; }
+        if (mine) { P.fa[sslot] = 0; P.spec[sslot] = 0; }
         retired += nb;
         const u32 room = retired * SUB_DW + (u32)RING_DW;
         wave_sync();
@@ -549,18 +585,25 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
           const u32 stage_items = (stage_hi - SLACK_DW) / SUB_DW;  // items whose bits (+ slack) are in the ring
           const u32 lim = n_items < stage_items ? n_items : stage_items;
           // (a) repairs (ordered: the one validation waits for comes first)
+          // (a repair's item lies in [V, V + 64) -- V as the scan above has just advanced it --, its start less than 48 bits
+          //  behind the item's boundary: the queue holds it as an offset from the window's first item)
+          const u32 vslot = V % (u32)ITEMS;
           const bool rr = ((rm >> lane) & 1) && pend / SUB < lim;
           const u64 rm2 = __ballot(rr);
           const u32 nrr = (u32)__popcll(rm2);
           const u32 na = nrr < nidle ? nrr : nidle;
           const u32 rr_rank = wave_rank(rm2);
-          if (rr && rr_rank < na) { P.q[rr_rank] = pend; P.fa[(pend / SUB) & ITEM_MASK] = 1u << 30; }
+          if (rr && rr_rank < na) { P.q[rr_rank] = (u16)(pend - V * SUB); P.fa[wrap_item(vslot + (pend / SUB - V))] = 1u << 30; }
 #ifdef AHIP_PROFILE
           st.rounds += na;  // (repairs: a diagnostic)
 #endif
+#ifdef AHIP_FLOW_STATS
+          st.cyc[4] += na;
+#endif
           // (b) runs whose predicted start is known: consecutive items from next_fix
           const u32 sb = next_fix + (u32)lane;
-          const bool okb = sb < lim && (P.spec[(sb - 1) & ITEM_MASK] & 0xc000u) == 0xc000u;
+          const u32 fslot1 = (next_fix - 1) % (u32)ITEMS;  // slot of the item in front of next_fix (next_fix >= 1)
+          const bool okb = sb < lim && (P.spec[wrap_item(fslot1 + (u32)lane)] & 0xc000u) == 0xc000u;
           const u64 okm = __ballot(okb);
           const u32 nready = okm == ~0ull ? 64u : (u32)__builtin_ctzll(~okm);
           // (c) speculation ahead
@@ -575,19 +618,26 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
           const bool take_c = idle && rank >= na && !take_b && u2 - nb_ < nc_;
           wave_sync();  // P.q
           if (take_a || take_b || take_c) {
-            u32 s_new, st_new;
-            if (take_a) { st_new = P.q[rank]; s_new = st_new / SUB; }
-            else if (take_b) { s_new = next_fix + u2; st_new = s_new * SUB + (P.spec[(s_new - 1) & ITEM_MASK] & 0xfffu); }
-            else {
-              s_new = next_spec + (u2 - nb_);
+            u32 s_new, st_new, slot_new;
+            if (take_a) {
+              const u32 rel = P.q[rank];  // bits behind the window's first item
+              st_new = V * SUB + rel; s_new = V + rel / SUB; slot_new = wrap_item(vslot + rel / SUB);
+            } else if (take_b) {
+              const u32 pslot = wrap_item(fslot1 + u2);  // the item in front of it
+              s_new = next_fix + u2; slot_new = wrap_item(pslot + 1);
+              st_new = s_new * SUB + (P.spec[pslot] & 0xfffu);
+            } else {
+              s_new = next_spec + (u2 - nb_); slot_new = wrap_item(next_spec % (u32)ITEMS + (u2 - nb_));
               st_new = (s_new + 1) * SUB - SPEC_BITS;
               if (st_new < t0) st_new = t0;  // item 0 of the epoch: nothing in front of the true start belongs to this block
             }
             ms = (take_c ? 1u << 28 : 2u << 28) | s_new;
+            myslot = slot_new;
             bound = (s_new + 1) * SUB;
             start = st_new; endp = st_new; fl = 0; nbytes = 0; need = 0; row0 = rowctr;
-            lb_init<RING_MASK>(d, P.inbuf, st_new);
-            if (take_b) P.fa[s_new & ITEM_MASK] = 1u << 30;  // in flight
+            // (the unit starts inside its item or, a repair / predicted start, less than 64 bits behind its end)
+            lb_init(d, P.inbuf, st_new, wrap_ring(slot_new * (u32)SUB_DW + ((st_new - s_new * SUB) >> 5)));
+            if (take_b) P.fa[slot_new] = 1u << 30;  // in flight
           }
           next_fix += nb_;
           next_spec += nc_;
@@ -597,12 +647,21 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
       AHIP_TICK(t_s3);
       AHIP_ACC(st.cyc[3], t_s2, t_s3);
       // ===== decode steps =====  (idle and finished lanes have bound == 0)
+#ifdef AHIP_FLOW_STATS  // dev (CPU emulation): what the lanes did -- cyc[0] lane-steps, [1] of them speculative, [2] scheduling points,
+                        // [3] lanes left idle by the assignment, [4] repairs
+      st.cyc[2] += 1;
+      st.cyc[3] += (u32)__popcll(__ballot((ms >> 28) == 0));
+#endif
       for (int k = 0; k < STEPS; ++k) {
         const bool go = endp < bound;
         if (!__any(go)) break;
+#ifdef AHIP_FLOW_STATS
+        st.cyc[0] += (u32)__popcll(__ballot(go));
+        st.cyc[1] += (u32)__popcll(__ballot(go && (ms >> 28) == 1));
+#endif
         if (go) {
           u32 e;
-          const u32 t = decode_token<RING_MASK>(d, L, P.inbuf, e);
+          const u32 t = decode_token(d, L, P.inbuf, e);
           endp = lb_pos(d);
           const bool spc = (i32)t >= 0 && (t & 0xffffu) == 0;
           if (AHIP_ANY_HINT(spc)) {
@@ -630,12 +689,12 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
             const u32 bnd = (s + 1) * SUB;
             if (mode == 1) {
               const bool usable = fl == 0 && endp - bnd < 64;
-              P.spec[s & ITEM_MASK] = (u16)(0x8000u | (usable ? 0x4000u : 0u) | ((endp - bnd) & 0xfffu));
+              P.spec[myslot] = (u16)(0x8000u | (usable ? 0x4000u : 0u) | ((endp - bnd) & 0xfffu));
             } else {
-              P.fb[s & ITEM_MASK] = row0;
-              P.fc[s & ITEM_MASK] = nbytes | (((rowctr - row0) & 0xfffu) << 20);
-              P.need[s & ITEM_MASK] = (u16)need;
-              P.fa[s & ITEM_MASK] = (2u << 30) | (fl << 28) | ((u32)lane << 22) | ((start - s * SUB) << 12) | (endp - s * SUB);
+              P.fb[myslot] = row0;
+              P.fc[myslot] = nbytes | (((rowctr - row0) & 0xfffu) << 20);
+              P.need[myslot] = (u16)need;
+              P.fa[myslot] = (2u << 30) | (fl << 28) | ((u32)lane << 22) | ((start - s * SUB) << 12) | (endp - s * SUB);
             }
             ms = 0; bound = 0; endp = 0;
           }
@@ -643,8 +702,7 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
         }
       }
     }
-    P.colpos[lane] = rowctr;
-    wave_sync();
+    colreg = rowctr;
     b.pos = gbyte * 8 + t_ret;
 #ifdef AHIP_PROFILE
     st.partial += g;  // decode steps of the wave
@@ -655,7 +713,7 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
     // the epoch is used up (V == n_items): go on from the new origin
   }
   AHIP_TICK(t_x0);
-  u32 rs = huffman_block_emit(L, b, o, sink, P.colpos, lane);
+  u32 rs = huffman_block_emit(L, b, o, sink, colreg, lane);
   AHIP_TICK(t_x1);
   AHIP_ACC(st.cyc[7], t_x0, t_x1);
   return rs;
@@ -676,7 +734,7 @@ AHIP_DEVINL void inflate_member(WaveLds &L, HeaderLds &H, TokLds *P, const u8 *i
   BitCursor b{in, in_len, in_len * 8, m.in_off * 8 + (CHUNK ? cx->start_bit : 0u), nullptr, 0, 0, 0};
   const u64 hist = CHUNK ? cx->hist : m.hist;
   OutCursor o{out + m.out_off - hist, hist, m.out_limit > ~0ull - hist ? ~0ull : m.out_limit + hist, CHUNK ? 0u : hist, 0, hist};
-  if (PAR) { P->colpos[lane] = 0; wave_sync(); }
+  u32 colreg = 0;  // words this lane's column of the member's token area holds (tokenizer only)
   // where the index expects the deflate data to end (a hint for speculation only: the decode itself never trusts it)
   const u64 hint_end_bits = (!CHUNK && m.expect_end != ~0ull) ? m.expect_end * 8 : 0ull;
   u32 status = MS_EOS, blocks = 0;
@@ -694,7 +752,7 @@ AHIP_DEVINL void inflate_member(WaveLds &L, HeaderLds &H, TokLds *P, const u8 *i
     const int btype = hdr >> 1;
     u32 r;
     if (btype == 0) {
-      r = PAR ? stored_block_emit(b, o, sink, P->colpos, lane) : stored_block<WRITE>(b, o, lane);
+      r = PAR ? stored_block_emit(b, o, sink, colreg, lane) : stored_block<WRITE>(b, o, lane);
     } else if (btype == 3) {
       r = MS_FALSE;
     } else {
@@ -749,7 +807,7 @@ AHIP_DEVINL void inflate_member(WaveLds &L, HeaderLds &H, TokLds *P, const u8 *i
             r = MS_OVERSUB;
           }
         }
-        else if (PAR) r = huffman_block_tokenize(L, *P, b, o, sink, lane, st, hint_end_bits);
+        else if (PAR) r = huffman_block_tokenize(L, *P, b, o, sink, colreg, lane, st, hint_end_bits);
         else r = huffman_block<WRITE>(L, b, o, lane);
         if (r == MS_FALSE && replayable) {  // a bad symbol: where exactly did the reference's reader stop?
           b.pos = data_pos;
@@ -816,6 +874,13 @@ AHIP_DEVINL void deposit16(u8 *dp, u32 len, u64 w0, u64 w1) {
 #define RACC(slot, t0, t1) do { } while (0)
 #endif
 
+// -DAHIP_RES_STATS (CPU emulation only): event counts of the resolver, summed over members
+#ifdef AHIP_RES_STATS
+static unsigned long long res_stats[16];
+#define RSTAT(i, n) do { if (lane == 0) res_stats[i] += (unsigned long long)(n); } while (0)
+#else
+#define RSTAT(i, n) do { } while (0)
+#endif
 #ifndef AHIP_WIN_CAP
 #define AHIP_WIN_CAP 2560
 #endif
@@ -988,6 +1053,7 @@ AHIP_DEVINL void resolve_member(ResLdsT<E> &P, const u8 *in, const u32 *area, co
     E *const ob = P.obuf + A;
     wave_sync();
     for (u32 b0 = 0; b0 < npend; b0 += 64) {
+      RSTAT(7, 1);
       const bool have = b0 + (u32)lane < npend;
       const uint2 e = P.plist[have ? b0 + lane : 0];
       const u32 wo = e.x & 0xffffu, len = e.x >> 16, dist = e.y;
@@ -997,10 +1063,11 @@ AHIP_DEVINL void resolve_member(ResLdsT<E> &P, const u8 *in, const u32 *area, co
       const u32 sa2 = (!MARK && simple && len > 16) ? sa + len - 16 : sa;  // bytes: the piece that ends at len
       const u64 lmask = len >= 32 ? 0xffffffffull : ((1ull << len) - 1);
       bool pl = have;
-      u32 guard = 0;
-      for (;;) {
+      for (;;) {  // (every round finishes at least the first pending match -- by the simple path, which nothing can block, or by
+                  //  the whole-wave copy -- so 64 rounds at most: no guard whose firing would drop matches silently)
         const u64 pend = __ballot(pl);
-        if (!pend || ++guard > 80) break;
+        if (!pend) break;
+        RSTAT(8, 1);
         // marks over the source, and the source bytes themselves, in one LDS round trip
         const u32 m0 = P.pmap[sa >> 5], m1 = P.pmap[(sa >> 5) + 1];
         const u8 *sb = (const u8 *)(ob + sa), *sb2 = MARK ? sb + 16 : (const u8 *)(ob + sa2);  // symbols: one piece of 32 bytes
@@ -1014,6 +1081,7 @@ AHIP_DEVINL void resolve_member(ResLdsT<E> &P, const u8 *in, const u32 *area, co
         if (!((am >> f) & 1)) {  // the first pending one is not a simple one (a simple first one is never blocked)
           RTICK(r_h0);
           const u32 fd = lane_bcast(wo, f), L_ = lane_bcast(len, f), D_ = lane_bcast(dist, f);
+          RSTAT(9, 1);
           wave_copy(fd, L_, D_);
           if (lane == f) mark(wo, len, false);
           pl = pl && lane != f;
@@ -1033,6 +1101,7 @@ AHIP_DEVINL void resolve_member(ResLdsT<E> &P, const u8 *in, const u32 *area, co
     RACC(4, r_r0, r_r1);
   };
   auto flush = [&]() {  // deferred matches, then window -> HBM: byte head up to 16-byte alignment, 16-byte body, byte tail
+    RSTAT(6, 1);
     if (npend) resolve_pending();
     RTICK(r_f0);
     wave_sync();
@@ -1072,6 +1141,7 @@ AHIP_DEVINL void resolve_member(ResLdsT<E> &P, const u8 *in, const u32 *area, co
     const u32 nplain = special ? (u32)__builtin_ctzll(special) : nleft;  // ordinary runs in front of the first special entry
     const u64 borg = wpos;
     u32 wrel = 0;
+    RSTAT(0, 1);
     // ---- one pass over a chunk, straight-line: the lanes of `rem` that fit the window (and its pending list), a prefix;
     //      returns the rest (the caller flushes and comes back) ----
     auto pass = [&](Ck &c, u64 rem) -> u64 {
@@ -1083,11 +1153,13 @@ AHIP_DEVINL void resolve_member(ResLdsT<E> &P, const u8 *in, const u32 *area, co
       const i32 so = wo - (i32)dist;    // window index of the source (negative: flushed output)
       // A match is deposited right here when deposit_now() says so; everything else is deferred to the flush.
       bool Gc = c.gc;  // as classified when the chunk was prepared ...
-      if (wrel != c.wrel0) Gc = deposit_now(isM, c.len, dist, so);  // ... unless the window has moved since
+      RSTAT(2, 1);
+      if (wrel != c.wrel0) { RSTAT(10, 1); Gc = deposit_now(isM, c.len, dist, so); }  // ... unless the window has moved since
       const bool defer_ = isM && !Gc;
       bool fit = c.inb;
       const bool whole = rem == c.inbm && (u32)(c.cend - (i32)wrel) <= WIN_CAP && npend + 64 <= PEND_CAP;
       if (!whole) {  // the window or its pending list ends inside the chunk: what fits has to be a prefix of what remains
+        RSTAT(3, 1);
         fit = ((rem >> lane) & 1) && (u32)wo + c.len <= WIN_CAP;
         const u64 dm = __ballot(fit && defer_);
         const u32 before = (u32)__popcll(dm & ((1ull << lane) - 1));
@@ -1106,6 +1178,7 @@ AHIP_DEVINL void resolve_member(ResLdsT<E> &P, const u8 *in, const u32 *area, co
       // now, and waited for inside this branch, so that nothing else waits for the loads of the NEXT chunk
       const bool late = G && !c.pre;  // (only after a flush: otherwise `pre` is exactly the classification)
       if (wrel != c.wrel0 && __any(late)) {
+        RSTAT(4, 1);
         if (late) {
           fetch(so, c.len, c.w0, c.w1, c.w2, c.w3);
           c.pre = true;
@@ -1114,6 +1187,9 @@ AHIP_DEVINL void resolve_member(ResLdsT<E> &P, const u8 *in, const u32 *area, co
       }
       if (G) store_match(ob + wo, c.len, c.w0, c.w1, c.w2, c.w3);
       const u64 dm = __ballot(D);
+#ifdef AHIP_RES_STATS
+      { const u64 gm_ = __ballot(G), lm_ = __ballot(fit && lit); RSTAT(5, __popcll(dm)); RSTAT(11, __popcll(gm_)); RSTAT(12, __popcll(lm_)); }
+#endif
       if (dm) {
         if (D) {
           P.plist[npend + (u32)__popcll(dm & ((1ull << lane) - 1))] = make_uint2((u32)wo | (c.len << 16), dist);
@@ -1129,6 +1205,7 @@ AHIP_DEVINL void resolve_member(ResLdsT<E> &P, const u8 *in, const u32 *area, co
     };
     // a whole chunk: passes and flushes (ONE flush site per loop: the flush is a lot of code and registers)
     auto process = [&](Ck &c) {
+      RSTAT(1, 1);
       u64 rem = c.inbm;
       for (u32 guard = 0; guard < 300; ++guard) {  // (a pass after a flush always takes at least one token: never spins)
         if (rem) rem = pass(c, rem);

@@ -6,15 +6,18 @@ One "step" = one complete decode of the rank's device-resident stream: member in
 one collective the path has: an all-gather of per-rank output sizes (RCCL) whose exclusive scan
 is each shard's offset in the logical concatenated output.  Inputs and outputs stay in HBM.
 
-Workload (config.workload): BASELINE.json configs[3] -- 65 536 gzip members x 64 KiB of
-synthetic log text (4 GiB out, ~1.7 GiB in) PER GPU (weak scaling: rank r holds members
-[r*M, (r+1)*M) of a stream of N*M members).  --members shrinks it for quick runs.
+Workload (config.workload): BASELINE.json configs[3] -- ONE stream of 65 536 gzip members x 64 KiB of
+synthetic log text (4 GiB out, ~1.7 GiB in).  N = 1: that stream on one GPU.  N > 1: the SAME stream, cut into N
+contiguous member ranges balanced on compressed bytes (archive_amd.sharding.partition_members); every rank indexes and
+decodes only its slice -- `scaling: "strong"`, which is what BASELINE.json's "4 GiB ... 1/2/4/8 GPU" metric asks for.
+--members shrinks it for quick runs.
 
 The JSON line also carries
   check     CRC-32 of the decoded bytes taken on the device vs the CRC-32 the generator's gzip trailers imply
-            (per-member CRCs combined with the GF(2) shift x^(8 len)) -- the number carries its own proof;
-  strong    (N > 1) the same 4 GiB stream ONCE, partitioned over the ranks on compressed bytes; every rank indexes
-            and decodes only its slice, the shard CRCs combine to the whole stream's;
+            (per-member CRCs combined with the GF(2) shift x^(8 len)) -- the number carries its own proof; for N > 1
+            the shard CRCs are combined the same way and must equal the whole stream's;
+  weak      (N > 1, unless --no-extras) every rank decoding its OWN 65 536 members (rank r holds members
+            [r*M, (r+1)*M) of a stream of N*M members): per-GPU work fixed, reported next to the headline;
   extras    (N = 1) the other BASELINE configs, device-resident unless said otherwise: 2a one 256 MiB member, 2b
             4 096 members of wiki-like text, 3 Deflate level 6 on 1 GiB, 4 without the BGZF BC subfield, 5 bzip2,
             and the host-pointer entry point end to end (PCIe included).
@@ -156,28 +159,25 @@ def main():
     kind = corpus.LOG if args.kind == "log" else corpus.WIKI
     seed = 1234 if kind == corpus.LOG else 8
     threads = max(1, (os.cpu_count() or 1) // max(1, local_world))
-    t0 = time.time()
-    comp, plain = corpus.make_gzip(kind=kind, seed=seed, n_members=args.members, member_bytes=args.member_bytes,
-                                   level=6, bc=not args.no_bc, threads=threads, first_chunk=rank * args.members,
-                                   want_plain=args.check)
-    gen_s = time.time() - t0
-    out_bytes = args.members * args.member_bytes
-    d_in = torch.from_numpy(comp).to(dev)
-    d_out = torch.empty(out_bytes + 64, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream()
     sh = ctypes.c_void_p(stream.cuda_stream)
 
-    def decode_loop(d_src, d_dst, expect_bytes, steps, warmup, exchange):
-        """times `steps` whole decodes of d_src; returns (elapsed seconds, mean ms of the inflate stage)"""
+    def decode_loop(d_src, d_dst, expect_bytes, steps, warmup, exchange, with_index=False):
+        """times `steps` whole decodes of d_src; returns (elapsed seconds, mean ms of the inflate stage, bytes out).
+        The HIP events bracket ahip_gzip_plan_run -- the inflate kernels -- or, with_index, plan_create + plan_run:
+        members without the BC subfield are sized by a run of the tokenizer INSIDE plan_create, which the stage time
+        must then include."""
         ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
         ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
 
         def step(i=None):
             plan = ctypes.c_void_p()
+            if i is not None and with_index:
+                ev0[i].record(stream)
             rc = L.ahip_gzip_plan_create(d_src.data_ptr(), d_src.numel(), sh, ctypes.byref(plan))
             if rc != 0:
                 raise SystemExit("plan_create: %d %s" % (rc, N.last_error()))
-            if i is not None:
+            if i is not None and not with_index:
                 ev0[i].record(stream)
             rc = L.ahip_gzip_plan_run(plan, d_dst.data_ptr(), d_dst.numel(), sh)
             if i is not None:
@@ -212,54 +212,80 @@ def main():
         kern_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / steps
         return float(el.item()), kern_ms, n_out
 
-    elapsed, kern_ms, _ = decode_loop(d_in, d_out, out_bytes, args.steps, args.warmup, True)
-    tot = torch.tensor([float(out_bytes)], dtype=torch.float64, device=cdev)
-    if world > 1:
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    total_out = float(tot.item())
+    t0 = time.time()
+    # N = 1: the stream.  N > 1: rank 0 makes THE stream (chunks 0 .. M-1); the others receive it below.
+    comp, plain = (None, None)
+    if world == 1 or rank == 0:
+        comp, plain = corpus.make_gzip(kind=kind, seed=seed, n_members=args.members, member_bytes=args.member_bytes,
+                                       level=6, bc=not args.no_bc, threads=threads if world == 1 else (os.cpu_count() or 1),
+                                       first_chunk=0, want_plain=args.check and world == 1)
+    gen_s = time.time() - t0
+    out_bytes = args.members * args.member_bytes
 
-    # ---- the proof: CRC-32 of what sits in d_out (device kernel) vs what the gzip trailers say it must be ----
-    offs, crcs, sizes = member_table(comp, args.members)
-    want_crc = crc32_of_concat(crcs, sizes)
-    got = ctypes.c_uint32()
-    if L.ahip_crc32_device(d_out.data_ptr(), out_bytes, 0, ctypes.byref(got), sh) != 0:
-        raise SystemExit("crc32_device: " + N.last_error())
-    crc_ok = got.value == want_crc and sum(sizes) == out_bytes
-    if args.check:
-        if not np.array_equal(d_out[:out_bytes].cpu().numpy(), plain):
-            raise SystemExit("decoded bytes differ from the generator's plain text")
-    ok_all = torch.tensor([1.0 if crc_ok else 0.0], dtype=torch.float64, device=cdev)
-    if world > 1:
-        dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
-    if float(ok_all.item()) != 1.0:
-        raise SystemExit("rank %d: device CRC-32 %08x != %08x expected from the member trailers" % (rank, got.value, want_crc))
+    if world == 1:
+        d_in = torch.from_numpy(comp).to(dev)
+        d_out = torch.empty(out_bytes + 64, dtype=torch.uint8, device=dev)
+        elapsed, kern_ms, _ = decode_loop(d_in, d_out, out_bytes, args.steps, args.warmup, True, with_index=args.no_bc)
+        total_out = float(out_bytes)
+        in_bytes_rank0 = int(d_in.numel())
+        out_bytes_rank0 = out_bytes
+        # ---- the proof: CRC-32 of what sits in d_out (device kernel) vs what the gzip trailers say it must be ----
+        offs, crcs, sizes = member_table(comp, args.members)
+        want_crc = crc32_of_concat(crcs, sizes)
+        got = ctypes.c_uint32()
+        if L.ahip_crc32_device(d_out.data_ptr(), out_bytes, 0, ctypes.byref(got), sh) != 0:
+            raise SystemExit("crc32_device: " + N.last_error())
+        crc_ok = got.value == want_crc and sum(sizes) == out_bytes
+        if args.check:
+            if not np.array_equal(d_out[:out_bytes].cpu().numpy(), plain):
+                raise SystemExit("decoded bytes differ from the generator's plain text")
+        if not crc_ok:
+            raise SystemExit("device CRC-32 %08x != %08x expected from the member trailers" % (got.value, want_crc))
+        check = {"crc32_device": "%08x" % got.value, "crc32_expected": "%08x" % want_crc, "ok": True,
+                 "what": "CRC-32 of the decoded bytes (ahip_crc32_device) vs the member trailers' CRCs combined over GF(2)"}
+        sharding, members_per_rank = "single GPU", None
+    else:
+        sr = strong_scaling(args, L, N, corpus, dist, torch, np, dev, cdev, sh, rank, world, comp, decode_loop)
+        elapsed, kern_ms, total_out = sr["elapsed"], sr["kern_ms"], float(sr["total"])
+        in_bytes_rank0, out_bytes_rank0 = sr["slice_in"], sr["slice_out"]
+        check = sr["check"]
+        members_per_rank = sr["members_per_rank"]
+        sharding = ("ONE stream cut into %d contiguous member ranges balanced on compressed bytes, one process per GPU" % world
+                    if not args.one_device else "ONE stream cut into %d member ranges, %d processes on ONE GPU (functional run)" % (world, world))
 
-    strong = None
+    weak = None
     if world > 1 and not args.no_extras:
-        strong = strong_scaling(args, L, N, corpus, dist, torch, np, dev, cdev, sh, rank, world, comp, offs, crcs, sizes, decode_loop)
+        weak = weak_scaling(args, L, N, corpus, dist, torch, np, dev, cdev, sh, rank, world, kind, seed, threads, decode_loop)
 
     if rank == 0:
-        algo_bytes = float(d_in.numel() + out_bytes)  # C + U: compressed read once + output written once
+        # C + U of what rank 0's kernels handled: compressed read once + output written once (N = 1: the whole stream)
+        algo_bytes = float(in_bytes_rank0 + out_bytes_rank0)
         achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
+        step_ms = elapsed / args.steps * 1e3
         value = total_out * args.steps / elapsed / 1e9
+        stage = ("ahip_gzip_plan_create + ahip_gzip_plan_run (the sizing run of the tokenizer sits inside plan_create)" if args.no_bc
+                 else "ahip_gzip_plan_run")
         line = {
             "metric": "Inflate GB/s (uncompressed out) on multi-member gzip",
             "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(step_ms, 4), "higher_is_better": True, "scaling": "weak" if world == 1 else "strong",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "%d gzip members x %d B %s text per GPU (%s), zlib level 6" % (
-                args.members, args.member_bytes, args.kind, "BGZF BC subfield" if not args.no_bc else "no BC"),
-                "members_per_gpu": args.members, "member_bytes": args.member_bytes,
-                "compressed_bytes_per_gpu": int(d_in.numel()), "ratio": round(out_bytes / d_in.numel(), 4),
-                "sharding": ("members, one process per GPU" if not args.one_device else "members, %d processes on ONE GPU (functional run)" % world) if world > 1 else "single GPU",
-                "collectives": ("RCCL (nccl backend), GPU tensors" if args.backend == "nccl" else "gloo, CPU tensors") if world > 1 else None,
+            "config": {"workload": "ONE stream of %d gzip members x %d B %s text (%s), zlib level 6%s" % (
+                args.members, args.member_bytes, args.kind, "BGZF BC subfield" if not args.no_bc else "no BC",
+                "" if world == 1 else ", decoded once by %d ranks" % world),
+                "members": args.members, "member_bytes": args.member_bytes,
+                "compressed_bytes": int(len(comp)), "ratio": round(out_bytes / len(comp), 4),
+                "sharding": sharding, "members_per_rank": members_per_rank,
+                "collectives": ("RCCL (nccl backend), GPU tensors: one all-gather of 8 bytes per rank and step" if args.backend == "nccl" else "gloo, CPU tensors") if world > 1 else None,
                 "gen_seconds": round(gen_s, 1)},
-            "check": {"crc32_device": "%08x" % got.value, "crc32_expected": "%08x" % want_crc, "ok": bool(crc_ok),
-                      "what": "CRC-32 of the decoded bytes (ahip_crc32_device) vs the member trailers' CRCs combined over GF(2); every rank"},
+            "check": check,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5),
+                         "frac_step": round(algo_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "traffic": None,
                          "kernel": "inflate_tokenize_kernel + inflate_resolve_kernel (one launch each per decode; "
-                                   "HIP events on the launch stream around ahip_gzip_plan_run)",
+                                   "HIP events on the launch stream around %s)%s" % (stage, "" if world == 1 else "; rank 0's shard"),
+                         "what": "frac = algorithmic bytes / kernel_ms (the inflate stage alone); frac_step = the same bytes / ms_per_step "
+                                 "(index build, verification and verdict read-back included): the figure of record is the smaller one",
                          "kernel_ms": round(kern_ms, 4), "algorithmic_bytes": int(algo_bytes)},
         }
         # HBM-side traffic of the inflate stage: PMC counters cannot be read from inside this
@@ -271,15 +297,17 @@ def main():
             with open(latest) as f:
                 pmc = json.load(f)
             w = pmc["workload"]
-            if (w["members"], w["member_bytes"], w["kind"], w["bc"]) == (args.members, args.member_bytes, args.kind, not args.no_bc):
+            if world == 1 and (w["members"], w["member_bytes"], w["kind"], w["bc"]) == (args.members, args.member_bytes, args.kind, not args.no_bc):
                 line["roofline"]["traffic"] = round(pmc["traffic_bytes_per_launch"] / 1e9, 2)
                 line["roofline"]["traffic_unit"] = "GB per decode"
+                if "per_kernel" in pmc:
+                    line["roofline"]["traffic_per_kernel"] = pmc["per_kernel"]
                 line["roofline"]["traffic_source"] = ("NOT measured in this run: read from the committed profile profiles/%s (rocprofv3 --pmc passes over "
                                                       "this same command, L2 request counters by request size; tools/run_prof.sh)" % os.path.basename(latest))
         except Exception:
             pass
-        if strong is not None:
-            line["strong"] = strong
+        if weak is not None:
+            line["weak"] = weak
         if world == 1 and not args.no_extras:
             del d_out
             line["extras"] = extras(args, L, N, corpus, torch, np, dev, sh, comp, d_in, out_bytes, decode_loop)
@@ -291,26 +319,56 @@ def main():
         dist.destroy_process_group()
 
 
-def strong_scaling(args, L, N, corpus, dist, torch, np, dev, cdev, sh, rank, world, comp0, offs0, crcs0, sizes0, decode_loop):
-    """BASELINE config 4 as written: ONE stream (rank 0's), partitioned over the ranks on compressed bytes
-    (archive_amd.sharding.partition_members); a rank indexes and decodes only its slice; the exchange is the size
-    all-gather; the shard CRCs (device kernel) must combine to the whole stream's."""
+def weak_scaling(args, L, N, corpus, dist, torch, np, dev, cdev, sh, rank, world, kind, seed, threads, decode_loop):
+    """Per-GPU work fixed: rank r decodes its own members [r*M, (r+1)*M) of a stream of N*M members, with the same
+    per-step size exchange.  Reported next to the strong-scaled headline, never as `value`."""
+    comp, _ = corpus.make_gzip(kind=kind, seed=seed, n_members=args.members, member_bytes=args.member_bytes,
+                               level=6, bc=not args.no_bc, threads=threads, first_chunk=rank * args.members)
+    out_bytes = args.members * args.member_bytes
+    d_in = torch.from_numpy(comp).to(dev)
+    d_out = torch.empty(out_bytes + 64, dtype=torch.uint8, device=dev)
+    steps = max(3, args.steps // 2)
+    elapsed, kern_ms, _ = decode_loop(d_in, d_out, out_bytes, steps, 1, True, with_index=args.no_bc)
+    offs, crcs, sizes = member_table(comp, args.members)
+    want_crc = crc32_of_concat(crcs, sizes)
+    got = ctypes.c_uint32()
+    if L.ahip_crc32_device(d_out.data_ptr(), out_bytes, 0, ctypes.byref(got), sh) != 0:
+        raise SystemExit("crc32_device: " + N.last_error())
+    ok_all = torch.tensor([1.0 if (got.value == want_crc and sum(sizes) == out_bytes) else 0.0], dtype=torch.float64, device=cdev)
+    dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
+    if float(ok_all.item()) != 1.0:
+        raise SystemExit("rank %d (weak leg): device CRC-32 %08x != %08x expected from the member trailers" % (rank, got.value, want_crc))
+    if rank != 0:
+        return None
+    return {"scaling": "weak", "value": round(out_bytes * world * steps / elapsed / 1e9, 3), "unit": "GB/s", "steps": steps,
+            "ms_per_step": round(elapsed / steps * 1e3, 4), "n_gpus": world, "kernel_ms": round(kern_ms, 4),
+            "workload": "%d members x %d B PER GPU (rank r: members r*M .. (r+1)*M of one stream of N*M)" % (args.members, args.member_bytes),
+            "check": {"ok": True, "what": "per-rank device CRC-32 vs the member trailers, every rank"}}
+
+
+def strong_scaling(args, L, N, corpus, dist, torch, np, dev, cdev, sh, rank, world, comp0, decode_loop):
+    """The headline of N > 1 -- BASELINE config 4 as written: ONE stream (rank 0's, broadcast untimed), partitioned over
+    the ranks on compressed bytes (archive_amd.sharding.partition_members); a rank indexes and decodes only its slice;
+    the exchange is the size all-gather of every step; the shard CRCs (device kernel) must combine to the whole
+    stream's.  W warm-up and exactly K timed steps, like the N = 1 run."""
     from archive_amd.sharding import exchange_output_offsets, partition_members
     n_in = torch.tensor([len(comp0) if rank == 0 else 0], dtype=torch.int64, device=cdev)
     dist.broadcast(n_in, 0)
     whole = torch.from_numpy(comp0).to(cdev) if rank == 0 else torch.empty(int(n_in.item()), dtype=torch.uint8, device=cdev)
     dist.broadcast(whole, 0)  # setup, untimed: afterwards every rank only touches its own slice
     whole = whole.to(dev)
+    if rank == 0:
+        offs0, crcs0, sizes0 = member_table(comp0, args.members)
     meta = torch.tensor(offs0, dtype=torch.int64, device=cdev) if rank == 0 else torch.empty(args.members + 1, dtype=torch.int64, device=cdev)
     dist.broadcast(meta, 0)
     offs = [int(v) for v in meta.tolist()]
     csize = [offs[i + 1] - offs[i] for i in range(args.members)]
-    lo, hi = partition_members(csize, world)[rank]
+    parts = partition_members(csize, world)
+    lo, hi = parts[rank]
     d_slice = whole[offs[lo]:offs[hi]]
     expect = (hi - lo) * args.member_bytes
     d_dst = torch.empty(expect + 64, dtype=torch.uint8, device=dev)
-    steps = max(3, args.steps // 2)
-    elapsed, kern_ms, n_out = decode_loop(d_slice, d_dst, expect, steps, 1, True)
+    elapsed, kern_ms, n_out = decode_loop(d_slice, d_dst, expect, args.steps, args.warmup, True, with_index=args.no_bc)
     offset, total, all_sizes = exchange_output_offsets(n_out, device=cdev)
     got = ctypes.c_uint32()
     if L.ahip_crc32_device(d_dst.data_ptr(), n_out, 0, ctypes.byref(got), sh) != 0:
@@ -318,17 +376,18 @@ def strong_scaling(args, L, N, corpus, dist, torch, np, dev, cdev, sh, rank, wor
     shard = torch.tensor([got.value], dtype=torch.int64, device=cdev)
     allc = torch.zeros(world, dtype=torch.int64, device=cdev)
     dist.all_gather_into_tensor(allc, shard)
+    res = {"elapsed": elapsed, "kern_ms": kern_ms, "total": total, "slice_in": offs[hi] - offs[lo], "slice_out": expect,
+           "members_per_rank": [b - a for a, b in parts], "check": None}
     if rank != 0:
-        return None
+        return res
     combined = crc32_of_concat([int(v) for v in allc.tolist()], all_sizes)
     want = crc32_of_concat(crcs0, sizes0)
     if combined != want or total != args.members * args.member_bytes:
         raise SystemExit("strong scaling: shard CRCs combine to %08x, expected %08x (total %d bytes)" % (combined, want, total))
-    return {"scaling": "strong", "value": round(total * steps / elapsed / 1e9, 3), "unit": "GB/s", "steps": steps,
-            "ms_per_step": round(elapsed / steps * 1e3, 4), "n_gpus": world,
-            "workload": "ONE stream of %d members (%d B out), partitioned on compressed bytes; every rank indexes + decodes its slice" % (args.members, total),
-            "members_per_rank": [b - a for a, b in partition_members(csize, world)],
-            "check": {"crc32_combined": "%08x" % combined, "crc32_expected": "%08x" % want, "ok": True}}
+    res["check"] = {"crc32_combined": "%08x" % combined, "crc32_expected": "%08x" % want, "ok": True,
+                    "what": "per-shard CRC-32 of the decoded bytes (ahip_crc32_device), combined over GF(2) in rank order, vs the "
+                            "member trailers' CRCs of the whole stream"}
+    return res
 
 
 def extras(args, L, N, corpus, torch, np, dev, sh, comp, d_in, out_bytes, decode_loop):

@@ -36,7 +36,7 @@ int main(int argc, char **argv) {
   const bool auto_sizes = szs.size() >= 4 && !memcmp(szs.data(), "auto", 4);
   std::vector<uint64_t> sizes; if (!auto_sizes) { szs.push_back(0); char *p = (char *)szs.data(); for (;;) { char *e; unsigned long long v = strtoull(p, &e, 10); if (e == p) break; sizes.push_back(v); p = e; } }
   std::vector<uint8_t> out(want.size() + 64, 0xEE);
-  size_t pos = 0, k = 0; uint64_t out_off = 0, flow_windows = 0, fallbacks = 0, runs = 0, late = 0;
+  size_t pos = 0, k = 0; uint64_t out_off = 0, flow_windows = 0, fallbacks = 0, runs = 0, late = 0, steps_total = 0, fstat[8] = {0};
   while (pos + 18 <= n && comp[pos] == 0x1f && comp[pos + 1] == 0x8b) {
     if (!auto_sizes && k >= sizes.size()) { printf("more members than sizes\n"); return 1; }
     const uint64_t limit = auto_sizes ? want.size() - out_off : sizes[k];
@@ -73,7 +73,7 @@ int main(int argc, char **argv) {
     }
     wave([&](int lane) { inflate_member<false, true>(TL.w, hdr, &TL.p, comp.data(), n, d, (u8 *)nullptr, sk, res, lane); });
     if (res.status != MS_OK || (auto_sizes ? res.out_len > limit : res.out_len != limit)) { printf("member %zu: tokenizer status %u out_len %llu (want %llu) blocks %x\n", k, res.status, (unsigned long long)res.out_len, (unsigned long long)limit, res.blocks); return 1; }
-    flow_windows += res.windows; fallbacks += res.fallbacks; runs += res.tok_words;
+    flow_windows += res.windows; fallbacks += res.fallbacks; runs += res.tok_words; steps_total += res.partial; for (int q = 0; q < 8; ++q) fstat[q] += res.cyc[q];
     if (res.blocks & MR_FAR) late++;  // reaches into earlier members' output (q8): the late kernel resolves it after them -- as here, in order
     wave([&](int lane) { u32 cyc[8] = {}; resolve_member(PL, comp.data(), area.data(), dir.data(), (u32)res.tok_words, out.data() + out_off, cyc, lane); });
     const uint64_t got_len = res.out_len;
@@ -95,5 +95,14 @@ int main(int argc, char **argv) {
   if (out_off != want.size()) { printf("decoded %llu of %zu bytes in %zu members\n", (unsigned long long)out_off, want.size(), k); return 1; }
   printf("inflate emu ok: %zu members, %llu bytes; flow epochs %llu, fallbacks to the serial emitter %llu, directory runs %llu, members reaching into earlier ones %llu\n", k, (unsigned long long)out_off,
          (unsigned long long)flow_windows, (unsigned long long)fallbacks, (unsigned long long)runs, (unsigned long long)late);
+  if (steps_total) printf("decode steps of the wave (-DAHIP_PROFILE builds): %llu, %.1f per member\n", (unsigned long long)steps_total, (double)steps_total / (double)k);
+#ifdef AHIP_RES_STATS
+  { const char *nm[13] = {"looks", "chunks", "passes", "passes that split", "late fetches", "deferred matches", "flushes", "pending batches", "rounds", "wave copies", "reclassified passes", "deposited matches", "literals"};
+    for (int q = 0; q < 13; ++q) printf("  res %-20s %10.1f per member\n", nm[q], (double)res_stats[q] / k); }
+#endif
+#ifdef AHIP_FLOW_STATS
+  printf("flow stats per member: lane-steps %.0f (%.1f %% of 64 x steps), speculative %.0f, scheduling points %.1f, idle lanes after assignment %.1f per point, repairs %.1f\n",
+         (double)fstat[0] / k, steps_total ? 100.0 * fstat[0] / (64.0 * steps_total) : 0.0, (double)fstat[1] / k, (double)fstat[2] / k, fstat[2] ? (double)fstat[3] / fstat[2] : 0.0, (double)fstat[4] / k);
+#endif
   return k ? 0 : 7;
 }

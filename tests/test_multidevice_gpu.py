@@ -68,13 +68,14 @@ def test_two_ranks_one_stream_rccl(native_built):
     assert r.returncode == 0, r.stderr[-2000:]
     import json
     line = json.loads(r.stdout.strip().splitlines()[-1])
-    assert line["n_gpus"] == 2 and line["check"]["ok"] and line["strong"]["check"]["ok"]
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["check"]["ok"] and line["weak"]["check"]["ok"]
+    assert sum(line["config"]["members_per_rank"]) == 4096
 
 
 def test_two_ranks_on_one_device_gloo(native_built):
     """Every line of the N > 1 path the driver launches on 8 GPUs, on the hardware there is: two ranks of bench.py on
-    ONE device, the collectives on CPU tensors (gloo) -- weak leg (every rank its own members, size exchange every step),
-    strong leg (ONE stream partitioned on compressed bytes, shard CRCs combined over GF(2))."""
+    ONE device, the collectives on CPU tensors (gloo) -- the headline is the strong-scaled ONE stream (partitioned on compressed
+    bytes, size exchange every step, shard CRCs combined over GF(2)); the weak leg (every rank its own members) rides along."""
     import json
     import socket
     s = socket.socket()
@@ -88,10 +89,14 @@ def test_two_ranks_on_one_device_gloo(native_built):
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
     line = json.loads(r.stdout.strip().splitlines()[-1])
-    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["check"]["ok"]
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["check"]["ok"]
+    assert line["check"]["crc32_combined"] == line["check"]["crc32_expected"]
     assert line["config"]["collectives"].startswith("gloo")
-    st = line["strong"]
-    assert st["check"]["ok"] and st["n_gpus"] == 2 and sum(st["members_per_rank"]) == 2048 and min(st["members_per_rank"]) > 0
+    mpr = line["config"]["members_per_rank"]
+    assert sum(mpr) == 2048 and min(mpr) > 0
+    assert 0 < line["roofline"]["frac_step"] <= line["roofline"]["frac"]
+    wk = line["weak"]
+    assert wk["scaling"] == "weak" and wk["check"]["ok"] and wk["n_gpus"] == 2
 
 
 def _decode_shards(L, N, devs, d_ins, out_caps):
@@ -202,6 +207,22 @@ def test_device_resident_framed_encoders(native_built):
         ref = bytes(host[:n.value])
         assert dev[:2] == ref[:2] and dev[-4:] == ref[-4:] == struct.pack(">I", zlib.adler32(data))
         assert zlib.decompress(dev) == data and zlib.decompress(ref) == data
+    # parameters the reference's Deflate refuses silently (deflate.dart:105-115): no DEFLATE bytes at all, the gzip trailer
+    # carries the Deflate object's crc32 (0), but the zlib encoder took the Adler-32 of the input BEFORE it called
+    # Deflate.stream (_zlib_encoder_web.dart:62-72): the real checksum, in the host and in the device-resident form
+    for level, wb in ((12, 15), (6, 20), (6, 8)):
+        host = np.zeros(cap, dtype=np.uint8)
+        n, m = ctypes.c_size_t(), ctypes.c_size_t()
+        d_out = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+        assert L.ahip_zlib_encode(src.ctypes.data, len(data), level, wb, host.ctypes.data, cap, ctypes.byref(n)) == 0
+        assert L.ahip_zlib_encode_device(d_in.data_ptr(), len(data), level, wb, d_out.data_ptr(), cap, ctypes.byref(m), None) == 0, N.last_error()
+        assert n.value == m.value == 6
+        dev, ref = bytes(d_out[:6].cpu().numpy()), bytes(host[:6])
+        assert dev == ref and ref[2:] == struct.pack(">I", zlib.adler32(data)) and (ref[0] * 256 + ref[1]) % 31 == 0
+        assert L.ahip_gzip_encode(src.ctypes.data, len(data), level, wb, 7, host.ctypes.data, cap, ctypes.byref(n)) == 0
+        assert L.ahip_gzip_encode_device(d_in.data_ptr(), len(data), level, wb, 7, d_out.data_ptr(), cap, ctypes.byref(m), None) == 0
+        assert n.value == m.value == 18
+        assert bytes(d_out[:18].cpu().numpy()) == bytes(host[:18]) and bytes(host[10:18]) == struct.pack("<II", 0, len(data))
     # too small a buffer reports the bound
     m = ctypes.c_size_t()
     tiny = torch.zeros(8, dtype=torch.uint8, device="cuda")

@@ -60,10 +60,10 @@ static int SUB = 1024, CPW = 128, STEPS = 12, RING = 64, NL = 64, MULTILIT = 0, 
 enum { IDLE = 0, RUN = 1 };
 enum { ST_NONE = 0, ST_MERGE, ST_EXACT, ST_EOB, ST_ERR };
 typedef struct { int mode; int origin; uint64_t pos; int cur_item; } Lane;
-typedef struct { int assigned, owner; uint64_t *cp; int stop_kind; int stop_item, stop_j; uint64_t stop_pos; int exact_start; } Item;
+typedef struct { int assigned, owner; uint64_t *cp; int stop_kind; int stop_item, stop_j; uint64_t stop_pos; int exact_start; uint64_t reserved, start_pos; } Item;
 
 static uint64_t g_wave_steps, g_lane_steps, g_sched, g_tokens, g_blocks, g_exact_stops, g_miss_empty, g_merges, g_items, g_true_tokens_steps;
-static uint64_t g_idle_lane_steps, g_killed;
+static uint64_t g_idle_lane_steps, g_killed, g_restarts;
 
 static void sim_block(const Code *ll, const Code *dc, uint64_t p0, uint64_t pend, uint64_t ntok) {
   const uint64_t org = ((p0 >> 3) & ~3ull) * 8;
@@ -73,7 +73,7 @@ static void sim_block(const Code *ll, const Code *dc, uint64_t p0, uint64_t pend
   for (int i = 0; i < n_items + 2; ++i) it[i].cp = calloc(ncp, sizeof(uint64_t));
   Lane ln[MAXL]; memset(ln, 0, sizeof ln);
   int next_item = 0, retired = 0, chain = 0 /* origin of the runner the truth is in */, done = 0;
-  int64_t pending_exact = (int64_t)p0;  /* position a runner stopped at exactly: the next runner starts there (item 0: the true start) */
+  it[0].reserved = p0;  /* item 0 starts at the true start */
   const int n_spec = (int)((pend - org + SUB - 1) / SUB);  /* items the member reaches into (the index's hint) */
   uint64_t guard = 0;
   while (!done && ++guard < 1000000) {
@@ -85,10 +85,11 @@ static void sim_block(const Code *ll, const Code *dc, uint64_t p0, uint64_t pend
       if (r->stop_kind == ST_EOB) { done = 1; break; }
       if (r->stop_kind == ST_ERR) { fprintf(stderr, "true stream hit an error?\n"); exit(1); }
       if (r->stop_kind == ST_MERGE) { chain = r->stop_item; g_merges++; }
-      else { /* EXACT: the runner stopped in front of an unassigned item */
+      else { /* EXACT: the runner stopped in front of an unassigned item, which it reserved for its continuation */
         const int s = (int)((r->stop_pos - org) / SUB);
-        if (it[s].assigned) { chain = s; }
-        else { pending_exact = (int64_t)r->stop_pos; break; }
+        if (it[s].assigned && it[s].start_pos == r->stop_pos) { chain = s; }
+        else if (it[s].assigned || (it[s].reserved && it[s].reserved != r->stop_pos)) { g_restarts++; fprintf(stderr, "restart needed\n"); exit(1); }
+        else break;  /* reserved by this runner, not given out yet */
       }
     }
     if (done) break;
@@ -98,22 +99,13 @@ static void sim_block(const Code *ll, const Code *dc, uint64_t p0, uint64_t pend
     /* ---- assign ---- */
     for (int l = 0; l < NL; ++l) {
       if (ln[l].mode != IDLE) continue;
-      if (pending_exact >= 0) {
-        const int s = (int)(((uint64_t)pending_exact - org) / SUB);
-        if (it[s].assigned) { fprintf(stderr, "exact start into an assigned item\n"); exit(1); }
-        if (s != next_item && !(s == 0 && next_item == 0)) { fprintf(stderr, "exact start %d is not the next item %d\n", s, next_item); exit(1); }
-        it[s].assigned = 1; it[s].owner = l; it[s].exact_start = 1;
-        ln[l].mode = RUN; ln[l].origin = s; ln[l].pos = (uint64_t)pending_exact;
-        next_item = s + 1;
-        pending_exact = -1;
-        g_items++;
-        continue;
-      }
       if (next_item < n_spec && next_item < retired + RING && next_item < n_items) {
         const int s = next_item++;
         it[s].assigned = 1; it[s].owner = l;
-        ln[l].mode = RUN; ln[l].origin = s; ln[l].pos = org + (uint64_t)s * SUB;
-        it[s].cp[0] = ln[l].pos;
+        ln[l].mode = RUN; ln[l].origin = s;
+        if (it[s].reserved) { ln[l].pos = it[s].reserved; it[s].exact_start = 1; }
+        else { ln[l].pos = org + (uint64_t)s * SUB; it[s].cp[0] = ln[l].pos; }
+        it[s].start_pos = ln[l].pos;
         g_items++;
       }
     }
@@ -146,8 +138,9 @@ static void sim_block(const Code *ll, const Code *dc, uint64_t p0, uint64_t pend
         const int s = (int)(c * CPW / SUB), j = (int)((c * CPW % SUB) / CPW);
         if (s >= n_items) { me->stop_kind = ST_ERR; L->mode = IDLE; continue; }
         if (s == L->origin || (it[s].assigned && it[s].owner == l)) { it[s].cp[j] = p; continue; }
-        if (!it[s].assigned) {  /* nobody decodes this item yet: stop exactly here, it will be given out with a true start */
+        if (!it[s].assigned) {  /* nobody decodes this item yet: stop exactly here; the item is reserved for the continuation */
           me->stop_kind = ST_EXACT; me->stop_pos = p; L->mode = IDLE; g_exact_stops++;
+          if (!it[s].reserved) it[s].reserved = p;
           continue;
         }
         if (it[s].cp[j] == p) { me->stop_kind = ST_MERGE; me->stop_item = s; me->stop_j = j; me->stop_pos = p; L->mode = IDLE; continue; }
