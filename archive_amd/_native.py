@@ -21,6 +21,7 @@ EXPORTS = [
     "ahip_bzip2_decode", "ahip_bzip2_decode_device", "ahip_crc32_device", "ahip_adler32_device", "ahip_inflate_batch", "ahip_inflate_batch_device", "ahip_deflate_raw", "ahip_gzip_encode", "ahip_zlib_encode", "ahip_deflate_raw_device", "ahip_deflate_bound",
     "ahip_crc32", "ahip_adler32", "ahip_decode_bound",
     "ahip_gzip_decode_shards", "ahip_debug_last_exchange", "ahip_gzip_encode_device", "ahip_zlib_encode_device",
+    "ahip_debug_last_chunks",
 ]
 
 _lib = None
@@ -52,6 +53,7 @@ def lib():
     L.ahip_init_devices.argtypes = [u64]; L.ahip_init_devices.restype = i32
     L.ahip_device_count.argtypes = []; L.ahip_device_count.restype = i32
     L.ahip_debug_last_shards.argtypes = []; L.ahip_debug_last_shards.restype = i32
+    L.ahip_debug_last_chunks.argtypes = []; L.ahip_debug_last_chunks.restype = i32
     L.ahip_shutdown.argtypes = []; L.ahip_shutdown.restype = None
     L.ahip_last_error.argtypes = []; L.ahip_last_error.restype = ctypes.c_char_p
     L.ahip_abi_version.argtypes = []; L.ahip_abi_version.restype = u32

@@ -288,6 +288,14 @@ int32_t fail(int32_t code, const std::string &msg) {
       return fail(AHIP_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));                   \
   } while (0)
 
+// A copy the host waits for, ORDERED ON THE CALLER'S STREAM: worker contexts run on non-blocking streams, which the legacy
+// null stream (plain hipMemcpy) does not synchronise with.
+static inline hipError_t copy_on(void *dst, const void *src, size_t n, hipMemcpyKind kind, hipStream_t st) {
+  hipError_t e = hipMemcpyAsync(dst, src, n, kind, st);
+  if (e != hipSuccess) return e;
+  return hipStreamSynchronize(st);
+}
+
 // Device scratch with a process-wide free list: hipMalloc/hipFree cost far more than the index
 // kernels they would serve, so released blocks are kept and handed to the next plan.
 struct DevBlock { void *p; size_t cap; };
@@ -535,12 +543,15 @@ hipError_t launch_inflate_listed(const u8 *in, u64 n, const MemberDesc *members,
 
 // host_out_off: output offset of every member plus one trailing total (M + 1 entries), or nullptr when
 // the whole range is known to be small / a sizing run.
+// [m_begin, m_end): the members to launch (with host_out_off; default all M)
 template <bool WRITE>
 hipError_t launch_inflate(const u8 *in, u64 n, const MemberDesc *members, u32 M, u8 *out, MemberResult *res,
                           hipStream_t st, const u64 *host_out_off = nullptr, u64 total_out = 0, const u64 *lay_pos = nullptr,
-                          u64 *gen_out = nullptr) {
+                          u64 *gen_out = nullptr, u32 m_begin = 0, u32 m_end = 0xffffffffu) {
   if (gen_out) *gen_out = 0;
   if (M == 0) return hipSuccess;
+  if (m_end > M) m_end = M;
+  if (m_begin >= m_end) return hipSuccess;
   if (use_serial_kernel()) {
     hipLaunchKernelGGL(inflate_members_serial_kernel<WRITE>, dim3(M), dim3(64), 0, st, in, n, members, M, out, res);
     return hipGetLastError();
@@ -549,10 +560,10 @@ hipError_t launch_inflate(const u8 *in, u64 n, const MemberDesc *members, u32 M,
     const u64 total = host_out_off ? host_out_off[M] : total_out;
     return launch_inflate_group<WRITE>(in, n, members, 0, M, 0, total, out, res, st, lay_pos, gen_out);
   }
-  u32 first = 0;
-  while (first < M) {
+  u32 first = m_begin;
+  while (first < m_end) {
     u32 last = first + 1;
-    while (last < M && host_out_off[last + 1] - host_out_off[first] <= GROUP_OUT_MAX) ++last;
+    while (last < m_end && host_out_off[last + 1] - host_out_off[first] <= GROUP_OUT_MAX) ++last;
     hipError_t e = launch_inflate_group<WRITE>(in, n, members, first, last - first, host_out_off[first], host_out_off[last],
                                                out, res, st);
     if (e != hipSuccess) return e;
@@ -590,7 +601,7 @@ struct ahip_gzip_plan {
   bool ran = false;
   hipStream_t run_stream = nullptr;  // the stream the last ahip_gzip_plan_run was enqueued on
   std::vector<u64> host_out_off;  // M + 1 entries: output offset of every member, then the total
-  struct Big { u32 cand, member; u64 in_off, out_off, out_len; };
+  struct Big { u32 cand, member; u64 in_off, out_off, out_len; bool reaches; };  // reaches: into the output of earlier members (q8)
   std::vector<Big> big;           // long members decoded by many waves each (sm_inflate), outside the member launch
   ~ahip_gzip_plan() {
     for (DevBuf *b : {&tile_counts, &tile_offsets, &tile_slots, &cand_pos, &hdr, &scratch_u32, &members, &expect_status, &results,
@@ -601,9 +612,12 @@ struct ahip_gzip_plan {
 
 namespace {
 
+// hist0: bytes of EARLIER output (in front of d_out) the stream's back-references may reach -- what the gzip members before
+// this one appended to the shared OutputStream (quirk q8); 0 for a stream with an output of its own.  A result with
+// MR_REACH / MR_FAR in `blocks` did reach into them.
 int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool write, MemberResult *res, bool *handled,
-                   hipStream_t st);
-int32_t inflate_one_wave(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool write, MemberResult *res, hipStream_t st);
+                   hipStream_t st, u32 hist0 = 0);
+int32_t inflate_one_wave(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool write, MemberResult *res, hipStream_t st, u32 hist0 = 0);
 u64 sm_min_bytes();
 
 // Build (or rebuild with force_sizing) the member index for d_in[start..n).
@@ -681,11 +695,16 @@ int32_t plan_build(ahip_gzip_plan *pl, bool force_sizing, hipStream_t st) {
         if (gap < sm_min_bytes() || (measured.size() >= 8 && gap < (32ull << 20))) continue;
         MemberResult r{};
         bool handled = false;
-        int32_t rc = sm_inflate(in, n, hh[i].payload_off, nullptr, 0, false, &r, &handled, st);
+        // (output offsets are not known yet: every member but the stream's first may reach 32 KiB back, like the sizing
+        //  run of the ordinary members; the decode proper passes the exact figure)
+        const u32 hist0 = (i == 0 && cp[0] == start) ? 0u : 32768u;
+        int32_t rc = sm_inflate(in, n, hh[i].payload_off, nullptr, 0, false, &r, &handled, st, hist0);
         if (rc != AHIP_OK) return rc;
-        if (!handled) { rc = inflate_one_wave(in, n, hh[i].payload_off, nullptr, ~0ull, false, &r, st); if (rc != AHIP_OK) return rc; }
+        if (!handled) { rc = inflate_one_wave(in, n, hh[i].payload_off, nullptr, ~0ull, false, &r, st, hist0); if (rc != AHIP_OK) return rc; }
+        const bool reaches = (r.blocks & (MR_REACH | MR_FAR)) != 0;
+        r.blocks &= ~(MR_REACH | MR_FAR);  // (of no concern to the member index: the long members are decoded apart)
         measured.push_back({i, r});
-        pl->big.push_back({i, 0xffffffffu, hh[i].payload_off, 0, 0});
+        pl->big.push_back({i, 0xffffffffu, hh[i].payload_off, 0, 0, reaches});
         sd[i].in_off = n;  // nothing to read: the member launch is done with it at once
         changed = true;
         if (r.status == MS_OK) covered_until = r.end_pos;
@@ -783,7 +802,7 @@ int32_t plan_build(ahip_gzip_plan *pl, bool force_sizing, hipStream_t st) {
     // which members are the long ones (false candidates among them never reach the chain); neutralise those
     // descriptors for the member launch and remember where their output goes
     std::vector<MemberDesc> md(pl->sum.members);
-    HIP_TRY(hipMemcpy(md.data(), pl->members.p, md.size() * sizeof(MemberDesc), hipMemcpyDeviceToHost));
+    HIP_TRY(copy_on(md.data(), pl->members.p, md.size() * sizeof(MemberDesc), hipMemcpyDeviceToHost, st));
     std::vector<ahip_gzip_plan::Big> keep;
     for (auto bg : pl->big)
       for (size_t m = 0; m < md.size(); ++m)
@@ -791,7 +810,7 @@ int32_t plan_build(ahip_gzip_plan *pl, bool force_sizing, hipStream_t st) {
           bg.member = (u32)m; bg.out_off = md[m].out_off; bg.out_len = md[m].out_limit;
           keep.push_back(bg);
           md[m].in_off = n;
-          HIP_TRY(hipMemcpy(pl->members.as<MemberDesc>() + m, &md[m], sizeof(MemberDesc), hipMemcpyHostToDevice));
+          HIP_TRY(copy_on(pl->members.as<MemberDesc>() + m, &md[m], sizeof(MemberDesc), hipMemcpyHostToDevice, st));
           break;
         }
     pl->big = keep;
@@ -800,9 +819,11 @@ int32_t plan_build(ahip_gzip_plan *pl, bool force_sizing, hipStream_t st) {
   }
   // output offsets on the host: the decode is launched in groups whose token streams fit the scratch
   pl->host_out_off.clear();
-  if (pl->sum.members && pl->sum.total_out > GROUP_OUT_MAX) {
+  bool stream_order = false;  // a long member reaches into earlier output: plan_run decodes range by range
+  for (const auto &bg : pl->big) stream_order = stream_order || bg.reaches;
+  if (pl->sum.members && (pl->sum.total_out > GROUP_OUT_MAX || stream_order)) {
     std::vector<MemberDesc> md(pl->sum.members);
-    HIP_TRY(hipMemcpy(md.data(), pl->members.p, md.size() * sizeof(MemberDesc), hipMemcpyDeviceToHost));
+    HIP_TRY(copy_on(md.data(), pl->members.p, md.size() * sizeof(MemberDesc), hipMemcpyDeviceToHost, st));
     pl->host_out_off.resize(md.size() + 1);
     for (size_t i = 0; i < md.size(); ++i) pl->host_out_off[i] = md[i].out_off;
     pl->host_out_off[md.size()] = pl->sum.total_out;
@@ -827,19 +848,48 @@ int32_t plan_run(ahip_gzip_plan *pl, u8 *d_out, size_t out_cap, hipStream_t st) 
   const u64 whole[2] = {0, pl->sum.total_out};  // one group: only its total is needed
   if (getenv("AHIP_DEBUG")) fprintf(stderr, "[ahip] plan_run: sized=%d kept tokens %llu (scratch holds %llu) retok=%u\n", (int)pl->sized,
                                     (unsigned long long)pl->tok_gen, (unsigned long long)g_tok_gen, pl->sum.retok);
-  // Long members first: many waves each, straight into place.  They come before the member launch because its late
-  // kernel resolves back-references into EARLIER members' output (quirk q8) in stream order at its very end -- the
-  // bytes of a long member in front of such a member have to exist by then.  (A long member that itself reaches
-  // into earlier output is not reproduced: it reports the reference's RangeError verdict for a reach in front of
-  // the stream)
+  // Long members: many waves each, straight into place, with the bytes of earlier members in front of them as history
+  // (quirk q8: the reference's members append to one OutputStream, _gzip_decoder_web.dart:27-41).  Normally they come
+  // BEFORE the member launch, because its late kernel resolves back-references into earlier members' output in stream
+  // order at its very end -- the bytes of a long member in front of such a member have to exist by then.  A long member
+  // that itself reaches into earlier output (the sizing run noticed) needs everything in front of IT first: the stream is
+  // then decoded in stream order, range of ordinary members / long member / range / ...
   std::vector<MemberResult> big_res(pl->big.size());
-  const bool kept = pl->sized && pl->tok_gen && pl->tok_gen == g_tok_gen && !use_serial_kernel();
-  for (size_t b = 0; b < pl->big.size() && !kept; ++b) {
+  bool any_reach = false;
+  for (const auto &bg : pl->big) any_reach = any_reach || bg.reaches;
+  const bool kept = pl->sized && pl->tok_gen && pl->tok_gen == g_tok_gen && !use_serial_kernel() && !any_reach;
+  auto run_big = [&](size_t b) -> int32_t {
     const auto &bg = pl->big[b];
+    const u32 hist0 = (u32)std::min<u64>(bg.out_off, 32768);
     bool handled = false;
-    int32_t rc = sm_inflate(pl->d_in, pl->in_len, bg.in_off, d_out + bg.out_off, bg.out_len, true, &big_res[b], &handled, st);
+    int32_t rc = sm_inflate(pl->d_in, pl->in_len, bg.in_off, d_out + bg.out_off, bg.out_len, true, &big_res[b], &handled, st, hist0);
     if (rc != AHIP_OK) return rc;
-    if (!handled) { rc = inflate_one_wave(pl->d_in, pl->in_len, bg.in_off, d_out + bg.out_off, bg.out_len, true, &big_res[b], st); if (rc != AHIP_OK) return rc; }
+    if (!handled) rc = inflate_one_wave(pl->d_in, pl->in_len, bg.in_off, d_out + bg.out_off, bg.out_len, true, &big_res[b], st, hist0);
+    big_res[b].blocks &= ~(MR_REACH | MR_FAR);
+    return rc;
+  };
+  if (any_reach) {
+    if (pl->host_out_off.size() != (size_t)M + 1) return fail(AHIP_E_DEVICE, "internal: member offsets missing for a stream-order decode");
+    for (size_t b = 0; b < pl->big.size(); ++b)
+      if (!pl->big[b].reaches) { int32_t rc = run_big(b); if (rc != AHIP_OK) return rc; }
+    std::vector<size_t> order;
+    for (size_t b = 0; b < pl->big.size(); ++b) if (pl->big[b].reaches) order.push_back(b);
+    std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return pl->big[x].member < pl->big[y].member; });
+    u32 first = 0;
+    for (size_t b : order) {
+      const u32 m = pl->big[b].member;  // (its own, neutralised, descriptor rides along with the range behind it)
+      if (m > first) HIP_TRY(launch_inflate<true>(pl->d_in, pl->in_len, pl->members.as<MemberDesc>(), M, d_out, pl->results.as<MemberResult>(), st,
+                                                  pl->host_out_off.data(), whole[1], nullptr, nullptr, first, m));
+      int32_t rc = run_big(b);
+      if (rc != AHIP_OK) return rc;
+      first = m;
+    }
+    HIP_TRY(launch_inflate<true>(pl->d_in, pl->in_len, pl->members.as<MemberDesc>(), M, d_out, pl->results.as<MemberResult>(), st,
+                                 pl->host_out_off.data(), whole[1], nullptr, nullptr, first, M));
+  } else {
+  for (size_t b = 0; b < pl->big.size() && !kept; ++b) {
+    int32_t rc = run_big(b);
+    if (rc != AHIP_OK) return rc;
   }
   if (kept) {
     // the sizing run's tokens are still in the scratch: resolve them, then tokenize + resolve the few members whose
@@ -849,11 +899,8 @@ int32_t plan_run(ahip_gzip_plan *pl, u8 *d_out, size_t out_cap, hipStream_t st) 
     HIP_TRY(launch_resolve_kept(pl->d_in, pl->in_len, pl->members.as<MemberDesc>(), M, d_out, pl->results.as<MemberResult>(),
                                 pl->cand_pos.as<u64>(), pl->K, pl->sizing_results.as<MemberResult>(), st));
     for (size_t b = 0; b < pl->big.size(); ++b) {
-      const auto &bg = pl->big[b];
-      bool handled = false;
-      int32_t rc = sm_inflate(pl->d_in, pl->in_len, bg.in_off, d_out + bg.out_off, bg.out_len, true, &big_res[b], &handled, st);
+      int32_t rc = run_big(b);
       if (rc != AHIP_OK) return rc;
-      if (!handled) { rc = inflate_one_wave(pl->d_in, pl->in_len, bg.in_off, d_out + bg.out_off, bg.out_len, true, &big_res[b], st); if (rc != AHIP_OK) return rc; }
     }
     HIP_TRY(launch_inflate_listed(pl->d_in, pl->in_len, pl->members.as<MemberDesc>(), pl->retok_ids.as<u32>(), pl->retok_rel.as<u64>(),
                                   pl->retok_n, pl->retok_span, d_out, pl->results.as<MemberResult>(), st));
@@ -861,6 +908,7 @@ int32_t plan_run(ahip_gzip_plan *pl, u8 *d_out, size_t out_cap, hipStream_t st) 
     HIP_TRY(launch_inflate<true>(pl->d_in, pl->in_len, pl->members.as<MemberDesc>(), M, d_out,
                                  pl->results.as<MemberResult>(), st,
                                  pl->host_out_off.empty() ? nullptr : pl->host_out_off.data(), whole[1]));
+  }
   }
   for (size_t b = 0; b < pl->big.size(); ++b)
     HIP_TRY(hipMemcpyAsync(pl->results.as<MemberResult>() + pl->big[b].member, &big_res[b], sizeof(MemberResult), hipMemcpyHostToDevice, st));
@@ -881,9 +929,9 @@ int32_t plan_verdict(ahip_gzip_plan *pl, hipStream_t st, bool *needs_sizing) {
   if (rs.mismatches) {
     if (getenv("AHIP_DEBUG") && rs.first_bad < pl->sum.members) {
       MemberResult r{}; MemberDesc d{}; u32 ex = 0;
-      (void)hipMemcpy(&r, pl->results.as<MemberResult>() + rs.first_bad, sizeof r, hipMemcpyDeviceToHost);
-      (void)hipMemcpy(&d, pl->members.as<MemberDesc>() + rs.first_bad, sizeof d, hipMemcpyDeviceToHost);
-      (void)hipMemcpy(&ex, pl->expect_status.as<u32>() + rs.first_bad, 4, hipMemcpyDeviceToHost);
+      (void)copy_on(&r, pl->results.as<MemberResult>() + rs.first_bad, sizeof r, hipMemcpyDeviceToHost, st);
+      (void)copy_on(&d, pl->members.as<MemberDesc>() + rs.first_bad, sizeof d, hipMemcpyDeviceToHost, st);
+      (void)copy_on(&ex, pl->expect_status.as<u32>() + rs.first_bad, 4, hipMemcpyDeviceToHost, st);
       fprintf(stderr, "[ahip] verify: %u mismatches, first member %u: status %u (expected %u) out_len %llu (limit %llu) end %llu (expected %llu) blocks %x runs %llu hist %u sized=%d\n",
               rs.mismatches, rs.first_bad, r.status, ex, (unsigned long long)r.out_len, (unsigned long long)d.out_limit,
               (unsigned long long)r.end_pos, (unsigned long long)d.expect_end, r.blocks, (unsigned long long)r.tok_words, d.hist, (int)pl->sized);
@@ -975,11 +1023,13 @@ struct SmPlan {  // what the sizing pass learned, kept for the write pass of the
   std::vector<MemberResult> sized;
   u64 total_out = 0, end_pos = 0;
   u32 blocks = 0;
+  u32 hist0 = 0;               // the bytes of earlier output the stream was sized with (see sm_inflate)
   bool valid = false;
   u64 tok_gen = 0;             // the sizing pass kept its tokens (along the input) as scratch contents number tok_gen (0: it did not)
   std::vector<u32> chain_cand; // candidate index of every chunk of the chain
 };
 static thread_local SmPlan g_sm;
+static thread_local int32_t g_last_chunks = 0;  // chunks of this thread's last long stream (ahip_debug_last_chunks)
 
 static int sm_resident_waves() {
   static int v = 0;
@@ -995,8 +1045,9 @@ static int sm_resident_waves() {
 // *handled = false: not a case for this path (too short, no block found, chain broken, an error inside a chunk) --
 // the caller decodes the stream on one wave, which restates the reference exactly.
 int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool write, MemberResult *res, bool *handled,
-                   hipStream_t st) {
+                   hipStream_t st, u32 hist0) {
   *handled = false;
+  if (write) g_last_chunks = 0;
   if (getenv("AHIP_NO_SM") || n <= off || n - off < sm_min_bytes()) return AHIP_OK;
   const auto t_start = std::chrono::steady_clock::now();
   static thread_local DevBuf dcand, dchunks, dres, dsym, dwin;
@@ -1038,7 +1089,7 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
     const u32 nc = (u32)cand.size();
     // sizing: every candidate decodes (no tokens stored) until a block starts on a later candidate
     std::vector<ChunkDesc> cd(nc);
-    for (u32 i = 0; i < nc; ++i) cd[i] = ChunkDesc{cand[i], 0, 1ull << 62, i ? SM_WINDOW : 0u, 0};
+    for (u32 i = 0; i < nc; ++i) cd[i] = ChunkDesc{cand[i], 0, 1ull << 62, i ? SM_WINDOW : hist0, 0};
     HIP_TRY(dcand.reserve((size_t)nc * 8));
     HIP_TRY(dchunks.reserve((size_t)nc * sizeof(ChunkDesc)));
     HIP_TRY(dres.reserve((size_t)nc * sizeof(MemberResult)));
@@ -1065,13 +1116,14 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
     u64 total = 0;
     for (;;) {
       const MemberResult &r = rs[i];
-      g_sm.chain.push_back(ChunkDesc{cand[i], total, r.out_len, (u32)(total < SM_WINDOW ? total : SM_WINDOW), i});
+      // what a chunk may reach: the stream's own output in front of it, and behind that the hist0 bytes of earlier output
+      g_sm.chain.push_back(ChunkDesc{cand[i], total, r.out_len, (u32)(total + hist0 < SM_WINDOW ? total + hist0 : SM_WINDOW), i});
       g_sm.sized.push_back(r);
       // the kept tokens serve only if the chunk was sized with the window it really has, and its token area held
-      if (i && total < SM_WINDOW) kept_gen = 0;
+      if (i && total + hist0 < SM_WINDOW) kept_gen = 0;
       if (r.blocks & MR_FAR) kept_gen = 0;
       total += r.out_len;
-      g_sm.blocks += r.blocks;
+      g_sm.blocks += (r.blocks & 0x00ffffffu) | (i == 0 ? (r.blocks & MR_REACH) : 0u);
       if (r.status == MS_OK) { g_sm.end_pos = r.end_pos; break; }
       if (r.status != MS_CHUNK_END) { if (dbg) fprintf(stderr, "[ahip] sm: chunk %u ended with status %u: one-wave path\n", i, r.status); return AHIP_OK; }
       auto it = std::lower_bound(cand.begin(), cand.end(), r.end_pos);
@@ -1080,7 +1132,7 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
     }
     g_sm.cand = cand;
     g_sm.total_out = total;
-    g_sm.d_in = d_in; g_sm.n = n; g_sm.off = off;
+    g_sm.d_in = d_in; g_sm.n = n; g_sm.off = off; g_sm.hist0 = hist0;
     g_sm.valid = true;
     g_sm.tok_gen = kept_gen;
     if (dbg) fprintf(stderr, "[ahip] sm: %zu chunks on the chain, %llu bytes out (find + sizing + chain: %.2f ms)\n", g_sm.chain.size(),
@@ -1092,6 +1144,15 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
   res->end_pos = g_sm.end_pos;
   res->blocks = g_sm.blocks;
   if (!write) { *handled = true; return AHIP_OK; }
+  if (g_sm.hist0 != hist0) {
+    // sized with another history than the output really has in front of this stream (the sizing run of a gzip member does
+    // not know its output offset yet and allows the full 32 KiB): the chunks near the start get their true windows and are
+    // tokenized again -- a reference that now reaches in front of the whole output shows up as a changed verdict below
+    // and sends the stream to the one-wave path, which reports it exactly like the reference
+    for (auto &c : g_sm.chain) c.hist = (u32)(c.out_off + hist0 < SM_WINDOW ? c.out_off + hist0 : SM_WINDOW);
+    g_sm.tok_gen = 0;
+    g_sm.hist0 = hist0;
+  }
   if (g_sm.total_out > out_cap) { res->status = MS_CAP; *handled = true; return AHIP_OK; }
   // ---- tokens (exact offsets), symbols, windows, bytes ----
   const u32 nch = (u32)g_sm.chain.size(), nc = (u32)g_sm.cand.size();
@@ -1138,20 +1199,22 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
     HIP_TRY(dgwin.reserve((size_t)ng * SM_WINDOW));
     hipLaunchKernelGGL(sm_windows_group, dim3(ng), dim3(1024), 0, st, dchunks.as<ChunkDesc>(), dres.as<MemberResult>(), nch, gs,
                        dsym.as<u16>(), dwsym.as<u16>());
-    hipLaunchKernelGGL(sm_windows_link, dim3(1), dim3(1024), 0, st, nch, gs, dwsym.as<u16>(), dgwin.as<u8>());
-    hipLaunchKernelGGL(sm_windows_apply, dim3(8, nch), dim3(256), 0, st, gs, dwsym.as<u16>(), dgwin.as<u8>(), dwin.as<u8>());
+    // (the window in front of the stream: the hist0 bytes that end right in front of d_out -- already final, see plan_run)
+    hipLaunchKernelGGL(sm_windows_link, dim3(1), dim3(1024), 0, st, nch, gs, dwsym.as<u16>(), dgwin.as<u8>(), (const u8 *)d_out - SM_WINDOW, hist0);
+    hipLaunchKernelGGL(sm_windows_apply, dim3(8, nch), dim3(256), 0, st, gs, dwsym.as<u16>(), dgwin.as<u8>(), dwin.as<u8>(),
+                       (const u8 *)d_out - SM_WINDOW, hist0);
   }
   hipLaunchKernelGGL(sm_translate_kernel, dim3(32, nch), dim3(256), 0, st, dchunks.as<ChunkDesc>(), dres.as<MemberResult>(), dsym.as<u16>(),
-                     dwin.as<u8>(), d_out);
+                     dwin.as<u8>(), d_out, (const u8 *)d_out - SM_WINDOW, hist0);
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipGetLastError());
   g_sm.valid = false;
   *handled = true;
+  g_last_chunks = (int32_t)nch;
   if (dbg) fprintf(stderr, "[ahip] sm: write pass %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
   return AHIP_OK;
 }
 
-int32_t inflate_one_wave(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool write, MemberResult *res, hipStream_t st);
 int32_t inflate_one(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool write, MemberResult *res,
                     hipStream_t st) {
   bool handled = false;
@@ -1160,11 +1223,11 @@ int32_t inflate_one(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool
   if (handled) return AHIP_OK;
   return inflate_one_wave(d_in, n, off, d_out, out_cap, write, res, st);
 }
-int32_t inflate_one_wave(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool write, MemberResult *res, hipStream_t st) {
+int32_t inflate_one_wave(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool write, MemberResult *res, hipStream_t st, u32 hist0) {
   static thread_local DevBuf dd, dr;
   HIP_TRY(dd.reserve(sizeof(MemberDesc)));
   HIP_TRY(dr.reserve(sizeof(MemberResult)));
-  MemberDesc d{off, 0, out_cap, POS_UNKNOWN, 0};
+  MemberDesc d{off, 0, out_cap, POS_UNKNOWN, 0, hist0, 0};  // (hist0 bytes of earlier output end right in front of d_out)
   HIP_TRY(hipMemcpyAsync(dd.p, &d, sizeof d, hipMemcpyHostToDevice, st));
   const u64 one_off[2] = {0, out_cap};
   if (write) HIP_TRY(launch_inflate<true>(d_in, n, dd.as<MemberDesc>(), 1u, d_out, dr.as<MemberResult>(), st, one_off));
@@ -1953,7 +2016,7 @@ static int32_t gzip_decode_impl(const u8 *host_in, const u8 *d_in, size_t in_len
   const u8 *h = host_in;
   if (!h) {
     tail_host.resize(in_len - pl.sum.tail_pos);
-    HIP_TRY(hipMemcpy(tail_host.data(), d_in + pl.sum.tail_pos, tail_host.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(copy_on(tail_host.data(), d_in + pl.sum.tail_pos, tail_host.size(), hipMemcpyDeviceToHost, st));
     h = tail_host.data() - pl.sum.tail_pos;
   }
   // `1f 8b` and then the end of the input: _readHeader has matched the 16-bit signature and its next readByte()
@@ -1974,7 +2037,7 @@ static int32_t gzip_decode_impl(const u8 *host_in, const u8 *d_in, size_t in_len
     if (rc == AHIP_OK || rc == AHIP_FALSE) {
       if (out_len) *out_len = committed + tail_committed;
       if (committed + tail_committed > out_cap) { scratch.release(); return fail(AHIP_E_CAP, "output buffer too small"); }
-      if (tail_committed) HIP_TRY(hipMemcpy(d_out + committed, scratch.p, tail_committed, hipMemcpyDeviceToDevice));
+      if (tail_committed) HIP_TRY(copy_on(d_out + committed, scratch.p, tail_committed, hipMemcpyDeviceToDevice, st));
     }
     scratch.release();
     return rc;
@@ -2061,7 +2124,11 @@ struct Worker {
     cv.wait(lk, [&] { return done; });
   }
 };
-std::vector<std::unique_ptr<Worker>> g_workers;  // guarded by g_mu
+std::vector<std::unique_ptr<Worker>> g_workers;  // guarded by g_mu; the set does not change while g_shards_mu is held
+// A shards call owns the workers while its shards decode -- with g_mu RELEASED, so that the rest of the library stays
+// usable from other threads meanwhile.  Lock order: g_mu, then g_shards_mu (never the other way round: the shards call
+// lets go of g_shards_mu before it takes g_mu again).
+std::mutex g_shards_mu;
 // One device, host pointers: contexts on the SAME device that only exist to overlap PCIe traffic with the decode
 // (started on first use by a large stream when ahip_init_devices() selected nothing; AHIP_HOST_PIPE=0 turns it off,
 // =k asks for k contexts)
@@ -2075,7 +2142,11 @@ void stop_set(std::vector<std::unique_ptr<Worker>> &set) {
   }
   set.clear();
 }
-void stop_workers() { stop_set(g_workers); stop_set(g_pipe); }
+void stop_workers() {
+  std::lock_guard<std::mutex> use(g_shards_mu);  // (a shards call in flight on another thread finishes first)
+  stop_set(g_workers);
+  stop_set(g_pipe);
+}
 // Worker threads must be gone before the process tears its statics down (a joinable std::thread in a static is
 // std::terminate, and a thread blocked inside the HIP runtime at exit hangs the process): stop them at exit.
 void stop_at_exit() {
@@ -2223,6 +2294,7 @@ struct Rccl {
   std::vector<int> devs;      // the devices the communicators below were made for
   std::vector<void *> comms;
   std::vector<u64 *> send, recv;
+  std::vector<hipStream_t> streams;  // one non-blocking stream per device: the exchange waits for ITS work only
   bool load() {
     if (tried) return ok;
     tried = true;
@@ -2245,43 +2317,48 @@ struct Rccl {
       if (comms[i]) CommDestroy(comms[i]);
       if (send[i]) (void)hipFree(send[i]);
       if (recv[i]) (void)hipFree(recv[i]);
+      if (i < streams.size() && streams[i]) (void)hipStreamDestroy(streams[i]);
     }
-    comms.clear(); send.clear(); recv.clear(); devs.clear();
+    comms.clear(); send.clear(); recv.clear(); devs.clear(); streams.clear();
   }
   bool prepare(const std::vector<int> &d) {
     if (!load()) return false;
     if (d == devs) return true;
     drop();
-    comms.assign(d.size(), nullptr); send.assign(d.size(), nullptr); recv.assign(d.size(), nullptr);
+    comms.assign(d.size(), nullptr); send.assign(d.size(), nullptr); recv.assign(d.size(), nullptr); streams.assign(d.size(), nullptr);
     devs = d;
     if (CommInitAll(comms.data(), (int)d.size(), d.data()) != 0) { comms.assign(d.size(), nullptr); drop(); return false; }
     for (size_t i = 0; i < d.size(); ++i) {
       if (hipSetDevice(d[i]) != hipSuccess || hipMalloc((void **)&send[i], 8) != hipSuccess ||
-          hipMalloc((void **)&recv[i], 8 * d.size()) != hipSuccess) { drop(); return false; }
+          hipMalloc((void **)&recv[i], 8 * d.size()) != hipSuccess ||
+          hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking) != hipSuccess) { drop(); return false; }
     }
     return true;
   }
   // sizes[i] of device devs[i] -> every device holds all of them; `all` = what device 0 ended up with
   bool all_gather(const std::vector<u64> &sizes, std::vector<u64> &all) {
     const size_t n = devs.size();
+    // everything on the devices' own streams: the size goes up, the all-gather follows it in stream order, device 0's
+    // copy of the result comes down behind it -- no device-wide barrier, only these streams are waited for
     for (size_t i = 0; i < n; ++i) {
       if (hipSetDevice(devs[i]) != hipSuccess) return false;
-      if (hipMemcpy(send[i], &sizes[i], 8, hipMemcpyHostToDevice) != hipSuccess) return false;
+      if (hipMemcpyAsync(send[i], &sizes[i], 8, hipMemcpyHostToDevice, streams[i]) != hipSuccess) return false;
     }
     constexpr int kNcclUint64 = 5;
     if (GroupStart() != 0) return false;
     bool good = true;
     for (size_t i = 0; i < n; ++i) {
       (void)hipSetDevice(devs[i]);
-      good = good && AllGather(send[i], recv[i], 1, kNcclUint64, comms[i], (hipStream_t) nullptr) == 0;
+      good = good && AllGather(send[i], recv[i], 1, kNcclUint64, comms[i], streams[i]) == 0;
     }
     if (GroupEnd() != 0 || !good) return false;
-    for (size_t i = 0; i < n; ++i) {
-      if (hipSetDevice(devs[i]) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return false;
-    }
     all.resize(n);
     (void)hipSetDevice(devs[0]);
-    return hipMemcpy(all.data(), recv[0], 8 * n, hipMemcpyDeviceToHost) == hipSuccess;
+    if (hipMemcpyAsync(all.data(), recv[0], 8 * n, hipMemcpyDeviceToHost, streams[0]) != hipSuccess) return false;
+    for (size_t i = 0; i < n; ++i) {
+      if (hipSetDevice(devs[i]) != hipSuccess || hipStreamSynchronize(streams[i]) != hipSuccess) return false;
+    }
+    return true;
   }
 };
 Rccl g_rccl;      // guarded by g_mu
@@ -2290,10 +2367,11 @@ int32_t g_last_exchange = 0;
 
 void rccl_drop() { if (g_rccl.ok) g_rccl.drop(); }
 int32_t ahip_debug_last_exchange(void) { return g_last_exchange; }
+int32_t ahip_debug_last_chunks(void) { return g_last_chunks; }
 
 int32_t ahip_gzip_decode_shards(uint32_t n_shards, const int32_t *devices, const void *const *d_in, const size_t *in_len,
                                 void *const *d_out, const size_t *out_cap, size_t *out_len, uint64_t *offsets, int32_t *status) {
-  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  std::unique_lock<std::recursive_mutex> lk(g_mu);
   int32_t rc = ensure_init();
   if (rc != AHIP_OK) return rc;
   if (n_shards == 0 || !devices || !d_in || !in_len || !d_out || !out_cap || !out_len || !offsets) return fail(AHIP_E_ARG, "NULL shard table");
@@ -2317,20 +2395,28 @@ int32_t ahip_gzip_decode_shards(uint32_t n_shards, const int32_t *devices, const
   std::vector<int32_t> rcs(n_shards, AHIP_OK);
   std::vector<std::string> errs(n_shards);
   std::vector<size_t> got(n_shards, 0);
-  auto run_shard = [&](u32 s) {
-    rcs[s] = gzip_decode_impl(nullptr, (const u8 *)d_in[s], in_len[s], 0, 0, (u8 *)d_out[s], out_cap[s], false, nullptr, &got[s], nullptr);
+  auto run_shard = [&](u32 s) {  // (on a worker: its own non-blocking stream; on the caller's thread: the default stream)
+    rcs[s] = gzip_decode_impl(nullptr, (const u8 *)d_in[s], in_len[s], 0, 0, (u8 *)d_out[s], out_cap[s], false, nullptr, &got[s], g_ctx_stream);
     if (rcs[s] < 0) errs[s] = g_err;
   };
   if (g_workers.empty()) {
     for (u32 s = 0; s < n_shards; ++s) run_shard(s);
   } else {
-    // every worker takes its shards in order; the workers run side by side
-    for (size_t w = 0; w < g_workers.size(); ++w) {
+    // every worker takes its shards in order; the workers run side by side.  The workers are this call's until they are
+    // done (g_shards_mu); g_mu is let go meanwhile -- the shards decode in the workers' own thread-local contexts, nothing
+    // of the process-wide state g_mu guards is touched -- and taken again for the exchange.
+    std::unique_lock<std::mutex> use(g_shards_mu);
+    std::vector<Worker *> ws;
+    for (auto &w : g_workers) ws.push_back(w.get());
+    lk.unlock();
+    for (size_t w = 0; w < ws.size(); ++w) {
       std::vector<u32> mine;
       for (u32 s = 0; s < n_shards; ++s) if (wk[s] == (int)w) mine.push_back(s);
-      g_workers[w]->submit([mine, &run_shard] { for (u32 s : mine) run_shard(s); });
+      ws[w]->submit([mine, &run_shard] { for (u32 s : mine) run_shard(s); });
     }
-    for (auto &w : g_workers) w->wait();
+    for (Worker *w : ws) w->wait();
+    use.unlock();
+    lk.lock();
   }
   int32_t worst = AHIP_OK;
   for (u32 s = 0; s < n_shards; ++s) {

@@ -45,6 +45,8 @@ struct MemberDesc {
   u32 pad;
 };
 constexpr u32 MR_FAR = 0x80000000u;  // MemberResult::blocks: some back-reference reaches into earlier output (resolved late, in order)
+constexpr u32 MR_REACH = 0x40000000u;  // MemberResult::blocks of a watched CHUNK (the first one of a long member): some back-reference
+                                      // reaches in front of the chunk's own output, i.e. into what earlier gzip members produced (q8)
 
 // Chunked decode of ONE long stream (sm_inflate): a chunk starts at a block header found by the block finder
 // (any bit offset), may refer to `hist` bytes of output before its own, and stops in front of the first block
@@ -61,6 +63,7 @@ struct ChunkCtx {
   u32 n_cand;
   u32 start_bit;         // 0..7 within the first byte
   u32 hist;
+  u32 watch;             // report (MR_REACH) whether a back-reference reaches in front of the chunk's own output
 };
 
 struct MemberResult {
@@ -144,6 +147,9 @@ AHIP_DEVINL u32 dpp_zero(u32 v) {  // lanes without a source (or masked rows) re
 }
 AHIP_DEVINL u32 lane_bcast(u32 v, int src_lane /* wave-uniform */) {
   return (u32)__builtin_amdgcn_readlane((int)v, src_lane);
+}
+AHIP_DEVINL unsigned long long lane_bcast64(unsigned long long v, int src_lane /* wave-uniform */) {
+  return (unsigned long long)lane_bcast((u32)v, src_lane) | ((unsigned long long)lane_bcast((u32)(v >> 32), src_lane) << 32);
 }
 // value of lane-1 (0 for lane 0)
 AHIP_DEVINL u32 lane_prev(u32 v) { return dpp_zero<0x138, 0xf>(v); }

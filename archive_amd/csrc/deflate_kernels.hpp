@@ -40,7 +40,7 @@ constexpr u32 DF_SLAB = DF_CHUNK + 512;  // per-chunk output slab (a stored bloc
 //   levels 4-6: 4096 x 4 (16 K entries, 32 KiB, two workgroups per CU)
 //   levels 7-9: 8192 x 4 (32 K entries, 64 KiB, one workgroup per CU)      every window position indexed
 constexpr u32 DF_MINLEN = 4;             // 4-byte hash: 3-byte matches are not searched
-constexpr u32 DF_EMPTY = 0xffff;
+constexpr u32 DF_EMPTY = 0;              // a table slot nobody wrote
 #ifndef AHIP_DF_CAP
 #define AHIP_DF_CAP 32
 #endif
@@ -58,6 +58,21 @@ struct DeflateParams {
 };
 
 template <u32 HB> AHIP_DEVINL u32 df_hash4(u32 w) { return (w * 2654435761u) >> (32 - HB); }
+// Insertion into a table of 16-bit window positions, two to a dword, such that among the writers of one slot in one
+// step a DEFINED one wins -- not whichever wave the hardware happens to serve last: two encodes of the same input are
+// byte for byte the same (the reference is one sequential pass and trivially so, deflate.dart:997-1118).  A position is
+// stored as key = pos ^ (SUB - 1) (SUB = positions per step, a power of two; 0 = empty: position SUB - 1 is never found):
+// keys grow from step to step and, inside a step, towards the LOWER positions, so the largest key of a slot is the
+// lowest position of the youngest step -- the one every later position of that step can still use as a candidate.
+// Entry `e` is one half of dword e >> 1; `word` = that dword as read since the last barrier.  During a step only ONE
+// half of any dword is written -- the ways of a bucket take turns step by step, the two halves of a long-string bucket
+// alternate with the step's parity -- so every writer of the slot carries the same other half, and an LDS atomicMax on
+// the whole dword compares just the keys.
+AHIP_DEVINL void df_insert(u16 *tab, u32 e, u32 key, u32 word) {
+  const u32 nw = (e & 1) ? ((word & 0xffffu) | (key << 16)) : ((word & 0xffff0000u) | key);
+  atomicMax((u32 *)tab + (e >> 1), nw);
+}
+AHIP_DEVINL u32 df_word(const u16 *tab, u32 e) { return ((const u32 *)tab)[e >> 1]; }
 // hashes of LONGER strings (8 and 16 bytes): a candidate that shares that much context is worth what a deep walk
 // down the reference's hash chain finds (_longestMatch, deflate.dart:1120-1206, up to 128 / 4096 candidates)
 template <u32 HB> AHIP_DEVINL u32 df_hash8(u64 w) { return (u32)(((w * 0x9E3779B97F4A7C15ull) >> 32) * 2654435761u) >> (32 - HB); }
@@ -129,9 +144,11 @@ __global__ __launch_bounds__(SUB) void deflate_match_kernel(const u8 *__restrict
   constexpr u32 DF_SUB = SUB;
   constexpr u32 AHEAD = SUB > 512 ? 2 * SUB : DF_AHEAD;  // bytes staged in front of the step
   static_assert(SUB % 64 == 0 && AHEAD % SUB == 0 && AHEAD >= 2 * SUB && DF_CHUNK + AHEAD + SUB <= DF_RING, "step geometry");
-  __shared__ u16 tbl[(1u << DF_HASH_BITS) * DF_WAYS];
-  __shared__ u16 tblA[LA ? (1u << LA) : 1u];
-  __shared__ u16 tblB[LB ? (1u << LB) : 1u];
+  __shared__ u16 tbl[(1u << DF_HASH_BITS) * DF_WAYS] __attribute__((aligned(4)));
+  __shared__ u16 tblA[LA ? (1u << LA) : 2u] __attribute__((aligned(4)));
+  __shared__ u16 tblB[LB ? (1u << LB) : 2u] __attribute__((aligned(4)));
+  constexpr u32 KX = SUB - 1;  // position <-> key (df_insert)
+  static_assert((SUB & (SUB - 1)) == 0, "positions per step: a power of two");
   constexpr u32 NX = (LA ? 1u : 0u) + (LB ? 1u : 0u);  // candidates from the long-string tables
   constexpr u32 MERGE = DF_WAYS < 4 ? DF_WAYS : 4;  // history steps inserted per barrier (distinct ways)
   __shared__ u32 ring[(DF_RING + DF_MIRROR) / 4 + 2];
@@ -167,14 +184,20 @@ __global__ __launch_bounds__(SUB) void deflate_match_kernel(const u8 *__restrict
   for (; base + MERGE * DF_SUB <= dict; base += MERGE * DF_SUB) {
     if (tid < MERGE * (SUB / 4)) stage(base + AHEAD + 4 * tid);
     __syncthreads();  // the last position's 4 bytes reach into what was just staged
+    // the steps of one parity together (their slots are different dwords, or the same half of one), then the others
 #pragma unroll
-    for (u32 k = 0; k < MERGE; ++k) {
-      const u32 p = base + k * DF_SUB + tid;  // p + 4 <= wlen: the chunk follows
-      tbl[df_hash4<DF_HASH_BITS>(df_rd4(ring, df_rc(p))) * DF_WAYS + (((base / DF_SUB) + k) & (DF_WAYS - 1))] = (u16)p;
-      if (LA && p + 8 <= wlen) tblA[df_hash8<LA ? LA : 1>(df_rd8(ring, df_rc(p)))] = (u16)p;
-      if (LB && p + 16 <= wlen) tblB[df_hash16<LB ? LB : 1>(df_rd8(ring, df_rc(p)), df_rd8(ring, df_rc(p) + 8))] = (u16)p;
+    for (u32 phase = 0; phase < 2; ++phase) {
+#pragma unroll
+      for (u32 k = phase; k < MERGE; k += 2) {
+        const u32 p = base + k * DF_SUB + tid;  // p + 4 <= wlen: the chunk follows
+        const u32 step = (base / DF_SUB) + k;
+        const u32 e = df_hash4<DF_HASH_BITS>(df_rd4(ring, df_rc(p))) * DF_WAYS + (step & (DF_WAYS - 1));
+        df_insert(tbl, e, p ^ KX, df_word(tbl, e));
+        if (LA && p + 8 <= wlen) { const u32 eA = df_hash8<LA ? LA - 1 : 1>(df_rd8(ring, df_rc(p))) * 2 + (step & 1); df_insert(tblA, eA, p ^ KX, df_word(tblA, eA)); }
+        if (LB && p + 16 <= wlen) { const u32 eB = df_hash16<LB ? LB - 1 : 1>(df_rd8(ring, df_rc(p)), df_rd8(ring, df_rc(p) + 8)) * 2 + (step & 1); df_insert(tblB, eB, p ^ KX, df_word(tblB, eB)); }
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
   // 256 positions per step.  A position is compared with the strings earlier steps left in its bucket
   // (read before this step's insertion) and with the string this step put into the bucket's current slot
@@ -203,24 +226,31 @@ __global__ __launch_bounds__(SUB) void deflate_match_kernel(const u8 *__restrict
     maxl = maxl < DF_CAP ? maxl : DF_CAP;
     if (has4) { w = df_rd4(ring, rp); h = df_hash4<DF_HASH_BITS>(w); }
     u32 cand[DF_WAYS + 1 + NX];
+    // the bucket's dwords (two ways each): the candidates, and the halves an insertion below has to carry along
+    u32 bw[DF_WAYS / 2];
 #pragma unroll
-    for (u32 way = 0; way < DF_WAYS; ++way) cand[way] = search ? tbl[h * DF_WAYS + way] : DF_EMPTY;
-    const u32 slot = h * DF_WAYS + ((base / DF_SUB) & (DF_WAYS - 1));
-    u32 hA = 0, hB = 0;
+    for (u32 d = 0; d < DF_WAYS / 2; ++d) bw[d] = has4 ? ((const u32 *)tbl)[h * (DF_WAYS / 2) + d] : 0u;
+#pragma unroll
+    for (u32 way = 0; way < DF_WAYS; ++way) cand[way] = search ? ((bw[way >> 1] >> (16 * (way & 1))) & 0xffffu) : DF_EMPTY;  // (keys)
+    const u32 step = base / DF_SUB;
+    const u32 slot = h * DF_WAYS + (step & (DF_WAYS - 1));
+    u32 eA = 0, eB = 0, wA = 0, wB = 0;
     const bool has8 = p + 8 <= wlen, has16 = p + 16 <= wlen;
+    // the long-string tables: a bucket is one dword, its halves written in even / odd steps; the younger one is the candidate
     if (LA) {
-      if (has8) hA = df_hash8<LA ? LA : 1>(df_rd8(ring, rp));
-      cand[DF_WAYS + 1] = (search && has8) ? tblA[hA] : DF_EMPTY;
+      if (has8) { eA = df_hash8<LA ? LA - 1 : 1>(df_rd8(ring, rp)) * 2 + (step & 1); wA = df_word(tblA, eA); }
+      cand[DF_WAYS + 1] = (search && has8) ? ((wA >> 16) > (wA & 0xffffu) ? (wA >> 16) : (wA & 0xffffu)) : DF_EMPTY;
     }
     if (LB) {
-      if (has16) hB = df_hash16<LB ? LB : 1>(df_rd8(ring, rp), df_rd8(ring, rp + 8));
-      cand[DF_WAYS + NX] = (search && has16) ? tblB[hB] : DF_EMPTY;
+      if (has16) { eB = df_hash16<LB ? LB - 1 : 1>(df_rd8(ring, rp), df_rd8(ring, rp + 8)) * 2 + (step & 1); wB = df_word(tblB, eB); }
+      cand[DF_WAYS + NX] = (search && has16) ? ((wB >> 16) > (wB & 0xffffu) ? (wB >> 16) : (wB & 0xffffu)) : DF_EMPTY;
     }
     AHIP_TICK(t1);
     df_lds_barrier();
-    if (has4) tbl[slot] = (u16)p;  // same-hash writers of one step race: any winner is valid
-    if (LA && has8) tblA[hA] = (u16)p;
-    if (LB && has16) tblB[hB] = (u16)p;
+    // (same-slot writers of one step: the largest position wins, df_insert -- not whoever is served last)
+    if (has4) df_insert(tbl, slot, p ^ KX, bw[(step & (DF_WAYS - 1)) >> 1]);
+    if (LA && has8) df_insert(tblA, eA, p ^ KX, wA);
+    if (LB && has16) df_insert(tblB, eB, p ^ KX, wB);
     df_lds_barrier();
     AHIP_TICK(t2);
     AHIP_ACC(pc[0], t0, t1);
@@ -232,9 +262,9 @@ __global__ __launch_bounds__(SUB) void deflate_match_kernel(const u8 *__restrict
       bool alive[NC];
 #pragma unroll
       for (u32 k = 0; k < NC; ++k) {
-        const u32 c = cand[k];
+        const u32 c = cand[k] ^ KX;  // key -> position
         dist[k] = p - c;
-        alive[k] = k != DF_WAYS ? (c != DF_EMPTY && c < p && dist[k] <= P.max_dist) : (c < p && c >= base && dist[k] <= P.max_dist);
+        alive[k] = k != DF_WAYS ? (cand[k] != DF_EMPTY && c < p && dist[k] <= P.max_dist) : (cand[k] != DF_EMPTY && c < p && c >= base && dist[k] <= P.max_dist);
         rc[k] = alive[k] ? df_rc(c) : rp;
       }
       AHIP_TICK(t3);

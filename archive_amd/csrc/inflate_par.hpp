@@ -42,7 +42,7 @@ namespace ahip {
 #define AHIP_STEPS 12
 #endif
 #ifndef AHIP_EMIT_MIN
-#define AHIP_EMIT_MIN 8
+#define AHIP_EMIT_MIN 16
 #endif
 constexpr int SUB_BITS = AHIP_SUB_BITS;          // bits per work item ("subsequence") of the tokenizer
 constexpr int SUB_DW = SUB_BITS / 32;
@@ -54,16 +54,12 @@ constexpr int SUB_DW = SUB_BITS / 32;
 constexpr int RING_DW = AHIP_RING_DW;
 constexpr int ITEMS = RING_DW / SUB_DW;          // items the ring (and the scoreboard) holds
 constexpr int RING_MIRROR = SUB_DW + 8;          // dwords 0 .. RING_MIRROR-1 again at RING_DW ..
-#ifndef AHIP_STAGE_UNIT
-#define AHIP_STAGE_UNIT 128
-#endif
-constexpr u32 STAGE_UNIT = AHIP_STAGE_UNIT;      // dwords per staging unit (<= 256: 16 bytes a lane)
 constexpr u32 SPEC_BITS = AHIP_SPEC_BITS;        // a speculative run covers the last SPEC_BITS of its item
 constexpr int STEPS = AHIP_STEPS;                // decode steps between two scheduling points
 constexpr u32 EMIT_MIN = AHIP_EMIT_MIN;          // items retired per emit (<= 64)
+constexpr u32 REPAIRS = 16;                      // repairs handed out per scheduling point (the one validation waits for comes first)
 constexpr u32 EPOCH_ITEMS = (1u << 27) / SUB_BITS;  // positions inside an epoch stay below 2^27 + slack
 static_assert(RING_DW % SUB_DW == 0 && RING_DW % 4 == 0 && RING_MIRROR % 4 == 0 && ITEMS >= 64, "ring geometry");
-static_assert(STAGE_UNIT >= 64 && STAGE_UNIT <= 256 && STAGE_UNIT % 4 == 0 && RING_DW % STAGE_UNIT == 0 && (u32)RING_MIRROR <= STAGE_UNIT, "staging geometry");
 static_assert(SUB_BITS % 128 == 0 && SPEC_BITS <= (u32)SUB_BITS && SUB_BITS + 64 < 4096, "item geometry");
 static_assert(EMIT_MIN >= 1 && EMIT_MIN <= 64 && (u32)ITEMS >= 2 * EMIT_MIN && ITEMS >= 32, "scheduler geometry");
 // x in [0, 2 N) -> x mod N
@@ -100,12 +96,14 @@ constexpr u32 DIR_BYTES = 16;
 struct TokLds {
   u32 inbuf[RING_DW + RING_MIRROR] __attribute__((aligned(16)));
   u32 fa[ITEMS];    // decode run of item s: state<<30 | flags<<28 | lane<<22 | (start - s*SUB)<<12 | (end - s*SUB)
+                    //   state 0 nothing yet, 1 a run is in flight, 2 a run has finished,
+                    //   3 no run yet but a PREDICTED START: the speculative run over the tail of item s-1 ended (usably) at
+                    //     s*SUB + (fa & 0xfff)
   u32 fb[ITEMS];    //   where its first token sits in the recording lane's column (words)
   u32 fc[ITEMS];    //   bytes | tokens<<20
   u16 need[ITEMS];  //   max over its matches of (distance - bytes of the item in front of the match): the "source
                     //   before the start of the output" check
-  u16 spec[ITEMS];  // speculative run of item s: 0x8000 done | 0x4000 usable | (end - (s+1)*SUB)
-  u16 q[64];        // repair queue of one scheduling point: the starts to decode from, counted from the window's first item
+  u16 q[REPAIRS];   // repair queue of one scheduling point: the starts to decode from, counted from the window's first item
 };
 // (The words used in every column of the member's token area are per-lane data: they live in a register of the owning
 //  lane -- `colreg`, handed through the emitters by reference -- and the serial writer reads / writes another lane's with
@@ -422,34 +420,20 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
     }
     const u32 spec_cap = (n_spec ? n_spec - 1 : 0u) < n_items - 1 ? (n_spec ? n_spec - 1 : 0u) : n_items - 1;  // SPEC(s) serves item s+1
     AHIP_TICK(t_a);
-    for (u32 i = lane; i < (u32)ITEMS; i += 64) { P.fa[i] = 0; P.spec[i] = 0; }
+    for (u32 i = lane; i < (u32)ITEMS; i += 64) P.fa[i] = 0;
     const u32 total_dw = n_items * SUB_DW + SLACK_DW;
-    // The ring is filled in UNITS of STAGE_UNIT dwords (16 bytes a lane), and the unit that will be wanted next is always
-    // already on its way into registers (`pf`): a retire step that frees a unit's worth of slots stores data that was
-    // requested a whole retire step earlier instead of waiting ~ 2 us for a fresh load (the retire phase was 8.6 % of the
-    // tokenizer's time, nearly all of it this wait).
-    u32 stage_hi = 0;  // dwords staged so far (whole units, or total_dw)
-    uint4 pf = make_uint4(0u, 0u, 0u, 0u);
-    u32 pf_at = ~0u;   // the unit `pf` holds (its first dword)
-    auto load_unit = [&](u32 base) -> uint4 {
-      const u32 w = base + (u32)lane * 4;
-      return (u32)lane * 4 < STAGE_UNIT && w < total_dw ? load_u128_unaligned(b.in + gbyte + 4 * (u64)w) : make_uint4(0u, 0u, 0u, 0u);
-    };
-    auto stage_to = [&](u32 limit) {  // whole units that end at or below `limit` (the stream's last one may be short)
-      while (stage_hi < total_dw) {
-        const u32 end = stage_hi + STAGE_UNIT < total_dw ? stage_hi + STAGE_UNIT : total_dw;
-        if (end > limit) break;
-        const uint4 v = pf_at == stage_hi ? pf : load_unit(stage_hi);
-        const u32 w = stage_hi + (u32)lane * 4;
-        if ((u32)lane * 4 < STAGE_UNIT && w < total_dw) {
-          const u32 rw = stage_hi % (u32)RING_DW + (u32)lane * 4;  // (RING_DW is a multiple of the unit: no unit straddles the ring's end)
-          *(uint4 *)(P.inbuf + rw) = v;
-          if (rw < (u32)RING_MIRROR) *(uint4 *)(P.inbuf + RING_DW + rw) = v;  // the head of the ring, again behind its end
-        }
-        stage_hi = end;
-        pf_at = ~0u;
+    // (Measured and not kept, profiles/r04_experiments.md: filling the ring in units whose data was requested one retire
+    //  step ahead -- the retire step's wait for its loads is not what the phase costs; smaller retire batches cost more
+    //  in per-batch work than their fewer decode steps save.)
+    u32 stage_hi = 0;  // dwords staged so far (multiple of 4)
+    auto stage_to = [&](u32 target) {
+      for (u32 w = stage_hi + (u32)lane * 4; w < target; w += 256) {
+        const u32 rw = w % (u32)RING_DW;
+        const uint4 v = load_u128_unaligned(b.in + gbyte + 4 * (u64)w);
+        *(uint4 *)(P.inbuf + rw) = v;
+        if (rw < (u32)RING_MIRROR) *(uint4 *)(P.inbuf + RING_DW + rw) = v;  // the head of the ring, again behind its end
       }
-      if (pf_at != stage_hi && stage_hi < total_dw) { pf = load_unit(stage_hi); pf_at = stage_hi; }  // the next unit: on its way
+      stage_hi = target;
     };
     stage_to(total_dw < (u32)RING_DW ? total_dw : (u32)RING_DW);
     wave_sync();
@@ -511,7 +495,7 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
         else if (stop_flags) stop_serial = true;
         if ((ms >> 28) == 1 && (ms & 0x0fffffffu) < V) { ms = 0; bound = 0; endp = 0; }  // speculation nobody needs any more
         if (next_fix <= V) next_fix = V + 1;
-        const bool rerun = win && (u32)lane >= n && pend != ~0u && wi < next_fix && (wstate == 0 || (wstate == 2 && wstart != pend));
+        const bool rerun = win && (u32)lane >= n && pend != ~0u && wi < next_fix && (wstate == 0 || wstate == 3 || (wstate == 2 && wstart != pend));
         rm = (block_done || stop_serial) ? 0ull : __ballot(rerun);
       }
       AHIP_TICK(t_s1);
@@ -557,7 +541,7 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
         }
         o.pos += tot_bytes;
         t_ret = lane_bcast(s * SUB + (a & 0xfffu), (int)nb - 1);
-        if (mine) { P.fa[sslot] = 0; P.spec[sslot] = 0; }
+        if (mine) P.fa[sslot] = 0;
         retired += nb;
         const u32 room = retired * SUB_DW + (u32)RING_DW;
         wave_sync();
@@ -590,7 +574,7 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
           const u32 vslot = V % (u32)ITEMS;
           const bool rr = ((rm >> lane) & 1) && pend / SUB < lim;
           const u64 rm2 = __ballot(rr);
-          const u32 nrr = (u32)__popcll(rm2);
+          const u32 nrr = (u32)__popcll(rm2) < REPAIRS ? (u32)__popcll(rm2) : REPAIRS;
           const u32 na = nrr < nidle ? nrr : nidle;
           const u32 rr_rank = wave_rank(rm2);
           if (rr && rr_rank < na) { P.q[rr_rank] = (u16)(pend - V * SUB); P.fa[wrap_item(vslot + (pend / SUB - V))] = 1u << 30; }
@@ -602,8 +586,9 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
 #endif
           // (b) runs whose predicted start is known: consecutive items from next_fix
           const u32 sb = next_fix + (u32)lane;
-          const u32 fslot1 = (next_fix - 1) % (u32)ITEMS;  // slot of the item in front of next_fix (next_fix >= 1)
-          const bool okb = sb < lim && (P.spec[wrap_item(fslot1 + (u32)lane)] & 0xc000u) == 0xc000u;
+          const u32 fslot = next_fix % (u32)ITEMS;
+          const u32 bfa = sb < lim && sb < retired + (u32)ITEMS ? P.fa[wrap_item(fslot + (u32)lane)] : 0u;
+          const bool okb = (bfa >> 30) == 3u;  // a predicted start is known
           const u64 okm = __ballot(okb);
           const u32 nready = okm == ~0ull ? 64u : (u32)__builtin_ctzll(~okm);
           // (c) speculation ahead
@@ -623,9 +608,8 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
               const u32 rel = P.q[rank];  // bits behind the window's first item
               st_new = V * SUB + rel; s_new = V + rel / SUB; slot_new = wrap_item(vslot + rel / SUB);
             } else if (take_b) {
-              const u32 pslot = wrap_item(fslot1 + u2);  // the item in front of it
-              s_new = next_fix + u2; slot_new = wrap_item(pslot + 1);
-              st_new = s_new * SUB + (P.spec[pslot] & 0xfffu);
+              s_new = next_fix + u2; slot_new = wrap_item(fslot + u2);
+              st_new = s_new * SUB + (P.fa[slot_new] & 0xfffu);
             } else {
               s_new = next_spec + (u2 - nb_); slot_new = wrap_item(next_spec % (u32)ITEMS + (u2 - nb_));
               st_new = (s_new + 1) * SUB - SPEC_BITS;
@@ -688,8 +672,12 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
           if (fin) {
             const u32 bnd = (s + 1) * SUB;
             if (mode == 1) {
-              const bool usable = fl == 0 && endp - bnd < 64;
-              P.spec[myslot] = (u16)(0x8000u | (usable ? 0x4000u : 0u) | ((endp - bnd) & 0xfffu));
+              // the predicted start of the NEXT item goes into that item's slot -- if it lies inside the ring's window and
+              // nobody has given it a run meanwhile (an unusable speculation leaves nothing: the item is decoded when its
+              // predecessor's run has ended)
+              const bool usable = fl == 0 && endp - bnd < 64 && s + 1 < retired + (u32)ITEMS && s + 1 < n_items;
+              const u32 nslot = wrap_item(myslot + 1);
+              if (usable && (P.fa[nslot] >> 30) == 0u) P.fa[nslot] = (3u << 30) | (endp - bnd);
             } else {
               P.fb[myslot] = row0;
               P.fc[myslot] = nbytes | (((rowctr - row0) & 0xfffu) << 20);
@@ -733,7 +721,7 @@ AHIP_DEVINL void inflate_member(WaveLds &L, HeaderLds &H, TokLds *P, const u8 *i
   ParStats st{};
   BitCursor b{in, in_len, in_len * 8, m.in_off * 8 + (CHUNK ? cx->start_bit : 0u), nullptr, 0, 0, 0};
   const u64 hist = CHUNK ? cx->hist : m.hist;
-  OutCursor o{out + m.out_off - hist, hist, m.out_limit > ~0ull - hist ? ~0ull : m.out_limit + hist, CHUNK ? 0u : hist, 0, hist};
+  OutCursor o{out + m.out_off - hist, hist, m.out_limit > ~0ull - hist ? ~0ull : m.out_limit + hist, CHUNK ? (cx->watch ? hist : 0u) : hist, 0, hist};
   u32 colreg = 0;  // words this lane's column of the member's token area holds (tokenizer only)
   // where the index expects the deflate data to end (a hint for speculation only: the decode itself never trusts it)
   const u64 hint_end_bits = (!CHUNK && m.expect_end != ~0ull) ? m.expect_end * 8 : 0ull;
@@ -829,7 +817,7 @@ AHIP_DEVINL void inflate_member(WaveLds &L, HeaderLds &H, TokLds *P, const u8 *i
     if (CHUNK && status == MS_CHUNK_END) res.end_pos = b.pos;
     res.out_len = o.pos - hist;
     res.status = (PAR && sink.full && !sink.sizing) ? (u32)MS_TOKFULL : status;
-    res.blocks = blocks | ((o.far || (PAR && sink.full && sink.sizing)) ? MR_FAR : 0u);
+    res.blocks = blocks | (((!CHUNK && o.far) || (PAR && sink.full && sink.sizing)) ? MR_FAR : 0u) | ((CHUNK && o.far) ? MR_REACH : 0u);
     res.windows = st.windows;
     res.rounds = st.rounds;
     res.fallbacks = st.fallbacks;

@@ -4,12 +4,14 @@
 // says where a block starts, and a back-reference may reach 32 KiB into what the previous block produced.
 // Multi-member input side-steps both (members are independent).  For a single long stream:
 //
-//   S1 sm_find_kernel      the compressed data is cut every `chunk_bytes`; one wave per cut looks for the first
-//                          DYNAMIC block header behind it: 64 bit positions per step pass a cheap filter (BTYPE,
-//                          HLIT/HDIST range, complete code-length code), survivors are run-length decoded one per
-//                          lane and must describe complete trees with an end-of-block code.  What still slips
-//                          through is judged by S2.  Stored / fixed blocks are not searched; a cut without a find
-//                          simply extends the previous chunk.
+//   S1 sm_find_kernel      the compressed data is cut every `chunk_bytes`; waves behind each cut look for the first
+//                          block start: a DYNAMIC block header (a cheap bit-parallel filter on BTYPE and the HLIT / HDIST
+//                          ranges, then a complete code-length code, then survivors are run-length decoded one per
+//                          lane and must describe complete trees with an end-of-block code), or a STORED block on a
+//                          byte boundary (header byte 0 / 1, LEN, ~LEN: inflate.dart:213-237 -- what an incompressible
+//                          stretch is made of: stored blocks back to back, each starting where the data of the one
+//                          before ends).  What still slips through is judged by S2.  Fixed blocks carry no signature
+//                          and are not searched; a cut without a find simply extends the previous chunk.
 //   S2 sm_tokenize_kernel  the ordinary tokenizer (inflate_member<.., CHUNK>) from each find to the block that
 //                          starts on the next find.  Run twice: sizes first (a false find decodes garbage and is
 //                          dropped when the host follows the chain of ends == starts), then recording tokens at
@@ -181,6 +183,34 @@ AHIP_DEVINL u64 sm_find_wave(SmFindLds &S, const u8 *__restrict__ in, u64 in_len
     u32 m = (u32)(~(v >> 1) & (v >> 2));                                   // BTYPE == 2: bit 1 clear, bit 2 set
     m &= ~(u32)((v >> 4) & (v >> 5) & (v >> 6) & (v >> 7));                // HLIT <= 29: not 1111x
     m &= ~(u32)((v >> 9) & (v >> 10) & (v >> 11) & (v >> 12));             // HDIST <= 29
+    // ---- a stored block on a byte boundary: BFINAL + BTYPE 00 + zero padding in one byte, then LEN and its complement ----
+    // (the four bytes of this lane's dword; 2^-23 of random positions look like one: false finds die in S2 like false headers)
+    u32 sj = 4;
+#pragma unroll
+    for (int j = 3; j >= 0; --j) {
+      const u64 x = v >> (8 * j);
+      if (((u32)x & 0xfeu) == 0 && ((((u32)(x >> 8)) ^ ((u32)(x >> 24))) & 0xffffu) == 0xffffu) sj = (u32)j;
+    }
+    const u64 sq = wq + 8ull * sj;
+    bool shit = sj < 4 && sq >= q0 && sq < q1 && sq + 40 <= end_bits;
+    if (AHIP_ANY_HINT(shit)) {
+      AHIP_ASM_NOTE("stored block candidate");
+      // ... and the stored block it announces is followed by another one (same test where its data ends): the 2^-23 of
+      // random positions that pass the first test become 2^-46 -- a false find inside a chunk costs that chunk the
+      // tokens its sizing pass keeps (its area is cut short), so it has to be rare.  The last block of a stored stretch
+      // is not found; a chunk simply starts one block earlier.
+      if (shit) {
+        const u64 h0 = sm_bits64(in, in_len, sq);
+        const u64 q2 = sq + 40 + 8ull * (u32)((h0 >> 8) & 0xffffu);
+        shit = q2 + 40 <= end_bits;
+        if (shit) {
+          const u64 h1 = sm_bits64(in, in_len, q2);
+          shit = ((u32)h1 & 0xfeu) == 0 && ((((u32)(h1 >> 8)) ^ ((u32)(h1 >> 24))) & 0xffffu) == 0xffffu;
+        }
+      }
+    }
+    const u64 sm_ = __ballot(shit);
+    const u64 stored_at = sm_ ? lane_bcast64(sq, __builtin_ctzll(sm_)) : ~0ull;  // (lanes ascend with the position)
     // inside [q0, q1) and with the 29 bits a header needs at least
     if (wq < q0) m &= q0 - wq >= 32 ? 0u : ~0u << (u32)(q0 - wq);
     const u64 lastp1 = end_bits >= 29 ? end_bits - 28 : 0, hi = q1 < lastp1 ? q1 : lastp1;  // first position not to test
@@ -213,6 +243,10 @@ AHIP_DEVINL u64 sm_find_wave(SmFindLds &S, const u8 *__restrict__ in, u64 in_len
       qn += (u32)__popcll(pm);
       wave_sync();
       while (qn >= 64 && found == ~0ull) second();
+    }
+    if (stored_at != ~0ull) {  // nothing behind it matters: settle what is queued, the lower position wins
+      while (qn && found == ~0ull) second();
+      return found < stored_at ? found : stored_at;
     }
   }
   while (qn && found == ~0ull) second();
@@ -258,7 +292,7 @@ __global__ __launch_bounds__(64) void sm_tokenize_kernel(const u8 *__restrict__ 
     d.out_limit = uniform64(c.out_limit);
     d.expect_end = POS_UNKNOWN;
     d.in_end = 0;
-    ChunkCtx cx{cand_bits, n_cand, (u32)uniform64(c.start_bit) & 7, uniform(c.hist)};
+    ChunkCtx cx{cand_bits, n_cand, (u32)uniform64(c.start_bit) & 7, uniform(c.hist), k == 0 ? 1u : 0u};  // (chunk 0 = the stream's first bytes)
     TokSink sk{nullptr, 0, nullptr, 0, 0, ~0u, 0, 0, false};
     if (tokens) {
       u64 toff, doff;
@@ -333,10 +367,15 @@ __global__ __launch_bounds__(1024) void sm_windows_group(const ChunkDesc *__rest
   }
 }
 // gwin[g] = concrete window at the END of group g
-__global__ __launch_bounds__(1024) void sm_windows_link(u32 n_chunks, u32 group_size, const u16 *__restrict__ wsym, u8 *__restrict__ gwin) {
+// hist_win / hist0: the window in front of the whole stream -- element j = the byte 32768 - j in front of its first output
+// byte; only its last hist0 elements exist (what EARLIER gzip members wrote into the shared output, quirk q8; 0 for a
+// stream with an output of its own: nothing in front of it is ever referenced)
+AHIP_DEVINL u8 sm_hist_byte(const u8 *hist_win, u32 hist0, u32 j) { return j >= SM_WINDOW - hist0 ? hist_win[j] : (u8)0; }
+__global__ __launch_bounds__(1024) void sm_windows_link(u32 n_chunks, u32 group_size, const u16 *__restrict__ wsym, u8 *__restrict__ gwin,
+                                                        const u8 *hist_win, u32 hist0) {
   __shared__ u8 W[2][SM_WINDOW];
   const u32 tid = threadIdx.x, n_groups = (n_chunks + group_size - 1) / group_size;
-  for (u32 j = tid; j < SM_WINDOW; j += 1024) W[1][j] = 0;  // in front of the stream: never referenced
+  for (u32 j = tid; j < SM_WINDOW; j += 1024) W[1][j] = sm_hist_byte(hist_win, hist0, j);
   __syncthreads();
   for (u32 g = 0; g < n_groups; ++g) {
     const u32 last = (g + 1) * group_size - 1 < n_chunks ? (g + 1) * group_size - 1 : n_chunks - 1;
@@ -352,25 +391,25 @@ __global__ __launch_bounds__(1024) void sm_windows_link(u32 n_chunks, u32 group_
   }
 }
 __global__ __launch_bounds__(256) void sm_windows_apply(u32 group_size, const u16 *__restrict__ wsym, const u8 *__restrict__ gwin,
-                                                        u8 *__restrict__ windows) {
+                                                        u8 *__restrict__ windows, const u8 *hist_win, u32 hist0) {
   const u32 k = blockIdx.y, g = k / group_size;
   const u8 *in_win = g ? gwin + (u64)(g - 1) * SM_WINDOW : nullptr;
   for (u32 j = blockIdx.x * 256 + threadIdx.x; j < SM_WINDOW; j += gridDim.x * 256) {
     const u32 s = wsym[(u64)k * SM_WINDOW + j];
-    windows[(u64)k * SM_WINDOW + j] = s < SYM_MARK ? (u8)s : (in_win ? in_win[s - SYM_MARK] : (u8)0);
+    windows[(u64)k * SM_WINDOW + j] = s < SYM_MARK ? (u8)s : (in_win ? in_win[s - SYM_MARK] : sm_hist_byte(hist_win, hist0, s - SYM_MARK));
   }
 }
 
 // symbols -> bytes, every chunk with the window of the chunk before it
 __global__ __launch_bounds__(256) void sm_translate_kernel(const ChunkDesc *__restrict__ chunks, const MemberResult *__restrict__ results,
                                                            const u16 *__restrict__ sym, const u8 *__restrict__ windows,
-                                                           u8 *__restrict__ out) {
+                                                           u8 *__restrict__ out, const u8 *hist_win, u32 hist0) {
   const u32 k = blockIdx.y;
   const u64 off = chunks[k].out_off, len = results[k].out_len;
-  const u8 *w = k ? windows + (u64)(k - 1) * SM_WINDOW : windows;
+  const u8 *w = k ? windows + (u64)(k - 1) * SM_WINDOW : nullptr;  // chunk 0: the window in front of the stream
   for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < len; i += (u64)gridDim.x * 256) {
     const u32 s = sym[off + i];
-    out[off + i] = s < SYM_MARK ? (u8)s : w[s - SYM_MARK];
+    out[off + i] = s < SYM_MARK ? (u8)s : (w ? w[s - SYM_MARK] : sm_hist_byte(hist_win, hist0, s - SYM_MARK));
   }
 }
 

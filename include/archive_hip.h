@@ -110,6 +110,9 @@ int32_t ahip_gzip_decode_shards(uint32_t n_shards, const int32_t *devices, const
                                 int32_t *status);
 /* Diagnostics: how the last ahip_gzip_decode_shards() exchanged the sizes (1 = RCCL all-gather, 0 = host sums). */
 int32_t ahip_debug_last_exchange(void);
+/* Diagnostics: chunks the calling thread's last long stream (one DEFLATE stream of >= 2 MiB: ahip_inflate_raw, a zlib
+ * stream, a long gzip member) was decoded in by the many-waves path; 0 = it went to the one-wave path. */
+int32_t ahip_debug_last_chunks(void);
 
 /* Plan/run split of the same path: the plan holds the member index (payload offsets, output
  * offsets) in device memory, so repeated runs time only the decode (bench.py times run). */

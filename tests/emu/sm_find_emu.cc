@@ -1,7 +1,7 @@
 // sm_find_emu.cc -- the block finder of the single-long-member path (sm_find_wave of sm_inflate.hpp: bit-parallel
-// filter, Kraft filter, header filter) on the CPU wave emulation, against the plain statement of what it looks for:
-// the first bit position in [q0, q1) where BTYPE == 2, HLIT / HDIST <= 29, the code-length code is complete and
-// sm_header_plausible() agrees.  Test infrastructure only.
+// filter, Kraft filter, header filter; stored blocks on byte boundaries) on the CPU wave emulation, against the plain
+// statement of what it looks for: the first bit position in [q0, q1) where BTYPE == 2, HLIT / HDIST <= 29, the code-length
+// code is complete and sm_header_plausible() agrees -- or where a byte 0 / 1 is followed by LEN and ~LEN.  Test infrastructure only.
 //
 //   g++ -std=c++17 -O2 -pthread -o sm_find_emu tests/emu/sm_find_emu.cc
 //   sm_find_emu <raw deflate stream> <ranges: q0 q1 pairs, decimal, whitespace separated>
@@ -23,6 +23,17 @@ template <class F> static void wave(F f) {
   for (auto &x : th) x.join();
 }
 static bool plain_test(const u8 *in, u64 n, u64 q) {
+  // a stored block on a byte boundary: header byte 0 / 1, LEN, ~LEN
+  if ((q & 7) == 0 && q + 40 <= n * 8) {
+    const u8 *p = in + (q >> 3);
+    if ((p[0] & 0xfe) == 0 && ((p[1] ^ p[3]) & 0xff) == 0xff && ((p[2] ^ p[4]) & 0xff) == 0xff) {
+      const u64 q2 = q + 40 + 8ull * (p[1] | ((u32)p[2] << 8));  // ... followed by another stored block
+      if (q2 + 40 <= n * 8) {
+        const u8 *r = in + (q2 >> 3);
+        if ((r[0] & 0xfe) == 0 && ((r[1] ^ r[3]) & 0xff) == 0xff && ((r[2] ^ r[4]) & 0xff) == 0xff) return true;
+      }
+    }
+  }
   if (q + 29 > n * 8) return false;
   const u64 v = sm_bits64(in, n, q);
   if (((v >> 1) & 3) != 2) return false;

@@ -111,3 +111,20 @@ def test_encoder_framing(amd, orc):
     assert zlib.decompress(amd.ZLibEncoder().encode_bytes(d, raw=True), -15) == d
     # cross test of test/gzip_test.dart:16-42: encoder -> decoder both ways
     assert amd.GZipDecoder().decode_bytes(orc.gzip_encode(d, 6)) == d
+
+
+def test_two_encodes_are_byte_identical(amd):
+    """The reference is one sequential pass (deflate.dart:997-1118): the same input gives the same bytes.  Here positions
+    are inserted into the match tables a whole step at a time by many waves; which of several same-slot writers stays is
+    DEFINED (the lowest position of the step, an LDS atomicMax on a step-reversed key), not left to the order the hardware
+    serves the waves in -- so archives are reproducible and callers may compare compressed bytes."""
+    from tools import corpus
+    data = bytes(corpus.text(corpus.LOG, 1234, 0, 3 << 20)) + streams.text(400000, 5) + bytes(200000) + bytes(corpus.text(corpus.WIKI, 8, 0, 1 << 20))
+    for level in (1, 4, 6, 9):
+        for wb in (15, 11):
+            first = amd.Deflate(data, level=level, window_bits=wb).get_bytes()
+            assert zlib.decompress(first, -15) == data
+            for _ in range(3):
+                assert amd.Deflate(data, level=level, window_bits=wb).get_bytes() == first, (level, wb)
+    g1 = amd.GZipEncoder().encode_bytes(data, mtime=1)
+    assert all(amd.GZipEncoder().encode_bytes(data, mtime=1) == g1 for _ in range(2))

@@ -276,6 +276,39 @@ def test_back_reference_into_a_long_member(amd, orc):
         assert _gz(amd, c) == want, i
 
 
+def test_long_member_reaching_into_earlier_members(amd, orc):
+    """q8 ON a long member (>= 2 MiB compressed: the chunked path): its back-references reach into what the members in front
+    of it wrote -- the reference appends all members to one OutputStream (_gzip_decoder_web.dart:27-41,
+    output_memory_stream.dart:79-98), so that is legal there.  The stream is made with a preset dictionary = the tail of
+    the output in front of the member: its first matches copy from there.  Also an ordinary member behind it that reaches
+    back into IT, a second long member, and a reach that goes in front of the whole output (the reference's RangeError)."""
+    import random
+    rnd = random.Random(7)
+    words = [bytes(rnd.getrandbits(8) for _ in range(rnd.randrange(3, 9))) for _ in range(6000)]
+    front = b" ".join(rnd.choice(words) for _ in range(9000))            # ~ 58 KB in front of the long member
+    big = b" ".join(rnd.choice(words) for _ in range(900000))            # ~ 5.8 MB, compresses to > 2 MiB
+
+    def member_with_history(data, history, level=1):
+        co = zlib.compressobj(level, zlib.DEFLATED, -15, 9, zlib.Z_DEFAULT_STRATEGY, history[-32768:])
+        raw = co.compress(data) + co.flush()
+        return streams.gz_wrap(raw, data)
+
+    long_q8 = member_with_history(front[-20000:] + big, front)           # starts by copying 20 000 bytes out of `front`
+    assert len(long_q8) > (2 << 20) + 4096
+    far = streams.gz_wrap(streams.raw_far_reference())
+    small = streams.text(30000, 9)
+    cases = [streams.gz_member(front) + long_q8,
+             streams.gz_member(small) + streams.gz_member(front) + long_q8 + far + streams.gz_member(small[:999]),
+             streams.gz_member(front) + long_q8 + member_with_history(big[-5000:] + big[:3000000], front[-20000:] + big),
+             streams.gz_member(front[-9000:]) + long_q8]                 # reaches in front of the whole output: RangeError
+    for i, c in enumerate(cases):
+        want = _noneify(orc.gzip_decode(c, cap=3 * len(big) + (1 << 20)))
+        assert want[0] == (2 if i == 3 else 0), (i, want[0])
+        if i < 3:
+            assert front[-20000:] + big[:1000] in want[1]
+        assert _gz(amd, c) == want, i
+
+
 def test_over_subscribed_code_lengths(amd, orc):
     """HuffmanTable never checks the Kraft sum (_huffman_table.dart:24-45): later codes overwrite earlier ones."""
     raw = streams.oversubscribed_dynamic_block()

@@ -82,3 +82,33 @@ def test_damaged_long_streams_keep_reference_verdicts(native_built, corpora):
         except errors.ArchiveHipError:
             continue  # over-subscribed code lengths: reported, not reproduced
         assert got == ((2, None) if ost == 2 else (ost, oout)), (i, got[0], ost)
+
+
+def test_which_path_ran(native_built, corpora):
+    """The many-waves path engages where it should (ahip_debug_last_chunks): text of dynamic blocks, an incompressible
+    stretch of stored blocks back to back (the block finder knows their starts: byte 0 / 1, LEN, ~LEN -- ref
+    inflate.dart:213-237), a mix of both; a Z_FIXED stream has no block start the finder could recognise and goes to one
+    wave -- stated, not hidden."""
+    import archive_amd
+    from archive_amd import _native as N
+    L = N.lib()
+    assert L.ahip_init(0) == 0
+    rnd = random.Random(9)
+    noise = rnd.randbytes(6 << 20)                       # zlib stores it: ~ 96 stored blocks of 65 535 bytes
+    raw_noise = _raw(noise)
+    pos, nstored = 0, 0
+    while pos + 5 <= len(raw_noise) and raw_noise[pos] in (0, 1):  # (the blocks really are stored ones, back to back)
+        ln = raw_noise[pos + 1] | (raw_noise[pos + 2] << 8)
+        assert ln ^ (raw_noise[pos + 3] | (raw_noise[pos + 4] << 8)) == 0xffff
+        pos += 5 + ln
+        nstored += 1
+    assert nstored >= 90 and pos == len(raw_noise)
+    for name, data, raw in (("text", corpora["log"], _raw(corpora["log"])), ("stored", noise, raw_noise),
+                            ("mixed", corpora["mixed"], _raw(corpora["mixed"]))):
+        assert archive_amd.Inflate(raw).get_bytes() == data, name
+        assert L.ahip_debug_last_chunks() >= 16, (name, L.ahip_debug_last_chunks())
+    g = gzip.compress(noise, 6, mtime=0)
+    assert archive_amd.GZipDecoder().decode_bytes(g) == noise and L.ahip_debug_last_chunks() >= 16
+    fixed = _raw(corpora["log"], strategy=zlib.Z_FIXED)
+    assert archive_amd.Inflate(fixed).get_bytes() == corpora["log"]
+    assert L.ahip_debug_last_chunks() == 0

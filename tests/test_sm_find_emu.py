@@ -28,9 +28,13 @@ def emu():
     return exe
 
 
-@pytest.mark.parametrize("kind,level", [(corpus.WIKI, 6), (corpus.LOG, 9)])
+@pytest.mark.parametrize("kind,level", [(corpus.WIKI, 6), (corpus.LOG, 9), ("incompressible", 6)])
 def test_finder_matches_a_plain_scan(emu, tmp_path, kind, level):
-    data = bytes(corpus.text(kind, 8, 0, 2 << 20))
+    if kind == "incompressible":  # stored blocks back to back, text in between: the stored-block starts of the finder
+        rnd0 = random.Random(3)
+        data = b"".join(rnd0.randbytes(300000) + bytes(corpus.text(corpus.LOG, 8, i, 100000)) for i in range(5))
+    else:
+        data = bytes(corpus.text(kind, 8, 0, 2 << 20))
     co = zlib.compressobj(level, zlib.DEFLATED, -15)
     raw = co.compress(data) + co.flush()
     p = tmp_path / "s.deflate"

@@ -7,7 +7,11 @@ from tools import corpus
 N.lib().ahip_init(0)
 mb = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 kind = corpus.WIKI if (len(sys.argv) > 2 and sys.argv[2] == "wiki") else corpus.LOG
-data = bytes(corpus.text(kind, 8, 0, mb << 20))
+if len(sys.argv) > 2 and sys.argv[2] == "noise":  # incompressible: zlib stores it, block after block
+    import random
+    data = random.Random(9).randbytes(mb << 20)
+else:
+    data = bytes(corpus.text(kind, 8, 0, mb << 20))
 c = zlib.compressobj(6, zlib.DEFLATED, -15)
 raw = c.compress(data) + c.flush()
 print("raw deflate: %d -> %d bytes" % (len(data), len(raw)))
@@ -32,7 +36,7 @@ for it in range(3):
     torch.cuda.synchronize(); t = time.perf_counter()
     rc = N.lib().ahip_gzip_decode_device(d_in.data_ptr(), d_in.numel(), d_out.data_ptr(), d_out.numel(), ctypes.byref(olen), None)
     torch.cuda.synchronize(); dt = time.perf_counter() - t
-    print("gzip_decode_device: rc %d %.1f ms  %.2f GB/s out" % (rc, dt * 1e3, olen.value / dt / 1e9))
+    print("gzip_decode_device: rc %d %.1f ms  %.2f GB/s out  (chunks: %d)" % (rc, dt * 1e3, olen.value / dt / 1e9, N.lib().ahip_debug_last_chunks()))
 print("device bytes ok:", bytes(d_out[:olen.value].cpu().numpy()) == data)
 os.environ["AHIP_NO_SM"] = "1"
 t = time.perf_counter(); out = archive_amd.Inflate(raw).get_bytes(); dt = time.perf_counter() - t
