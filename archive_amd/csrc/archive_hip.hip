@@ -1376,8 +1376,20 @@ uint32_t ahip_adler32(const uint8_t *data, size_t len, uint32_t adler) {
 static bool bz_parallel_huffman() { return getenv("AHIP_BZ_SERIAL_HUFFMAN") == nullptr; }  // (read per call: the tests switch it)
 // bzip2 on device memory.  `in` = the first bytes of the stream on the host (header checks), d_in = the whole
 // stream on the device, d_out = device output of out_cap bytes.
+// sh (sharded decode, ahip_bzip2_decode_shards): this call decodes only the blocks among candidates
+// [ncand * index / count, ncand * (index + 1) / count) of the stream -- every device scans the whole (small) compressed
+// stream for block magics, so all agree on the list -- and reports what the caller needs to merge the shards in order:
+// how its part of the chain ended, and the fold of its block CRCs (the stream CRC is rotl-xor over the blocks: linear).
+struct BzShard {
+  u32 index = 0, count = 1;
+  u64 nblocks = 0;       // block CRCs folded
+  u32 fold = 0;          // combined CRC of those blocks, starting from 0
+  bool saw_eos = false;  // met the end-of-stream block
+  u32 eos_stored = 0;
+  bool stopped = false;  // the stream ended inside this shard (end-of-stream block, clean end of input, or a verdict)
+};
 static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, int32_t verify, u8 *d_out, size_t out_cap,
-                                 size_t *out_len) {
+                                 size_t *out_len, BzShard *sh = nullptr) {
   if (out_len) *out_len = 0;
   // BZh + level, read through the bit reader: fewer than 4 bytes is a RangeError in the reference
   if (in_len < 4) {
@@ -1406,8 +1418,11 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
   std::sort(cands.begin(), cands.end(), [](const BzCand &a, const BzCand &b) { return a.bit < b.bit; });
   // the first block type is read at bit 32; anything else there is "Invalid Block Signature"
   if (ncand == 0 || cands[0].bit != 32) {
+    if (sh) sh->stopped = true;
     return in_len * 8 < 32 + 48 ? AHIP_RANGE : AHIP_FALSE;
   }
+  const size_t c_lo = sh ? (size_t)((u64)ncand * sh->index / sh->count) : 0, c_hi = sh ? (size_t)((u64)ncand * (sh->index + 1) / sh->count) : ncand;
+  if (c_lo >= c_hi) return AHIP_OK;  // (more shards than blocks)
   HIP_TRY(hipMemcpy(dcand.p, cands.data(), (size_t)ncand * sizeof(BzCand), hipMemcpyHostToDevice));
   const u64 nblock_max = 100000ull * (u64)level;
   const u64 wstride = nblock_max / BZ_G + 2;
@@ -1426,7 +1441,7 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
   }
   if (const char *e = getenv("AHIP_BZ_BATCH_BYTES")) { if (atoll(e) > 0) batch_mem = (u64)atoll(e); }
   const u64 j50_per_block = bz_parallel_huffman() ? (u64)in_len * 8 / std::max<u32>(1, ncand) * 12 : 0;  // 6 tables x 2 bytes per bit
-  u32 batch = (u32)std::min<u64>(ncand, std::max<u64>(4, batch_mem / (per_block + j50_per_block)));
+  u32 batch = (u32)std::min<u64>(c_hi - c_lo, std::max<u64>(4, batch_mem / (per_block + j50_per_block)));
   static thread_local DevBuf dsyms, dlist0, dchunks, dperms, dlists, dchoff, dtab, dj50, dgstart, dgcount;
   // the work memory of one batch; a device that cannot spare it gets smaller batches, not an error
   auto reserve_batch = [&](u32 b) -> hipError_t {
@@ -1484,10 +1499,11 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
   int32_t verdict = AHIP_OK;
   bool saw_eos = false, stopped = false, crc_stop = false, over_cap = false;
   u32 eos_stored = 0, combined = 0;
-  size_t next = 0;      // candidate the chain expects next
-  for (size_t c0 = 0; c0 < ncand && !stopped; c0 += batch) {
+  size_t next = c_lo;   // candidate the chain expects next
+  u64 folded = 0;       // block CRCs folded into `combined`
+  for (size_t c0 = c_lo; c0 < c_hi && !stopped && next < c_hi; c0 += batch) {
     if (next >= c0 + batch) continue;  // the chain has already stepped over this whole batch (false magics inside data)
-    const u32 nb = (u32)std::min<size_t>(batch, ncand - c0);
+    const u32 nb = (u32)std::min<size_t>(batch, c_hi - c0);
     const BzCand *dc = dcand.as<BzCand>() + c0;
     // phase 1: the Huffman side of every block (one wave each) -> symbol streams; what the symbols mean by chunks
     const u64 bit0 = cands[c0].bit, bit1 = c0 + nb < ncand ? cands[c0 + nb].bit : (u64)in_len * 8;
@@ -1594,6 +1610,7 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
           break;
         }
         combined = ((combined << 1) | (combined >> 31)) ^ crc;
+        ++folded;
         keep = pl.off + pl.len;
       }
     }
@@ -1609,6 +1626,10 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
   }
 #endif
   if (over_cap) { if (out_len) *out_len = total; return fail(AHIP_E_CAP, "output buffer too small"); }
+  if (sh) {  // the caller merges the shards: the end-of-stream CRC is checked there
+    sh->nblocks = folded; sh->fold = combined; sh->saw_eos = saw_eos; sh->eos_stored = eos_stored;
+    sh->stopped = stopped || verdict != AHIP_OK;
+  } else
   if (saw_eos && verify && eos_stored != combined && verdict == AHIP_OK) verdict = AHIP_FALSE;
   if (out_len) *out_len = crc_stop ? keep : total;
   return verdict;
@@ -1648,6 +1669,9 @@ int32_t ahip_bzip2_decode(const uint8_t *in, size_t in_len, int32_t verify, uint
   return rc;
 }
 
+int32_t ahip_bzip2_decode_shards(uint32_t n_shards, const int32_t *devices, const void *const *d_in, size_t in_len, int32_t verify,
+                                 void *const *d_out, const size_t *out_cap, size_t *out_len, uint64_t *offsets, int32_t *status);
+
 size_t ahip_decode_bound(const uint8_t *in, size_t in_len) {
   // walk the members through their BC subfields (FEXTRA {'B','C',2,0,BSIZE-1}); anything else: unknown
   size_t pos = 0, total = 0, members = 0;
@@ -1679,11 +1703,13 @@ size_t ahip_deflate_bound(size_t in_len) {
 }
 
 // Deflate on device memory.  Returns the compressed size through *out_len.
+// open: the input is a shard of a longer one and not its last (DeflateParams::open): no final block, ends on a byte boundary
 static int32_t deflate_device_impl(const u8 *d_in, size_t n, int level, int window_bits, u8 *d_out, size_t cap, size_t *out_len,
-                                   hipStream_t st) {
+                                   hipStream_t st, bool open = false) {
   static thread_local DevBuf b_match, b_tok, b_ntok, b_slabs, b_csize, b_coff;
   if (out_len) *out_len = 0;
   if (level < 0 || level > 9 || window_bits < 9 || window_bits > 15) return AHIP_OK;  // the reference's _init fails silently: no output (deflate.dart:105-115)
+  if (n == 0 && open) return AHIP_OK;  // an empty shard in the middle adds nothing
   if (n == 0) {  // reference: one fixed-Huffman block holding only the end-of-block code (level >= 1), or an empty stored block
     const u8 fixed_empty[2] = {0x03, 0x00}, stored_empty[5] = {0x01, 0x00, 0x00, 0xff, 0xff};
     const u8 *src = level == 0 ? stored_empty : fixed_empty;
@@ -1702,6 +1728,7 @@ static int32_t deflate_device_impl(const u8 *d_in, size_t n, int level, int wind
   P.max_cmp = 258;
   P.max_dist = (1u << window_bits) - 262;
   P.nice = level <= 3 ? DF_CAP : (level <= 6 ? 128u : 258u);
+  P.open = open ? 1u : 0u;
   HIP_TRY(b_match.reserve(n * 4 + 64 + (size_t)P.chunks * 32 + 64));
   HIP_TRY(b_tok.reserve(n * 4 + 64));
   HIP_TRY(b_ntok.reserve((size_t)P.chunks * 4));
@@ -2176,15 +2203,51 @@ bool walk_bc_members(const uint8_t *in, size_t n, std::vector<GzMember> &ms) {
   return !ms.empty();
 }
 
+// Members WITHOUT size hints (an ordinary `cat a.gz b.gz`: the reference's header parser skips FEXTRA anyway,
+// _gzip_decoder_web.dart:119-122): where they begin and end is only known after inflating them.  One device does that
+// sizing pass for the whole stream (member index + a store-less run of the tokenizer: plan_build), the table it yields
+// is what the contexts then partition -- each decodes its slice from its own upload.  Only a clean chain qualifies
+// (every member complete and sound, nothing behind the last one, no member long enough for the chunked path); anything
+// else is left to the exact single-context path.
+bool size_members_on_device(const uint8_t *in, size_t in_len, std::vector<GzMember> &ms) {
+  static thread_local DevBuf din;
+  if (din.reserve(in_len + 16) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (hipMemcpy(din.p, in, in_len, hipMemcpyHostToDevice) != hipSuccess) return false;
+  ahip_gzip_plan pl;
+  pl.d_in = din.as<u8>();
+  pl.in_len = in_len;
+  if (plan_build(&pl, false, nullptr) != AHIP_OK) return false;
+  const u64 M = pl.sum.members;
+  if (!pl.sum.first_is_gzip || M < 2 || pl.sum.range_error || pl.sum.tail_pos != in_len || !pl.big.empty() || !pl.sized) return false;
+  std::vector<MemberDesc> md(M);
+  std::vector<u64> cp(pl.K);
+  std::vector<u32> ex(M);
+  if (copy_on(md.data(), pl.members.p, M * sizeof(MemberDesc), hipMemcpyDeviceToHost, nullptr) != hipSuccess ||
+      copy_on(cp.data(), pl.cand_pos.p, (size_t)pl.K * 8, hipMemcpyDeviceToHost, nullptr) != hipSuccess ||
+      copy_on(ex.data(), pl.expect_status.p, M * 4, hipMemcpyDeviceToHost, nullptr) != hipSuccess) return false;
+  ms.clear();
+  for (u64 m = 0; m < M; ++m) {
+    if (ex[m] != MS_OK || md[m].pad >= pl.K || md[m].expect_end == POS_UNKNOWN || md[m].out_limit > 0xffffffffull) return false;
+    const u64 begin = cp[md[m].pad], end = md[m].expect_end + 8;
+    if (end > in_len || end <= begin || (m && begin != ms.back().end)) return false;
+    ms.push_back({(size_t)begin, (size_t)end, (uint32_t)md[m].out_limit});
+  }
+  return !ms.empty() && ms.front().begin == 0 && ms.back().end == in_len;
+}
+
 // returns true when the sharded path produced the final answer in *rc_out.  The stream is cut into `per` slices per
 // context (contiguous member ranges balanced on compressed bytes, sharding.partition_members); context w takes slices
 // w, w + W, ... one after the other, so that while it downloads one slice the others upload and decode theirs.
 bool gzip_decode_sharded(std::vector<std::unique_ptr<Worker>> &set, size_t per, const uint8_t *in, size_t in_len, int32_t verify, uint8_t *out,
-                         size_t out_cap, size_t *out_len, int32_t *rc_out) {
+                         size_t out_cap, size_t *out_len, int32_t *rc_out, bool may_size) {
   const size_t W = set.size();
   if (W < 2 || in_len < (4u << 20)) return false;
   std::vector<GzMember> ms;
-  if (!walk_bc_members(in, in_len, ms) || ms.size() < 2 * W) return false;
+  if (!walk_bc_members(in, in_len, ms)) {
+    ms.clear();
+    if (!may_size || !size_members_on_device(in, in_len, ms)) return false;
+  }
+  if (ms.size() < 2 * W) return false;
   size_t S = W * per;
   while (S > W && ms.size() < 2 * S) S -= W;
   std::vector<size_t> bounds{0};
@@ -2369,6 +2432,153 @@ void rccl_drop() { if (g_rccl.ok) g_rccl.drop(); }
 int32_t ahip_debug_last_exchange(void) { return g_last_exchange; }
 int32_t ahip_debug_last_chunks(void) { return g_last_chunks; }
 
+// ---- the one exchange of the sharded calls: sizes -> offsets (exclusive prefix sum), offsets[n] = the total ----
+// an all-gather of one uint64 per device over RCCL when the shards sit on distinct devices, host sums otherwise
+static void exchange_sizes(uint32_t n_shards, const int32_t *devices, const size_t *got, uint64_t *offsets, int cur_device) {
+  std::vector<u64> sizes(n_shards), all;
+  for (u32 s = 0; s < n_shards; ++s) sizes[s] = got[s];
+  g_last_exchange = 0;
+  bool distinct = true;
+  std::vector<int> devs(devices, devices + n_shards);
+  for (u32 a = 0; a < n_shards; ++a) for (u32 b = a + 1; b < n_shards; ++b) if (devs[a] == devs[b]) distinct = false;
+  const char *no = getenv("AHIP_NO_RCCL");
+  if (distinct && !(no && no[0] == '1') && g_rccl.prepare(devs) && g_rccl.all_gather(sizes, all)) g_last_exchange = 1;
+  else all = sizes;
+  (void)hipSetDevice(cur_device);
+  u64 acc = 0;
+  for (u32 s = 0; s < n_shards; ++s) { offsets[s] = acc; acc += all[s]; }
+  offsets[n_shards] = acc;
+}
+// which worker context takes shard s (-1: the calling thread); false = a device ahip_init_devices() did not select
+static bool shard_workers(uint32_t n_shards, const int32_t *devices, int cur, std::vector<int> &wk) {
+  wk.assign(n_shards, -1);
+  for (u32 s = 0; s < n_shards; ++s) {
+    if (g_workers.empty()) {
+      if (devices[s] != cur) return false;
+      continue;
+    }
+    // contexts of the same device (AHIP_FAKE_DEVICES) are dealt out round robin
+    int pick = -1, seen = 0;
+    for (size_t w = 0; w < g_workers.size(); ++w)
+      if (g_workers[w]->device == devices[s]) { if (pick < 0 || seen <= (int)(s % g_workers.size())) pick = (int)w; ++seen; }
+    if (pick < 0) return false;
+    wk[s] = pick;
+  }
+  return true;
+}
+// run_shard(s) for every shard: on the calling thread when no workers exist, else every worker takes its shards in order
+// and the workers run side by side.  The workers are this call's until they are done (g_shards_mu); g_mu is let go
+// meanwhile -- the shards run in the workers' own thread-local contexts, nothing of the process-wide state g_mu guards
+// is touched -- and taken again afterwards.
+static void run_shards(uint32_t n_shards, const std::vector<int> &wk, const std::function<void(u32)> &run_shard,
+                       std::unique_lock<std::recursive_mutex> &lk) {
+  if (g_workers.empty()) {
+    for (u32 s = 0; s < n_shards; ++s) run_shard(s);
+    return;
+  }
+  std::unique_lock<std::mutex> use(g_shards_mu);
+  std::vector<Worker *> ws;
+  for (auto &w : g_workers) ws.push_back(w.get());
+  lk.unlock();
+  for (size_t w = 0; w < ws.size(); ++w) {
+    std::vector<u32> mine;
+    for (u32 s = 0; s < n_shards; ++s) if (wk[s] == (int)w) mine.push_back(s);
+    ws[w]->submit([mine, &run_shard] { for (u32 s : mine) run_shard(s); });
+  }
+  for (Worker *w : ws) w->wait();
+  use.unlock();
+  lk.lock();
+}
+
+// Deflate of ONE input cut into shards (ref: deflate.dart:219 -- the byte-aligning empty stored block
+// `_trStoredBlock(0, 0, false)` the reference itself emits as a flush marker is what lets independently compressed pieces
+// be spliced): shard s (any length; the caller cuts, multiples of 32 KiB lose nothing) is compressed by the context of
+// its device into d_out[s]; every shard but the last ends with that marker instead of a final block, so the
+// concatenation of the shards' outputs at offsets[] is one raw DEFLATE stream of the concatenated input.  A match
+// never reaches into another shard (its 32 KiB of history start afresh).  crc32s (may be NULL): CRC-32 of every
+// shard's INPUT, taken on its device -- what a gzip trailer is combined from.  The exchange is the size all-gather.
+int32_t ahip_deflate_shards(uint32_t n_shards, const int32_t *devices, const void *const *d_in, const size_t *in_len, int32_t level,
+                            int32_t window_bits, void *const *d_out, const size_t *out_cap, size_t *out_len, uint64_t *offsets,
+                            uint32_t *crc32s) {
+  std::unique_lock<std::recursive_mutex> lk(g_mu);
+  int32_t rc = ensure_init();
+  if (rc != AHIP_OK) return rc;
+  if (n_shards == 0 || !devices || !d_in || !in_len || !d_out || !out_cap || !out_len || !offsets) return fail(AHIP_E_ARG, "NULL shard table");
+  int cur = 0;
+  HIP_TRY(hipGetDevice(&cur));
+  std::vector<int> wk;
+  if (!shard_workers(n_shards, devices, cur, wk)) return fail(AHIP_E_ARG, "shard on a device that ahip_init_devices() did not select");
+  std::vector<int32_t> rcs(n_shards, AHIP_OK);
+  std::vector<std::string> errs(n_shards);
+  std::vector<size_t> got(n_shards, 0);
+  // (the reference's silent no-op on invalid parameters: every shard produces nothing)
+  std::function<void(u32)> run_shard = [&](u32 s) {
+    rcs[s] = deflate_device_impl((const u8 *)d_in[s], in_len[s], level, window_bits, (u8 *)d_out[s], out_cap[s], &got[s], g_ctx_stream, s + 1 < n_shards);
+    if (rcs[s] == AHIP_OK && crc32s) rcs[s] = crc32_device_impl((const u8 *)d_in[s], in_len[s], 0, &crc32s[s], g_ctx_stream);
+    if (rcs[s] < 0) errs[s] = g_err;
+  };
+  run_shards(n_shards, wk, run_shard, lk);
+  int32_t worst = AHIP_OK;
+  for (u32 s = 0; s < n_shards; ++s) {
+    out_len[s] = got[s];
+    if (rcs[s] < 0 && worst >= 0) { worst = rcs[s]; g_err = "shard " + std::to_string(s) + ": " + errs[s]; }
+  }
+  exchange_sizes(n_shards, devices, got.data(), offsets, cur);
+  return worst;
+}
+
+// BZip2 blocks are independent once their bit positions are known (ref: bzip2_decoder.dart:20-88 walks them one after the
+// other): shard s decodes the blocks among candidates [K s / n, K (s + 1) / n) of the stream -- d_in[s] is a copy of the
+// WHOLE compressed stream on its device (blocks start at arbitrary bit positions; the compressed stream is the small side)
+// -- into d_out[s].  The shards are merged in stream order exactly like decodeStream: the first verdict that is not OK,
+// or the end-of-stream block, ends the stream (shards behind it count for nothing: out_len 0); block CRCs fold into the
+// stream CRC linearly, so every shard reports its own fold.  offsets[] from the size exchange.
+int32_t ahip_bzip2_decode_shards(uint32_t n_shards, const int32_t *devices, const void *const *d_in, size_t in_len, int32_t verify,
+                                 void *const *d_out, const size_t *out_cap, size_t *out_len, uint64_t *offsets, int32_t *status) {
+  std::unique_lock<std::recursive_mutex> lk(g_mu);
+  int32_t rc = ensure_init();
+  if (rc != AHIP_OK) return rc;
+  if (n_shards == 0 || !devices || !d_in || !d_out || !out_cap || !out_len || !offsets) return fail(AHIP_E_ARG, "NULL shard table");
+  int cur = 0;
+  HIP_TRY(hipGetDevice(&cur));
+  std::vector<int> wk;
+  if (!shard_workers(n_shards, devices, cur, wk)) return fail(AHIP_E_ARG, "shard on a device that ahip_init_devices() did not select");
+  std::vector<int32_t> rcs(n_shards, AHIP_OK);
+  std::vector<std::string> errs(n_shards);
+  std::vector<size_t> got(n_shards, 0);
+  std::vector<BzShard> shs(n_shards);
+  std::function<void(u32)> run_shard = [&](u32 s) {
+    u8 hdr[4] = {0, 0, 0, 0};
+    if (in_len && hipMemcpy(hdr, d_in[s], in_len < 4 ? in_len : 4, hipMemcpyDeviceToHost) != hipSuccess) { rcs[s] = AHIP_E_DEVICE; errs[s] = "header read-back"; return; }
+    shs[s].index = s; shs[s].count = n_shards;
+    rcs[s] = bzip2_device_impl(hdr, (const u8 *)d_in[s], in_len, verify, (u8 *)d_out[s], out_cap[s], &got[s], &shs[s]);
+    if (rcs[s] < 0) errs[s] = g_err;
+  };
+  run_shards(n_shards, wk, run_shard, lk);
+  // merge in stream order
+  int32_t worst = AHIP_OK;
+  bool ended = false, saw_eos = false;
+  u32 combined = 0, eos_stored = 0;
+  for (u32 s = 0; s < n_shards; ++s) {
+    if (ended) { got[s] = 0; if (status) status[s] = AHIP_OK; out_len[s] = 0; continue; }
+    out_len[s] = got[s];
+    if (status) status[s] = rcs[s];
+    const u32 r = (u32)(shs[s].nblocks & 31);
+    combined = (r ? ((combined << r) | (combined >> (32 - r))) : combined) ^ shs[s].fold;
+    if (rcs[s] != AHIP_OK) {
+      if (rcs[s] < 0) g_err = "shard " + std::to_string(s) + ": " + errs[s];
+      worst = rcs[s];
+      ended = true;
+    } else if (shs[s].stopped) {
+      ended = true;
+      saw_eos = shs[s].saw_eos; eos_stored = shs[s].eos_stored;
+    }
+  }
+  if (saw_eos && verify && eos_stored != combined && worst == AHIP_OK) worst = AHIP_FALSE;
+  exchange_sizes(n_shards, devices, got.data(), offsets, cur);
+  return worst;
+}
+
 int32_t ahip_gzip_decode_shards(uint32_t n_shards, const int32_t *devices, const void *const *d_in, const size_t *in_len,
                                 void *const *d_out, const size_t *out_cap, size_t *out_len, uint64_t *offsets, int32_t *status) {
   std::unique_lock<std::recursive_mutex> lk(g_mu);
@@ -2379,45 +2589,16 @@ int32_t ahip_gzip_decode_shards(uint32_t n_shards, const int32_t *devices, const
   HIP_TRY(hipGetDevice(&cur));
   // a shard runs in the context of its device: worker k of ahip_init_devices (several shards of one device take turns),
   // or this thread when no workers exist and the shard sits on the current device
-  std::vector<int> wk(n_shards, -1);
-  for (u32 s = 0; s < n_shards; ++s) {
-    if (g_workers.empty()) {
-      if (devices[s] != cur) return fail(AHIP_E_ARG, "shard on a device that ahip_init_devices() did not select");
-      continue;
-    }
-    // contexts of the same device (AHIP_FAKE_DEVICES) are dealt out round robin
-    int pick = -1, seen = 0;
-    for (size_t w = 0; w < g_workers.size(); ++w)
-      if (g_workers[w]->device == devices[s]) { if (pick < 0 || seen <= (int)(s % g_workers.size())) pick = (int)w; ++seen; }
-    if (pick < 0) return fail(AHIP_E_ARG, "shard on a device that ahip_init_devices() did not select");
-    wk[s] = pick;
-  }
+  std::vector<int> wk;
+  if (!shard_workers(n_shards, devices, cur, wk)) return fail(AHIP_E_ARG, "shard on a device that ahip_init_devices() did not select");
   std::vector<int32_t> rcs(n_shards, AHIP_OK);
   std::vector<std::string> errs(n_shards);
   std::vector<size_t> got(n_shards, 0);
-  auto run_shard = [&](u32 s) {  // (on a worker: its own non-blocking stream; on the caller's thread: the default stream)
+  std::function<void(u32)> run_shard = [&](u32 s) {  // (on a worker: its own non-blocking stream; on the caller's thread: the default stream)
     rcs[s] = gzip_decode_impl(nullptr, (const u8 *)d_in[s], in_len[s], 0, 0, (u8 *)d_out[s], out_cap[s], false, nullptr, &got[s], g_ctx_stream);
     if (rcs[s] < 0) errs[s] = g_err;
   };
-  if (g_workers.empty()) {
-    for (u32 s = 0; s < n_shards; ++s) run_shard(s);
-  } else {
-    // every worker takes its shards in order; the workers run side by side.  The workers are this call's until they are
-    // done (g_shards_mu); g_mu is let go meanwhile -- the shards decode in the workers' own thread-local contexts, nothing
-    // of the process-wide state g_mu guards is touched -- and taken again for the exchange.
-    std::unique_lock<std::mutex> use(g_shards_mu);
-    std::vector<Worker *> ws;
-    for (auto &w : g_workers) ws.push_back(w.get());
-    lk.unlock();
-    for (size_t w = 0; w < ws.size(); ++w) {
-      std::vector<u32> mine;
-      for (u32 s = 0; s < n_shards; ++s) if (wk[s] == (int)w) mine.push_back(s);
-      ws[w]->submit([mine, &run_shard] { for (u32 s : mine) run_shard(s); });
-    }
-    for (Worker *w : ws) w->wait();
-    use.unlock();
-    lk.lock();
-  }
+  run_shards(n_shards, wk, run_shard, lk);
   int32_t worst = AHIP_OK;
   for (u32 s = 0; s < n_shards; ++s) {
     out_len[s] = got[s];
@@ -2425,20 +2606,7 @@ int32_t ahip_gzip_decode_shards(uint32_t n_shards, const int32_t *devices, const
     if (rcs[s] < 0 && worst >= 0) { worst = rcs[s]; g_err = "shard " + std::to_string(s) + ": " + errs[s]; }
     else if (worst >= 0 && rcs[s] > worst) worst = rcs[s];
   }
-  // ---- the exchange: sizes -> offsets ----
-  std::vector<u64> sizes(n_shards), all;
-  for (u32 s = 0; s < n_shards; ++s) sizes[s] = got[s];
-  g_last_exchange = 0;
-  bool distinct = true;
-  std::vector<int> devs(devices, devices + n_shards);
-  for (u32 a = 0; a < n_shards; ++a) for (u32 b = a + 1; b < n_shards; ++b) if (devs[a] == devs[b]) distinct = false;
-  const char *no = getenv("AHIP_NO_RCCL");
-  if (distinct && !(no && no[0] == '1') && g_rccl.prepare(devs) && g_rccl.all_gather(sizes, all)) g_last_exchange = 1;
-  else all = sizes;
-  (void)hipSetDevice(cur);
-  u64 acc = 0;
-  for (u32 s = 0; s < n_shards; ++s) { offsets[s] = acc; acc += all[s]; }
-  offsets[n_shards] = acc;
+  exchange_sizes(n_shards, devices, got.data(), offsets, cur);
   return worst;
 }
 
@@ -2453,10 +2621,11 @@ int32_t ahip_gzip_decode(const uint8_t *in, size_t in_len, int32_t verify, int32
   int32_t rc = ensure_init();
   if (rc != AHIP_OK) return rc;
   g_last_shards = 1;
-  if (!raw && !g_workers.empty() && gzip_decode_sharded(g_workers, 1, in, in_len, verify, out, out_cap, out_len, &rc)) { g_last_shards = (int32_t)g_workers.size(); return rc; }
+  // (several devices: streams without size hints are partitioned too, after a sizing pass on this thread's device)
+  if (!raw && !g_workers.empty() && gzip_decode_sharded(g_workers, 1, in, in_len, verify, out, out_cap, out_len, &rc, true)) { g_last_shards = (int32_t)g_workers.size(); return rc; }
   // one device: a large stream of BGZF members is cut into slices whose upload / decode / download overlap
   if (!raw && g_workers.empty() && in_len >= (32u << 20) && ensure_pipe() &&
-      gzip_decode_sharded(g_pipe, 4, in, in_len, verify, out, out_cap, out_len, &rc)) { g_last_shards = (int32_t)g_pipe.size(); return rc; }
+      gzip_decode_sharded(g_pipe, 4, in, in_len, verify, out, out_cap, out_len, &rc, false)) { g_last_shards = (int32_t)g_pipe.size(); return rc; }
   return gzip_decode_host_impl(in, in_len, verify, raw, out, out_cap, out_len);
 }
 

@@ -55,6 +55,9 @@ struct DeflateParams {
   u32 max_dist; // farthest match: 2^windowBits - 262 (deflate.dart:1120-1131, MAX_DIST)
   u32 nice;     // candidates that still tie after DF_CAP bytes are compared on up to this length (the reference's
                 // nice_length, deflate.dart:1253-1272: 128 at level 6, 258 at level 9); DF_CAP = never
+  u32 open;     // 1 = this input is a SHARD of a longer one and not its last: its last chunk is not the stream's final
+                // block either -- it ends with the byte-aligning empty stored block like every other chunk, so that the next
+                // shard's stream can be spliced on behind it (ahip_deflate_shards)
 };
 
 template <u32 HB> AHIP_DEVINL u32 df_hash4(u32 w) { return (w * 2654435761u) >> (32 - HB); }
@@ -599,7 +602,7 @@ __global__ __launch_bounds__(256) void deflate_encode_kernel(const u8 *__restric
   const u32 chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const u64 cstart = (u64)chunk * DF_CHUNK;
   const u32 clen = (u32)((P.n - cstart) < DF_CHUNK ? (P.n - cstart) : DF_CHUNK);
-  const bool last = chunk + 1 == P.chunks;
+  const bool last = chunk + 1 == P.chunks && !P.open;
   const u32 nt = ntok[chunk];
   const u32 *t = tok + cstart;
   u8 *slab = slabs + (u64)chunk * DF_SLAB;

@@ -48,6 +48,74 @@ def exchange_output_offsets(local_out_bytes, device=None, group=None):
     return int(excl[rank].item()), int(sum(sizes_l)), sizes_l
 
 
+def partition_bytes(n, world_size, align=32768):
+    """Contiguous byte ranges [(lo, hi), ...] of an n-byte Deflate input, one per rank, cut on multiples of `align`
+    (the encoder's chunk size: a cut there loses nothing; only the 32 KiB of history behind a cut are not used)."""
+    units = (n + align - 1) // align
+    cuts = [min(n, (units * r // world_size) * align) for r in range(world_size)] + [n]
+    return [(cuts[r], max(cuts[r], cuts[r + 1])) for r in range(world_size)]
+
+
+def partition_blocks(n_candidates, world_size):
+    """Candidate (block magic) ranges per rank: [K r / n, K (r + 1) / n) -- the rule ahip_bzip2_decode_shards applies."""
+    return [(n_candidates * r // world_size, n_candidates * (r + 1) // world_size) for r in range(world_size)]
+
+
+def fold_block_crcs(crcs, start=0):
+    """bzip2's stream CRC over block CRCs: combined = rotl(combined, 1) ^ crc (bzip2_decoder.dart:77-78)."""
+    c = start
+    for v in crcs:
+        c = (((c << 1) | (c >> 31)) & 0xffffffff) ^ v
+    return c
+
+
+def merge_block_folds(folds):
+    """Stream CRC from per-shard (number of blocks, fold started at 0) in stream order: the fold is linear over XOR, a
+    shard of m blocks rotates what came before it by m."""
+    c = 0
+    for m, f in folds:
+        r = m & 31
+        c = (((c << r) | (c >> (32 - r))) & 0xffffffff if r else c) ^ f
+    return c
+
+
+_GF2_POLY = 0xEDB88320
+
+
+def _gf2_times(mat, vec):
+    s, i = 0, 0
+    while vec:
+        if vec & 1:
+            s ^= mat[i]
+        vec >>= 1
+        i += 1
+    return s
+
+
+def crc32_combine(crc1, crc2, len2):
+    """CRC-32 of A + B from crc32(A), crc32(B), len(B) (zlib's crc32_combine): what a gzip trailer over sharded Deflate
+    output is built from (ahip_deflate_shards returns the per-shard CRCs)."""
+    if len2 <= 0:
+        return crc1
+    odd = [_GF2_POLY] + [1 << n for n in range(31)]
+    even = [_gf2_times(odd, odd[n]) for n in range(32)]
+    odd = [_gf2_times(even, even[n]) for n in range(32)]
+    while True:
+        even = [_gf2_times(odd, odd[n]) for n in range(32)]
+        if len2 & 1:
+            crc1 = _gf2_times(even, crc1)
+        len2 >>= 1
+        if not len2:
+            break
+        odd = [_gf2_times(even, even[n]) for n in range(32)]
+        if len2 & 1:
+            crc1 = _gf2_times(odd, crc1)
+        len2 >>= 1
+        if not len2:
+            break
+    return crc1 ^ crc2
+
+
 class ShardedGZipDecoder:
     """Rank-local decode of one shard (a byte range of whole gzip members) on this rank's GPU."""
 

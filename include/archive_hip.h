@@ -108,8 +108,33 @@ int32_t ahip_gzip_decode_device(const void *d_in, size_t in_len, void *d_out, si
 int32_t ahip_gzip_decode_shards(uint32_t n_shards, const int32_t *devices, const void *const *d_in, const size_t *in_len,
                                 void *const *d_out, const size_t *out_cap, size_t *out_len, uint64_t *offsets,
                                 int32_t *status);
-/* Diagnostics: how the last ahip_gzip_decode_shards() exchanged the sizes (1 = RCCL all-gather, 0 = host sums). */
+/* Diagnostics: how the last sharded call exchanged the sizes (1 = RCCL all-gather, 0 = host sums). */
 int32_t ahip_debug_last_exchange(void);
+
+/* Deflate of ONE input cut into per-device shards (same contexts, same size exchange as ahip_gzip_decode_shards).
+ * ref: codecs/zlib/deflate.dart:219 -- `_trStoredBlock(0, 0, false)`, the byte-aligning empty stored block the reference
+ * itself emits as a flush marker, is what lets independently compressed pieces be spliced.  Shard s = d_in[s][0, in_len[s])
+ * on devices[s] (the caller cuts the input anywhere; multiples of 32 KiB lose nothing) is compressed into d_out[s]; every
+ * shard but the last ends with that marker instead of a final block, so the shards' outputs laid end to end at
+ * offsets[] (exclusive prefix sum of out_len[], offsets[n_shards] = the total) are ONE raw DEFLATE stream of the
+ * concatenated input, for this library's Inflate and for any other.  A match never reaches into another shard.
+ * crc32s (may be NULL): CRC-32 of every shard's input, taken on its device -- a gzip trailer's CRC is combined from them.
+ * level / window_bits as in ahip_deflate_raw (invalid values: the reference's silent no-op, every out_len[s] = 0). */
+int32_t ahip_deflate_shards(uint32_t n_shards, const int32_t *devices, const void *const *d_in, const size_t *in_len,
+                            int32_t level, int32_t window_bits, void *const *d_out, const size_t *out_cap, size_t *out_len,
+                            uint64_t *offsets, uint32_t *crc32s);
+
+/* BZip2 blocks over per-device shards.  ref: codecs/bzip2_decoder.dart:20-88 decodes the blocks of ONE stream one after
+ * the other; they are independent once their bit positions are known.  d_in[s] = a copy of the WHOLE compressed stream
+ * (in_len bytes) on devices[s] -- blocks start at arbitrary bit positions and the compressed stream is the small side;
+ * shard s decodes the blocks among candidates [K s / n, K (s + 1) / n) of the K block magics every device finds, into
+ * d_out[s].  The shards are merged in stream order exactly like decodeStream: the first verdict that is not AHIP_OK, or
+ * the end-of-stream block, ends the stream (shards behind it report out_len 0); the stream CRC is folded from the
+ * shards' block CRCs (verify != 0: a mismatch is AHIP_FALSE).  offsets[] as above; status[s] (may be NULL) = shard s's
+ * own verdict.  Returns the stream's verdict: what ahip_bzip2_decode_device returns for the same stream. */
+int32_t ahip_bzip2_decode_shards(uint32_t n_shards, const int32_t *devices, const void *const *d_in, size_t in_len,
+                                 int32_t verify, void *const *d_out, const size_t *out_cap, size_t *out_len,
+                                 uint64_t *offsets, int32_t *status);
 /* Diagnostics: chunks the calling thread's last long stream (one DEFLATE stream of >= 2 MiB: ahip_inflate_raw, a zlib
  * stream, a long gzip member) was decoded in by the many-waves path; 0 = it went to the one-wave path. */
 int32_t ahip_debug_last_chunks(void);

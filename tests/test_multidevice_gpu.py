@@ -42,6 +42,11 @@ def test_one_process_three_contexts(native_built, monkeypatch):
         lying = bytearray(comp)
         lying[third - 4] ^= 0x40                                                   # ISIZE of one member lies
         cases["lying_isize"] = bytes(lying)
+        # members WITHOUT size hints (an ordinary `cat a.gz b.gz`; the reference skips FEXTRA anyway): a sizing pass on one
+        # device finds the member boundaries, then the contexts take their slices like above
+        nobc, plain2 = corpus.make_gzip(n_members=200, bc=False, want_plain=True, seed=77)
+        cases["no_size_hints"] = bytes(nobc)
+        sharded = {"plain_gzip_members", "no_size_hints"}
         for name, c in cases.items():
             st, out = orc.gzip_decode(c, cap=len(plain) + (1 << 20))
             try:
@@ -50,7 +55,8 @@ def test_one_process_three_contexts(native_built, monkeypatch):
             except archive_amd.errors.RangeError:
                 got = (2, None)
             assert got == ((2, None) if st == 2 else (st, out)), name
-            assert L.ahip_debug_last_shards() == 1, name
+            assert L.ahip_debug_last_shards() == (3 if name in sharded else 1), name
+        assert dec.decode_bytes(bytes(nobc)) == bytes(plain2)
     finally:
         monkeypatch.delenv("AHIP_FAKE_DEVICES")
         assert L.ahip_init_devices(1) == 0 and L.ahip_device_count() == 1
@@ -249,3 +255,82 @@ def test_host_pointer_pipeline_on_one_device(native_built):
     mixed = bytes(comp) + streams.gz_member(streams.text(50000, 3))
     out2 = dec.decode_bytes(mixed)
     assert L.ahip_debug_last_shards() == 1 and out2 == bytes(plain) + streams.text(50000, 3)
+
+
+def test_sharded_deflate_and_bzip2(native_built, monkeypatch):
+    """ahip_deflate_shards / ahip_bzip2_decode_shards on three contexts of the one device there is (AHIP_FAKE_DEVICES):
+    the shards' outputs laid end to end at the exchanged offsets are one DEFLATE stream of the whole input (zlib and the
+    library's own Inflate agree), the per-shard CRCs combine to the input's; the bzip2 blocks of one stream decoded by
+    three contexts give the bytes and the verdict of the unsharded call -- also when a block is damaged."""
+    import bz2
+    import ctypes
+    import numpy as np
+    import torch
+    import archive_amd
+    from archive_amd import _native as N
+    from archive_amd.sharding import crc32_combine, partition_bytes
+    L = N.lib()
+    assert L.ahip_init(0) == 0
+    monkeypatch.setenv("AHIP_FAKE_DEVICES", "3")
+    assert L.ahip_init_devices(1) == 0, N.last_error()
+    try:
+        data = streams.text(900000, 3) + bytes(150000) + streams.text(333333, 4)
+        src = np.frombuffer(data, dtype=np.uint8)
+        for level, cuts in ((6, partition_bytes(len(data), 3)), (1, [(0, 100001), (100001, 100001), (100001, len(data))]), (0, partition_bytes(len(data), 3))):
+            n = len(cuts)
+            d_ins = [torch.from_numpy(src[lo:hi].copy()).cuda() if hi > lo else torch.zeros(1, dtype=torch.uint8, device="cuda") for lo, hi in cuts]
+            lens = [hi - lo for lo, hi in cuts]
+            caps = [L.ahip_deflate_bound(v) + 64 for v in lens]
+            d_outs = [torch.zeros(c, dtype=torch.uint8, device="cuda") for c in caps]
+            arr_dev = (ctypes.c_int32 * n)(*([0] * n))
+            arr_in = (ctypes.c_void_p * n)(*[t.data_ptr() for t in d_ins])
+            arr_len = (ctypes.c_size_t * n)(*lens)
+            arr_out = (ctypes.c_void_p * n)(*[t.data_ptr() for t in d_outs])
+            arr_cap = (ctypes.c_size_t * n)(*caps)
+            out_len = (ctypes.c_size_t * n)()
+            offsets = (ctypes.c_uint64 * (n + 1))()
+            crcs = (ctypes.c_uint32 * n)()
+            rc = L.ahip_deflate_shards(n, arr_dev, arr_in, arr_len, level, 15, arr_out, arr_cap, out_len, offsets, crcs)
+            assert rc == 0, N.last_error()
+            whole = bytearray(offsets[n])
+            crc = 0
+            for s in range(n):
+                assert offsets[s + 1] - offsets[s] == out_len[s]
+                whole[offsets[s]:offsets[s] + out_len[s]] = bytes(d_outs[s][:out_len[s]].cpu().numpy())
+                crc = crc32_combine(crc, crcs[s], lens[s])
+            assert zlib.decompress(bytes(whole), -15) == data, level
+            assert archive_amd.Inflate(bytes(whole)).get_bytes() == data, level
+            assert crc == zlib.crc32(data)
+        # ---- bzip2 ----
+        text = streams.text(1400000, 8) + bytes(range(256)) * 400
+        stream = bz2.compress(text, 1)                       # 100 k blocks: about fifteen of them
+        damaged = bytearray(stream)
+        damaged[len(damaged) * 2 // 3] ^= 0x10               # inside some block of the last third
+        for name, comp, verify in (("clean", stream, 1), ("damaged", bytes(damaged), 1), ("damaged, unverified", bytes(damaged), 0),
+                                   ("truncated", stream[:len(stream) * 3 // 4], 1)):
+            cap = len(text) + 65536
+            one = torch.from_numpy(np.frombuffer(comp, dtype=np.uint8).copy()).cuda()
+            ref_out = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+            ref_n = ctypes.c_size_t()
+            ref_rc = L.ahip_bzip2_decode_device(one.data_ptr(), len(comp), verify, ref_out.data_ptr(), cap, ctypes.byref(ref_n), None)
+            n = 3
+            copies = [one.clone() for _ in range(n)]
+            d_outs = [torch.zeros(cap, dtype=torch.uint8, device="cuda") for _ in range(n)]
+            arr_dev = (ctypes.c_int32 * n)(*([0] * n))
+            arr_in = (ctypes.c_void_p * n)(*[t.data_ptr() for t in copies])
+            arr_out = (ctypes.c_void_p * n)(*[t.data_ptr() for t in d_outs])
+            arr_cap = (ctypes.c_size_t * n)(*([cap] * n))
+            out_len = (ctypes.c_size_t * n)()
+            offsets = (ctypes.c_uint64 * (n + 1))()
+            status = (ctypes.c_int32 * n)()
+            rc = L.ahip_bzip2_decode_shards(n, arr_dev, arr_in, len(comp), verify, arr_out, arr_cap, out_len, offsets, status)
+            assert rc == ref_rc, (name, rc, ref_rc, N.last_error())
+            got = b"".join(bytes(d_outs[s][:out_len[s]].cpu().numpy()) for s in range(n))
+            assert offsets[n] == len(got)
+            if ref_rc in (0, 1):
+                assert got == bytes(ref_out[:ref_n.value].cpu().numpy()), name
+            if name == "clean":
+                assert got == text and min(out_len) > 0
+    finally:
+        monkeypatch.delenv("AHIP_FAKE_DEVICES")
+        assert L.ahip_init_devices(1) == 0 and L.ahip_device_count() == 1

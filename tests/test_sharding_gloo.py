@@ -94,3 +94,115 @@ def test_partition_properties_random():
             fair, biggest = sum(sizes) / w, max(sizes)
             for lo, hi in r:
                 assert sum(sizes[lo:hi]) <= fair + biggest + 1e-9, (sizes, w, r)
+
+
+def _deflate_worker(rank, world, port, data, ranges, q):
+    """One rank of a sharded Deflate: its byte range compressed on its own, closed by the byte-aligning empty stored
+    block (Z_SYNC_FLUSH: the marker the reference itself writes, deflate.dart:219) unless it is the last; sizes exchanged."""
+    import zlib
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from archive_amd.sharding import exchange_output_offsets
+        lo, hi = ranges[rank]
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        piece = co.compress(data[lo:hi])
+        piece += co.flush(zlib.Z_FINISH if rank == world - 1 else zlib.Z_SYNC_FLUSH)
+        if hi == lo and rank != world - 1:
+            piece = b""  # an empty shard in the middle adds nothing
+        off, total, sizes = exchange_output_offsets(len(piece))
+        q.put((rank, off, total, sizes, piece, zlib.crc32(data[lo:hi]), hi - lo))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharded_deflate_splices_into_one_stream():
+    """ahip_deflate_shards' contract on CPU: byte ranges cut on chunk multiples, every piece but the last ends on the
+    flush marker, pieces laid end to end at the exchanged offsets inflate (through the reference's Inflate: the oracle) to
+    the whole input; the per-shard CRCs combine to the whole input's."""
+    import zlib
+    from archive_amd.sharding import crc32_combine, partition_bytes
+    from oracle import pyoracle
+    data = streams.text(700000, 3) + bytes(100000) + streams.text(300001, 4)
+    for n_bytes in (len(data), 40000, 0):
+        d = data[:n_bytes]
+        ranges = partition_bytes(len(d), 2)
+        assert ranges[0][0] == 0 and ranges[-1][1] == len(d) and ranges[0][1] == ranges[1][0] and ranges[0][1] % 32768 == 0
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_deflate_worker, args=(r, 2, port, d, ranges, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = sorted(q.get(timeout=120) for _ in range(2))
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+        buf = bytearray(res[0][2])
+        crc = 0
+        for rank, off, total, sizes, piece, c, n in res:
+            buf[off:off + len(piece)] = piece
+            crc = crc32_combine(crc, c, n)
+        st, out, pos = pyoracle.inflate_raw(bytes(buf), cap=len(d) + 64)
+        assert st == 0 and out == d and pos == len(buf)
+        assert crc == zlib.crc32(d)
+
+
+def _bz_candidates(stream):
+    """(bit position, kind) of every block / end-of-stream magic of a bzip2 stream, and the 32-bit field behind it."""
+    bits = int.from_bytes(stream, "big")
+    nbits = len(stream) * 8
+    out = []
+    for p in range(32, nbits - 80 + 1):
+        v = (bits >> (nbits - p - 48)) & ((1 << 48) - 1)
+        if v in (0x314159265359, 0x177245385090):
+            crc = (bits >> (nbits - p - 80)) & 0xffffffff
+            out.append((p, 1 if v == 0x314159265359 else 2, crc))
+    return out
+
+
+def _bz_worker(rank, world, port, cands, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from archive_amd.sharding import fold_block_crcs, partition_blocks
+        lo, hi = partition_blocks(len(cands), world)[rank]
+        mine = [c for c in cands[lo:hi] if c[1] == 1]
+        rep = torch.tensor([len(mine), fold_block_crcs([c[2] for c in mine])], dtype=torch.int64)
+        allr = torch.zeros(2 * world, dtype=torch.int64)
+        dist.all_gather_into_tensor(allr, rep)
+        q.put((rank, [int(v) for v in allr.tolist()]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_bzip2_block_ranges_and_crc_fold():
+    """ahip_bzip2_decode_shards' merge rule on CPU: block magics found by every rank alike, candidate ranges
+    [K r / n, K (r + 1) / n), and the stream CRC (rotl-xor over the blocks, bzip2_decoder.dart:77-78) recovered from the
+    ranks' own folds -- it has to equal the combined CRC the stream stores behind its end-of-stream magic."""
+    import bz2
+    from archive_amd.sharding import merge_block_folds, partition_blocks
+    data = streams.text(950000, 6)
+    stream = bz2.compress(data, 1)  # 100 k blocks: ten of them
+    cands = _bz_candidates(stream)
+    assert [c[1] for c in cands].count(1) >= 9 and cands[-1][1] == 2 and cands[0][0] == 32
+    for w in (2, 3):
+        r = partition_blocks(len(cands), w)
+        assert r[0][0] == 0 and r[-1][1] == len(cands) and all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bz_worker, args=(r, 2, port, cands, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1]
+    flat = res[0][1]
+    assert merge_block_folds([(flat[0], flat[1]), (flat[2], flat[3])]) == cands[-1][2]
