@@ -597,7 +597,7 @@ struct ahip_gzip_plan {
   bool cands_ready = false;  // cand_pos / hdr hold this stream's candidates (a rebuild with sizes from the data keeps them)
   ChainSummary sum{};
   DevBuf tile_counts, tile_offsets, tile_slots, cand_pos, hdr, scratch_u32, members, expect_status, results, sizing_descs,
-      sizing_results, dsum, drun, retok_ids, retok_rel, chain_aux;
+      sizing_results, dsum, drun, retok_ids, retok_rel, chain_aux, tile_recs, cand_rec;
   bool ran = false;
   hipStream_t run_stream = nullptr;  // the stream the last ahip_gzip_plan_run was enqueued on
   std::vector<u64> host_out_off;  // M + 1 entries: output offset of every member, then the total
@@ -605,7 +605,7 @@ struct ahip_gzip_plan {
   std::vector<Big> big;           // long members decoded by many waves each (sm_inflate), outside the member launch
   ~ahip_gzip_plan() {
     for (DevBuf *b : {&tile_counts, &tile_offsets, &tile_slots, &cand_pos, &hdr, &scratch_u32, &members, &expect_status, &results,
-                      &sizing_descs, &sizing_results, &dsum, &drun, &retok_ids, &retok_rel, &chain_aux})
+                      &sizing_descs, &sizing_results, &dsum, &drun, &retok_ids, &retok_rel, &chain_aux, &tile_recs, &cand_rec})
       b->release();
   }
 };
@@ -644,7 +644,9 @@ int32_t plan_build(ahip_gzip_plan *pl, bool force_sizing, hipStream_t st) {
     HIP_TRY(pl->tile_offsets.reserve((size_t)tiles * 4 + 4));
     u32 *d_total = pl->tile_offsets.as<u32>() + tiles;
     HIP_TRY(pl->tile_slots.reserve((size_t)tiles * TILE_SLOTS * 2 + 16));
-    hipLaunchKernelGGL(gz_count_candidates, dim3(tiles), dim3(256), 0, st, in, start, n, pl->tile_counts.as<u32>(), pl->tile_slots.as<u16>());
+    HIP_TRY(pl->tile_recs.reserve((size_t)tiles * TILE_SLOTS * sizeof(CandRec) + 16));
+    hipLaunchKernelGGL(gz_count_candidates, dim3(tiles), dim3(256), 0, st, in, start, n, pl->tile_counts.as<u32>(), pl->tile_slots.as<u16>(),
+                       pl->tile_recs.as<CandRec>());
     hipLaunchKernelGGL(scan_exclusive_u32, dim3(1), dim3(1024), 0, st, pl->tile_counts.as<u32>(),
                        pl->tile_offsets.as<u32>(), (u64)tiles, d_total);
     K = 0;
@@ -657,10 +659,12 @@ int32_t plan_build(ahip_gzip_plan *pl, bool force_sizing, hipStream_t st) {
     }
     HIP_TRY(pl->cand_pos.reserve((size_t)K * 8));
     HIP_TRY(pl->hdr.reserve((size_t)K * sizeof(GzHeader)));
+    HIP_TRY(pl->cand_rec.reserve((size_t)K * sizeof(CandRec) + 16));
     hipLaunchKernelGGL(gz_write_candidates, dim3(tiles + (tiles + 255) / 256), dim3(256), 0, st, in, start, n, pl->tile_counts.as<u32>(),
-                       pl->tile_offsets.as<u32>(), pl->cand_pos.as<u64>(), pl->tile_slots.as<u16>(), tiles);
+                       pl->tile_offsets.as<u32>(), pl->cand_pos.as<u64>(), pl->tile_slots.as<u16>(), tiles, pl->tile_recs.as<CandRec>(),
+                       pl->cand_rec.as<CandRec>());
     hipLaunchKernelGGL(gz_parse_headers, dim3(cdiv(K, 256)), dim3(256), 0, st, in, n, pl->cand_pos.as<u64>(), K,
-                       pl->hdr.as<GzHeader>(), pl->dsum.as<ChainSummary>());
+                       pl->hdr.as<GzHeader>(), pl->dsum.as<ChainSummary>(), pl->cand_rec.as<CandRec>());
     pl->cands_ready = true;
   }
   if (force_sizing) {
@@ -1061,7 +1065,9 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
     const u32 n_chunks = (u32)((n - off + cb - 1) / cb);
     if (n_chunks < 4) return AHIP_OK;
     constexpr u32 SPLIT = 4;  // waves searching behind each cut
-    HIP_TRY(dcand.reserve((size_t)n_chunks * SPLIT * 8 * 4));  // (x 4: -DAHIP_PROFILE builds leave three cycle counts per workgroup behind the finds)
+    HIP_TRY(dcand.reserve((size_t)n_chunks * SPLIT * 8 * 4 + (size_t)n_chunks * 4));  // (x 4: -DAHIP_PROFILE builds leave three cycle counts per workgroup behind the finds)
+    // behind the finds: per cut, the lowest part that has found something (0xff..: none) -- later parts stop searching
+    HIP_TRY(hipMemsetAsync(dcand.as<u64>() + (size_t)n_chunks * SPLIT * 4, 0xff, (size_t)n_chunks * 4, st));
     hipLaunchKernelGGL(sm_find_kernel, dim3((n_chunks - 1) * SPLIT), dim3(64), 0, st, d_in, n, off, cb, n_chunks, SPLIT, dcand.as<u64>());
 #ifdef AHIP_PROFILE
     if (dbg) {
@@ -1323,7 +1329,7 @@ int32_t zlib_stream_device(const u8 *host_in, const u8 *d_in, u64 n, u64 pos, bo
 // ------------------------------------------------------------------------------------------
 extern "C" {
 
-uint32_t ahip_abi_version(void) { return (2u << 16) | 1u; }
+uint32_t ahip_abi_version(void) { return (2u << 16) | 2u; }
 
 const char *ahip_last_error(void) { return g_err.c_str(); }
 

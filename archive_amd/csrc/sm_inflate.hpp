@@ -133,7 +133,11 @@ struct SmFindLds {
   u32 slab[(SM_SLAB + 64) / 4];
   u16 list[SM_STEP];  // filter 0's survivors: bit offsets inside the slab
 };
-AHIP_DEVINL u64 sm_find_wave(SmFindLds &S, const u8 *__restrict__ in, u64 in_len, u64 q0, u64 q1, const int lane) {
+// first_part (device only; nullptr in the emulation): the lowest part of this cut that has found a block start so far.
+// The host keeps the first find behind a cut, so a wave searching a LATER part of the same cut gives up as soon as an
+// earlier part has one (its own find could not be used): about half of the finder's work on text.
+AHIP_DEVINL u64 sm_find_wave(SmFindLds &S, const u8 *__restrict__ in, u64 in_len, u64 q0, u64 q1, const int lane,
+                             u32 *first_part = nullptr, u32 part = 0) {
   for (u32 i = lane; i < 4096; i += 64) {
     u32 t = 0;
     for (u32 f = 0; f < 4; ++f) { const u32 l = (i >> (3 * f)) & 7; t += l ? (128u >> l) : 0u; }
@@ -160,6 +164,7 @@ AHIP_DEVINL u64 sm_find_wave(SmFindLds &S, const u8 *__restrict__ in, u64 in_len
     wave_sync();
   };
   for (u64 base = q0 & ~31ull; found == ~0ull && base < q1; base += SM_STEP) {
+    if (first_part && uniform(__atomic_load_n(first_part, __ATOMIC_RELAXED)) < part) return ~0ull;
     // the step's windows need bytes [base / 8, (base + SM_STEP - 1 + 17 + 64) / 8]: restage when they leave the slab
     if (slab_byte == ~0ull || ((base + SM_STEP - 1 + 17 + 64) >> 3) + 4 > slab_byte + SM_SLAB + 64) {
       slab_byte = (base >> 3) & ~3ull;
@@ -261,8 +266,12 @@ __global__ __launch_bounds__(64) void sm_find_kernel(const u8 *__restrict__ in, 
   if (k >= n_chunks) return;
   const u64 part_bits = chunk_bytes * 8 / split;
   const u64 q0 = (data_start + (u64)k * chunk_bytes) * 8 + part * part_bits;
-  const u64 found = sm_find_wave(S, in, in_len, q0, q0 + part_bits, lane);
-  if (lane == 0) cand[(u64)k * split + part] = found;
+  u32 *first_part = (u32 *)(cand + (u64)n_chunks * split * 4) + k;  // (behind the finds and the profile slots; set to "none" by the host)
+  const u64 found = sm_find_wave(S, in, in_len, q0, q0 + part_bits, lane, first_part, part);
+  if (lane == 0) {
+    cand[(u64)k * split + part] = found;
+    if (found != ~0ull) atomicMin(first_part, part);
+  }
 }
 #endif
 

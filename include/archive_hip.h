@@ -58,7 +58,8 @@ void ahip_shutdown(void);
 /* Text of the last AHIP_E_* error on this thread ("" if none).  Never NULL. */
 const char *ahip_last_error(void);
 /* ABI version of this header (major << 16 | minor). */
-uint32_t ahip_abi_version(void);  /* 2.1: + ahip_gzip_decode_shards, ahip_gzip_encode_device, ahip_zlib_encode_device */
+uint32_t ahip_abi_version(void);  /* 2.1: + ahip_gzip_decode_shards, ahip_gzip_encode_device, ahip_zlib_encode_device;
+                                    * 2.2: + ahip_deflate_shards, ahip_bzip2_decode_shards, ahip_debug_last_chunks */
 
 /* ---- Inflate: host-pointer entry points (what dart:ffi binds) ---- */
 

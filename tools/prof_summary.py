@@ -143,6 +143,8 @@ def request_traffic(rnd, bench_line, js):
     js["request_counters"] = {"read_bytes": stage_r, "write_bytes": stage_w,
                               "kernels": {k: {"read_bytes": rbytes(rq.get(k, {})), "write_bytes": wbytes(wq.get(k, {}))} for k in sorted(set(rq) | set(wq)) if any(s_ in k for s_ in STAGE)}}
     js["traffic_bytes_per_launch"] = stage_r + stage_w
+    js["per_kernel"] = {k: {"read_GB": round(v["read_bytes"] / 1e9, 2), "write_GB": round(v["write_bytes"] / 1e9, 2)}
+                        for k, v in js["request_counters"]["kernels"].items()}
     js["note"] = ("traffic_bytes_per_launch = memory-side bytes of inflate_tokenize_kernel + inflate_resolve_kernel per decode from the L2 request "
                   "counters by request size (TCC_EA0_RDREQ_{32B,64B,128B}_sum x size, TCC_EA0_WRREQ_64B_sum x 64 + the rest x 32; separate --pmc "
                   "passes), which reproduce the known byte counts of tools/pmc_calib.py (2 GiB copy: reads and writes exact) -- no scale factor. "
@@ -247,7 +249,7 @@ def main():
     stage_f = sum(v["fetch_kb_raw"] for k, v in kernels.items() if any(s in k for s in STAGE)) * 1024
     stage_w = sum(v["write_kb_raw"] for k, v in kernels.items() if any(s in k for s in STAGE)) * 1024
     if bench_line:
-        U = info["members_per_gpu"] * info["member_bytes"]
+        U = info.get("members", info.get("members_per_gpu")) * info["member_bytes"]
         rw = sum(v["write_kb_raw"] for k, v in kernels.items() if "inflate_resolve_kernel" in k) * 1024
         if rw > 0:
             wscale = U / rw
@@ -255,7 +257,7 @@ def main():
     ws = wscale if wscale else 1.0
     js = {
         "stage": "inflate_tokenize_kernel + inflate_resolve_kernel",
-        "workload": {"members": info.get("members_per_gpu"), "member_bytes": info.get("member_bytes"),
+        "workload": {"members": info.get("members", info.get("members_per_gpu")), "member_bytes": info.get("member_bytes"),
                      "kind": "log", "bc": True},
         "kernels": kernels,
         "calibration": {"bytes": cal_n, "kernels": {k: {"fetch_bytes_raw": v[0], "write_bytes_raw": v[1]} for k, v in cal.items()},
