@@ -219,6 +219,29 @@ __global__ __launch_bounds__(256) void gz_write_candidates(const u8 *in, u64 sta
 // Fast path: the first 32 bytes of the header in four registers -- a BGZF header is 18 bytes, a plain one 10 -- so the
 // flags, XLEN and the subfields cost ONE round trip to memory instead of one per field; FNAME / FCOMMENT (a scan for a
 // zero byte) or a longer FEXTRA take the byte-wise path, which is the same parse.
+// FNAME / FCOMMENT: the position behind the first zero byte at or after q (n when there is none) -- what the reference's
+// readString loop leaves (_gzip_decoder_web.dart:124-131).  64 bytes per round trip to memory: the few dozen FALSE
+// candidates inside compressed data have random flag bytes, and one of them walking byte by byte (a dependent load
+// each) to the next zero byte set the whole kernel's time -- 0.25 ms for 0.03 ms of work.
+AHIP_DEVINL u64 gz_skip_string(const u8 *in, u64 n, u64 q) {
+  while (q + 64 <= n) {
+    uint4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = load_u128_unaligned(in + q + 16 * k);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const u32 d[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32 z = (d[j] - 0x01010101u) & ~d[j] & 0x80808080u;  // the lowest set flag marks the first zero byte
+        if (z) return q + 16 * k + 4 * j + ((u32)__builtin_ctz(z) >> 3) + 1;
+      }
+    }
+    q += 64;
+  }
+  while (q < n) { if (in[q++] == 0) break; }
+  return q;
+}
 AHIP_DEVINL u32 hdr_byte(const u64 (&w)[4], u32 k) {  // k < 32
   const u64 a = k < 16 ? (k < 8 ? w[0] : w[1]) : (k < 24 ? w[2] : w[3]);
   return (u32)(a >> (8 * (k & 7))) & 0xffu;
@@ -293,8 +316,8 @@ __global__ __launch_bounds__(256) void gz_parse_headers(const u8 *in, u64 n, con
         q = xend;
       }
     }
-    if (!range && (flags & 0x08)) { while (q < n) { if (in[q++] == 0) break; } }
-    if (!range && (flags & 0x10)) { while (q < n) { if (in[q++] == 0) break; } }
+    if (!range && (flags & 0x08)) q = gz_skip_string(in, n, q);
+    if (!range && (flags & 0x10)) q = gz_skip_string(in, n, q);
     if (!range && (flags & 0x02)) { if (q + 2 > n) range = true; else q += 2; }
   }
   h.payload_off = q;
