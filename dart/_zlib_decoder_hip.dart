@@ -20,7 +20,11 @@ class _ZLibDecoderHip extends ZLibDecoderBase {
   @override
   bool decodeStream(InputStream input, OutputStream output, {bool verify = false, bool raw = false}) {
     final hip = ArchiveHip.instance;
-    output.writeBytes(hip.zlibDecode(input.toUint8List(), verify: verify, raw: raw));
+    final data = input.toUint8List();  // what is left of the stream, from its current position
+    output.writeBytes(hip.zlibDecode(data, verify: verify, raw: raw));
+    // The reference's decodeStream CONSUMES the stream (it reads member after member until isEOS, or hands the rest to
+    // the zlib decoder, which reads to where it stops): callers that go on reading `input` must find it there.
+    input.skip(data.length);
     return hip.lastStatus == ArchiveHip.ok;
   }
 }
