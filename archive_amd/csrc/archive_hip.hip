@@ -1064,7 +1064,7 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
     while ((n - off + cb - 1) / cb > 32768) cb *= 2;  // grid.y of the per-chunk kernels; 32 Ki chunks are plenty
     const u32 n_chunks = (u32)((n - off + cb - 1) / cb);
     if (n_chunks < 4) return AHIP_OK;
-    constexpr u32 SPLIT = 4;  // waves searching behind each cut
+    static const u32 SPLIT = [] { const char *e = getenv("AHIP_SM_SPLIT"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 64 ? (u32)v : 4u; }();  // waves searching behind each cut
     HIP_TRY(dcand.reserve((size_t)n_chunks * SPLIT * 8 * 4 + (size_t)n_chunks * 4));  // (x 4: -DAHIP_PROFILE builds leave three cycle counts per workgroup behind the finds)
     // behind the finds: per cut, the lowest part that has found something (0xff..: none) -- later parts stop searching
     HIP_TRY(hipMemsetAsync(dcand.as<u64>() + (size_t)n_chunks * SPLIT * 4, 0xff, (size_t)n_chunks * 4, st));
@@ -1497,7 +1497,15 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
     HIP_TRY(dcrc.reserve(sizeof(table)));
     HIP_TRY(hipMemcpy(dcrc.p, table, sizeof(table), hipMemcpyHostToDevice));
   }
+  static thread_local DevBuf dcktab, dckacc;  // the reflected CRC's tables (bz_block_crc mirrors it)
+  HIP_TRY(ck_prepare(dcktab, dckacc));
   const u32 wgrid = (u32)cdiv(wstride, 256);
+  // workgroups of 256 threads per XCD (bz_walk): more hide latency, but threads beyond a block's ~7 000 sublists work on the
+  // next blocks' vectors and the XCD's L2 holds about one
+  static const u32 wpx = [] { const char *e = getenv("AHIP_BZ_WALK_WGS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 4096 ? (u32)v : 2u * BZ_WALK_WGS; }();
+  (void)wgrid;
+  static thread_local DevBuf dwq;  // the XCDs' work queues, one set for each of the two walks
+  HIP_TRY(dwq.reserve(64));
   static thread_local DevBuf ddir;
   // chain state (decodeStream's loop)
   u64 total = 0;        // bytes placed so far
@@ -1545,11 +1553,12 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
     hipLaunchKernelGGL(bz_mtf_chunks<true>, dim3(BZ_CHUNKS / 4, nb), dim3(256), 0, st, dsyms.as<u16>(), dres.as<BzResult>(), (u32)level,
                        dchunks.as<BzChunk>(), dperms.as<u8>(), dlists.as<u8>(), dchoff.as<u32>(), dtt.as<u32>());
     hipLaunchKernelGGL(bz_tinv_scatter, dim3(nb), dim3(1024), 0, st, dtt.as<u32>(), (u32)level, dc, dres.as<BzResult>());
-    hipLaunchKernelGGL(bz_walk<false>, dim3(wgrid, nb), dim3(256), 0, st, dtt.as<u32>(), (u32)level, dc, dres.as<BzResult>(),
-                       dwalk.as<BzWalk>(), drank.as<u32>(), dpre.as<u8>());
+    HIP_TRY(hipMemsetAsync(dwq.p, 0, 64, st));
+    hipLaunchKernelGGL(bz_walk<false>, dim3(8 * wpx), dim3(256), 0, st, dtt.as<u32>(), (u32)level, dc, dres.as<BzResult>(),
+                       dwalk.as<BzWalk>(), drank.as<u32>(), dpre.as<u8>(), nb, dwq.as<u32>() + 0);
     hipLaunchKernelGGL(bz_rank, dim3(nb), dim3(256), 0, st, (u32)level, dc, dres.as<BzResult>(), dwalk.as<BzWalk>(), drank.as<u32>());
-    hipLaunchKernelGGL(bz_walk<true>, dim3(wgrid, nb), dim3(256), 0, st, dtt.as<u32>(), (u32)level, dc, dres.as<BzResult>(),
-                       dwalk.as<BzWalk>(), drank.as<u32>(), dpre.as<u8>());
+    hipLaunchKernelGGL(bz_walk<true>, dim3(8 * wpx), dim3(256), 0, st, dtt.as<u32>(), (u32)level, dc, dres.as<BzResult>(),
+                       dwalk.as<BzWalk>(), drank.as<u32>(), dpre.as<u8>(), nb, dwq.as<u32>() + 8);
     hipLaunchKernelGGL(bz_rle_scan, dim3(nb), dim3(1024), 0, st, (u32)level, dc, dres.as<BzResult>(), dpre.as<u8>(), dspans.as<BzSpan>());
     // blocks the parallel path handed back (BZ_ST_SERIAL): the reference loop, counting only (no slab)
     hipLaunchKernelGGL(bz_unbwt, dim3(cdiv(nb, 64)), dim3(64), 0, st, dtt.as<u32>(), (u32)level, nb, dc, (u8 *)nullptr, (u64)0,
@@ -1598,7 +1607,9 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
       }
       HIP_TRY(hipMemcpy(doff.p, par_off.data(), (size_t)nb * 8, hipMemcpyHostToDevice));
       hipLaunchKernelGGL(bz_rle_expand, dim3(BZ_SPANS / 256, nb), dim3(256), 0, st, (u32)level, dc, dres.as<BzResult>(), dpre.as<u8>(),
-                         dspans.as<BzSpan>(), doff.as<u64>(), d_out, dcrc.as<u32>());
+                         dspans.as<BzSpan>(), doff.as<u64>(), d_out);
+      hipLaunchKernelGGL(bz_block_crc, dim3((u32)cdiv(cdiv(nblock_max * 2, CK_SEG), 4), nb), dim3(256), 0, st, dc, dres.as<BzResult>(), doff.as<u64>(),
+                         d_out, dcktab.as<u32>(), dcrc.as<u32>());
       if (any_serial) {
         HIP_TRY(ddir.reserve((size_t)nb * 8));
         HIP_TRY(hipMemcpy(ddir.p, ser_off.data(), (size_t)nb * 8, hipMemcpyHostToDevice));

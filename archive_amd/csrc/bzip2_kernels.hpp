@@ -35,6 +35,9 @@
 // The obsolete randomised-block mode is not implemented (BZ_ST_UNSUPPORTED).
 #pragma once
 #include "common.hpp"
+#ifndef AHIP_HOST_EMU
+#include "checksum_kernels.hpp"  // the block CRCs are taken over the finished output (bz_block_crc)
+#endif
 
 namespace ahip {
 
@@ -43,6 +46,8 @@ constexpr u32 BZ_ST_OK = 0, BZ_ST_FALSE = 1, BZ_ST_RANGE = 2, BZ_ST_OVERFLOW = 1
 constexpr u32 BZ_ST_HUFF_SERIAL = 19;  // between kernels only: the position-parallel Huffman pass hands the block to the serial one
 constexpr u32 BZ_G = 128;      // splitter stride of the list ranking
 constexpr u32 BZ_SPANS = 1024;  // run-length spans per block
+constexpr u32 BZ_WALK_BATCH = 128;  // sublists a wave takes from its XCD's queue at a time
+constexpr u32 BZ_WALK_WGS = (900000 / BZ_G + 2 + 255) / 256;  // workgroups of 256 threads that hold one thread per sublist of a 900k block
 
 struct BzCand { u64 bit; u32 kind; u32 pad; };  // kind 0 = compressed block, 2 = end of stream
 struct BzResult {
@@ -1206,39 +1211,129 @@ fin:
 struct BzWalk { u32 next, len; };
 AHIP_DEVINL u32 bz_nsplit(u32 nblock) { return (nblock + BZ_G - 1) / BZ_G; }
 
+// Who walks what.  The walk is 0.9 M dependent 4-byte reads at random places of the block's 3.6 MB vector, and a sublist
+// ends where the chain happens to reach the next multiple of BZ_G: its length is geometric (mean BZ_G, the longest of a
+// block's seven thousand some nine times that).
+//  * With every block of a batch in flight at once (a 2-D grid, one thread per splitter) the vectors of some seventy
+//    blocks -- 260 MB -- were walked side by side and nearly every read went to memory.  Workgroups are dealt to the
+//    eight XCDs in turn (workgroup i runs on XCD i mod 8) and each XCD has its own 4 MB L2, so the grid is 8 x `wpx`
+//    PERSISTENT workgroups and the ones with blockIdx.x mod 8 == x take the blocks x, x + 8, ... one after the other:
+//    a block's vector is read by one XCD only, through an L2 it (nearly) fits in.
+//  * A lane whose sublist has ended takes the next one from the XCD's queue (queue[x]: the next item, an item = block
+//    x + 8 (q / stride), splitter q mod stride; one atomic for all the idle lanes of a wave) instead of waiting for the
+//    longest sublist of its workgroup.
+//    What a sublist needs to start -- the block's verdict, size and head, its rank in the WRITE pass -- is fetched when the
+//    wave takes a batch from the queue (a batch lies inside one block: BZ_WALK_IPB items per block), not when a lane
+//    starts: those loads, three deep, stalled the whole wave at four steps out of ten.
 template <bool WRITE>
 __global__ __launch_bounds__(256) void bz_walk(const u32 *__restrict__ tt_all, u32 block_size100k,
                                                const BzCand *__restrict__ cands, const BzResult *__restrict__ results,
                                                BzWalk *__restrict__ walk_all, const u32 *__restrict__ rank_all,
-                                               u8 *__restrict__ pre_all) {
-  const u32 blk = blockIdx.y;
-  if (cands[blk].kind != 0 || results[blk].status != BZ_ST_OK) return;
-  const u32 nblock = results[blk].nblock;
+                                               u8 *__restrict__ pre_all, u32 nb, u32 *__restrict__ queue) {
+  const u32 xcd = blockIdx.x & 7;
   const u32 nblock_max = 100000u * block_size100k;
-  const u32 S = bz_nsplit(nblock), stride = nblock_max / BZ_G + 2;
-  const u32 s = blockIdx.x * 256 + threadIdx.x;
-  if (s > S || nblock == 0) return;
-  const u32 *tt = tt_all + (u64)blk * nblock_max;
-  const u32 p0 = tt[results[blk].pad_orig_ptr] >> 8;
-  u32 cur = s == S ? p0 : s * BZ_G;
-  u32 k = 0;
-  if (WRITE) {
-    k = rank_all[(u64)blk * stride + s];
-    if (k == ~0u) return;  // not on the head's cycle (duplicate of the head, or corrupt data)
-  }
-  u8 *pre = pre_all + (u64)blk * nblock_max;
-  u32 len = 0;
-  do {
-    const u32 w = tt[cur];
-    if (WRITE) pre[k + len] = (u8)w;
-    cur = w >> 8;
-    ++len;
-  } while ((cur & (BZ_G - 1)) != 0 && cur != p0 && len < nblock);
-  if (!WRITE) {
-    BzWalk r;
-    r.next = cur == p0 ? S : cur / BZ_G;
-    r.len = len;
-    walk_all[(u64)blk * stride + s] = r;
+  const u32 stride = nblock_max / BZ_G + 2;
+  const u32 ipb = (stride + BZ_WALK_BATCH - 1) / BZ_WALK_BATCH * BZ_WALK_BATCH;  // queue items per block
+  const u32 nitems = (nb > xcd ? (nb - xcd + 7) / 8 : 0u) * ipb;
+  const int lane = threadIdx.x & 63;
+  const u64 below = (1ull << lane) - 1;
+  bool active = false;
+  // the chain a lane is on
+  const u32 *tt = tt_all;
+  u8 *pre = pre_all;
+  u32 cur = 0, len = 0, p0 = 0, nblock = 0, s = 0, blk = 0;
+  u32 acc = 0, na = 0, at = 0;  // WRITE: bytes [at, at + na) are still in `acc`; whole aligned dwords are stored as such
+  // the wave's batch (wave-uniform): items [pool_next, pool_end) of block b_blk are not handed to a lane yet
+  u32 pool_base = 0, pool_next = 0, pool_end = 0, b_blk = 0, b_nblock = 0, b_S = 0, b_p0 = 0;
+  u32 rk[BZ_WALK_BATCH / 64];  // WRITE: rank of item pool_base + 64 i + lane
+  bool out_of_work = false;
+  for (;;) {
+    const u64 idle = __ballot(!active);
+    if (idle && !out_of_work) {
+      if (pool_next == pool_end) {
+        u32 base = 0;
+        if (lane == 0) base = atomicAdd(&queue[xcd], BZ_WALK_BATCH);
+        base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+        if (base >= nitems) out_of_work = true;
+        else {
+          pool_base = pool_next = base;
+          pool_end = base + BZ_WALK_BATCH;
+          b_blk = xcd + 8 * (base / ipb);
+          const u32 s0 = base % ipb;
+          const bool ok = cands[b_blk].kind == 0 && results[b_blk].status == BZ_ST_OK && results[b_blk].nblock != 0;
+          b_nblock = ok ? (u32)__builtin_amdgcn_readfirstlane((int)results[b_blk].nblock) : 0u;
+          b_S = bz_nsplit(b_nblock);
+          if (!ok || s0 > b_S) pool_next = pool_end;  // nothing to walk in this batch
+          else {
+            b_p0 = (u32)__builtin_amdgcn_readfirstlane((int)(tt_all[(u64)b_blk * nblock_max + results[b_blk].pad_orig_ptr] >> 8));
+            if (WRITE) {
+#pragma unroll
+              for (u32 i = 0; i < BZ_WALK_BATCH / 64; ++i) {
+                const u32 si = s0 + 64 * i + (u32)lane;
+                rk[i] = si <= b_S ? rank_all[(u64)b_blk * stride + si] : ~0u;
+              }
+            }
+          }
+        }
+      }
+      const u32 avail = pool_end - pool_next;
+      if (avail) {
+        const u32 rank = (u32)__popcll(idle & below), need = (u32)__popcll(idle);
+        const u32 q = pool_next + rank;
+        const bool served = !active && rank < avail;  // the others are served from the next batch
+        // (every lane takes part in the shuffles)
+        u32 my_at = 0;
+        if (WRITE) {
+          const u32 rel = served ? q - pool_base : 0u;
+#pragma unroll
+          for (u32 i = 0; i < BZ_WALK_BATCH / 64; ++i) { const u32 v = __shfl(rk[i], (int)(rel & 63)); if ((rel >> 6) == i) my_at = v; }
+        }
+        pool_next += need < avail ? need : avail;
+        if (served) {
+          s = q % ipb;
+          if (s <= b_S && !(WRITE && my_at == ~0u)) {  // (~0: not on the head's cycle -- a duplicate of the head, or corrupt data)
+            blk = b_blk;
+            nblock = b_nblock;
+            p0 = b_p0;
+            tt = tt_all + (u64)blk * nblock_max;
+            pre = pre_all + (u64)blk * nblock_max;
+            cur = s == b_S ? p0 : s * BZ_G;
+            len = 0;
+            at = my_at; acc = 0; na = 0;
+            active = true;
+          }
+        }
+      }
+    }
+    if (!__any(active)) {
+      if (out_of_work) break;
+      continue;
+    }
+    if (active) {
+      const u32 w = tt[cur];
+      if (WRITE) {
+        acc |= (w & 0xffu) << (8 * na);
+        ++na;
+        if (((at + na) & 3u) == 0) {
+          if (na == 4) *(u32 *)(pre + at) = acc;
+          else for (u32 b = 0; b < na; ++b) pre[at + b] = (u8)(acc >> (8 * b));
+          at += na; na = 0; acc = 0;
+        }
+      }
+      cur = w >> 8;
+      ++len;
+      if (!((cur & (BZ_G - 1)) != 0 && cur != p0 && len < nblock)) {  // the sublist ends here
+        if (WRITE) { for (u32 b = 0; b < na; ++b) pre[at + b] = (u8)(acc >> (8 * b)); }
+        else {
+          const u32 S = bz_nsplit(nblock);
+          BzWalk r;
+          r.next = cur == p0 ? S : cur / BZ_G;
+          r.len = len;
+          walk_all[(u64)blk * (nblock_max / BZ_G + 2) + s] = r;
+        }
+        active = false;
+      }
+    }
   }
 }
 
@@ -1325,10 +1420,39 @@ __global__ __launch_bounds__(1024) void bz_rle_scan(u32 block_size100k, const Bz
   u32 len[5];
 #pragma unroll
   for (u32 c = 0; c < 5; ++c) { st[c] = rle_entry(c, x0, 0); len[c] = 0; }
-  for (u32 i = lo; i < hi; ++i) {
-    const u32 x = pre[i];
+  // The five entry classes are walked side by side only until they have MERGED (the same state: from then on they stay
+  // together -- a byte that differs from the one before it does that, i.e. nearly always within the first few bytes);
+  // after that one machine runs and its output count goes to all five.  The span is read 16 bytes at a time: a lane's
+  // span is its own ~0.9 KB, so a byte load a step was 64 cache lines per load instruction and one byte of each.
+  bool merged = false;
+  RleState ms{0x100, 0};
+  u32 mlen = 0;
+  auto eat = [&](u32 x) {
+    if (merged) mlen += rle_step(ms, x);
+    else {
 #pragma unroll
-    for (u32 c = 0; c < 5; ++c) len[c] += rle_step(st[c], x);
+      for (u32 c = 0; c < 5; ++c) len[c] += rle_step(st[c], x);
+    }
+  };
+  auto settle = [&]() {
+    if (merged) return;
+    bool same = true;
+#pragma unroll
+    for (u32 c = 1; c < 5; ++c) same = same && st[c].prev == st[0].prev && st[c].cnt == st[0].cnt;
+    if (same) { merged = true; ms = st[0]; }
+  };
+  u32 i = lo;
+  for (; i + 16 <= hi; i += 16) {
+    const uint4 v = load_u128_unaligned(pre + i);
+    const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (u32 j = 0; j < 16; ++j) eat((w[j >> 2] >> (8 * (j & 3))) & 0xffu);
+    settle();
+  }
+  for (; i < hi; ++i) eat(pre[i]);
+  if (merged) {
+#pragma unroll
+    for (u32 c = 0; c < 5; ++c) { st[c] = ms; len[c] += mlen; }
   }
 #pragma unroll
   for (u32 c = 0; c < 5; ++c) {
@@ -1379,14 +1503,13 @@ AHIP_DEVINL u32 gf_xpow8(u64 nbytes, const u32 *pw) {
   return r;
 }
 
-// crc_tab: 256 table entries followed by 64 powers pw[k]
+// The output of every span is gathered eight bytes at a time and stored as one (unaligned) 8-byte word: a byte store a
+// step was, like the loads, 64 cache lines per instruction.  The block's CRC is taken afterwards over the finished
+// bytes (bz_block_crc): a table-driven CRC inside this loop was a dependent LDS look-up per output byte.
 __global__ __launch_bounds__(256) void bz_rle_expand(u32 block_size100k, const BzCand *__restrict__ cands,
                                                      BzResult *__restrict__ results, const u8 *__restrict__ pre_all,
                                                      const BzSpan *__restrict__ spans_all, const u64 *__restrict__ dst_off,
-                                                     u8 *__restrict__ out, const u32 *__restrict__ crc_tab) {
-  __shared__ u32 tab[256];
-  tab[threadIdx.x] = crc_tab[threadIdx.x];
-  __syncthreads();
+                                                     u8 *__restrict__ out) {
   const u32 blk = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
   if (cands[blk].kind != 0 || results[blk].status != BZ_ST_OK || dst_off[blk] == ~0ull) return;
   const u32 nblock = results[blk].nblock;
@@ -1395,27 +1518,54 @@ __global__ __launch_bounds__(256) void bz_rle_expand(u32 block_size100k, const B
   const u32 sp = (nblock + BZ_SPANS - 1) / BZ_SPANS;
   const u32 lo = t * sp < nblock ? t * sp : nblock, hi = lo + sp < nblock ? lo + sp : nblock;
   const BzSpan e = spans_all[(u64)blk * BZ_SPANS + t];
-  const u64 total = results[blk].out_len;
   RleState s{e.prev, e.cnt};
   u8 *dst = out + dst_off[blk] + e.off;
-  u64 n = 0;
-  u32 crc = 0;  // remainder of this span's bytes alone (initial value 0)
-  for (u32 i = lo; i < hi; ++i) {
-    const u32 x = pre[i];
+  u64 acc = 0;  // bytes not stored yet, the oldest lowest
+  u32 na = 0;
+  auto eat = [&](u32 x) {
     const bool is_count = s.cnt == 4;
     const u32 run_byte = s.prev;
     u32 reps = rle_step(s, x);
-    const u32 ch = is_count ? run_byte : x;
+    const u64 rep8 = 0x0101010101010101ull * (is_count ? run_byte : x);
     if (is_count) s.prev = 0x100;  // fresh
-    for (; reps; --reps) {
-      dst[n++] = (u8)ch;
-      crc = (crc << 8) ^ tab[(crc >> 24) ^ ch];
+    while (reps) {
+      const u32 room = 8 - na, k = reps < room ? reps : room;
+      acc |= (k == 8 ? rep8 : (rep8 & ((1ull << (8 * k)) - 1))) << (8 * na);
+      na += k;
+      reps -= k;
+      if (na == 8) { ((unaligned_u64 *)dst)->v = acc; dst += 8; acc = 0; na = 0; }
     }
+  };
+  u32 i = lo;
+  for (; i + 16 <= hi; i += 16) {
+    const uint4 v = load_u128_unaligned(pre + i);
+    const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (u32 j = 0; j < 16; ++j) eat((w[j >> 2] >> (8 * (j & 3))) & 0xffu);
   }
-  u32 term = 0;
-  if (n) term = gf_mulmod(crc, gf_xpow8(total - e.off - n, crc_tab + 256));
-  if (t == 0) term ^= gf_mulmod(0xffffffffu, gf_xpow8(total, crc_tab + 256));  // the 0xffffffff initial value
-  if (term) atomicXor(&results[blk].crc, term);
+  for (; i < hi; ++i) eat(pre[i]);
+  for (u32 k = 0; k < na; ++k) dst[k] = (u8)(acc >> (8 * k));
+}
+
+// results[blk].crc ^= the MSB-first CRC-32 register (before the final inversion) over the block's output bytes: the waves'
+// shares of the zero-start register (ck_raw_wave on bit-reversed bytes, mirrored back) and, once, the contribution of the
+// 0xffffffff it starts from.  ck_tab: the tables of checksum_kernels.hpp; bz_tab: 256 MSB-first table entries followed by
+// the 64 powers pw[k] = x^(8 * 2^k).
+__global__ __launch_bounds__(256) void bz_block_crc(const BzCand *__restrict__ cands, BzResult *__restrict__ results,
+                                                    const u64 *__restrict__ dst_off, const u8 *__restrict__ out,
+                                                    const u32 *__restrict__ ck_tab, const u32 *__restrict__ bz_tab) {
+  __shared__ u32 T[256 * 5];
+  for (u32 i = threadIdx.x; i < 256 * 5; i += 256) T[i] = ck_tab[i];
+  __syncthreads();
+  const u32 blk = blockIdx.y;
+  if (cands[blk].kind != 0 || results[blk].status != BZ_ST_OK || dst_off[blk] == ~0ull) return;
+  const u64 total = results[blk].out_len;
+  const u32 lane = threadIdx.x & 63;
+  bool any;
+  const u32 raw = ck_raw_wave<true>(out + dst_off[blk], total, T, ck_tab + 1280, (u64)blockIdx.x * 4 + (threadIdx.x >> 6), (u64)gridDim.x * 4, lane, &any);
+  u32 term = any ? __brev(raw) : 0u;
+  if (blockIdx.x == 0 && threadIdx.x == 0) term ^= gf_mulmod(0xffffffffu, gf_xpow8(total, bz_tab + 256));  // the 0xffffffff initial value
+  if (lane == 0 && term) atomicXor(&results[blk].crc, term);
 }
 
 #endif  // AHIP_HOST_EMU

@@ -70,15 +70,15 @@ inline void ck_build_tables(u32 *t) {
   for (u32 k = 1; k < 64; ++k) t[1280 + k] = p = ck_mulmod(p, p);
 }
 
-// acc[0] ^= raw CRC state (zero initial value, no final inversion) of d[0, n)
-__global__ __launch_bounds__(256) void crc32_kernel(const u8 *__restrict__ d, u64 n, const u32 *__restrict__ tables,
-                                                    u32 *__restrict__ acc) {
-  __shared__ u32 T[256 * 5];
-  for (u32 i = threadIdx.x; i < 256 * 5; i += 256) T[i] = tables[i];
-  __syncthreads();
-  const u32 *pw = tables + 1280;
-  const u32 lane = threadIdx.x & 63;
-  const u64 wave = (u64)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (u64)gridDim.x * 4;
+// The wave's share (segments wave, wave + nwaves, ...) of the raw CRC state of d[0, n) -- zero initial value, no final
+// inversion -- already shifted to the end of the data: the XOR of these over all waves is the state.  T = the five LDS
+// tables, pw = the powers behind them.  *any = the wave had a segment at all.
+// REV8: every data byte is taken with its bits reversed.  The reflected register over bit-reversed bytes is the
+// mirror image of the MSB-first register over the bytes as they are, so __brev of the result is the state of the
+// MSB-first CRC-32 (polynomial 04c11db7: bzip2's, bzip2_decoder.dart:640-727 / util/crc32.dart's BZip2 table).
+template <bool REV8>
+AHIP_DEVINL u32 ck_raw_wave(const u8 *__restrict__ d, u64 n, const u32 *T, const u32 *pw, u64 wave, u64 nwaves, u32 lane, bool *any_out) {
+  auto word = [](u32 w) -> u32 { return REV8 ? __builtin_bswap32(__brev(w)) : w; };
   const u32 lane_shift = ck_xpow8(CK_ROW - 4 * lane, pw);  // aligns this lane's Horner sum with the end of a row
   const u64 nseg = (n + CK_SEG - 1) / CK_SEG;
   // the wave's segments are folded into one value aligned with the end of the latest one: consecutive
@@ -97,14 +97,14 @@ __global__ __launch_bounds__(256) void crc32_kernel(const u8 *__restrict__ d, u6
     for (; i + 4 <= rows; i += 4) {  // four loads in flight
       u32 w[4];
 #pragma unroll
-      for (u32 u = 0; u < 4; ++u) w[u] = load_u32_unaligned(p + (u64)(i + u) * CK_ROW);
+      for (u32 u = 0; u < 4; ++u) w[u] = word(load_u32_unaligned(p + (u64)(i + u) * CK_ROW));
 #pragma unroll
       for (u32 u = 0; u < 4; ++u)
         a = T[256 + (a & 0xff)] ^ T[512 + ((a >> 8) & 0xff)] ^ T[768 + ((a >> 16) & 0xff)] ^ T[1024 + (a >> 24)] ^ w[u];
     }
     for (; i < rows; ++i)
       a = T[256 + (a & 0xff)] ^ T[512 + ((a >> 8) & 0xff)] ^ T[768 + ((a >> 16) & 0xff)] ^ T[1024 + (a >> 24)] ^
-          load_u32_unaligned(p + (u64)i * CK_ROW);
+          word(load_u32_unaligned(p + (u64)i * CK_ROW));
     u32 v = rows ? ck_mulmod(lane_shift, a) : 0u;
     // xor across the wave
     for (int o = 32; o; o >>= 1) v ^= __shfl_xor(v, o);
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void crc32_kernel(const u8 *__restrict__ d, u6
     if (rem) {  // the last, partial row (only the data's final segment has one), byte by byte
       u32 r = 0;
       const u8 *q = d + s0 + (u64)rows * CK_ROW;
-      for (u32 k = 0; k < rem; ++k) r = T[(r ^ q[k]) & 0xff] ^ (r >> 8);
+      for (u32 k = 0; k < rem; ++k) r = T[(r ^ (REV8 ? __brev((u32)q[k]) >> 24 : (u32)q[k])) & 0xff] ^ (r >> 8);
       c = ck_mulmod(ck_xpow8(rem, pw), v) ^ r;
     }
     const u64 end = s0 + len;
@@ -121,10 +121,20 @@ __global__ __launch_bounds__(256) void crc32_kernel(const u8 *__restrict__ d, u6
     end_prev = end;
     any = true;
   }
-  if (any && lane == 0) {
-    const u32 total = ck_mulmod(ck_xpow8(n - end_prev, pw), accw);
-    if (total) atomicXor(acc, total);
-  }
+  *any_out = any;
+  return any ? ck_mulmod(ck_xpow8(n - end_prev, pw), accw) : 0u;
+}
+
+// acc[0] ^= raw CRC state (zero initial value, no final inversion) of d[0, n)
+__global__ __launch_bounds__(256) void crc32_kernel(const u8 *__restrict__ d, u64 n, const u32 *__restrict__ tables,
+                                                    u32 *__restrict__ acc) {
+  __shared__ u32 T[256 * 5];
+  for (u32 i = threadIdx.x; i < 256 * 5; i += 256) T[i] = tables[i];
+  __syncthreads();
+  const u32 lane = threadIdx.x & 63;
+  bool any;
+  const u32 total = ck_raw_wave<false>(d, n, T, tables + 1280, (u64)blockIdx.x * 4 + (threadIdx.x >> 6), (u64)gridDim.x * 4, lane, &any);
+  if (any && lane == 0 && total) atomicXor(acc, total);
 }
 
 // acc[0] += sum of bytes, acc[1] += sum of (index * byte), both over d[0, n)

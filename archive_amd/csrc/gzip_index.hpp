@@ -114,10 +114,28 @@ __global__ __launch_bounds__(256) void gz_count_candidates(const u8 *in, u64 sta
   if (threadIdx.x == 0) nslot = 0;
   __syncthreads();
   u32 c = 0;
+  // A candidate starts with the byte 1f.  Inside the stream (the whole tile and the 20 bytes behind it exist) the tile's
+  // sixteen 16-byte loads of a thread are issued back to back and screened for that byte with four operations a dword
+  // (the zero-byte test on x ^ 1f1f1f1f); only the rows that have one -- 6 % -- go through the byte-by-byte comparison.
+  // (One row after the other, each behind its own bounds checks, the loads waited for one another: 0.50 ms a decode.)
+  const u64 tile0 = start + (u64)blockIdx.x * TILE_BYTES;
+  u32 rows = 0xffffu;
+  if (tile0 + TILE_BYTES + 20 <= n) {
+    uint4 v[TILE_BYTES / 4096];
 #pragma unroll
-  for (u32 r = 0; r < TILE_BYTES / 4096; ++r) {
-    const u32 rel = r * 4096 + threadIdx.x * 16;
-    u32 mask = candidate_mask16(in, n, start + (u64)blockIdx.x * TILE_BYTES + rel);
+    for (u32 r = 0; r < TILE_BYTES / 4096; ++r) v[r] = load_u128_unaligned(in + tile0 + r * 4096 + threadIdx.x * 16);
+    rows = 0;
+#pragma unroll
+    for (u32 r = 0; r < TILE_BYTES / 4096; ++r) {
+      const u32 zx = v[r].x ^ 0x1f1f1f1fu, zy = v[r].y ^ 0x1f1f1f1fu, zz = v[r].z ^ 0x1f1f1f1fu, zw = v[r].w ^ 0x1f1f1f1fu;
+      const u32 any = (((zx - 0x01010101u) & ~zx) | ((zy - 0x01010101u) & ~zy) | ((zz - 0x01010101u) & ~zz) | ((zw - 0x01010101u) & ~zw)) & 0x80808080u;
+      rows |= any ? 1u << r : 0u;
+    }
+  }
+  static_assert(TILE_BYTES / 4096 == 16, "one bit of `rows` per row of the tile");
+  for (; rows; rows &= rows - 1) {
+    const u32 rel = ((u32)__ffs(rows) - 1) * 4096 + threadIdx.x * 16;
+    u32 mask = candidate_mask16(in, n, tile0 + rel);
     c += __popc(mask);
     while (mask) {  // (rare: one thread in a hundred thousand)
       const u32 k = (u32)__ffs(mask) - 1;

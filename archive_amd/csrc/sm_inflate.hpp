@@ -262,8 +262,11 @@ __global__ __launch_bounds__(64) void sm_find_kernel(const u8 *__restrict__ in, 
                                                      u32 n_chunks, u32 split, u64 *__restrict__ cand) {
   __shared__ SmFindLds S;
   const int lane = threadIdx.x;
-  const u32 k = blockIdx.x / split + 1, part = blockIdx.x % split;
-  if (k >= n_chunks) return;
+  // Part-major: the workgroups searching the FIRST part behind every cut are dispatched first, and by the time those of a
+  // later part get a slot most cuts have their find (first_part): they leave at once.  (Cut-major, the parts of a cut ran
+  // side by side and the early exit saved nothing.)
+  const u32 k = blockIdx.x % (n_chunks - 1) + 1, part = blockIdx.x / (n_chunks - 1);
+  if (part >= split) return;
   const u64 part_bits = chunk_bytes * 8 / split;
   const u64 q0 = (data_start + (u64)k * chunk_bytes) * 8 + part * part_bits;
   u32 *first_part = (u32 *)(cand + (u64)n_chunks * split * 4) + k;  // (behind the finds and the profile slots; set to "none" by the host)
