@@ -1437,7 +1437,7 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
   // block at level 9), following the chain of blocks exactly like decodeStream between them: a block ends where
   // the next magic starts.  A batch's blocks are placed and expanded before the next batch is decoded; nothing
   // behind the point where the chain stops is ever touched.
-  const u64 per_block = nblock_max * 5 + (u64)BZ_SYM_CAP * 2 + BZ_CHUNKS * 530 + sizeof(BzTables) + BZ_MAX_SELECTORS * 4 + wstride * (sizeof(BzWalk) + 4) + BZ_SPANS * sizeof(BzSpan) + BZ_MAX_SELECTORS + sizeof(BzResult) + 64;
+  const u64 per_block = nblock_max * 5 + (u64)BZ_SYM_CAP * 2 + BZ_CHUNKS * 530 + (u64)BZ_PARTS * 260 + sizeof(BzTables) + BZ_MAX_SELECTORS * 4 + wstride * (sizeof(BzWalk) + 4) + BZ_SPANS * sizeof(BzSpan) + BZ_MAX_SELECTORS + sizeof(BzResult) + 64;
   u64 batch_mem = 24ull << 30;  // (of 288 GB: every batch costs one latency-bound header + walk + rank round)
   {
     // ... but never more than half of what the device has free right now (other contexts, a caller's own tensors)
@@ -1448,7 +1448,7 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
   if (const char *e = getenv("AHIP_BZ_BATCH_BYTES")) { if (atoll(e) > 0) batch_mem = (u64)atoll(e); }
   const u64 j50_per_block = bz_parallel_huffman() ? (u64)in_len * 8 / std::max<u32>(1, ncand) * 12 : 0;  // 6 tables x 2 bytes per bit
   u32 batch = (u32)std::min<u64>(c_hi - c_lo, std::max<u64>(4, batch_mem / (per_block + j50_per_block)));
-  static thread_local DevBuf dsyms, dlist0, dchunks, dperms, dlists, dchoff, dtab, dj50, dgstart, dgcount;
+  static thread_local DevBuf dsyms, dlist0, dchunks, dperms, dlists, dchoff, dtab, dj50, dgstart, dgcount, dpperms, dpcounts;
   // the work memory of one batch; a device that cannot spare it gets smaller batches, not an error
   auto reserve_batch = [&](u32 b) -> hipError_t {
     hipError_t e;
@@ -1464,6 +1464,8 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
     BZ_RES(dperms, (size_t)b * BZ_CHUNKS * 256);
     BZ_RES(dlists, (size_t)b * BZ_CHUNKS * 256);
     BZ_RES(dchoff, (size_t)b * BZ_CHUNKS * 4);
+    BZ_RES(dpperms, (size_t)b * BZ_PARTS * 256);
+    BZ_RES(dpcounts, (size_t)b * BZ_PARTS * 4);
     BZ_RES(dpre, (size_t)b * nblock_max);
     BZ_RES(dwalk, (size_t)b * wstride * sizeof(BzWalk));
     BZ_RES(drank, (size_t)b * wstride * 4);
@@ -1502,7 +1504,7 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
   const u32 wgrid = (u32)cdiv(wstride, 256);
   // workgroups of 256 threads per XCD (bz_walk): more hide latency, but threads beyond a block's ~7 000 sublists work on the
   // next blocks' vectors and the XCD's L2 holds about one
-  static const u32 wpx = [] { const char *e = getenv("AHIP_BZ_WALK_WGS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 4096 ? (u32)v : 2u * BZ_WALK_WGS; }();
+  static const u32 wpx = [] { const char *e = getenv("AHIP_BZ_WALK_WGS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 4096 ? (u32)v : 40u; }();
   (void)wgrid;
   static thread_local DevBuf dwq;  // the XCDs' work queues, one set for each of the two walks
   HIP_TRY(dwq.reserve(64));
@@ -1546,17 +1548,18 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
       hipLaunchKernelGGL(bz_decode_block, dim3(nb), dim3(64), 0, st, d_in, (u64)in_len, dc, nb, dsyms.as<u16>(), dlist0.as<u8>(), dsel.as<u8>(),
                          dres.as<BzResult>(), 0u);
     }
-    hipLaunchKernelGGL(bz_mtf_chunks<false>, dim3(BZ_CHUNKS / 4, nb), dim3(256), 0, st, dsyms.as<u16>(), dres.as<BzResult>(), (u32)level,
-                       dchunks.as<BzChunk>(), dperms.as<u8>(), dlists.as<u8>(), dchoff.as<u32>(), dtt.as<u32>());
+    hipLaunchKernelGGL(bz_mtf_lanes<false>, dim3(BZ_CHUNKS, nb), dim3(64), 0, st, dsyms.as<u16>(), dres.as<BzResult>(), (u32)level,
+                       dchunks.as<BzChunk>(), dperms.as<u8>(), dlists.as<u8>(), dchoff.as<u32>(), dpre.as<u8>(), dpperms.as<u8>(), dpcounts.as<u32>());
     hipLaunchKernelGGL(bz_mtf_scan, dim3(nb), dim3(64), 0, st, dres.as<BzResult>(), dc, nb, (u32)level, dchunks.as<BzChunk>(), dperms.as<u8>(),
                        dlist0.as<u8>(), dlists.as<u8>(), dchoff.as<u32>());
-    hipLaunchKernelGGL(bz_mtf_chunks<true>, dim3(BZ_CHUNKS / 4, nb), dim3(256), 0, st, dsyms.as<u16>(), dres.as<BzResult>(), (u32)level,
-                       dchunks.as<BzChunk>(), dperms.as<u8>(), dlists.as<u8>(), dchoff.as<u32>(), dtt.as<u32>());
-    hipLaunchKernelGGL(bz_tinv_scatter, dim3(nb), dim3(1024), 0, st, dtt.as<u32>(), (u32)level, dc, dres.as<BzResult>());
+    hipLaunchKernelGGL(bz_mtf_lanes<true>, dim3(BZ_CHUNKS, nb), dim3(64), 0, st, dsyms.as<u16>(), dres.as<BzResult>(), (u32)level,
+                       dchunks.as<BzChunk>(), dperms.as<u8>(), dlists.as<u8>(), dchoff.as<u32>(), dpre.as<u8>(), dpperms.as<u8>(), dpcounts.as<u32>());
+    hipLaunchKernelGGL(bz_tinv_scatter, dim3(nb), dim3(1024), 0, st, dtt.as<u32>(), dpre.as<u8>(), (u32)level, dc, dres.as<BzResult>());  // (dpre: the bytes before the walk, the walk's output after it)
     HIP_TRY(hipMemsetAsync(dwq.p, 0, 64, st));
     hipLaunchKernelGGL(bz_walk<false>, dim3(8 * wpx), dim3(256), 0, st, dtt.as<u32>(), (u32)level, dc, dres.as<BzResult>(),
                        dwalk.as<BzWalk>(), drank.as<u32>(), dpre.as<u8>(), nb, dwq.as<u32>() + 0);
-    hipLaunchKernelGGL(bz_rank, dim3(nb), dim3(256), 0, st, (u32)level, dc, dres.as<BzResult>(), dwalk.as<BzWalk>(), drank.as<u32>());
+    HIP_TRY(hipMemsetAsync(drank.p, 0xff, (size_t)nb * wstride * 4, st));  // ~0: not on the head's cycle
+    hipLaunchKernelGGL(bz_rank, dim3(nb), dim3(1024), 0, st, (u32)level, dc, dres.as<BzResult>(), dwalk.as<BzWalk>(), drank.as<u32>());
     hipLaunchKernelGGL(bz_walk<true>, dim3(8 * wpx), dim3(256), 0, st, dtt.as<u32>(), (u32)level, dc, dres.as<BzResult>(),
                        dwalk.as<BzWalk>(), drank.as<u32>(), dpre.as<u8>(), nb, dwq.as<u32>() + 8);
     hipLaunchKernelGGL(bz_rle_scan, dim3(nb), dim3(1024), 0, st, (u32)level, dc, dres.as<BzResult>(), dpre.as<u8>(), dspans.as<BzSpan>());

@@ -44,10 +44,13 @@ namespace ahip {
 constexpr u32 BZ_MAX_SELECTORS = 18002;
 constexpr u32 BZ_ST_OK = 0, BZ_ST_FALSE = 1, BZ_ST_RANGE = 2, BZ_ST_OVERFLOW = 16, BZ_ST_UNSUPPORTED = 17, BZ_ST_SERIAL = 18;
 constexpr u32 BZ_ST_HUFF_SERIAL = 19;  // between kernels only: the position-parallel Huffman pass hands the block to the serial one
-constexpr u32 BZ_G = 128;      // splitter stride of the list ranking
+constexpr u32 BZ_G = 16;       // splitter stride of the list ranking (see bz_walk: short sublists keep a block's walk inside one L2)
 constexpr u32 BZ_SPANS = 1024;  // run-length spans per block
+#ifndef AHIP_BZ_HANDOUT
+#define AHIP_BZ_HANDOUT 16
+#endif
+constexpr u32 BZ_WALK_HANDOUT = AHIP_BZ_HANDOUT;  // idle lanes of a wave that make it worth handing out sublists
 constexpr u32 BZ_WALK_BATCH = 128;  // sublists a wave takes from its XCD's queue at a time
-constexpr u32 BZ_WALK_WGS = (900000 / BZ_G + 2 + 255) / 256;  // workgroups of 256 threads that hold one thread per sublist of a 900k block
 
 struct BzCand { u64 bit; u32 kind; u32 pad; };  // kind 0 = compressed block, 2 = end of stream
 struct BzResult {
@@ -933,6 +936,185 @@ AHIP_DEVINL void bz_mtf_chunk_wave(const u16 *__restrict__ syms, u32 nsyms, u32 
   res.bad = bad;
 }
 
+// ---- the same, a PART per lane ----
+// bz_mtf_chunk_wave spends a whole wave on one symbol at a time: the list lies across the lanes and a symbol's move to
+// the front is a handful of cross-lane operations -- 403 M symbols x two passes x ~16 instructions were 19.5 of the 66 ms
+// of a 448-block batch.  Here every LANE walks its own part of the chunk (a chunk = 64 parts, cut by the same rule as the
+// chunks) with its own list: 256 bytes in LDS, the lane's dwords BZ_LANE_STRIDE apart from the next lane's (any one
+// dword index is conflict-free across the lanes, and so is one lane's list across the dword indices).  A symbol's move
+// to the front shifts the dwords in front of it by one byte; the wave takes as many shift steps as its deepest lane
+// needs.  Pass 0 runs on the identity and leaves every part's permutation (global, for pass 1), its byte count, and the
+// chunk's permutation = the 64 composed (for bz_mtf_scan, unchanged); pass 1 unrolls the chunk's true list through the
+// parts' permutations into every lane's starting list and runs again with the bytes.
+constexpr u32 BZ_PARTS = BZ_CHUNKS * 64;      // parts per block
+constexpr u32 BZ_LANE_STRIDE = 65;            // dwords between two lanes' lists
+struct BzLaneLds {
+  u32 list[64 * BZ_LANE_STRIDE];
+  u8 cur[256] __attribute__((aligned(4)));  // the list being taken through the parts
+};
+AHIP_DEVINL u32 bz_part_start(const u16 *__restrict__ syms, u32 nsyms, u32 c) {
+  const u32 per = (nsyms + BZ_PARTS - 1) / BZ_PARTS;
+  const u64 nominal = (u64)c * per;
+  if (nominal >= nsyms) return nsyms;
+  u32 st = (u32)nominal;
+  if (st > 0 && syms[st - 1] <= 1)
+    for (u32 k = 0; k < 32 && st < nsyms && syms[st] <= 1; ++k) ++st;  // (more than 21 digits: the run's owner reports it)
+  return st;
+}
+// chunk c of a block.  part_perms: the chunk's 64 x 256 bytes (written by pass 0, read by pass 1); part_counts: its 64 counts.
+template <bool WRITE>
+AHIP_DEVINL void bz_mtf_lanes_wave(BzLaneLds &S, const u16 *__restrict__ syms, u32 nsyms, u32 c, u32 limit,
+                                   const u8 *__restrict__ list /* pass 1: the chunk's true list */, u32 out_off, u8 *__restrict__ b8,
+                                   u8 *__restrict__ part_perms, u32 *__restrict__ part_counts, u8 *__restrict__ perm_out, BzChunk &res,
+                                   const u32 lane) {
+  u32 *L = S.list + lane * BZ_LANE_STRIDE;  // this lane's list, four entries a dword
+  u32 my_off = 0;
+  if (WRITE) {
+    // every lane's starting list: the chunk's, taken through the parts in front of the lane
+    for (u32 i = lane; i < 256; i += 64) S.cur[i] = list[i];
+    wave_sync();
+    const u32 *pp = (const u32 *)part_perms;
+    u32 p_next = pp[lane];  // dword `lane` of part 0's permutation
+    for (u32 l = 0; l < 64; ++l) {
+      const u32 p = p_next;
+      if (l + 1 < 64) p_next = pp[(l + 1) * 64 + lane];
+      const u32 mine = ((const u32 *)S.cur)[lane];
+      S.list[l * BZ_LANE_STRIDE + lane] = mine;  // lane l starts from the list as it stands
+      const u32 y = (u32)S.cur[p & 0xff] | ((u32)S.cur[(p >> 8) & 0xff] << 8) | ((u32)S.cur[(p >> 16) & 0xff] << 16) | ((u32)S.cur[p >> 24] << 24);
+      wave_sync();
+      ((u32 *)S.cur)[lane] = y;
+      wave_sync();
+    }
+    u32 total;
+    my_off = out_off + wave_excl_sum(part_counts[lane], total);
+  } else {
+#pragma unroll 4
+    for (u32 d = 0; d < 64; ++d) L[d] = (4 * d) | ((4 * d + 1) << 8) | ((4 * d + 2) << 16) | ((4 * d + 3) << 24);
+  }
+  wave_sync();
+  const u32 part = c * 64 + lane;
+  const u32 s0 = bz_part_start(syms, nsyms, part);
+  u32 s1 = part + 1 < BZ_PARTS ? bz_part_start(syms, nsyms, part + 1) : nsyms;
+  if (s1 < s0) s1 = s0;
+  const u32 steps = wave_umax(s1 - s0);
+  u32 cnt = 0, r0 = 0, es = 0, bad = 0;  // bytes made; the zero run being read: digits so far, value so far
+  u32 sb[4] = {0, 0, 0, 0};              // the next (up to) eight symbols
+  // pass 1: the block's bytes go to b8[] (bz_tinv_scatter spreads them into tt[]); a lane gathers four and stores an aligned
+  // dword (a store per symbol was 64 cache lines per instruction for one byte of each: the pass took three times pass 0)
+  u32 ob = 0, nob = 0;  // bytes b8[my_off + cnt - nob .. my_off + cnt) are still here, the oldest lowest
+  auto spill = [&]() {
+    u8 *dst = b8 + (my_off + cnt - nob);
+    if (nob == 4) *(u32 *)dst = ob;
+    else for (u32 k = 0; k < nob; ++k) dst[k] = (u8)(ob >> (8 * k));
+    nob = 0; ob = 0;
+  };
+  auto emit = [&](u32 byte) {  // counts the byte
+    ob |= byte << (8 * nob);
+    ++nob; ++cnt;
+    if (((my_off + cnt) & 3u) == 0) spill();
+  };
+  // n copies of a byte (a zero run): whole dwords once the position is aligned -- the wave waits for its longest run at
+  // every step, so what a run costs per byte is what the pass costs
+  auto emit_run = [&](u32 byte, u32 n) {
+    while (n && ((my_off + cnt) & 3u)) { emit(byte); --n; }
+    if (n >= 4) {  // (aligned: nothing is pending)
+      u32 *d = (u32 *)(b8 + my_off + cnt);
+      const u32 nd = n >> 2, w = byte * 0x01010101u;
+      for (u32 k = 0; k < nd; ++k) d[k] = w;
+      cnt += 4 * nd;
+      n &= 3u;
+    }
+    while (n) { emit(byte); --n; }
+  };
+  for (u32 j = 0; j < steps; ++j) {
+    const bool on = s0 + j < s1 && !bad;
+    if ((j & 7) == 0 && on) {
+      const u32 at = s0 + j;
+      if (at + 8 <= nsyms) { const uint4 v = load_u128_unaligned((const u8 *)(syms + at)); sb[0] = v.x; sb[1] = v.y; sb[2] = v.z; sb[3] = v.w; }
+      else for (u32 k = 0; k < 8; ++k) { const u32 x = at + k < nsyms ? (u32)syms[at + k] : 0u; if (k & 1) sb[k >> 1] |= x << 16; else sb[k >> 1] = x; }
+    }
+    const u32 jj = j & 7;
+    const u32 w2 = jj < 2 ? sb[0] : (jj < 4 ? sb[1] : (jj < 6 ? sb[2] : sb[3]));
+    const u32 sym = (jj & 1) ? w2 >> 16 : w2 & 0xffffu;
+    const bool digit = on && sym <= 1;
+    if (digit) {
+      if (r0 >= 21) bad = 1;  // the 22nd digit finds N >= 2M
+      else { es += (1u + sym) << r0; ++r0; }
+    }
+    // a run ends in front of a list symbol
+    const bool flush = on && !digit && r0 != 0;
+    if (flush && cnt + es > limit) bad = 1;
+    if (WRITE) {
+      const bool big = flush && !bad && es >= 512;  // a long run is written by the whole wave
+      if (__any(big)) {
+        if (big) spill();
+        for (u64 bm = __ballot(big); bm; bm &= bm - 1) {
+          const int src = __builtin_ctzll(bm);
+          const u32 b0 = lane_bcast(my_off + cnt, src), n = lane_bcast(es, src), byte = lane_bcast(L[0] & 0xffu, src);
+          for (u32 i = lane; i < n; i += 64) b8[b0 + i] = (u8)byte;
+        }
+      }
+      if (flush && !bad && !big) {
+        const u32 byte = L[0] & 0xffu;
+        emit_run(byte, es);
+        es = 0;  // (counted)
+      }
+    }
+    if (flush && !bad) { cnt += es; r0 = 0; es = 0; }
+    // the list symbol: entry nn moves to the front
+    bool mtf = on && !digit && !bad;
+    if (mtf && cnt + 1 > limit) { bad = 1; mtf = false; }  // (the symbol finds nblock >= nblockMAX)
+    u32 q = 0, xq = 0, m = 0, carry = 0;
+    if (mtf) {
+      const u32 nn = sym - 1, r = nn & 3;
+      q = nn >> 2;
+      xq = L[q];
+      carry = (xq >> (8 * r)) & 0xffu;  // the byte itself: it goes to the front
+      m = r == 3 ? 0xffffffffu : (1u << (8 * (r + 1))) - 1;  // the bytes of dword q that move
+      if (WRITE) emit(carry); else ++cnt;
+    }
+    for (u32 d = 0; __any(mtf && d < q); d += 2) {
+      if (mtf && d < q) {
+        const bool two = d + 1 < q;
+        const u32 x0 = L[d], x1 = two ? L[d + 1] : 0u;
+        L[d] = (x0 << 8) | carry;
+        carry = x0 >> 24;
+        if (two) { L[d + 1] = (x1 << 8) | carry; carry = x1 >> 24; }
+      }
+    }
+    if (mtf) L[q] = ((((xq << 8) | carry) & m) | (xq & ~m));
+  }
+  if (r0 && !bad) {  // a run ends with its part
+    if (cnt + es > limit) bad = 1;
+    else {
+      if (WRITE) emit_run(L[0] & 0xffu, es);
+      else cnt += es;
+    }
+  }
+  if (WRITE) spill();
+  wave_sync();
+  if (!WRITE) {
+    // the parts' permutations (lane t writes dword t of part l: 256 bytes a store), and the chunk's = all of them composed
+    u32 *pp = (u32 *)part_perms;
+    S.cur[lane] = (u8)lane; S.cur[lane + 64] = (u8)(lane + 64); S.cur[lane + 128] = (u8)(lane + 128); S.cur[lane + 192] = (u8)(lane + 192);
+    wave_sync();
+    for (u32 l = 0; l < 64; ++l) {
+      const u32 p = S.list[l * BZ_LANE_STRIDE + lane];
+      pp[l * 64 + lane] = p;
+      const u32 y = (u32)S.cur[p & 0xff] | ((u32)S.cur[(p >> 8) & 0xff] << 8) | ((u32)S.cur[(p >> 16) & 0xff] << 16) | ((u32)S.cur[p >> 24] << 24);
+      wave_sync();
+      ((u32 *)S.cur)[lane] = y;
+      wave_sync();
+    }
+    ((u32 *)perm_out)[lane] = ((const u32 *)S.cur)[lane];
+    part_counts[lane] = cnt;
+  }
+  u32 total;
+  (void)wave_excl_sum(cnt, total);
+  res.count = total;
+  res.bad = __any(bad != 0) ? 1u : 0u;
+}
+
 // one wave per block: chunk offsets and lists, the block's size and verdict
 struct BzScanLds { u8 cur[256], nxt[256]; };
 AHIP_DEVINL void bz_mtf_scan_wave(BzScanLds &S, BzResult &R, u32 nblock_max, const BzChunk *__restrict__ chunks,
@@ -1059,6 +1241,24 @@ __global__ __launch_bounds__(256) void bz_mtf_chunks(const u16 *__restrict__ sym
                            perms_all + ((u64)blk * BZ_CHUNKS + c) * 256, res, lane);
   if (!WRITE && lane == 0) chunks_all[(u64)blk * BZ_CHUNKS + c] = res;
 }
+// grid (BZ_CHUNKS, blocks), 64 threads: one wave per chunk, one part of it per lane
+template <bool WRITE>
+__global__ __launch_bounds__(64) void bz_mtf_lanes(const u16 *__restrict__ syms_all, const BzResult *__restrict__ results,
+                                                   u32 block_size100k, BzChunk *__restrict__ chunks_all, u8 *__restrict__ perms_all,
+                                                   const u8 *__restrict__ lists_all, const u32 *__restrict__ offs_all,
+                                                   u8 *__restrict__ b8_all, u8 *__restrict__ part_perms_all, u32 *__restrict__ part_counts_all) {
+  __shared__ BzLaneLds S;
+  const u32 blk = blockIdx.y, c = blockIdx.x, lane = threadIdx.x;
+  const u32 nblock_max = 100000u * block_size100k;
+  const BzResult &R = results[blk];
+  if (WRITE && R.status != BZ_ST_OK) return;
+  BzChunk res;
+  const u64 ci = (u64)blk * BZ_CHUNKS + c;
+  bz_mtf_lanes_wave<WRITE>(S, syms_all + (u64)blk * BZ_SYM_CAP, R.nsyms, c, nblock_max, WRITE ? lists_all + ci * 256 : nullptr,
+                           WRITE ? offs_all[ci] : 0u, b8_all + (u64)blk * nblock_max, part_perms_all + ci * 64 * 256, part_counts_all + ci * 64,
+                           perms_all + ci * 256, res, lane);
+  if (!WRITE && lane == 0) chunks_all[ci] = res;
+}
 __global__ __launch_bounds__(64) void bz_mtf_scan(BzResult *__restrict__ results, const BzCand *__restrict__ cands, u32 ncand,
                                                   u32 block_size100k, const BzChunk *__restrict__ chunks_all, const u8 *__restrict__ perms_all,
                                                   const u8 *__restrict__ list0_all, u8 *__restrict__ lists_all,
@@ -1078,7 +1278,7 @@ __global__ __launch_bounds__(64) void bz_mtf_scan(BzResult *__restrict__ results
 // contiguous sixteenth: per-wave histograms, a (symbol, wave) exclusive scan, then 64 elements per step:
 // eight ballots give every lane the set of lanes holding the same byte, so its rank inside the step is a
 // popcount and only the first lane of each byte value bumps the wave's cursor.
-__global__ __launch_bounds__(1024) void bz_tinv_scatter(u32 *__restrict__ tt_all, u32 block_size100k,
+__global__ __launch_bounds__(1024) void bz_tinv_scatter(u32 *__restrict__ tt_all, const u8 *__restrict__ b8_all, u32 block_size100k,
                                                         const BzCand *__restrict__ cands, BzResult *__restrict__ results) {
   __shared__ u32 cur[16][256];
   __shared__ u32 tot[256];
@@ -1086,12 +1286,13 @@ __global__ __launch_bounds__(1024) void bz_tinv_scatter(u32 *__restrict__ tt_all
   if (cands[blk].kind != 0 || results[blk].status != BZ_ST_OK) return;
   const u32 nblock = results[blk].nblock;
   u32 *tt = tt_all + (u64)blk * (100000u * block_size100k);
+  const u8 *b8 = b8_all + (u64)blk * (100000u * block_size100k);  // the block's bytes as bz_mtf_lanes<true> left them
   for (u32 i = tid; i < 16 * 256; i += 1024) (&cur[0][0])[i] = 0;
   __syncthreads();
   const u32 seg = (((nblock + 15) / 16) + 63) & ~63u;
   const u32 lo = w * seg < nblock ? w * seg : nblock;
   const u32 hi = lo + seg < nblock ? lo + seg : nblock;
-  for (u32 i = lo + lane; i < hi; i += 64) atomicAdd(&cur[w][tt[i] & 0xff], 1u);
+  for (u32 i = lo + lane; i < hi; i += 64) { const u32 b = b8[i]; tt[i] = b; atomicAdd(&cur[w][b], 1u); }  // (tt[i]: the byte now, the link below)
   __syncthreads();
   if (tid < 256) {
     u32 acc = 0;
@@ -1115,7 +1316,7 @@ __global__ __launch_bounds__(1024) void bz_tinv_scatter(u32 *__restrict__ tt_all
   for (u32 i0 = lo; i0 < hi; i0 += 64) {
     const u32 i = i0 + lane;
     const bool act = i < hi;
-    const u32 sym = act ? (tt[i] & 0xff) : 0u;
+    const u32 sym = act ? (u32)b8[i] : 0u;
     u64 same = __ballot(act);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -1211,14 +1412,21 @@ fin:
 struct BzWalk { u32 next, len; };
 AHIP_DEVINL u32 bz_nsplit(u32 nblock) { return (nblock + BZ_G - 1) / BZ_G; }
 
-// Who walks what.  The walk is 0.9 M dependent 4-byte reads at random places of the block's 3.6 MB vector, and a sublist
-// ends where the chain happens to reach the next multiple of BZ_G: its length is geometric (mean BZ_G, the longest of a
-// block's seven thousand some nine times that).
+// Who walks what.  The walk is 0.9 M dependent 4-byte reads at random places of the block's 3.6 MB vector -- every entry
+// exactly once, so a 128-byte line is worth fetching only if it stays cached until its 32 entries have been read -- and
+// a sublist ends where the chain happens to reach the next multiple of BZ_G: its length is geometric (mean BZ_G, the
+// longest of a block's some eleven times that).
 //  * With every block of a batch in flight at once (a 2-D grid, one thread per splitter) the vectors of some seventy
-//    blocks -- 260 MB -- were walked side by side and nearly every read went to memory.  Workgroups are dealt to the
+//    blocks -- 260 MB -- were walked side by side and nearly every read went to memory (60 G reads/s: the rate of
+//    tools/micro/xcc_chase.hip on a 64 MB vector; 230 G/s on one that fits an L2).  Workgroups are dealt to the
 //    eight XCDs in turn (workgroup i runs on XCD i mod 8) and each XCD has its own 4 MB L2, so the grid is 8 x `wpx`
 //    PERSISTENT workgroups and the ones with blockIdx.x mod 8 == x take the blocks x, x + 8, ... one after the other:
 //    a block's vector is read by one XCD only, through an L2 it (nearly) fits in.
+//  * That alone changed little (70 % of the reads still missed, TCC_HIT / TCC_MISS): with BZ_G = 128 a block had as many
+//    sublists as the XCD has lanes at work, the lanes that were done went on to the next block while the long sublists of
+//    this one were still being walked, and three vectors shared the L2.  The share of the reads that fall into such an
+//    overlap is (lanes at work) / (sublists of a block): BZ_G = 16 makes it an eighth.  (The price is 56 thousand
+//    sublists to rank per block: bz_rank does it in two levels.)
 //  * A lane whose sublist has ended takes the next one from the XCD's queue (queue[x]: the next item, an item = block
 //    x + 8 (q / stride), splitter q mod stride; one atomic for all the idle lanes of a wave) instead of waiting for the
 //    longest sublist of its workgroup.
@@ -1244,12 +1452,14 @@ __global__ __launch_bounds__(256) void bz_walk(const u32 *__restrict__ tt_all, u
   u32 cur = 0, len = 0, p0 = 0, nblock = 0, s = 0, blk = 0;
   u32 acc = 0, na = 0, at = 0;  // WRITE: bytes [at, at + na) are still in `acc`; whole aligned dwords are stored as such
   // the wave's batch (wave-uniform): items [pool_next, pool_end) of block b_blk are not handed to a lane yet
-  u32 pool_base = 0, pool_next = 0, pool_end = 0, b_blk = 0, b_nblock = 0, b_S = 0, b_p0 = 0;
+  u32 pool_base = 0, pool_next = 0, pool_end = 0, b_blk = 0, b_nblock = 0, b_S = 0, b_p0 = 0, b_s0 = 0;
   u32 rk[BZ_WALK_BATCH / 64];  // WRITE: rank of item pool_base + 64 i + lane
   bool out_of_work = false;
   for (;;) {
     const u64 idle = __ballot(!active);
-    if (idle && !out_of_work) {
+    // (sublists are handed out to sixteen lanes at a time: the hand-out is some eighty instructions, a step of the walk
+    //  fifteen, and with sublists of sixteen entries some lane of a wave is done at nearly every step)
+    if (((u32)__popcll(idle) >= BZ_WALK_HANDOUT || idle == ~0ull) && !out_of_work) {
       if (pool_next == pool_end) {
         u32 base = 0;
         if (lane == 0) base = atomicAdd(&queue[xcd], BZ_WALK_BATCH);
@@ -1259,7 +1469,7 @@ __global__ __launch_bounds__(256) void bz_walk(const u32 *__restrict__ tt_all, u
           pool_base = pool_next = base;
           pool_end = base + BZ_WALK_BATCH;
           b_blk = xcd + 8 * (base / ipb);
-          const u32 s0 = base % ipb;
+          const u32 s0 = b_s0 = base % ipb;
           const bool ok = cands[b_blk].kind == 0 && results[b_blk].status == BZ_ST_OK && results[b_blk].nblock != 0;
           b_nblock = ok ? (u32)__builtin_amdgcn_readfirstlane((int)results[b_blk].nblock) : 0u;
           b_S = bz_nsplit(b_nblock);
@@ -1290,7 +1500,7 @@ __global__ __launch_bounds__(256) void bz_walk(const u32 *__restrict__ tt_all, u
         }
         pool_next += need < avail ? need : avail;
         if (served) {
-          s = q % ipb;
+          s = b_s0 + (q - pool_base);
           if (s <= b_S && !(WRITE && my_at == ~0u)) {  // (~0: not on the head's cycle -- a duplicate of the head, or corrupt data)
             blk = b_blk;
             nblock = b_nblock;
@@ -1315,7 +1525,11 @@ __global__ __launch_bounds__(256) void bz_walk(const u32 *__restrict__ tt_all, u
         acc |= (w & 0xffu) << (8 * na);
         ++na;
         if (((at + na) & 3u) == 0) {
+#ifdef AHIP_BZ_NT_PRE  // dev: the walk's output past the L2 (it is not read again by this kernel, and the vector needs the room)
+          if (na == 4) __builtin_nontemporal_store(acc, (u32 *)(pre + at));
+#else
           if (na == 4) *(u32 *)(pre + at) = acc;
+#endif
           else for (u32 b = 0; b < na; ++b) pre[at + b] = (u8)(acc >> (8 * b));
           at += na; na = 0; acc = 0;
         }
@@ -1337,38 +1551,62 @@ __global__ __launch_bounds__(256) void bz_walk(const u32 *__restrict__ tt_all, u
   }
 }
 
-// one workgroup per block: order the splitters along the cycle, starting at the head
-__global__ __launch_bounds__(256) void bz_rank(u32 block_size100k, const BzCand *__restrict__ cands,
-                                               BzResult *__restrict__ results, const BzWalk *__restrict__ walk_all,
-                                               u32 *__restrict__ rank_all) {
-  constexpr u32 S_MAX = 900000 / BZ_G + 2;
-  __shared__ u16 nxt[S_MAX];
-  __shared__ u32 ln[S_MAX];  // sublist length; overwritten by 0x80000000 | rank once the splitter is placed
-  const u32 blk = blockIdx.x;
+// One workgroup per block: the place of every sublist along the cycle, starting at the head.  The sublists (a block has
+// nblock / BZ_G + 1 of them, 56 thousand at BZ_G = 16) are themselves a linked list (BzWalk::next), ranked the same way
+// one level up: every BZ_G2-th splitter and the head are the second-level splitters (at most 1 024: a thread each), a
+// thread follows the sublists from its splitter to the next second-level one adding up their lengths, thread 0 orders
+// the second-level splitters along the cycle (in LDS), and every thread goes over its stretch again handing out the places.
+// rank_all is ~0 beforehand (the host's memset) and stays so for what is not on the head's cycle.
+constexpr u32 BZ_G2 = 64;
+static_assert((900000 / BZ_G + 1 + BZ_G2 - 1) / BZ_G2 + 1 <= 1024, "second-level splitters: one thread each");
+__global__ __launch_bounds__(1024) void bz_rank(u32 block_size100k, const BzCand *__restrict__ cands,
+                                                BzResult *__restrict__ results, const BzWalk *__restrict__ walk_all,
+                                                u32 *__restrict__ rank_all) {
+  __shared__ u16 nxt2[1024];
+  __shared__ u32 ln2[1024];  // stretch length (saturated); overwritten by 0x80000000 | place once the splitter is placed
+  const u32 blk = blockIdx.x, t = threadIdx.x;
   if (cands[blk].kind != 0 || results[blk].status != BZ_ST_OK) return;
   const u32 nblock = results[blk].nblock;
   if (nblock == 0) return;
   const u32 nblock_max = 100000u * block_size100k;
   const u32 S = bz_nsplit(nblock), stride = nblock_max / BZ_G + 2;
+  const u32 S2 = (S + BZ_G2 - 1) / BZ_G2;  // second-level splitters t < S2 are the sublists t * BZ_G2; t == S2 is the head (sublist S)
   const BzWalk *walk = walk_all + (u64)blk * stride;
-  for (u32 i = threadIdx.x; i <= S; i += 256) { nxt[i] = (u16)walk[i].next; ln[i] = walk[i].len & 0x7fffffffu; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    u32 s = S, pos = 0, hops = 0;
+  const bool mine = t <= S2;
+  const u32 start = t == S2 ? S : t * BZ_G2;
+  if (mine) {
+    u32 cur = start, hops = 0;
+    u64 sum = 0;
     do {
-      const u32 l = ln[s];
-      if (l & 0x80000000u) break;  // already placed: not a simple cycle through the head
-      ln[s] = 0x80000000u | pos;
-      pos += l;
-      s = nxt[s];
-    } while (s != S && ++hops <= S && pos < nblock);
-    // a valid block is ONE cycle of length nblock; anything else takes the serial path
-    if (s != S || pos != nblock) results[blk].status = BZ_ST_SERIAL;
+      const BzWalk w = walk[cur];
+      sum += w.len;
+      cur = w.next;
+    } while (cur != S && (cur % BZ_G2) != 0 && cur <= S && ++hops <= S);
+    nxt2[t] = (u16)(cur == S ? S2 : (cur <= S ? cur / BZ_G2 : S2 + 1));  // (S2 + 1: nowhere -- a damaged record)
+    ln2[t] = sum < 0x7fffffffull ? (u32)sum : 0x7fffffffu;
   }
   __syncthreads();
-  for (u32 i = threadIdx.x; i <= S; i += 256) {
-    const u32 v = ln[i];
-    rank_all[(u64)blk * stride + i] = (v & 0x80000000u) ? (v & 0x7fffffffu) : ~0u;
+  if (t == 0) {
+    u32 s = S2, pos = 0, hops = 0;
+    do {
+      const u32 l = ln2[s];
+      if (l & 0x80000000u) break;  // already placed: not a simple cycle through the head
+      ln2[s] = 0x80000000u | pos;
+      pos += l;
+      s = nxt2[s];
+    } while (s != S2 && s <= S2 && ++hops <= S2 && pos < nblock);
+    // a valid block is ONE cycle of length nblock; anything else takes the serial path
+    if (s != S2 || pos != nblock) results[blk].status = BZ_ST_SERIAL;
+  }
+  __syncthreads();
+  if (mine && (ln2[t] & 0x80000000u)) {
+    u32 cur = start, hops = 0, pos = ln2[t] & 0x7fffffffu;
+    do {
+      rank_all[(u64)blk * stride + cur] = pos;
+      const BzWalk w = walk[cur];
+      pos += w.len;
+      cur = w.next;
+    } while (cur != S && (cur % BZ_G2) != 0 && cur <= S && ++hops <= S);
   }
 }
 

@@ -106,15 +106,40 @@ int main(int argc, char **argv) {
       }
     }
     const uint32_t nmax = 100000u * level;
+    // the list side the way archive_hip.hip launches it: a part per lane (bz_mtf_lanes<false>), the scan over the chunks, the parts
+    // again with the bytes (bz_mtf_lanes<true>)
+    static BzLaneLds LL;
+    std::vector<uint8_t> pperms((size_t)BZ_PARTS * 256);
+    std::vector<uint32_t> pcounts(BZ_PARTS);
+    std::vector<uint8_t> b8(tt.size(), 0xdd);
+    const BzResult R_huff = R;
     for (uint32_t k = 0; k < BZ_CHUNKS; ++k)
-      wave([&](int lane) { BzChunk r; bz_mtf_chunk_wave<false>(syms.data(), R.nsyms, k, nmax, nullptr, 0, tt.data(), perms.data() + k * 256, r, (u32)lane); if (lane == 0) chunks[k] = r; });
+      wave([&](int lane) { BzChunk r; bz_mtf_lanes_wave<false>(LL, syms.data(), R.nsyms, k, nmax, nullptr, 0, b8.data(), pperms.data() + (size_t)k * 64 * 256, pcounts.data() + k * 64, perms.data() + k * 256, r, (u32)lane); if (lane == 0) chunks[k] = r; });
     wave([&](int lane) { BzResult r = R; bz_mtf_scan_wave(SLDS, r, nmax, chunks.data(), perms.data(), list0.data(), lists.data(), offs.data(), (u32)lane); wave_emu::barrier(); if (lane == 0) R = r; });
+    {
+      // ... and the wave-per-symbol form of the same passes (bz_mtf_chunk_wave; its chunks are cut elsewhere): same verdict, same bytes
+      std::vector<uint8_t> perms_w(BZ_CHUNKS * 256), lists_w(BZ_CHUNKS * 256);
+      std::vector<uint32_t> tt_w(tt.size(), 0xdead0000u), offs_w(BZ_CHUNKS);
+      std::vector<BzChunk> chunks_w(BZ_CHUNKS);
+      BzResult W = R_huff;
+      for (uint32_t k = 0; k < BZ_CHUNKS; ++k)
+        wave([&](int lane) { BzChunk r; bz_mtf_chunk_wave<false>(syms.data(), W.nsyms, k, nmax, nullptr, 0, tt_w.data(), perms_w.data() + k * 256, r, (u32)lane); if (lane == 0) chunks_w[k] = r; });
+      wave([&](int lane) { BzResult r = W; bz_mtf_scan_wave(SLDS, r, nmax, chunks_w.data(), perms_w.data(), list0.data(), lists_w.data(), offs_w.data(), (u32)lane); wave_emu::barrier(); if (lane == 0) W = r; });
+      if (W.status != R.status || (R.status == BZ_ST_OK && W.nblock != R.nblock)) { printf("block %zu: the two forms of the list pass differ: status %u / %u, size %u / %u\n", blocks, R.status, W.status, R.nblock, W.nblock); return 1; }
+      if (R.status == BZ_ST_OK) {
+        for (uint32_t k = 0; k < BZ_CHUNKS; ++k) {
+          wave([&](int lane) { BzChunk r; bz_mtf_lanes_wave<true>(LL, syms.data(), R.nsyms, k, nmax, lists.data() + k * 256, offs[k], b8.data(), pperms.data() + (size_t)k * 64 * 256, pcounts.data() + k * 64, nullptr, r, (u32)lane); });
+          wave([&](int lane) { BzChunk r; bz_mtf_chunk_wave<true>(syms.data(), W.nsyms, k, nmax, lists_w.data() + k * 256, offs_w[k], tt_w.data(), perms_w.data() + k * 256, r, (u32)lane); });
+        }
+        for (uint32_t i = 0; i < R.nblock; ++i)
+          if (tt_w[i] != b8[i]) { printf("block %zu: the two forms of the list pass wrote different bytes (at %u)\n", blocks, i); return 1; }
+        for (uint32_t i = 0; i < R.nblock; ++i) tt[i] = b8[i];  // (bz_tinv_scatter's first step)
+      }
+    }
     if (R.status != BZ_ST_OK) {
       if (damaged_ok) { printf("bzip2 emu agree: block %zu, the list side says status %u\n", blocks, R.status); return 0; }
       printf("block %zu: status %u\n", blocks, R.status); return 1;
     }
-    for (uint32_t k = 0; k < BZ_CHUNKS; ++k)
-      wave([&](int lane) { BzChunk r; bz_mtf_chunk_wave<true>(syms.data(), R.nsyms, k, nmax, lists.data() + k * 256, offs[k], tt.data(), perms.data() + k * 256, r, (u32)lane); });
     const uint32_t nb = R.nblock;
     // T^-1 and the walk, as bzip2_decoder.dart:406-439 / :610-727 do them
     uint32_t cf[257] = {0};
