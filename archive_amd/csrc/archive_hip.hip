@@ -1504,7 +1504,7 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
   const u32 wgrid = (u32)cdiv(wstride, 256);
   // workgroups of 256 threads per XCD (bz_walk): more hide latency, but threads beyond a block's ~7 000 sublists work on the
   // next blocks' vectors and the XCD's L2 holds about one
-  static const u32 wpx = [] { const char *e = getenv("AHIP_BZ_WALK_WGS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 4096 ? (u32)v : 40u; }();
+  static const u32 wpx = [] { const char *e = getenv("AHIP_BZ_WALK_WGS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 4096 ? (u32)v : 80u; }();
   (void)wgrid;
   static thread_local DevBuf dwq;  // the XCDs' work queues, one set for each of the two walks
   HIP_TRY(dwq.reserve(64));
@@ -1529,32 +1529,45 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
     // (12 bytes of jumps per bit; when even that allocation fails the serial wave, which needs none, does the batch)
     bool jumps = bz_parallel_huffman() && tstride * 12 <= std::max<u64>(batch_mem, 4ull << 30);
     if (jumps && dj50.reserve((size_t)tstride * 6 * 2) != hipSuccess) { (void)hipGetLastError(); jumps = false; }
-    if (jumps) {
-      // headers and tables (one wave per block), the 50-code jump from every bit position (tiles, any number of workgroups),
-      // the walk over the groups (one workgroup per block), the groups (one thread each); what is irregular, serially
-      u64 widest = 0;
-      for (u32 i = 0; i < nb; ++i) widest = std::max<u64>(widest, (c0 + i + 1 < ncand ? cands[c0 + i + 1].bit : (u64)in_len * 8) - cands[c0 + i].bit);
-      hipLaunchKernelGGL(bz_header, dim3(nb), dim3(64), 0, st, d_in, (u64)in_len, dc, nb, dtab.as<BzTables>(), dlist0.as<u8>(), dsel.as<u8>(),
-                         dres.as<BzResult>());
-      hipLaunchKernelGGL(bz_jump_tiles, dim3((u32)cdiv(widest, BZ_TW) + 1, nb), dim3(512), 0, st, d_in, (u64)in_len, dcand.as<BzCand>(), ncand,
-                         (u32)c0, dtab.as<BzTables>(), dj50.as<u16>(), bit0, tstride);
-      hipLaunchKernelGGL(bz_group_starts, dim3(nb), dim3(256), 0, st, d_in, (u64)in_len, dcand.as<BzCand>(), ncand, (u32)c0, dtab.as<BzTables>(),
-                         dsel.as<u8>(), dj50.as<u16>(), bit0, tstride, dgstart.as<u32>(), dgcount.as<u32>(), dres.as<BzResult>());
-      hipLaunchKernelGGL(bz_decode_groups, dim3(cdiv(BZ_MAX_SELECTORS, 256), nb), dim3(256), 0, st, d_in, (u64)in_len, dtab.as<BzTables>(),
-                         dsel.as<u8>(), dgstart.as<u32>(), dgcount.as<u32>(), dsyms.as<u16>(), dres.as<BzResult>());
-      hipLaunchKernelGGL(bz_decode_block, dim3(nb), dim3(64), 0, st, d_in, (u64)in_len, dc, nb, dsyms.as<u16>(), dlist0.as<u8>(), dsel.as<u8>(),
-                         dres.as<BzResult>(), 1u);
-    } else {
-      hipLaunchKernelGGL(bz_decode_block, dim3(nb), dim3(64), 0, st, d_in, (u64)in_len, dc, nb, dsyms.as<u16>(), dlist0.as<u8>(), dsel.as<u8>(),
-                         dres.as<BzResult>(), 0u);
-    }
-    hipLaunchKernelGGL(bz_mtf_lanes<false>, dim3(BZ_CHUNKS, nb), dim3(64), 0, st, dsyms.as<u16>(), dres.as<BzResult>(), (u32)level,
-                       dchunks.as<BzChunk>(), dperms.as<u8>(), dlists.as<u8>(), dchoff.as<u32>(), dpre.as<u8>(), dpperms.as<u8>(), dpcounts.as<u32>());
-    hipLaunchKernelGGL(bz_mtf_scan, dim3(nb), dim3(64), 0, st, dres.as<BzResult>(), dc, nb, (u32)level, dchunks.as<BzChunk>(), dperms.as<u8>(),
-                       dlist0.as<u8>(), dlists.as<u8>(), dchoff.as<u32>());
-    hipLaunchKernelGGL(bz_mtf_lanes<true>, dim3(BZ_CHUNKS, nb), dim3(64), 0, st, dsyms.as<u16>(), dres.as<BzResult>(), (u32)level,
-                       dchunks.as<BzChunk>(), dperms.as<u8>(), dlists.as<u8>(), dchoff.as<u32>(), dpre.as<u8>(), dpperms.as<u8>(), dpcounts.as<u32>());
-    hipLaunchKernelGGL(bz_tinv_scatter, dim3(nb), dim3(1024), 0, st, dtt.as<u32>(), dpre.as<u8>(), (u32)level, dc, dres.as<BzResult>());  // (dpre: the bytes before the walk, the walk's output after it)
+    // Everything up to the vector of the inverse transform, for the blocks [b0, b0 + n) of the batch on stream s.
+    // (Five of these kernels are one wave or one workgroup per block walking something serially -- header and selectors,
+    //  the group starts, the list scan, the counting sort, 4.9 of the 11.6 ms of a 64-block decode -- and the batch was
+    //  tried in 2 / 4 / 8 parts on streams of their own, one part's serial kernels under another's wide ones: 12.1 / 16.3 /
+    //  21.1 ms.  A serial kernel that shares its SIMD with a wide one is slowed by as much as it overlaps.)
+    auto front = [&](hipStream_t s, u32 b0, u32 n) {
+      const BzCand *dcs = dc + b0;
+      BzTables *tabs = dtab.as<BzTables>() + b0;
+      u8 *list0 = dlist0.as<u8>() + (size_t)b0 * 256, *sels = dsel.as<u8>() + (size_t)b0 * BZ_MAX_SELECTORS;
+      BzResult *ress = dres.as<BzResult>() + b0;
+      u16 *syms = dsyms.as<u16>() + (size_t)b0 * BZ_SYM_CAP;
+      BzChunk *chunks = dchunks.as<BzChunk>() + (size_t)b0 * BZ_CHUNKS;
+      u8 *perms = dperms.as<u8>() + (size_t)b0 * BZ_CHUNKS * 256, *lists = dlists.as<u8>() + (size_t)b0 * BZ_CHUNKS * 256;
+      u32 *choff = dchoff.as<u32>() + (size_t)b0 * BZ_CHUNKS;
+      u8 *b8 = dpre.as<u8>() + (size_t)b0 * nblock_max, *pperms = dpperms.as<u8>() + (size_t)b0 * BZ_PARTS * 256;
+      u32 *pcounts = dpcounts.as<u32>() + (size_t)b0 * BZ_PARTS, *tts = dtt.as<u32>() + (size_t)b0 * nblock_max;
+      if (jumps) {
+        // headers and tables (one wave per block), the 50-code jump from every bit position (tiles, any number of workgroups),
+        // the walk over the groups (one workgroup per block), the groups (one thread each); what is irregular, serially
+        u64 widest = 0;
+        for (u32 i = b0; i < b0 + n; ++i) widest = std::max<u64>(widest, (c0 + i + 1 < ncand ? cands[c0 + i + 1].bit : (u64)in_len * 8) - cands[c0 + i].bit);
+        u32 *gstart = dgstart.as<u32>() + (size_t)b0 * BZ_MAX_SELECTORS, *gcount = dgcount.as<u32>() + b0;
+        hipLaunchKernelGGL(bz_header, dim3(n), dim3(64), 0, s, d_in, (u64)in_len, dcs, n, tabs, list0, sels, ress);
+        hipLaunchKernelGGL(bz_jump_tiles, dim3((u32)cdiv(widest, BZ_TW) + 1, n), dim3(512), 0, s, d_in, (u64)in_len, dcand.as<BzCand>(), ncand,
+                           (u32)c0 + b0, tabs, dj50.as<u16>(), bit0, tstride);
+        hipLaunchKernelGGL(bz_group_starts, dim3(n), dim3(256), 0, s, d_in, (u64)in_len, dcand.as<BzCand>(), ncand, (u32)c0 + b0, tabs, sels,
+                           dj50.as<u16>(), bit0, tstride, gstart, gcount, ress);
+        hipLaunchKernelGGL(bz_decode_groups, dim3(cdiv(BZ_MAX_SELECTORS, 256), n), dim3(256), 0, s, d_in, (u64)in_len, tabs, sels, gstart, gcount,
+                           syms, ress);
+        hipLaunchKernelGGL(bz_decode_block, dim3(n), dim3(64), 0, s, d_in, (u64)in_len, dcs, n, syms, list0, sels, ress, 1u);
+      } else {
+        hipLaunchKernelGGL(bz_decode_block, dim3(n), dim3(64), 0, s, d_in, (u64)in_len, dcs, n, syms, list0, sels, ress, 0u);
+      }
+      hipLaunchKernelGGL(bz_mtf_lanes<false>, dim3(BZ_CHUNKS, n), dim3(64), 0, s, syms, ress, (u32)level, chunks, perms, lists, choff, b8, pperms, pcounts);
+      hipLaunchKernelGGL(bz_mtf_scan, dim3(n), dim3(64), 0, s, ress, dcs, n, (u32)level, chunks, perms, list0, lists, choff);
+      hipLaunchKernelGGL(bz_mtf_lanes<true>, dim3(BZ_CHUNKS, n), dim3(64), 0, s, syms, ress, (u32)level, chunks, perms, lists, choff, b8, pperms, pcounts);
+      hipLaunchKernelGGL(bz_tinv_scatter, dim3(n), dim3(1024), 0, s, tts, b8, (u32)level, dcs, ress);  // (dpre: the bytes before the walk, the walk's output after it)
+    };
+    front(st, 0, nb);
     HIP_TRY(hipMemsetAsync(dwq.p, 0, 64, st));
     hipLaunchKernelGGL(bz_walk<false>, dim3(8 * wpx), dim3(256), 0, st, dtt.as<u32>(), (u32)level, dc, dres.as<BzResult>(),
                        dwalk.as<BzWalk>(), drank.as<u32>(), dpre.as<u8>(), nb, dwq.as<u32>() + 0);

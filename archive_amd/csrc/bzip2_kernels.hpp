@@ -11,23 +11,23 @@
 //                 codes after any bit position, by doubling), bz_group_starts (one look-up per group of 50 codes),
 //                 bz_decode_groups (a thread per group) -> a stream of 16-bit symbols; irregular blocks through
 //                 bz_decode_block, one serial wave (256 positions looked up per step, the chain on scalar registers);
-//                 what the symbols mean -- move-to-front list, RUNA/RUNB zero runs -- into tt[]: bz_mtf_chunks
-//                 (64 chunks per block: the list after a chunk is a permutation of the list before it) twice, with
+//                 what the symbols mean -- move-to-front list, RUNA/RUNB zero runs -- into the block's bytes: bz_mtf_lanes
+//                 (64 chunks of 64 parts per block, a part per lane: the list after a stretch is a permutation of the list
+//                 before it) twice, with
 //                 bz_mtf_scan chaining the permutations in between;
 //        phase 2  T^-1 (:406-439) as a stable counting sort over 16 waves (bz_tinv_scatter) -- same
 //                 result as the reference's serial loop;
 //        phase 3  inverse BWT (:610-727).  The pointer chase tt[t] -> t is one cycle through the block;
 //                 walked serially every step waits for the previous load (~1 us x 900 000).  Instead
-//                 it is list-ranked: every 128th index (and the chain head) is a splitter; one thread
-//                 per splitter walks to the next splitter counting steps (bz_walk<false>), one thread
-//                 orders the <= 7 033 splitters in LDS (bz_rank), and the splitter threads walk again
-//                 writing their bytes at their rank (bz_walk<true>) -- ~500 dependent loads per
-//                 thread instead of 900 000.
-//        phase 4  run-length undo + MSB-first CRC-32 as a scan: 1 024 spans per block, each span's
+//                 it is list-ranked: every 16th index (and the chain head) is a splitter; the sublists
+//                 from splitter to splitter are walked counting steps (bz_walk<false>: persistent
+//                 workgroups, a block's vector read through ONE XCD's L2), ordered along the cycle in
+//                 two levels (bz_rank), and walked again writing their bytes at their place (bz_walk<true>).
+//        phase 4  run-length undo + MSB-first CRC-32: 1 024 spans per block, each span's
 //                 effect on the 5 possible entry states of the "4 equal bytes, then a count" machine
-//                 (bz_rle_scan), composed in order; then every span expands at its own offset and the
-//                 block CRC is assembled from per-span remainders times x^(8*suffix) in GF(2)
-//                 (bz_rle_expand).
+//                 (bz_rle_scan), composed in order; then every span expands at its own offset
+//                 (bz_rle_expand) and the block's CRC is taken over the finished bytes (bz_block_crc: the
+//                 reflected CRC kernel's wave sums over bit-reversed bytes, mirrored back).
 //   The host follows the chain of blocks (a block's end bit must be the next block's magic) between
 //   phases 4a and 4b to place blocks, and verifies CRCs when asked.  Blocks the parallel path cannot
 //   represent exactly (pointer cycle shorter than the block, data ending inside a run-length escape:
@@ -839,6 +839,9 @@ AHIP_DEVINL u32 bz_chunk_start(const u16 *__restrict__ syms, u32 nsyms, u32 c) {
   return st;
 }
 
+// (The wave-per-symbol form below was the device's until round 4; it is compiled for the CPU emulation only, where
+//  tests/emu/bzip2_emu.cc holds the part-per-lane form that replaced it against it, byte for byte.)
+#ifdef AHIP_HOST_EMU
 // list: 256 bytes the chunk starts from (pass 1) / nullptr = the identity (pass 0, result to perm_out)
 template <bool WRITE>
 AHIP_DEVINL void bz_mtf_chunk_wave(const u16 *__restrict__ syms, u32 nsyms, u32 c, u32 limit, const u8 *__restrict__ list,
@@ -935,6 +938,8 @@ AHIP_DEVINL void bz_mtf_chunk_wave(const u16 *__restrict__ syms, u32 nsyms, u32 
   res.count = cnt;
   res.bad = bad;
 }
+
+#endif  // AHIP_HOST_EMU
 
 // ---- the same, a PART per lane ----
 // bz_mtf_chunk_wave spends a whole wave on one symbol at a time: the list lies across the lanes and a symbol's move to
@@ -1223,23 +1228,6 @@ __global__ __launch_bounds__(256) void bz_decode_groups(const u8 *__restrict__ i
   bz_decode_group(S, T->eob, in, n, T->sym_bit, g, gstart_all[(u64)blk * BZ_MAX_SELECTORS + g], sel_all[(u64)blk * BZ_MAX_SELECTORS + g],
                   last, syms_all + (u64)blk * BZ_SYM_CAP, end);
   if (last) { results[blk].status = end.status; results[blk].nsyms = end.nsyms; results[blk].end_bit = end.end_bit; }
-}
-// grid (BZ_CHUNKS / 4, blocks), 256 threads: one wave per chunk
-template <bool WRITE>
-__global__ __launch_bounds__(256) void bz_mtf_chunks(const u16 *__restrict__ syms_all, const BzResult *__restrict__ results,
-                                                     u32 block_size100k, BzChunk *__restrict__ chunks_all, u8 *__restrict__ perms_all,
-                                                     const u8 *__restrict__ lists_all, const u32 *__restrict__ offs_all,
-                                                     u32 *__restrict__ tt_all) {
-  const u32 blk = blockIdx.y, c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const u32 nblock_max = 100000u * block_size100k;
-  const BzResult &R = results[blk];
-  if (WRITE && R.status != BZ_ST_OK) return;
-  BzChunk res;
-  bz_mtf_chunk_wave<WRITE>(syms_all + (u64)blk * BZ_SYM_CAP, R.nsyms, c, nblock_max,
-                           WRITE ? lists_all + ((u64)blk * BZ_CHUNKS + c) * 256 : nullptr,
-                           WRITE ? offs_all[(u64)blk * BZ_CHUNKS + c] : 0u, tt_all + (u64)blk * nblock_max,
-                           perms_all + ((u64)blk * BZ_CHUNKS + c) * 256, res, lane);
-  if (!WRITE && lane == 0) chunks_all[(u64)blk * BZ_CHUNKS + c] = res;
 }
 // grid (BZ_CHUNKS, blocks), 64 threads: one wave per chunk, one part of it per lane
 template <bool WRITE>
