@@ -1775,13 +1775,26 @@ static int32_t deflate_device_impl(const u8 *d_in, size_t n, int level, int wind
     // position indexed), 16384 of 8-byte and 8192 of 16-byte strings; the levels differ in nice_length (P.nice).
     // A position only sees the strings of EARLIER steps (plus one of its own step), so the step has to stay well
     // below the window: small windows (windowBits 9..12) take smaller workgroups.
-    if (window_bits <= 10) hipLaunchKernelGGL((deflate_match_kernel<12, 4, 0, 0, 64>), dim3(P.chunks), dim3(64), 0, st, d_in, P, b_match.as<u32>());
-    else if (window_bits <= 12) hipLaunchKernelGGL((deflate_match_kernel<12, 4, 12, 0, 256>), dim3(P.chunks), dim3(256), 0, st, d_in, P, b_match.as<u32>());
-    else if (level <= 3) hipLaunchKernelGGL((deflate_match_kernel<12, 2>), dim3(P.chunks), dim3(256), 0, st, d_in, P, b_match.as<u32>());
+    // The grid: as many workgroups as are resident at once, each taking a run of consecutive chunks -- from its second chunk on
+    // a workgroup finds the window's tables already there (deflate_match_kernel).  AHIP_DF_RUNS=0 (tests): one chunk a
+    // workgroup, every chunk inserts its history; =N: N workgroups -- the output must be the same byte for byte.
+    auto launch = [&](auto kernel, u32 threads) -> hipError_t {
+      static thread_local int cus = 0;
+      if (!cus) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256; }
+      int per_cu = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)threads, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
+      const char *e = getenv("AHIP_DF_RUNS");  // tests: 0 = one chunk a workgroup, N = N workgroups (long runs on a small input)
+      const u32 grid = !e ? std::min<u32>(P.chunks, (u32)cus * (u32)per_cu) : (atoi(e) <= 0 ? P.chunks : std::min<u32>(P.chunks, (u32)atoi(e)));
+      hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), 0, st, d_in, P, b_match.as<u32>());
+      return hipGetLastError();
+    };
+    if (window_bits <= 10) HIP_TRY(launch(deflate_match_kernel<12, 4, 0, 0, 64>, 64));
+    else if (window_bits <= 12) HIP_TRY(launch(deflate_match_kernel<12, 4, 12, 0, 256>, 256));
+    else if (level <= 3) HIP_TRY(launch(deflate_match_kernel<12, 2>, 256));
     // levels 4-7: 1 024 positions a step (16 waves hide the compare rounds' LDS latency: 1 GiB 32.9 -> 23 ms; a position sees
     // fewer candidates closer than a step: log text +4.1 % instead of +3.4 % over the reference); 8-9 keep 512
-    else if (level <= 7 && !getenv("AHIP_DF_SUB512")) hipLaunchKernelGGL((deflate_match_kernel<13, 4, 14, 13, 1024>), dim3(P.chunks), dim3(1024), 0, st, d_in, P, b_match.as<u32>());
-    else hipLaunchKernelGGL((deflate_match_kernel<13, 4, 14, 13, 512>), dim3(P.chunks), dim3(512), 0, st, d_in, P, b_match.as<u32>());
+    else if (level <= 7 && !getenv("AHIP_DF_SUB512")) HIP_TRY(launch(deflate_match_kernel<13, 4, 14, 13, 1024>, 1024));
+    else HIP_TRY(launch(deflate_match_kernel<13, 4, 14, 13, 512>, 512));
   }
 #ifdef AHIP_PROFILE
   if (!P.store && getenv("AHIP_DEBUG")) {

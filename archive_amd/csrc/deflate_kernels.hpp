@@ -155,16 +155,24 @@ __global__ __launch_bounds__(SUB) void deflate_match_kernel(const u8 *__restrict
   constexpr u32 NX = (LA ? 1u : 0u) + (LB ? 1u : 0u);  // candidates from the long-string tables
   constexpr u32 MERGE = DF_WAYS < 4 ? DF_WAYS : 4;  // history steps inserted per barrier (distinct ways)
   __shared__ u32 ring[(DF_RING + DF_MIRROR) / 4 + 2];
-  const u32 chunk = blockIdx.x, tid = threadIdx.x;
+  const u32 tid = threadIdx.x;
+  if (P.store) return;
+  // A workgroup takes a run of consecutive chunks.  The window of chunk c + 1 is the window of chunk c moved on by 32 KiB
+  // (its history IS chunk c), so the tables chunk c leaves behind -- minus what has dropped out of the window, positions
+  // counted from the new window's start, and the last fifteen positions of chunk c, which could not be hashed before the
+  // bytes behind them were there -- are exactly the tables the history insertion below would build: only the first
+  // chunk of a run inserts its history (it was ~15 % of the kernel); the output is the same whatever the runs are.
+  const u32 per = (P.chunks + gridDim.x - 1) / gridDim.x;
+  const u32 c_begin = blockIdx.x * per, c_end = c_begin + per < P.chunks ? c_begin + per : P.chunks;
+  u32 ro = 0;        // ring offset of window position 0
+  u64 wbase = 0;     // input offset of window position 0 (of the chunk before, when a new one starts)
+  auto rc_of = [&](u32 x) -> u32 { x += ro; x = x >= 2 * DF_RING ? x - 2 * DF_RING : x; return x >= DF_RING ? x - DF_RING : x; };  // window position -> ring offset
+  for (u32 chunk = c_begin; chunk < c_end; ++chunk) {
   const u64 cstart = (u64)chunk * DF_CHUNK;
   const u32 clen = (u32)((P.n - cstart) < DF_CHUNK ? (P.n - cstart) : DF_CHUNK);
   const u32 dict = cstart >= DF_CHUNK ? DF_CHUNK : (u32)cstart;  // raw bytes before the chunk that may be referenced
   const u8 *win = in + cstart - dict;                            // window base; positions are relative to it
   const u32 wlen = dict + clen;
-  if (P.store) return;
-  for (u32 i = tid; i < (1u << DF_HASH_BITS) * DF_WAYS; i += SUB) tbl[i] = (u16)DF_EMPTY;
-  if (LA) for (u32 i = tid; i < (1u << LA); i += SUB) tblA[i] = (u16)DF_EMPTY;
-  if (LB) for (u32 i = tid; i < (1u << LB); i += SUB) tblB[i] = (u16)DF_EMPTY;
   // bytes [q, q + 4) of the window (zero past the end) ...
   auto fetch = [&](u32 q) -> u32 {
     u32 v = 0;
@@ -174,34 +182,72 @@ __global__ __launch_bounds__(SUB) void deflate_match_kernel(const u8 *__restrict
   };
   // ... into the ring
   auto put = [&](u32 q, u32 v) {
-    const u32 r = df_rc(q);
+    const u32 r = rc_of(q);
     ring[r >> 2] = v;
     if (r < DF_MIRROR) ring[(DF_RING + r) >> 2] = v;
   };
   auto stage = [&](u32 q) { put(q, fetch(q)); };
-  for (u32 q = 4 * tid; q < AHEAD; q += 4 * SUB) stage(q);  // [0, AHEAD)
-  __syncthreads();
-  // History before the chunk is only inserted.  Consecutive steps write different ways, so up to four are
-  // done as one (same table as step by step, a quarter of the barriers).
   u32 base = 0;
-  for (; base + MERGE * DF_SUB <= dict; base += MERGE * DF_SUB) {
-    if (tid < MERGE * (SUB / 4)) stage(base + AHEAD + 4 * tid);
-    __syncthreads();  // the last position's 4 bytes reach into what was just staged
-    // the steps of one parity together (their slots are different dwords, or the same half of one), then the others
+  if (chunk == c_begin) {
+    ro = 0;
+    for (u32 i = tid; i < (1u << DF_HASH_BITS) * DF_WAYS; i += SUB) tbl[i] = (u16)DF_EMPTY;
+    if (LA) for (u32 i = tid; i < (1u << LA); i += SUB) tblA[i] = (u16)DF_EMPTY;
+    if (LB) for (u32 i = tid; i < (1u << LB); i += SUB) tblB[i] = (u16)DF_EMPTY;
+    for (u32 q = 4 * tid; q < AHEAD; q += 4 * SUB) stage(q);  // [0, AHEAD)
+    __syncthreads();
+    // History before the chunk is only inserted.  Consecutive steps write different ways, so up to four are
+    // done as one (same table as step by step, a quarter of the barriers).
+    for (; base + MERGE * DF_SUB <= dict; base += MERGE * DF_SUB) {
+      if (tid < MERGE * (SUB / 4)) stage(base + AHEAD + 4 * tid);
+      __syncthreads();  // the last position's 4 bytes reach into what was just staged
+      // the steps of one parity together (their slots are different dwords, or the same half of one), then the others
 #pragma unroll
-    for (u32 phase = 0; phase < 2; ++phase) {
+      for (u32 phase = 0; phase < 2; ++phase) {
 #pragma unroll
-      for (u32 k = phase; k < MERGE; k += 2) {
-        const u32 p = base + k * DF_SUB + tid;  // p + 4 <= wlen: the chunk follows
-        const u32 step = (base / DF_SUB) + k;
-        const u32 e = df_hash4<DF_HASH_BITS>(df_rd4(ring, df_rc(p))) * DF_WAYS + (step & (DF_WAYS - 1));
-        df_insert(tbl, e, p ^ KX, df_word(tbl, e));
-        if (LA && p + 8 <= wlen) { const u32 eA = df_hash8<LA ? LA - 1 : 1>(df_rd8(ring, df_rc(p))) * 2 + (step & 1); df_insert(tblA, eA, p ^ KX, df_word(tblA, eA)); }
-        if (LB && p + 16 <= wlen) { const u32 eB = df_hash16<LB ? LB - 1 : 1>(df_rd8(ring, df_rc(p)), df_rd8(ring, df_rc(p) + 8)) * 2 + (step & 1); df_insert(tblB, eB, p ^ KX, df_word(tblB, eB)); }
+        for (u32 k = phase; k < MERGE; k += 2) {
+          const u32 p = base + k * DF_SUB + tid;  // p + 4 <= wlen: the chunk follows
+          const u32 step = (base / DF_SUB) + k;
+          const u32 e = df_hash4<DF_HASH_BITS>(df_rd4(ring, rc_of(p))) * DF_WAYS + (step & (DF_WAYS - 1));
+          df_insert(tbl, e, p ^ KX, df_word(tbl, e));
+          if (LA && p + 8 <= wlen) { const u32 eA = df_hash8<LA ? LA - 1 : 1>(df_rd8(ring, rc_of(p))) * 2 + (step & 1); df_insert(tblA, eA, p ^ KX, df_word(tblA, eA)); }
+          if (LB && p + 16 <= wlen) { const u32 eB = df_hash16<LB ? LB - 1 : 1>(df_rd8(ring, rc_of(p)), df_rd8(ring, rc_of(p) + 8)) * 2 + (step & 1); df_insert(tblB, eB, p ^ KX, df_word(tblB, eB)); }
+        }
+        __syncthreads();
       }
-      __syncthreads();
     }
+  } else {
+    // carried over from the chunk before (a full one: it has a successor)
+    __syncthreads();  // its last step's compares are done with the ring and the tables
+    const u32 shift = (u32)((cstart - dict) - wbase);  // 0 behind the input's first chunk, else 32 KiB
+    if (shift) {
+      static_assert(SUB <= 32768 && DF_CHUNK == 32768, "a key's bit 15 is its position's: what drops out of the window has it clear");
+      auto rebase = [&](u16 *t, u32 entries) {  // two keys a dword: positions below `shift` are forgotten, the others move down
+        for (u32 i = tid; i < entries / 2; i += SUB) {
+          const u32 x = ((const u32 *)t)[i];
+          const u32 keep = ((x >> 15) & 0x00010001u) * 0xffffu;
+          ((u32 *)t)[i] = x & keep & 0x7fff7fffu;
+        }
+      };
+      rebase(tbl, (1u << DF_HASH_BITS) * DF_WAYS);
+      if (LA) rebase(tblA, 1u << LA);
+      if (LB) rebase(tblB, 1u << LB);
+      ro = rc_of(shift);
+    }
+    __syncthreads();
+    // the bytes behind the previous chunk's end were staged as zeros (there was nothing behind its window): the real ones,
+    // from the last dword that reached over the end on
+    for (u32 q = dict - 4 + 4 * tid; q < dict + AHEAD; q += 4 * SUB) stage(q);
+    __syncthreads();
+    if (tid < 16) {  // the positions the chunk before could not hash yet (4 / 8 / 16 bytes reached over its end), with their own step
+      const u32 p = dict - 16 + tid, step = p / DF_SUB;
+      if (p + 4 > dict) { const u32 e = df_hash4<DF_HASH_BITS>(df_rd4(ring, rc_of(p))) * DF_WAYS + (step & (DF_WAYS - 1)); df_insert(tbl, e, p ^ KX, df_word(tbl, e)); }
+      if (LA && p + 8 > dict) { const u32 eA = df_hash8<LA ? LA - 1 : 1>(df_rd8(ring, rc_of(p))) * 2 + (step & 1); df_insert(tblA, eA, p ^ KX, df_word(tblA, eA)); }
+      if (LB && p + 16 > dict) { const u32 eB = df_hash16<LB ? LB - 1 : 1>(df_rd8(ring, rc_of(p)), df_rd8(ring, rc_of(p) + 8)) * 2 + (step & 1); df_insert(tblB, eB, p ^ KX, df_word(tblB, eB)); }
+    }
+    __syncthreads();
+    base = dict;
   }
+  wbase = cstart - dict;
   // 256 positions per step.  A position is compared with the strings earlier steps left in its bucket
   // (read before this step's insertion) and with the string this step put into the bucket's current slot
   // if that one lies below it (distances under 256: runs and short periods) -- five candidates, one batch.
@@ -221,7 +267,7 @@ __global__ __launch_bounds__(SUB) void deflate_match_kernel(const u8 *__restrict
     const u32 p = base + tid;
     const bool has4 = p + 4 <= wlen;
     const bool search = has4 && p >= dict;
-    const u32 rp = df_rc(p);
+    const u32 rp = rc_of(p);
     u32 w = 0, h = 0, best_len = 0, best_dist = 0;
     // Compares stop at DF_CAP bytes: a wave waits for its longest compare, and neighbouring positions inside
     // one long match would each walk (nearly) all of it.  The parse extends the few matches it actually emits.
@@ -268,7 +314,7 @@ __global__ __launch_bounds__(SUB) void deflate_match_kernel(const u8 *__restrict
         const u32 c = cand[k] ^ KX;  // key -> position
         dist[k] = p - c;
         alive[k] = k != DF_WAYS ? (cand[k] != DF_EMPTY && c < p && dist[k] <= P.max_dist) : (cand[k] != DF_EMPTY && c < p && c >= base && dist[k] <= P.max_dist);
-        rc[k] = alive[k] ? df_rc(c) : rp;
+        rc[k] = alive[k] ? rc_of(c) : rp;
       }
       AHIP_TICK(t3);
       AHIP_ACC(pc[2], t2, t3);
@@ -304,6 +350,7 @@ __global__ __launch_bounds__(SUB) void deflate_match_kernel(const u8 *__restrict
   AHIP_ACC(pc[5], t_dict, t_end);
   if (tid == 0) for (int k = 0; k < 8; ++k) match[P.n + 16 + (u64)chunk * 8 + k] = pc[k];
 #endif
+  }  // chunk
 }
 
 // ------------------------------------------------------------------------------------------

@@ -128,3 +128,27 @@ def test_two_encodes_are_byte_identical(amd):
                 assert amd.Deflate(data, level=level, window_bits=wb).get_bytes() == first, (level, wb)
     g1 = amd.GZipEncoder().encode_bytes(data, mtime=1)
     assert all(amd.GZipEncoder().encode_bytes(data, mtime=1) == g1 for _ in range(2))
+
+
+def test_carried_match_tables_change_nothing(amd, monkeypatch):
+    """A workgroup of the match kernel takes a run of consecutive chunks and, from its second chunk on, keeps the hash
+    tables the chunk before left (moved on by 32 KiB, the fifteen positions that could not be hashed yet added) instead of
+    inserting the 32 KiB of history again.  That is an optimisation only: with one chunk per workgroup (AHIP_DF_RUNS=0,
+    every chunk builds its tables from scratch) the stream must be the same byte for byte -- at every table shape (levels,
+    small windows), for inputs that end inside a chunk, with runs of two chunks and runs of thirty."""
+    from tools import corpus
+    big = bytes(corpus.text(corpus.LOG, 77, 0, 40 << 20))          # 1 280 chunks: runs of five on 256 CUs by default
+    mixed = (streams.text(300000, 3) + bytes(100000) + bytes(corpus.text(corpus.WIKI, 9, 0, 2 << 20)) + random.Random(4).randbytes(70000) +
+             b"tail" * 999)                                        # 89 chunks, the last one short
+    for data, cases, grids in ((big, ((6, 15),), (None,)), (mixed, ((1, 15), (4, 15), (6, 15), (9, 15), (6, 12), (6, 9), (3, 10)), ("45", "3"))):
+        for level, wb in cases:
+            monkeypatch.setenv("AHIP_DF_RUNS", "0")
+            single = amd.Deflate(data, level=level, window_bits=wb).get_bytes()
+            assert zlib.decompress(single, -15) == data
+            for g in grids:
+                if g is None:
+                    monkeypatch.delenv("AHIP_DF_RUNS", raising=False)
+                else:
+                    monkeypatch.setenv("AHIP_DF_RUNS", g)
+                assert amd.Deflate(data, level=level, window_bits=wb).get_bytes() == single, (len(data), level, wb, g)
+    monkeypatch.delenv("AHIP_DF_RUNS", raising=False)
