@@ -212,6 +212,87 @@ AHIP_DEVINL u32 bzf_bits(BzFast &f, u32 nb, int lane) {  // nb <= 24; the refere
   return v;
 }
 
+// The selectors of a block (bzip2_decoder.dart:150-184: nsel unary numbers j < ngroups, each an index into a move-to-front
+// list of the tables) by the whole wave -- read one after the other they were ~ 1 ms of one wave per block, the longest
+// serial step a 64-block decode had.  A zero bit ends a number: 64 dwords of the stream a round, every lane counts the
+// zeros of its dword (prefix sum = which selectors they end) and knows where the zero before its first one lies (prefix
+// maximum), so every number is a difference of positions.  The list is six entries, four bits each in a register: every
+// lane runs its share of the numbers over the identity, the 64 results are composed in order, and every lane runs its
+// share again from its true starting list.  Returns the bit behind the last selector -- or 0 when anything is out of the
+// ordinary (a number >= ngroups, the input ending first): the caller's serial loop then finds the error exactly where
+// the reference does.
+AHIP_DEVINL u32 bz_mtf6_take(u32 &st, u32 j) {  // entry j of the packed list moves to the front
+  const u32 v = (st >> (4 * j)) & 15u;
+  const u32 low = st & ((1u << (4 * j)) - 1);
+  st = (st & ~((1u << (4 * (j + 1))) - 1)) | (low << 4) | v;
+  return v;
+}
+AHIP_DEVINL u32 bz_mtf6_compose(u32 r, u32 t) {  // the list r taken through t: entry k is r[t[k]]
+  u32 o = 0;
+#pragma unroll
+  for (u32 k = 0; k < 6; ++k) o |= ((r >> (4 * ((t >> (4 * k)) & 15u))) & 15u) << (4 * k);
+  return o;
+}
+AHIP_DEVINL u64 bz_selectors_wave(const u8 *__restrict__ in, u64 n, u64 bit0, u32 ngroups, u32 nsel, u8 *__restrict__ sel, const u32 lane) {
+  const u64 nbits = n * 8;
+  const u64 d0 = bit0 >> 5;                 // dword the region starts in
+  const u32 skip = (u32)bit0 & 31;
+  u32 count = 0;                            // zeros = selectors so far (wave-uniform)
+  u32 prev1 = skip;                         // 1 + position (bits from dword d0) of the last zero so far; the virtual one in front of bit0
+  u32 viol = 0, end_rel = 0;
+  const u32 max_rounds = (nsel * ngroups + 31 + 2047) / 2048 + 1;
+  for (u32 round = 0; round < max_rounds && count < nsel; ++round) {
+    const u64 idx = d0 + (u64)round * 64 + lane;
+    u32 w;
+    {
+      const u64 off = idx * 4;
+      if (off + 4 <= n) w = __builtin_bswap32(*(const u32 *)(in + off));
+      else { w = 0; for (int k = 0; k < 4; ++k) w = (w << 8) | (off + k < n ? (u32)in[off + k] : 0u); }
+    }
+    u32 x = ~w;                             // a one where the stream has a zero
+    if (round == 0 && lane == 0 && skip) x &= 0xffffffffu >> skip;   // bits in front of the region are nobody's
+    const u32 nz = (u32)__builtin_popcount(x);
+    u32 total;
+    const u32 base = count + wave_excl_sum(nz, total);
+    const u32 rel0 = (round * 64 + lane) * 32;
+    const u32 mylast1 = x ? rel0 + (31u - (u32)__builtin_ctz(x)) + 1u : 0u;  // 1 + position of my last zero
+    const u32 inc = wave_incl_umax(mylast1);
+    u32 before1 = lane_prev(inc);           // (lane 0: 0)
+    before1 = before1 > prev1 ? before1 : prev1;
+    u32 r = 0, p1 = before1;
+    while (x) {
+      const u32 k = (u32)__builtin_clz(x);
+      x &= ~(0x80000000u >> k);
+      const u32 pos = rel0 + k, j = pos + 1 - p1 - 1;  // ones between the zero before and this one
+      p1 = pos + 1;
+      const u32 i = base + r++;
+      if (i < nsel) {
+        if (j >= ngroups) viol = 1; else sel[i] = (u8)j;
+        if (i == nsel - 1) end_rel = pos + 1;
+      }
+    }
+    count += total;
+    const u32 last = lane_bcast(inc, 63);
+    prev1 = last > prev1 ? last : prev1;
+  }
+  const u32 end_all = wave_umax(end_rel);
+  if (__any(viol != 0) || count < nsel || end_all == 0 || d0 * 32 + end_all > nbits) return 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the numbers -> every lane's loads
+  wave_sync();
+  const u32 per = (nsel + 63) / 64, lo = lane * per < nsel ? lane * per : nsel, hi = lo + per < nsel ? lo + per : nsel;
+  u32 t = 0x543210u;
+  for (u32 i = lo; i < hi; ++i) (void)bz_mtf6_take(t, sel[i]);
+  u32 run = 0x543210u, mine = 0x543210u;
+  for (u32 l = 0; l < 64; ++l) {
+    if (lane == l) mine = run;
+    run = bz_mtf6_compose(run, lane_bcast(t, (int)l));
+  }
+  for (u32 i = lo; i < hi; ++i) sel[i] = (u8)bz_mtf6_take(mine, sel[i]);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the selectors -> every lane's loads
+  wave_sync();
+  return d0 * 32 + end_all;
+}
+
 // one wave per candidate block (a device function: tests/emu/bzip2_emu.cc runs it on the CPU wave emulation)
 // syms: room for BZ_SYM_CAP symbols; list0: the block's initial MTF list (256 bytes, seqToUnseq applied)
 // exp != nullptr: stop in front of the symbol stream and leave the tables there (BzTables)
@@ -266,8 +347,9 @@ AHIP_DEVINL void bz_decode_block_wave(BzLds &L, const u8 *__restrict__ in, u64 n
     // selectors and code lengths: ~30 000 bits read a few at a time -- from the stream held in registers (64 dwords a
     // lane-load, the next batch in flight), not one global load per 32 bits
     BzFast f;
-    bzf_init(f, in, n, b.bit, lane);
-    {
+    const u64 sel_end = bz_selectors_wave(in, n, b.bit, ngroups, nsel, sel, lane);
+    bzf_init(f, in, n, sel_end ? sel_end : b.bit, lane);
+    if (!sel_end) {  // out of the ordinary: one after the other, to the reference's exact stop
       u32 pos = 0x543210;  // MTF list of group numbers, 4 bits each
       bool bad = false;
       for (u32 i = 0; i < nsel; ++i) {
