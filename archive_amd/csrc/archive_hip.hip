@@ -1437,7 +1437,7 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
   // block at level 9), following the chain of blocks exactly like decodeStream between them: a block ends where
   // the next magic starts.  A batch's blocks are placed and expanded before the next batch is decoded; nothing
   // behind the point where the chain stops is ever touched.
-  const u64 per_block = nblock_max * 5 + (u64)BZ_SYM_CAP * 2 + BZ_CHUNKS * 530 + (u64)BZ_PARTS * 260 + sizeof(BzTables) + BZ_MAX_SELECTORS * 4 + wstride * (sizeof(BzWalk) + 4) + BZ_SPANS * sizeof(BzSpan) + BZ_MAX_SELECTORS + sizeof(BzResult) + 64;
+  const u64 per_block = nblock_max * 5 + (u64)BZ_SYM_CAP * 2 + BZ_CHUNKS * 530 + (u64)BZ_PARTS * 260 + (u64)BZ_TINV_WAVES * 1024 + sizeof(BzTables) + BZ_MAX_SELECTORS * 4 + wstride * (sizeof(BzWalk) + 4) + BZ_SPANS * sizeof(BzSpan) + BZ_MAX_SELECTORS + sizeof(BzResult) + 64;
   u64 batch_mem = 24ull << 30;  // (of 288 GB: every batch costs one latency-bound header + walk + rank round)
   {
     // ... but never more than half of what the device has free right now (other contexts, a caller's own tensors)
@@ -1448,7 +1448,7 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
   if (const char *e = getenv("AHIP_BZ_BATCH_BYTES")) { if (atoll(e) > 0) batch_mem = (u64)atoll(e); }
   const u64 j50_per_block = bz_parallel_huffman() ? (u64)in_len * 8 / std::max<u32>(1, ncand) * 12 : 0;  // 6 tables x 2 bytes per bit
   u32 batch = (u32)std::min<u64>(c_hi - c_lo, std::max<u64>(4, batch_mem / (per_block + j50_per_block)));
-  static thread_local DevBuf dsyms, dlist0, dchunks, dperms, dlists, dchoff, dtab, dj50, dgstart, dgcount, dpperms, dpcounts;
+  static thread_local DevBuf dsyms, dlist0, dchunks, dperms, dlists, dchoff, dtab, dj50, dgstart, dgcount, dpperms, dpcounts, dthist;
   // the work memory of one batch; a device that cannot spare it gets smaller batches, not an error
   auto reserve_batch = [&](u32 b) -> hipError_t {
     hipError_t e;
@@ -1466,6 +1466,7 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
     BZ_RES(dchoff, (size_t)b * BZ_CHUNKS * 4);
     BZ_RES(dpperms, (size_t)b * BZ_PARTS * 256);
     BZ_RES(dpcounts, (size_t)b * BZ_PARTS * 4);
+    BZ_RES(dthist, (size_t)b * BZ_TINV_WAVES * 256 * 4);
     BZ_RES(dpre, (size_t)b * nblock_max);
     BZ_RES(dwalk, (size_t)b * wstride * sizeof(BzWalk));
     BZ_RES(drank, (size_t)b * wstride * 4);
@@ -1554,7 +1555,7 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
         hipLaunchKernelGGL(bz_header, dim3(n), dim3(64), 0, s, d_in, (u64)in_len, dcs, n, tabs, list0, sels, ress);
         hipLaunchKernelGGL(bz_jump_tiles, dim3((u32)cdiv(widest, BZ_TW) + 1, n), dim3(512), 0, s, d_in, (u64)in_len, dcand.as<BzCand>(), ncand,
                            (u32)c0 + b0, tabs, dj50.as<u16>(), bit0, tstride);
-        hipLaunchKernelGGL(bz_group_starts, dim3(n), dim3(256), 0, s, d_in, (u64)in_len, dcand.as<BzCand>(), ncand, (u32)c0 + b0, tabs, sels,
+        hipLaunchKernelGGL(bz_group_starts, dim3(n), dim3(512), 0, s, d_in, (u64)in_len, dcand.as<BzCand>(), ncand, (u32)c0 + b0, tabs, sels,
                            dj50.as<u16>(), bit0, tstride, gstart, gcount, ress);
         hipLaunchKernelGGL(bz_decode_groups, dim3(cdiv(BZ_MAX_SELECTORS, 256), n), dim3(256), 0, s, d_in, (u64)in_len, tabs, sels, gstart, gcount,
                            syms, ress);
@@ -1565,7 +1566,10 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
       hipLaunchKernelGGL(bz_mtf_lanes<false>, dim3(BZ_CHUNKS, n), dim3(64), 0, s, syms, ress, (u32)level, chunks, perms, lists, choff, b8, pperms, pcounts);
       hipLaunchKernelGGL(bz_mtf_scan, dim3(n), dim3(64), 0, s, ress, dcs, n, (u32)level, chunks, perms, list0, lists, choff);
       hipLaunchKernelGGL(bz_mtf_lanes<true>, dim3(BZ_CHUNKS, n), dim3(64), 0, s, syms, ress, (u32)level, chunks, perms, lists, choff, b8, pperms, pcounts);
-      hipLaunchKernelGGL(bz_tinv_scatter, dim3(n), dim3(1024), 0, s, tts, b8, (u32)level, dcs, ress);  // (dpre: the bytes before the walk, the walk's output after it)
+      u32 *thist = dthist.as<u32>() + (size_t)b0 * BZ_TINV_WAVES * 256;
+      hipLaunchKernelGGL(bz_tinv_hist, dim3(BZ_TINV_PARTS, n), dim3(1024), 0, s, tts, b8, (u32)level, dcs, ress, thist);  // (dpre: the bytes before the walk, the walk's output after it)
+      hipLaunchKernelGGL(bz_tinv_cursors, dim3(n), dim3(256), 0, s, dcs, ress, thist);
+      hipLaunchKernelGGL(bz_tinv_scatter, dim3(BZ_TINV_PARTS, n), dim3(1024), 0, s, tts, b8, (u32)level, dcs, ress, thist);
     };
     front(st, 0, nb);
     HIP_TRY(hipMemsetAsync(dwq.p, 0, 64, st));

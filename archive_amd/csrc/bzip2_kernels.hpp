@@ -15,7 +15,7 @@
 //                 (64 chunks of 64 parts per block, a part per lane: the list after a stretch is a permutation of the list
 //                 before it) twice, with
 //                 bz_mtf_scan chaining the permutations in between;
-//        phase 2  T^-1 (:406-439) as a stable counting sort over 16 waves (bz_tinv_scatter) -- same
+//        phase 2  T^-1 (:406-439) as a stable counting sort over 64 waves (bz_tinv_hist / _cursors / _scatter) -- same
 //                 result as the reference's serial loop;
 //        phase 3  inverse BWT (:610-727).  The pointer chase tt[t] -> t is one cycle through the block;
 //                 walked serially every step waits for the previous load (~1 us x 900 000).  Instead
@@ -791,11 +791,13 @@ AHIP_DEVINL void bz_walk_groups(BzWalkLds &S, const BzTables *__restrict__ T, co
   for (u32 i = tid; i < nsel; i += nthreads) S.sel[i] = sel[i];
   if (tid == 0) { S.pos_lo = (u32)sym_bit; S.pos_hi = (u32)(sym_bit >> 32); S.g = 0; S.done = 0; }
   BZ_BLOCK_SYNC();
-  // a tile's jumps: 6 rows of BZ_TW 16-bit values, fetched 8 at a time; the NEXT tile's are requested before the walk
-  // through this one and stored behind it (a jump is < 1024 bits: the walk never skips a tile)
-  constexpr u32 VEC = 8, PER_ROW = BZ_TW / VEC, MAX_SLOTS = 12;  // 6 * 512 vectors over >= 256 threads
-  uint4 hold[MAX_SLOTS];
-  auto request = [&](u64 base) {  // tile at `base` -> registers
+  // a tile's jumps: 6 rows of BZ_TW 16-bit values, fetched 8 at a time.  The jumps of the NEXT TWO tiles are on their way
+  // while this one is walked (a walk through a tile is ~ 1 us, a load from memory two to three: with one tile in flight
+  // the workgroup waited for it at every tile -- 4 us a tile, 1.8 ms a block) and stored behind it (a jump is < 1024 bits:
+  // the walk never skips a tile)
+  constexpr u32 VEC = 8, PER_ROW = BZ_TW / VEC, MAX_SLOTS = 6;  // 6 * 512 vectors over >= 512 threads
+  uint4 holdA[MAX_SLOTS], holdB[MAX_SLOTS];
+  auto request = [&](uint4 (&hold)[MAX_SLOTS], u64 base) {  // tile at `base` -> registers
 #pragma unroll
     for (u32 k = 0; k < MAX_SLOTS; ++k) {
       const u32 v = tid + k * nthreads;
@@ -811,21 +813,23 @@ AHIP_DEVINL void bz_walk_groups(BzWalkLds &S, const BzTables *__restrict__ T, co
       }
     }
   };
-  auto deposit = [&]() {  // registers -> LDS
+  auto deposit = [&](const uint4 (&hold)[MAX_SLOTS]) {  // registers -> LDS
 #pragma unroll
     for (u32 k = 0; k < MAX_SLOTS; ++k) {
       const u32 v = tid + k * nthreads;
       if (v < 6 * PER_ROW) { const u32 t = v / PER_ROW, i = (v % PER_ROW) * VEC; *(uint4 *)&S.jt[t][i] = hold[k]; }
     }
   };
+  const bool wide = nthreads * MAX_SLOTS >= 6 * PER_ROW;  // (false: few threads -- the CPU emulation: plain copies)
   u64 base = sym_bit;
-  if (nthreads * MAX_SLOTS >= 6 * PER_ROW) request(base);
-  for (;;) {
+  if (wide) { request(holdA, base); request(holdB, base + BZ_TW); }
+  // one tile; returns false when the walk is over
+  auto tile = [&](uint4 (&hold)[MAX_SLOTS]) -> bool {
     const u64 pos = ((u64)S.pos_hi << 32) | S.pos_lo;
-    if (S.done || pos >= lim) break;
+    if (S.done || pos >= lim) return false;
     BZ_BLOCK_SYNC();
-    if (nthreads * MAX_SLOTS >= 6 * PER_ROW) { deposit(); request(base + BZ_TW); }
-    else {  // (few threads -- the CPU emulation: plain copies)
+    if (wide) { deposit(hold); request(hold, base + 2 * BZ_TW); }
+    else {
       for (u32 t = 0; t < ngroups; ++t)
         for (u32 i = tid; i < BZ_TW; i += nthreads) S.jt[t][i] = base + i < lim ? j50[t * tstride + (base - j50_bit0) + i] : BZ_TERM;
     }
@@ -849,6 +853,11 @@ AHIP_DEVINL void bz_walk_groups(BzWalkLds &S, const BzTables *__restrict__ T, co
     }
     base += BZ_TW;
     BZ_BLOCK_SYNC();
+    return true;
+  };
+  for (;;) {
+    if (!tile(holdA)) break;
+    if (!tile(holdB)) break;
   }
   found = S.g;
   marked = S.done == 1 ? 1u : (S.done == 2 ? 0u : 2u);  // 1 a marked group ends the walk, 0 out of selectors, 2 irregular
@@ -1272,7 +1281,7 @@ __global__ __launch_bounds__(512) void bz_jump_tiles(const u8 *__restrict__ in, 
   if (tile_bit >= lim) return;
   bz_jump_tile(S, in, n, T, tile_bit, lim, j50 + (tile_bit - j50_bit0), tstride, threadIdx.x, blockDim.x);
 }
-__global__ __launch_bounds__(256) void bz_group_starts(const u8 *__restrict__ in, u64 n, const BzCand *__restrict__ cands_all, u32 ncand_all,
+__global__ __launch_bounds__(512) void bz_group_starts(const u8 *__restrict__ in, u64 n, const BzCand *__restrict__ cands_all, u32 ncand_all,
                                                u32 first, const BzTables *__restrict__ tables, const u8 *__restrict__ sel_all,
                                                const u16 *__restrict__ j50, u64 j50_bit0, u64 tstride, u32 *__restrict__ gstart_all,
                                                u32 *__restrict__ gcount, BzResult *__restrict__ results) {
@@ -1344,31 +1353,45 @@ __global__ __launch_bounds__(64) void bz_mtf_scan(BzResult *__restrict__ results
 
 // ---- phase 2 (own launch): T^-1 ----
 // tt[i] holds the block's bytes (low 8 bits).  Result: tt[j] |= i << 8 for the j-th smallest (byte, i) --
-// a stable counting sort, i.e. the reference's serial loop (:406-439).  16 waves per block, each owning a
+// a stable counting sort, i.e. the reference's serial loop (:406-439).  64 waves per block, each owning a
 // contiguous sixteenth: per-wave histograms, a (symbol, wave) exclusive scan, then 64 elements per step:
 // eight ballots give every lane the set of lanes holding the same byte, so its rank inside the step is a
 // popcount and only the first lane of each byte value bumps the wave's cursor.
-__global__ __launch_bounds__(1024) void bz_tinv_scatter(u32 *__restrict__ tt_all, const u8 *__restrict__ b8_all, u32 block_size100k,
-                                                        const BzCand *__restrict__ cands, BzResult *__restrict__ results) {
+// Round 4: BZ_TINV_PARTS workgroups per block (a workgroup's 16 waves own a contiguous 1 / (16 PARTS) of the block each), in
+// three launches -- the histograms (and tt[i] = the byte), the cursors of every (wave, symbol) from a scan over the 64
+// waves and the 256 symbols, the placement -- because one workgroup per block was 1.4 ms however few blocks there were.
+constexpr u32 BZ_TINV_PARTS = 4, BZ_TINV_WAVES = 16 * BZ_TINV_PARTS;
+// grid (PARTS, blocks) x 1024: hist[blk][wave][sym]
+__global__ __launch_bounds__(1024) void bz_tinv_hist(u32 *__restrict__ tt_all, const u8 *__restrict__ b8_all, u32 block_size100k,
+                                                     const BzCand *__restrict__ cands, const BzResult *__restrict__ results,
+                                                     u32 *__restrict__ hist_all) {
   __shared__ u32 cur[16][256];
-  __shared__ u32 tot[256];
-  const u32 blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const u32 blk = blockIdx.y, part = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (cands[blk].kind != 0 || results[blk].status != BZ_ST_OK) return;
   const u32 nblock = results[blk].nblock;
   u32 *tt = tt_all + (u64)blk * (100000u * block_size100k);
   const u8 *b8 = b8_all + (u64)blk * (100000u * block_size100k);  // the block's bytes as bz_mtf_lanes<true> left them
   for (u32 i = tid; i < 16 * 256; i += 1024) (&cur[0][0])[i] = 0;
   __syncthreads();
-  const u32 seg = (((nblock + 15) / 16) + 63) & ~63u;
-  const u32 lo = w * seg < nblock ? w * seg : nblock;
+  const u32 seg = (((nblock + BZ_TINV_WAVES - 1) / BZ_TINV_WAVES) + 63) & ~63u;
+  const u32 gw = part * 16 + w;
+  const u32 lo = gw * seg < nblock ? gw * seg : nblock;
   const u32 hi = lo + seg < nblock ? lo + seg : nblock;
-  for (u32 i = lo + lane; i < hi; i += 64) { const u32 b = b8[i]; tt[i] = b; atomicAdd(&cur[w][b], 1u); }  // (tt[i]: the byte now, the link below)
+  for (u32 i = lo + lane; i < hi; i += 64) { const u32 b = b8[i]; tt[i] = b; atomicAdd(&cur[w][b], 1u); }  // (tt[i]: the byte now, the link later)
   __syncthreads();
-  if (tid < 256) {
-    u32 acc = 0;
-    for (u32 k = 0; k < 16; ++k) { const u32 c = cur[k][tid]; cur[k][tid] = acc; acc += c; }
-    tot[tid] = acc;
-  }
+  u32 *hist = hist_all + ((u64)blk * BZ_TINV_WAVES + part * 16) * 256;
+  for (u32 i = tid; i < 16 * 256; i += 1024) hist[i] = (&cur[0][0])[i];
+}
+// grid (blocks) x 256: hist[blk][wave][sym] -> the first place of that wave's bytes of that symbol
+__global__ __launch_bounds__(256) void bz_tinv_cursors(const BzCand *__restrict__ cands, const BzResult *__restrict__ results,
+                                                       u32 *__restrict__ hist_all) {
+  __shared__ u32 tot[256];
+  const u32 blk = blockIdx.x, tid = threadIdx.x;
+  if (cands[blk].kind != 0 || results[blk].status != BZ_ST_OK) return;
+  u32 *hist = hist_all + (u64)blk * BZ_TINV_WAVES * 256;
+  u32 acc = 0;
+  for (u32 k = 0; k < BZ_TINV_WAVES; ++k) { const u32 c = hist[k * 256 + tid]; hist[k * 256 + tid] = acc; acc += c; }
+  tot[tid] = acc;
   __syncthreads();
   if (tid < 64) {  // cftab: exclusive scan of the 256 symbol totals, 4 per lane
     u32 t0 = tot[4 * tid], t1 = tot[4 * tid + 1], t2 = tot[4 * tid + 2], t3 = tot[4 * tid + 3];
@@ -1377,11 +1400,26 @@ __global__ __launch_bounds__(1024) void bz_tinv_scatter(u32 *__restrict__ tt_all
     tot[4 * tid] = ex; tot[4 * tid + 1] = ex + t0; tot[4 * tid + 2] = ex + t0 + t1; tot[4 * tid + 3] = ex + t0 + t1 + t2;
   }
   __syncthreads();
-  if (tid < 256) {
-    const u32 basep = tot[tid];
-    for (u32 k = 0; k < 16; ++k) cur[k][tid] += basep;
-  }
+  const u32 basep = tot[tid];
+  for (u32 k = 0; k < BZ_TINV_WAVES; ++k) hist[k * 256 + tid] += basep;
+}
+// grid (PARTS, blocks) x 1024
+__global__ __launch_bounds__(1024) void bz_tinv_scatter(u32 *__restrict__ tt_all, const u8 *__restrict__ b8_all, u32 block_size100k,
+                                                        const BzCand *__restrict__ cands, const BzResult *__restrict__ results,
+                                                        const u32 *__restrict__ hist_all) {
+  __shared__ u32 cur[16][256];
+  const u32 blk = blockIdx.y, part = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (cands[blk].kind != 0 || results[blk].status != BZ_ST_OK) return;
+  const u32 nblock = results[blk].nblock;
+  u32 *tt = tt_all + (u64)blk * (100000u * block_size100k);
+  const u8 *b8 = b8_all + (u64)blk * (100000u * block_size100k);
+  const u32 *hist = hist_all + ((u64)blk * BZ_TINV_WAVES + part * 16) * 256;
+  for (u32 i = tid; i < 16 * 256; i += 1024) (&cur[0][0])[i] = hist[i];
   __syncthreads();
+  const u32 seg = (((nblock + BZ_TINV_WAVES - 1) / BZ_TINV_WAVES) + 63) & ~63u;
+  const u32 gw = part * 16 + w;
+  const u32 lo = gw * seg < nblock ? gw * seg : nblock;
+  const u32 hi = lo + seg < nblock ? lo + seg : nblock;
   const u64 below = (1ull << lane) - 1;
   for (u32 i0 = lo; i0 < hi; i0 += 64) {
     const u32 i = i0 + lane;
@@ -1399,7 +1437,7 @@ __global__ __launch_bounds__(1024) void bz_tinv_scatter(u32 *__restrict__ tt_all
     wave_sync();  // every lane has read its cursor before the leaders move them
     if (act && rank == 0) cur[w][sym] += (u32)__popcll(same);
     wave_sync();
-    // pos may lie in a part of tt[] another wave has not read yet: only the upper 24 bits are touched
+    // (tt[pos] holds its byte since bz_tinv_hist: only the upper 24 bits are touched)
     if (act) atomicOr(&tt[pos], i << 8);
   }
 }

@@ -1,0 +1,15 @@
+cd /root/repo
+O=/root/repo/gpurun_out
+timeout -k 5 900 python -m pytest tests/test_bzip2.py tests/test_multidevice_gpu.py -m gpu -q -x 2>&1 | grep -v "RCCL version\|HIP version\|ROCm version\|Hostname\|Librccl path" | tail -4 | tee $O/r4_pytest27.log
+timeout 300 python tests/perf/bzip2_stats.py 384 2>&1 | grep "device-resident\|ok=" | tail -2
+cd /tmp && export TMPDIR=/tmp
+rm -rf $O/prof_bz64
+timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bz64 -o bz -- python /root/repo/tests/perf/bzip2_stats.py 55 > $O/prof_bz64.log 2>&1
+grep "device-resident" $O/prof_bz64.log | tail -2
+python - <<'PY'
+import csv, glob
+f = glob.glob('/root/repo/gpurun_out/prof_bz64/**/*kernel_stats.csv', recursive=True)
+rows = list(csv.DictReader(open(f[0])))
+for r in rows[:12]:
+    print("%-50s calls %4s avg %9.1f us" % (r['Name'][:50], r['Calls'], float(r['AverageNs'])/1e3))
+PY
