@@ -340,8 +340,10 @@ AHIP_DEVINL void bz_decode_block_wave(BzLds &L, const u8 *__restrict__ in, u64 n
     if (num_in_use == 0) { status = BZ_ST_FALSE; break; }
     const u32 alpha = num_in_use + 2;
     const u32 ngroups = bz_bits(b, 3);
+    if (b.fault) { status = BZ_ST_RANGE; break; }  // (a read past the end is the reference's RangeError before any check of the value)
     if (ngroups < 2 || ngroups > 6) { status = BZ_ST_FALSE; break; }
     const u32 nsel = bz_bits(b, 15);
+    if (b.fault) { status = BZ_ST_RANGE; break; }
     if (nsel < 1) { status = BZ_ST_FALSE; break; }
     if (nsel > BZ_MAX_SELECTORS) { status = BZ_ST_RANGE; break; }  // Dart: store past the Uint8List
     // selectors and code lengths: ~30 000 bits read a few at a time -- from the stream held in registers (64 dwords a

@@ -143,3 +143,47 @@ def test_gpu_many_blocks_in_small_batches(native_built, monkeypatch):
     assert N.lib().ahip_crc32_device(d_out.data_ptr(), len(data), 0, ctypes.byref(crc), None) == 0
     assert crc.value == zlib.crc32(data)
     assert bytes(d_out[:100000].cpu().numpy()) == data[:100000] and bytes(d_out[-100000:].cpu().numpy()) == data[-100000:]
+
+
+@pytest.mark.gpu
+def test_gpu_damage_in_header_and_selectors(native_built):
+    """Round 4 moved three serial steps onto the whole wave / the lanes: the selectors (zeros delimit the unary numbers; the
+    serial loop only takes over when something is out of the ordinary), the move-to-front list (a part per lane) and the
+    ranking of the inverse transform's sublists (two levels).  Damage aimed at what they read -- every bit of the header and
+    the first selectors, then bits spread over the selector and code-length area and the block's payload, truncations inside
+    the selectors -- must leave the verdict and the bytes the oracle's, with and without CRC verification."""
+    import archive_amd
+    from archive_amd import _native as N
+    from archive_amd import errors
+    from oracle import pyoracle as orc
+    assert N.lib().ahip_init(0) == 0
+    rnd = random.Random(11)
+    # several tables, ~ 800 groups of 50 symbols (a dozen selectors per lane)
+    data = streams.text(24000, 4) + bytes(rnd.getrandbits(8) for _ in range(6000)) + bytes(500) + streams.text(9000, 6)
+    c = bz2.compress(data, 9)
+
+    def run(buf, verify):
+        d = archive_amd.BZip2Decoder()
+        try:
+            out = d.decode_bytes(buf, verify=verify)
+            return d.last_status, out
+        except errors.RangeError:
+            return 2, None
+    cases = []
+    for bit in range(10 * 8, 10 * 8 + 19 * 8 + 3 + 15 + 64):        # block CRC, origPtr, the in-use maps' head ... first selectors
+        if bit == 14 * 8:  # the `randomised` flag: the obsolete mode is AHIP_E_UNSUPPORTED here (DESIGN.md section 8), not a verdict
+            continue
+        b = bytearray(c); b[bit >> 3] ^= 0x80 >> (bit & 7); cases.append(bytes(b))
+    for k in range(160):                                              # selectors, code lengths, payload
+        bit = 45 * 8 + (k * 104729) % ((len(c) - 60) * 8)
+        b = bytearray(c); b[bit >> 3] ^= 0x80 >> (bit & 7); cases.append(bytes(b))
+    for cut in list(range(4, 130)) + [140, 200, 300, 1000, len(c) - 11, len(c) - 1]:  # every end inside the header (52 and 53: inside the
+        cases.append(c[:cut])                                                            # selector count -- RangeError, not `false`), then a few behind it
+    seen = set()
+    for i, buf in enumerate(cases):
+        for verify in (False, True):
+            st, out = orc.bzip2_decode(buf, verify=verify)
+            got = run(buf, verify)
+            assert got == ((2, None) if st == 2 else (st, out)), (i, verify, got[0], st)
+            seen.add(st)
+    assert {0, 1, 2} <= seen, seen  # decoded all the same (the damage hit nothing that is checked), `false`, RangeError
