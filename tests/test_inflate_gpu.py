@@ -4,6 +4,7 @@ import ctypes
 import gzip
 import hashlib
 import os
+import random
 import zlib
 
 import pytest
@@ -394,3 +395,48 @@ def test_kept_tokens_of_the_sizing_run(amd):
     run_and_check()   # the plan notices and tokenizes again
     L.ahip_gzip_plan_destroy(plan)
     assert _gz(amd, g) == (0, want)  # and the one-call path
+
+
+def test_damaged_gzip_framing_matches_oracle(amd, orc):
+    """The member index parses headers on the device (gz_parse_headers: the fixed fields and short FEXTRA from four
+    registers gathered while the scan streams by, FNAME / FCOMMENT through a zero-byte scan 64 bytes at a time -- both new
+    in round 4) and everything after it trusts what it found.  Streams whose headers use every optional field -- names and
+    comments shorter and longer than the gathered 32 bytes and than the 64-byte scan step, extras with and without a `BC`
+    subfield, header CRCs -- cut at every byte of the first member's header and around every member boundary, and with every
+    header byte damaged in turn: verdict and bytes are the oracle's (`_readHeader`, _gzip_decoder_web.dart:60-138)."""
+    rnd = random.Random(3)
+    a, b, c = streams.text(3000, 21), streams.text(40000, 22), streams.text(500, 23)
+    long_name = bytes(rnd.randrange(1, 256) for _ in range(150))      # no zero byte: two scan steps and a bit
+    name63 = bytes(rnd.randrange(1, 256) for _ in range(63))         # the terminator is the last byte of a scan step
+    variants = [
+        streams.gz_member(a, name=b"a.txt", comment=b"hi", hcrc=True) + streams.gz_member(b, extra=b"XY\x02\x00zz") + streams.bgzf_member(c),
+        streams.gz_member(a, name=long_name, comment=long_name[:70]) + streams.bgzf_member(c) + streams.gz_member(b, name=name63, hcrc=True),
+        streams.gz_member(c, extra=bytes(rnd.getrandbits(8) for _ in range(300)), name=b"n") + streams.gz_member(a, extra=b"BC\x02\x00\xff\xff", comment=b"lying BC"),
+        streams.bgzf_member(a) + streams.bgzf_member(c) + streams.gz_member(b, comment=name63 + b"x"),
+    ]
+    cases = []
+    for g in variants:
+        first = g.index(b"\x1f\x8b\x08", 4)   # where the second member starts
+        for cut in list(range(0, min(first, 420))) + list(range(max(0, first - 12), first + 40)) + list(range(len(g) - 30, len(g) + 1)):
+            cases.append(g[:cut])
+        hdr_end = min(first, 400)
+        for p in range(hdr_end):                      # every header byte of the first member: a bit flipped, a zero byte
+            for v in (g[p] ^ (1 << (p % 8)), 0):
+                m = bytearray(g); m[p] = v; cases.append(bytes(m))
+        for p in range(first, first + 24):            # and the second member's
+            m = bytearray(g); m[p] ^= 1 << rnd.randrange(8); cases.append(bytes(m))
+    from archive_amd import errors
+    seen = set()
+    for i, buf in enumerate(cases):
+        want = _noneify(orc.gzip_decode(buf))
+        if want[0] == 3:  # the reference would loop for ever on this input: both say so
+            want = (3, None)
+        try:
+            got = _gz(amd, buf)
+        except errors.ReferenceWouldHang:
+            got = (3, None)
+        except Exception as e:  # keep the case index visible
+            raise AssertionError("case %d: %r (oracle %r)" % (i, e, want[0]))
+        assert got == want, (i, len(buf), got[0], want[0])
+        seen.add(want[0])
+    assert {0, 1, 2} <= seen, seen
