@@ -346,6 +346,7 @@ AHIP_DEVINL u32 stored_block_emit(BitCursor &b, OutCursor &o, TokSink &sink, u32
   int nlen_raw = read_bits(b, 16);
   int nlen = nlen_raw ^ 0xffff;
   if (len != 0 && len != nlen) return (len < 0 || nlen_raw < 0) ? MS_FALSE_EOS : MS_FALSE;
+  if (nlen_raw < 0) b.pos = b.total_bits;  // an empty block whose NLEN the input's end cuts short: see stored_block()
   u64 byte = b.pos >> 3;
   if ((u64)len > b.in_len - byte) return MS_FALSE;
   if (o.pos + (u64)len > o.limit) return MS_CAP;

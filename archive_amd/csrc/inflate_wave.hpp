@@ -576,6 +576,10 @@ AHIP_DEVINL u32 stored_block(BitCursor &b, OutCursor &o, int lane) {
   int nlen_raw = read_bits(b, 16);
   int nlen = nlen_raw ^ 0xffff;
   if (len != 0 && len != nlen) return (len < 0 || nlen_raw < 0) ? MS_FALSE_EOS : MS_FALSE;
+  // LEN == 0 is never compared with its complement (inflate.dart:213-234) -- so an EMPTY stored block whose NLEN is cut
+  // short by the end of the input passes; the reference's reader has taken what bytes there were by then, and the block
+  // loop ends on isEOS instead of parsing the leftover byte as a block header
+  if (nlen_raw < 0) b.pos = b.total_bits;
   u64 byte = b.pos >> 3;
   if ((u64)len > b.in_len - byte) return MS_FALSE;
   if (o.pos + (u64)len > o.limit) return MS_CAP;

@@ -440,3 +440,34 @@ def test_damaged_gzip_framing_matches_oracle(amd, orc):
         assert got == want, (i, len(buf), got[0], want[0])
         seen.add(want[0])
     assert {0, 1, 2} <= seen, seen
+
+
+def test_every_cut_and_every_header_bit(amd, orc):
+    """Short streams of every block kind cut at EVERY byte, and zlib streams with every bit of the header and the trailer
+    flipped: verdict, bytes and (for raw streams) the position the reference's reader stops at are the oracle's.  The
+    random mutants of test_fuzz_gpu.py sample these; here the small cases are complete."""
+    texts = [streams.text(700, 31), bytes(range(256)) * 2, b"ab" * 300 + streams.text(200, 32)]
+    raws = []
+    for t in texts:
+        raws += [streams.raw_deflate(t), streams.raw_deflate(t, level=1), streams.raw_deflate(t, strategy=zlib.Z_FIXED), streams.raw_deflate(t, level=0)]
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    raws.append(c.compress(texts[0]) + c.flush(zlib.Z_SYNC_FLUSH) + c.compress(texts[2]) + c.flush(zlib.Z_FULL_FLUSH) + c.compress(texts[1]) + c.flush())
+    n = 0
+    for r in raws:
+        for cut in range(len(r) + 1):
+            buf = r[:cut]
+            st, out, pos = orc.inflate_raw(buf)
+            want = (2, None, None) if st == 2 else ((3, None, None) if st == 3 else (st, out, pos))
+            assert _raw(amd, buf) == want, (len(r), cut, st)
+            n += 1
+    z = zlib.compress(texts[0], 6)
+    zcases = [z[:cut] for cut in range(len(z) + 1)]
+    for bit in list(range(16)) + list(range((len(z) - 4) * 8, len(z) * 8)):
+        m = bytearray(z); m[bit >> 3] ^= 1 << (bit & 7); zcases.append(bytes(m))
+    zd = zlib.compressobj(6, zlib.DEFLATED, 15, zdict=b"preset dictionary")
+    zcases.append(zd.compress(texts[0]) + zd.flush())   # FDICT set
+    for buf in zcases:
+        for verify in (False, True):
+            assert _zl(amd, buf, verify=verify) == _noneify(orc.zlib_decode(buf, verify=verify)), (len(buf), verify)
+            n += 1
+    assert n > 3000
