@@ -177,8 +177,8 @@ def test_gpu_damage_in_header_and_selectors(native_built):
     for k in range(160):                                              # selectors, code lengths, payload
         bit = 45 * 8 + (k * 104729) % ((len(c) - 60) * 8)
         b = bytearray(c); b[bit >> 3] ^= 0x80 >> (bit & 7); cases.append(bytes(b))
-    for cut in list(range(4, 130)) + [140, 200, 300, 1000, len(c) - 11, len(c) - 1]:  # every end inside the header (52 and 53: inside the
-        cases.append(c[:cut])                                                            # selector count -- RangeError, not `false`), then a few behind it
+    for cut in list(range(4, 130)) + list(range(130, len(c) - 80, 7)) + list(range(len(c) - 80, len(c))):  # every end inside the header (52 and 53: inside the
+        cases.append(c[:cut])                                                            # selector count -- RangeError, not `false`), every 7th behind it, every one in the end-of-stream marker and CRCs
     seen = set()
     for i, buf in enumerate(cases):
         for verify in (False, True):
