@@ -471,3 +471,37 @@ def test_every_cut_and_every_header_bit(amd, orc):
             assert _zl(amd, buf, verify=verify) == _noneify(orc.zlib_decode(buf, verify=verify)), (len(buf), verify)
             n += 1
     assert n > 3000
+
+
+def test_magics_at_every_edge_of_the_index_scan(amd, orc):
+    """gz_count_candidates reads a 64 KiB tile as 16 rows of 256 x 16 bytes, screens every 16 bytes for the byte 1f, and
+    takes the tile's interior path only when the whole tile and 20 bytes behind it exist (round 4).  `1f 8b 08` -- true
+    member starts and false ones inside stored payloads -- are planted around every edge there is: the 16-byte, 4 096-byte
+    and 64 KiB boundaries (the magic's three bytes on either side and across), the last tiles of the stream, and the byte
+    1f alone where nothing follows.  The oracle decodes the same streams."""
+    rnd = random.Random(17)
+
+    def build(total, plants):
+        # one stored-payload member whose bytes the test owns, so that a plant lands on a chosen offset of the STREAM
+        pay = bytearray(b"x" * total)
+        hdr = 10 + 5                       # gzip header + the first stored block's header (level 0: blocks of 65 535 bytes)
+        for off in plants:
+            rel = off - hdr - 5 * ((off - hdr) // 65540)   # (about: every 65 535 payload bytes cost 5 more)
+            if 0 <= rel < total - 24:
+                pay[rel:rel + 3] = b"\x1f\x8b\x08"
+        return bytes(pay)
+    for total, tail in ((200000, b""), (65536 * 2 - 40, b""), (131072 + 9, b"\x1f"), (70000, b"\x1f\x8b")):
+        edges = []
+        for base in (16, 4096, 65536, 131072, 16 * 777, 4096 * 9):
+            edges += [base + d for d in (-4, -3, -2, -1, 0, 1, 13, 14, 15)]
+        pay = build(total, edges)
+        small = streams.text(300, 5)
+        g = streams.gz_member(pay, level=0) + streams.bgzf_member(small) + streams.gz_member(small, name=b"n") + tail
+        want = _noneify(orc.gzip_decode(g, cap=len(pay) + 2 * len(small) + 64))
+        assert _gz(amd, g) == want, (total, len(tail))
+        assert want[0] == 2 if tail else (want[0] == 0 and want[1][:len(pay)] == pay)  # (a lone 1f / 1f 8b behind the last member: the reference's RangeError)
+        # ... and member starts themselves on the edges: short members in front shift the long one byte by byte
+        for shift in range(0, 20):
+            pre = streams.gz_member(b"s" * 3, level=0, name=b"n" * shift)
+            g2 = pre + g
+            assert _gz(amd, g2) == _noneify(orc.gzip_decode(g2, cap=len(pay) + 2 * len(small) + 80)), (total, shift)
