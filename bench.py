@@ -508,7 +508,10 @@ def extras(args, L, N, corpus, torch, np, dev, sh, comp, d_in, out_bytes, decode
         got = ctypes.c_uint32()
         L.ahip_crc32_device(o6.data_ptr(), len(data), 0, ctypes.byref(got), None)
         res["config5_bzip2_64x900k"] = {"value": round(len(data) / sec / 1e9, 3), "unit": "GB/s out", "ms": round(sec * 1e3, 1),
-                                        "hbm_frac": frac(len(cz), len(data), sec), "crc_ok": bool(got.value == zlib.crc32(data))}
+                                        "hbm_frac": frac(len(cz), len(data), sec), "crc_ok": bool(got.value == zlib.crc32(data)),
+                                        "what": "ahip_bzip2_decode_device on ONE stream of 64 blocks; a third of this time is steps that are serial "
+                                                "per block, so larger streams run faster (448 blocks: profiles/r04_bz_kernel_stats.md, "
+                                                "python tests/perf/bzip2_stats.py 384)"}
     except AssertionError as e:
         res["config5_bzip2_64x900k"] = {"error": str(e)}
     return res
