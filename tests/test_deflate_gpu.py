@@ -152,3 +152,27 @@ def test_carried_match_tables_change_nothing(amd, monkeypatch):
                     monkeypatch.setenv("AHIP_DF_RUNS", g)
                 assert amd.Deflate(data, level=level, window_bits=wb).get_bytes() == single, (len(data), level, wb, g)
     monkeypatch.delenv("AHIP_DF_RUNS", raising=False)
+
+
+def test_sizes_around_every_edge(amd, orc, monkeypatch):
+    """Inputs of 0 .. 70 bytes and of every length within three bytes of a chunk boundary (one, two and three chunks; the
+    match kernel hashes 4 / 8 / 16 bytes ahead and a carried table gets its last fifteen positions late), with two
+    workgroups taking runs of chunks and with one chunk per workgroup: the same bytes either way, and they inflate to the
+    input through zlib and through the oracle's restatement of the reference's Inflate."""
+    rnd = random.Random(23)
+    base = streams.text(3 * 32768 + 40, 13)
+    rep = (b"abcdefghijklmnop" * 5000)[: 3 * 32768 + 40]          # matches that run across every boundary
+    sizes = list(range(0, 71)) + [k * 32768 + d for k in (1, 2, 3) for d in range(-17, 18)]
+    for src in (base, rep):
+        for n in sizes:
+            d = src[:n]
+            for level in (1, 6, 9):
+                monkeypatch.setenv("AHIP_DF_RUNS", "2")
+                a = amd.Deflate(d, level=level).get_bytes()
+                monkeypatch.setenv("AHIP_DF_RUNS", "0")
+                b = amd.Deflate(d, level=level).get_bytes()
+                assert a == b, (n, level)
+                assert zlib.decompress(a, -15) == d, (n, level)
+            if n % 5 == 0:
+                assert orc.inflate_raw(a + bytes(4))[:2] == (0, d), n
+    monkeypatch.delenv("AHIP_DF_RUNS", raising=False)

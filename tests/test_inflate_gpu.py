@@ -505,3 +505,28 @@ def test_magics_at_every_edge_of_the_index_scan(amd, orc):
             pre = streams.gz_member(b"s" * 3, level=0, name=b"n" * shift)
             g2 = pre + g
             assert _gz(amd, g2) == _noneify(orc.gzip_decode(g2, cap=len(pay) + 2 * len(small) + 80)), (total, shift)
+
+
+def test_every_trailer_bit_of_a_gzip_stream(amd, orc):
+    """CRC-32 and ISIZE of every member -- each of their 64 bits flipped in turn, in a stream of three members (plain, BGZF
+    with its `BC` size hint, plain), with and without verification: the reference checks neither unless asked
+    (_gzip_decoder_web.dart:27-58), a BGZF hint that no longer fits is caught by the index' check and measured instead."""
+    a, b = streams.text(5000, 61), streams.text(900, 62)
+    members = [streams.gz_member(a, name=b"x"), streams.bgzf_member(b), streams.gz_member(b + a)]
+    g = b"".join(members)
+    ends, o = [], 0
+    for m in members:
+        o += len(m); ends.append(o)
+    n = 0
+    for e in ends:
+        for bit in range((e - 8) * 8, e * 8):
+            buf = bytearray(g); buf[bit >> 3] ^= 1 << (bit & 7); buf = bytes(buf)
+            for verify in (False, True):
+                assert _gz(amd, buf, verify=verify) == _noneify(orc.gzip_decode(buf, verify=verify)), (e, bit, verify)
+                n += 1
+    # ... and the BSIZE field of the BGZF member's BC subfield
+    p0 = len(members[0]) + 16
+    for bit in range(p0 * 8, (p0 + 2) * 8):
+        buf = bytearray(g); buf[bit >> 3] ^= 1 << (bit & 7); buf = bytes(buf)
+        assert _gz(amd, buf) == _noneify(orc.gzip_decode(buf)), bit
+    assert n == 384
