@@ -784,19 +784,21 @@ AHIP_DEVINL void bz_jump_tile(BzTileLds &S, const u8 *__restrict__ in, u64 n, co
 // One workgroup per block: the starts of its groups (bits from sym_bit).  jt = LDS room for 6 x BZ_TW jumps.
 // Returns (thread 0) the number of groups that have a start: the last of them is the one standing on a mark, or -- no
 // mark within nsel groups -- there is none and the block is `false` (the reference runs out of selectors).
-struct alignas(16) BzWalkLds { u16 jt[6][BZ_TW + 8]; u8 sel[BZ_MAX_SELECTORS + 14]; u32 pos_lo, pos_hi, g, done; };
+struct BzWalkState { u32 pos_lo, pos_hi, g, done; };
+struct alignas(16) BzWalkLds { u16 jt[2][6][BZ_TW + 8]; u8 sel[BZ_MAX_SELECTORS + 14]; BzWalkState st[2]; };  // two tiles, two states: see bz_walk_groups
 AHIP_DEVINL void bz_walk_groups(BzWalkLds &S, const BzTables *__restrict__ T, const u8 *__restrict__ sel, u64 lim,
                                 const u16 *__restrict__ j50, u64 j50_bit0, u64 tstride, u32 *__restrict__ gstart,
                                 u32 &found, u32 &marked, const u32 tid, const u32 nthreads) {  // marked: see below
   const u32 ngroups = T->ngroups, nsel = T->nsel;
   const u64 sym_bit = T->sym_bit;
   for (u32 i = tid; i < nsel; i += nthreads) S.sel[i] = sel[i];
-  if (tid == 0) { S.pos_lo = (u32)sym_bit; S.pos_hi = (u32)(sym_bit >> 32); S.g = 0; S.done = 0; }
+  if (tid == 0) { S.st[0].pos_lo = (u32)sym_bit; S.st[0].pos_hi = (u32)(sym_bit >> 32); S.st[0].g = 0; S.st[0].done = 0; }
   BZ_BLOCK_SYNC();
-  // a tile's jumps: 6 rows of BZ_TW 16-bit values, fetched 8 at a time.  The jumps of the NEXT TWO tiles are on their way
-  // while this one is walked (a walk through a tile is ~ 1 us, a load from memory two to three: with one tile in flight
-  // the workgroup waited for it at every tile -- 4 us a tile, 1.8 ms a block) and stored behind it (a jump is < 1024 bits:
-  // the walk never skips a tile)
+  // a tile's jumps: 6 rows of BZ_TW 16-bit values, fetched 8 at a time.  While thread 0 walks through tile t (in one half of
+  // S.jt, reading the state the tile before left in S.st[t & 1] and leaving its own in the other), everybody stores the
+  // jumps of tile t + 1 into the other half and asks for those of tile t + 3: ONE barrier a tile.  (With one buffer it was
+  // three -- before the deposit, before the walk, behind it: 4 us a tile where the walk itself, ~ 16 dependent LDS
+  // look-ups, is one.)  A jump is < 1024 bits: the walk never skips a tile.
   constexpr u32 VEC = 8, PER_ROW = BZ_TW / VEC, MAX_SLOTS = 6;  // 6 * 512 vectors over >= 512 threads
   uint4 holdA[MAX_SLOTS], holdB[MAX_SLOTS];
   auto request = [&](uint4 (&hold)[MAX_SLOTS], u64 base) {  // tile at `base` -> registers
@@ -815,35 +817,39 @@ AHIP_DEVINL void bz_walk_groups(BzWalkLds &S, const BzTables *__restrict__ T, co
       }
     }
   };
-  auto deposit = [&](const uint4 (&hold)[MAX_SLOTS]) {  // registers -> LDS
+  const bool wide = nthreads * MAX_SLOTS >= 6 * PER_ROW;  // (false: few threads -- the CPU emulation: plain copies)
+  auto fill = [&](u32 half, const uint4 (&hold)[MAX_SLOTS], u64 tbase) {  // the tile at tbase -> S.jt[half]
+    if (wide) {
 #pragma unroll
-    for (u32 k = 0; k < MAX_SLOTS; ++k) {
-      const u32 v = tid + k * nthreads;
-      if (v < 6 * PER_ROW) { const u32 t = v / PER_ROW, i = (v % PER_ROW) * VEC; *(uint4 *)&S.jt[t][i] = hold[k]; }
+      for (u32 k = 0; k < MAX_SLOTS; ++k) {
+        const u32 v = tid + k * nthreads;
+        if (v < 6 * PER_ROW) { const u32 t = v / PER_ROW, i = (v % PER_ROW) * VEC; *(uint4 *)&S.jt[half][t][i] = hold[k]; }
+      }
+    } else {
+      for (u32 t = 0; t < ngroups; ++t)
+        for (u32 i = tid; i < BZ_TW; i += nthreads) S.jt[half][t][i] = tbase + i < lim ? j50[t * tstride + (tbase - j50_bit0) + i] : BZ_TERM;
     }
   };
-  const bool wide = nthreads * MAX_SLOTS >= 6 * PER_ROW;  // (false: few threads -- the CPU emulation: plain copies)
   u64 base = sym_bit;
   if (wide) { request(holdA, base); request(holdB, base + BZ_TW); }
-  // one tile; returns false when the walk is over
-  auto tile = [&](uint4 (&hold)[MAX_SLOTS]) -> bool {
-    const u64 pos = ((u64)S.pos_hi << 32) | S.pos_lo;
-    if (S.done || pos >= lim) return false;
-    BZ_BLOCK_SYNC();
-    if (wide) { deposit(hold); request(hold, base + 2 * BZ_TW); }
-    else {
-      for (u32 t = 0; t < ngroups; ++t)
-        for (u32 i = tid; i < BZ_TW; i += nthreads) S.jt[t][i] = base + i < lim ? j50[t * tstride + (base - j50_bit0) + i] : BZ_TERM;
-    }
-    BZ_BLOCK_SYNC();
+  fill(0, holdA, base);
+  if (wide) request(holdA, base + 2 * BZ_TW);
+  BZ_BLOCK_SYNC();
+  u32 last = 0;  // the state the walk ended in
+  // tile number `par` mod 2, held in S.jt[par]; `hold` has the tile behind it; returns false when the walk is over
+  auto tile = [&](u32 par, uint4 (&hold)[MAX_SLOTS]) -> bool {
+    const BzWalkState in = S.st[par];
+    const u64 pos = ((u64)in.pos_hi << 32) | in.pos_lo;
+    last = par;
+    if (in.done || pos >= lim) return false;
     if (tid == 0) {
       u32 o = (u32)(pos - base);  // position inside the tile
       const u32 rel = (u32)(base - sym_bit);
-      u32 g = S.g, done = 0;
+      u32 g = in.g, done = 0;
       u32 sg = g < nsel ? S.sel[g] : 0u;
       while (o < BZ_TW) {
         if (g >= nsel) { done = 2; break; }  // out of selectors
-        const u32 j = S.jt[sg][o];
+        const u32 j = S.jt[par][sg][o];
         sg = S.sel[g + 1];  // (room for one past the end) -- independent of the jump just requested
         gstart[g] = rel + o;
         ++g;
@@ -851,18 +857,23 @@ AHIP_DEVINL void bz_walk_groups(BzWalkLds &S, const BzTables *__restrict__ T, co
         o += j;
       }
       const u64 q = base + o;
-      S.pos_lo = (u32)q; S.pos_hi = (u32)(q >> 32); S.g = g; S.done = done;
+      BzWalkState out;
+      out.pos_lo = (u32)q; out.pos_hi = (u32)(q >> 32); out.g = g; out.done = done;
+      S.st[par ^ 1] = out;
     }
+    fill(par ^ 1, hold, base + BZ_TW);
+    if (wide) request(hold, base + 3 * BZ_TW);
     base += BZ_TW;
     BZ_BLOCK_SYNC();
     return true;
   };
   for (;;) {
-    if (!tile(holdA)) break;
-    if (!tile(holdB)) break;
+    if (!tile(0, holdB)) break;
+    if (!tile(1, holdA)) break;
   }
-  found = S.g;
-  marked = S.done == 1 ? 1u : (S.done == 2 ? 0u : 2u);  // 1 a marked group ends the walk, 0 out of selectors, 2 irregular
+  const BzWalkState fin = S.st[last];
+  found = fin.g;
+  marked = fin.done == 1 ? 1u : (fin.done == 2 ? 0u : 2u);  // 1 a marked group ends the walk, 0 out of selectors, 2 irregular
 }
 struct BzGroupLds {
   i32 limit[6][24], base[6][24];
