@@ -1820,10 +1820,11 @@ static int32_t deflate_device_impl(const u8 *d_in, size_t n, int level, int wind
     (void)hipStreamSynchronize(st);
     std::vector<u8> sl((size_t)P.chunks * DF_SLAB);
     (void)hipMemcpy(sl.data(), b_slabs.p, sl.size(), hipMemcpyDeviceToHost);
-    double s4[4] = {0, 0, 0, 0};
-    for (u32 c = 0; c < P.chunks; ++c) { const u32 *pc = (const u32 *)(sl.data() + (size_t)c * DF_SLAB + DF_SLAB - 32); for (int k = 0; k < 4; ++k) s4[k] += pc[k] * 16.0; }
-    fprintf(stderr, "[ahip] encode kernel cycles per chunk: zero+histogram %.0f  trees+header (one lane) %.0f  size pass %.0f  token rounds %.0f\n",
-            s4[0] / P.chunks, s4[1] / P.chunks, s4[2] / P.chunks, s4[3] / P.chunks);
+    double s4[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (u32 c = 0; c < P.chunks; ++c) { const u32 *pc = (const u32 *)(sl.data() + (size_t)c * DF_SLAB + DF_SLAB - 32); for (int k = 0; k < 8; ++k) s4[k] += pc[k] * 16.0; }
+    fprintf(stderr, "[ahip] encode kernel cycles per chunk: zero+histogram %.0f  trees+header %.0f (literal/length tree %.0f, run-length scan of the lengths %.0f, "
+            "code-length tree %.0f, header emission %.0f)  size pass %.0f  token rounds %.0f\n",
+            s4[0] / P.chunks, s4[1] / P.chunks, s4[4] / P.chunks, s4[5] / P.chunks, s4[6] / P.chunks, s4[7] / P.chunks, s4[2] / P.chunks, s4[3] / P.chunks);
   }
 #endif
   std::vector<u32> csize(P.chunks);

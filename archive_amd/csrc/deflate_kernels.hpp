@@ -446,6 +446,10 @@ struct EncLds {
   u32 opt_len;
   u32 wsum[4];
   u32 run_bits;
+  u16 cl_tok[DF_LCODES + DF_DCODES + 8];  // the code lengths of both trees as run-length tokens: symbol | extra value << 5
+  u16 cl_pos[320];                          // df_cl_tokens: tokens in front of the run that starts at i
+  u32 cl_ntok;
+  u32 cl_freq[32];                          // how often each of the 19 code-length symbols occurs among them
   u32 obuf[DF_SLAB / 4];
 };
 
@@ -604,42 +608,81 @@ AHIP_DEVINL void df_put(DfBits &b, u32 v, u32 n) {
 }
 AHIP_DEVINL void df_put_code(DfBits &b, const u16 *tree, int c) { df_put(b, tree[c * 2], tree[c * 2 + 1]); }
 
-__device__ inline void df_scan_tree(EncLds &E, u16 *tree, int max_code) {
-  int prevlen = -1, curlen, nextlen = tree[1], count = 0, max_count = 7, min_count = 4;
-  if (nextlen == 0) { max_count = 138; min_count = 3; }
-  tree[(max_code + 1) * 2 + 1] = 0xffff;
-  for (int n = 0; n <= max_code; n++) {
-    curlen = nextlen;
-    nextlen = tree[(n + 1) * 2 + 1];
-    if (++count < max_count && curlen == nextlen) continue;
-    else if (count < min_count) E.bltree[curlen * 2] = (u16)(E.bltree[curlen * 2] + count);
-    else if (curlen != 0) { if (curlen != prevlen) E.bltree[curlen * 2]++; E.bltree[16 * 2]++; }
-    else if (count <= 10) E.bltree[17 * 2]++;
-    else E.bltree[18 * 2]++;
-    count = 0; prevlen = curlen;
-    if (nextlen == 0) { max_count = 138; min_count = 3; }
-    else if (curlen == nextlen) { max_count = 6; min_count = 3; }
-    else { max_count = 7; min_count = 4; }
+// The code lengths of one tree as the run-length tokens of the block header (deflate.dart:2820-2920 = zlib's scan_tree /
+// send_tree: symbols 0..15 a length, 16 = repeat the previous length 3..6 times, 17 / 18 = 3..10 / 11..138 zeros), by the
+// whole workgroup.  The reference's loop is a small state machine (count, max_count, min_count, prevlen); what it does with
+// a maximal run of L equal lengths v is a closed form of (v, L) alone -- a run starts with prevlen != v and the counts the
+// length in front of it left: (7, 4), or (138, 3) for zeros --
+//   v != 0:  the first 7 (or all L <= 7): fewer than 4 -> that many literals; else v, REP(count - 1).  Behind them groups
+//            of 6 -> REP(6); a rest of 3..5 -> REP(rest), of 1..2 -> literals;
+//   v == 0:  groups of 138 -> REPZ_11_138(138); a rest of 11.. -> REPZ_11_138, of 3..10 -> REPZ_3_10, of 1..2 -> literals --
+// so a thread per run writes its tokens where a prefix sum of the token counts says, and one pass serves both the
+// frequencies of the code-length tree (scan_tree) and, once that tree is built, the emission (send_tree).  One lane
+// walking the 316 lengths twice was 153 K of the kernel's 425 K cycles per chunk.
+// Appends the tokens of tree[0 .. max_code] to E.cl_tok at E.cl_ntok (all threads call; barriers inside).
+__device__ inline void df_cl_tokens(EncLds &E, const u16 *tree, int max_code, u32 tid) {
+  const int n = max_code + 1;
+  const u32 base = E.cl_ntok;
+  __syncthreads();
+  // tokens of the run that starts at i (0 elsewhere)
+  auto run_tokens = [&](int i, int &L) -> u32 {
+    const u32 v = tree[i * 2 + 1];
+    L = 1;
+    while (i + L < n && tree[(i + L) * 2 + 1] == v) ++L;
+    if (v != 0) {
+      const int first = L < 7 ? L : 7;
+      u32 t = first < 4 ? (u32)first : 2u;
+      int rest = L - first;
+      t += (u32)(rest / 6);
+      rest %= 6;
+      t += rest >= 3 ? 1u : (u32)rest;
+      return t;
+    }
+    u32 t = (u32)(L / 138);
+    const int rest = L % 138;
+    t += rest >= 3 ? 1u : (u32)rest;
+    return t;
+  };
+  for (int i = (int)tid; i < 320; i += 256) {
+    u32 t = 0;
+    if (i < n && (i == 0 || tree[i * 2 + 1] != tree[(i - 1) * 2 + 1])) { int L; t = run_tokens(i, L); }
+    E.cl_pos[i] = (u16)t;
   }
-}
-__device__ inline void df_send_tree(EncLds &E, DfBits &b, const u16 *tree, int max_code) {
-  int prevlen = -1, curlen, nextlen = tree[1], count = 0, max_count = 7, min_count = 4;
-  if (nextlen == 0) { max_count = 138; min_count = 3; }
-  for (int n = 0; n <= max_code; n++) {
-    curlen = nextlen;
-    nextlen = tree[(n + 1) * 2 + 1];
-    if (++count < max_count && curlen == nextlen) continue;
-    else if (count < min_count) { do { df_put_code(b, E.bltree, curlen); } while (--count != 0); }
-    else if (curlen != 0) {
-      if (curlen != prevlen) { df_put_code(b, E.bltree, curlen); count--; }
-      df_put_code(b, E.bltree, 16); df_put(b, (u32)(count - 3), 2);
-    } else if (count <= 10) { df_put_code(b, E.bltree, 17); df_put(b, (u32)(count - 3), 3); }
-    else { df_put_code(b, E.bltree, 18); df_put(b, (u32)(count - 11), 7); }
-    count = 0; prevlen = curlen;
-    if (nextlen == 0) { max_count = 138; min_count = 3; }
-    else if (curlen == nextlen) { max_count = 6; min_count = 3; }
-    else { max_count = 7; min_count = 4; }
+  __syncthreads();
+  if (tid < 64) {  // exclusive prefix sum over the 320 entries, five a lane
+    u32 v[5], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { v[k] = E.cl_pos[tid * 5 + k]; sum += v[k]; }
+    u32 total;
+    u32 ex = wave_excl_sum(sum, total);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { E.cl_pos[tid * 5 + k] = (u16)ex; ex += v[k]; }
+    if (tid == 0) E.cl_ntok = base + total;
   }
+  __syncthreads();
+  for (int i = (int)tid; i < n; i += 256) {
+    if (!(i == 0 || tree[i * 2 + 1] != tree[(i - 1) * 2 + 1])) continue;
+    int L;
+    (void)run_tokens(i, L);
+    const u32 v = tree[i * 2 + 1];
+    u16 *o = E.cl_tok + base + E.cl_pos[i];
+    if (v != 0) {
+      const int first = L < 7 ? L : 7;
+      if (first < 4) { for (int k = 0; k < first; ++k) *o++ = (u16)v; }
+      else { *o++ = (u16)v; *o++ = (u16)(16u | ((u32)(first - 1 - 3) << 5)); }
+      int rest = L - first;
+      for (; rest >= 6; rest -= 6) *o++ = (u16)(16u | (3u << 5));
+      if (rest >= 3) *o++ = (u16)(16u | ((u32)(rest - 3) << 5));
+      else for (int k = 0; k < rest; ++k) *o++ = (u16)v;
+    } else {
+      int rest = L;
+      for (; rest >= 138; rest -= 138) *o++ = (u16)(18u | (127u << 5));
+      if (rest >= 11) *o++ = (u16)(18u | ((u32)(rest - 11) << 5));
+      else if (rest >= 3) *o++ = (u16)(17u | ((u32)(rest - 3) << 5));
+      else for (int k = 0; k < rest; ++k) *o++ = 0;
+    }
+  }
+  __syncthreads();
 }
 
 __global__ __launch_bounds__(256) void deflate_encode_kernel(const u8 *__restrict__ in, DeflateParams P,
@@ -656,7 +699,7 @@ __global__ __launch_bounds__(256) void deflate_encode_kernel(const u8 *__restric
   AHIP_TICK(e0);
   for (u32 i = tid; i < DF_SLAB / 4; i += 256) E.obuf[i] = 0;
   for (u32 i = tid; i < 288; i += 256) E.fl[i] = 0;
-  if (tid < 32) E.fd[tid] = 0;
+  if (tid < 32) { E.fd[tid] = 0; E.cl_freq[tid] = 0; }
   __syncthreads();
   bool stored = P.store != 0;
   u32 total_bits = 0;
@@ -687,13 +730,22 @@ __global__ __launch_bounds__(256) void deflate_encode_kernel(const u8 *__restric
     __syncthreads();
     int l_max_code, d_max_code, b_max_code;
     df_build_tree_wg<512>(E, E.ltree, DF_LCODES, 15, l_max_code, tid);
+    AHIP_TICK(e1a);
     df_build_tree_wg<32>(E, E.dtree, DF_DCODES, 15, d_max_code, tid);
-    if (tid == 0) {
-      df_scan_tree(E, E.ltree, l_max_code);
-      df_scan_tree(E, E.dtree, d_max_code);
-    }
+    AHIP_TICK(e1b);
+    // the code lengths of both trees as run-length tokens (each tree a stream of its own), and their frequencies
+    if (tid == 0) E.cl_ntok = 0;
     __syncthreads();
+    df_cl_tokens(E, E.ltree, l_max_code, tid);
+    df_cl_tokens(E, E.dtree, d_max_code, tid);
+    const u32 n_cl = E.cl_ntok;
+    for (u32 i = tid; i < n_cl; i += 256) atomicAdd(&E.cl_freq[E.cl_tok[i] & 31u], 1u);
+    __syncthreads();
+    if (tid < DF_BLCODES) E.bltree[tid * 2] = (u16)E.cl_freq[tid];
+    __syncthreads();
+    AHIP_TICK(e1c);
     df_build_tree_wg<32>(E, E.bltree, DF_BLCODES, 7, b_max_code, tid);
+    AHIP_TICK(e1d);
     if (tid == 0) {
       int max_blindex;
       for (max_blindex = DF_BLCODES - 1; max_blindex >= 3; max_blindex--)
@@ -704,11 +756,36 @@ __global__ __launch_bounds__(256) void deflate_encode_kernel(const u8 *__restric
       df_put(b, (u32)(d_max_code + 1 - 1), 5);
       df_put(b, (u32)(max_blindex + 1 - 4), 4);
       for (int r = 0; r <= max_blindex; r++) df_put(b, E.bltree[k_bl_order[r] * 2 + 1], 3);
-      df_send_tree(E, b, E.ltree, l_max_code);
-      df_send_tree(E, b, E.dtree, d_max_code);
       E.run_bits = b.pos;
     }
     __syncthreads();
+    // the tokens' codes, 256 a round: bit offsets by a prefix sum, the bits by atomicOr (like the block's own tokens below)
+    for (u32 base = 0; base < n_cl; base += 256) {
+      const u32 i = base + tid;
+      u32 bits = 0, nb = 0;
+      if (i < n_cl) {
+        const u32 tk = E.cl_tok[i], sym = tk & 31u;
+        bits = E.bltree[sym * 2];
+        nb = E.bltree[sym * 2 + 1];
+        bits |= (tk >> 5) << nb;
+        nb += k_extra_blbits[sym];
+      }
+      u32 wtotal;
+      const u32 inc = wave_excl_sum(nb, wtotal);
+      if (lane == 0) E.wsum[wave] = wtotal;
+      __syncthreads();
+      u32 off = E.run_bits + inc;
+      for (u32 w = 0; w < wave; ++w) off += E.wsum[w];
+      if (nb) {
+        const u32 wi = off >> 5, sft = off & 31;
+        const u64 lo = (u64)bits << sft;
+        atomicOr(&E.obuf[wi], (u32)lo);
+        if ((u32)(lo >> 32)) atomicOr(&E.obuf[wi + 1], (u32)(lo >> 32));
+      }
+      __syncthreads();
+      if (tid == 0) E.run_bits += E.wsum[0] + E.wsum[1] + E.wsum[2] + E.wsum[3];
+      __syncthreads();
+    }
     AHIP_TICK(e2);
     // ---- exact size first: a chunk that does not shrink (or would not fit the LDS image) is stored ----
     {
@@ -733,7 +810,8 @@ __global__ __launch_bounds__(256) void deflate_encode_kernel(const u8 *__restric
     }
     AHIP_TICK(e3);
 #ifdef AHIP_PROFILE
-    if (tid == 0) { u32 *pc = (u32 *)(slab + DF_SLAB - 32); pc[0] = (u32)((e1 - e0) >> 4); pc[1] = (u32)((e2 - e1) >> 4); pc[2] = (u32)((e3 - e2) >> 4); }
+    if (tid == 0) { u32 *pc = (u32 *)(slab + DF_SLAB - 32); pc[0] = (u32)((e1 - e0) >> 4); pc[1] = (u32)((e2 - e1) >> 4); pc[2] = (u32)((e3 - e2) >> 4);
+                    pc[4] = (u32)((e1a - e1) >> 4); pc[5] = (u32)((e1c - e1b) >> 4); pc[6] = (u32)((e1d - e1c) >> 4); pc[7] = (u32)((e2 - e1d) >> 4); }
 #endif
     if (!stored) {
     // ---- tokens, 256 per round ----
