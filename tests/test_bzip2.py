@@ -187,3 +187,15 @@ def test_gpu_damage_in_header_and_selectors(native_built):
             assert got == ((2, None) if st == 2 else (st, out)), (i, verify, got[0], st)
             seen.add(st)
     assert {0, 1, 2} <= seen, seen  # decoded all the same (the damage hit nothing that is checked), `false`, RangeError
+
+
+def test_bench_stream_of_repeated_blocks():
+    """bench.py measures a long bzip2 stream it builds from a short one (bz2_repeat: the block section spliced bit by bit,
+    the stream CRC folded from the block CRCs): libbzip2 and the oracle must read it as the data repeated."""
+    import bench
+    from oracle import pyoracle as orc
+    data = streams.text(250000, 8) + bytes(5000)
+    c = bz2.compress(data, 1)                      # three blocks, none of them byte aligned but the first
+    big, n = bench.bz2_repeat(c, 3)
+    assert n == 9 and bz2.decompress(big) == data * 3
+    assert orc.bzip2_decode(big, verify=True) == (0, data * 3)
