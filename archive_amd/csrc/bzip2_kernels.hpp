@@ -345,7 +345,20 @@ AHIP_DEVINL void bz_decode_block_wave(BzLds &L, const u8 *__restrict__ in, u64 n
     const u32 nsel = bz_bits(b, 15);
     if (b.fault) { status = BZ_ST_RANGE; break; }
     if (nsel < 1) { status = BZ_ST_FALSE; break; }
-    if (nsel > BZ_MAX_SELECTORS) { status = BZ_ST_RANGE; break; }  // Dart: store past the Uint8List
+    if (nsel > BZ_MAX_SELECTORS) {
+      // More selectors than the reference's Uint8List holds: it reads on, one unary number after the other, and the STORE of
+      // number 18 002 is its RangeError -- unless a number in front of it is bad (`false`) or the input ends first
+      // (RangeError as well, but where the reader stands).  Damaged input only: bit by bit.
+      BzFast fo;
+      bzf_init(fo, in, n, b.bit, lane);
+      bool bad = false;
+      for (u32 i = 0; i <= BZ_MAX_SELECTORS && !bad && !fo.fault; ++i) {
+        u32 j = 0;
+        while (bzf_bits(fo, 1, lane) && !fo.fault) { if (++j >= ngroups) { bad = true; break; } }
+      }
+      status = (bad && !fo.fault) ? BZ_ST_FALSE : BZ_ST_RANGE;
+      break;
+    }
     // selectors and code lengths: ~30 000 bits read a few at a time -- from the stream held in registers (64 dwords a
     // lane-load, the next batch in flight), not one global load per 32 bits
     BzFast f;

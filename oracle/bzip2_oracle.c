@@ -168,7 +168,7 @@ static int read_compressed(bz_t *s, uint32_t *crc_out) {
       if (j >= num_groups) return -1;
     }
     if (i < BZ_MAX_SELECTORS) s->selector_mtf[i] = (uint8_t)j;
-    else return -1; /* Dart: index past the Uint8List -> RangeError; libbzip2 >= 1.0.8 discards */
+    else { br->fault = 1; return -1; } /* Dart: index past the Uint8List -> RangeError (reported like the reader's own); libbzip2 >= 1.0.8 discards */
     if (br->fault) return -1;
   }
   uint8_t pos[BZ_N_GROUPS];

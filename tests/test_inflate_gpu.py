@@ -530,3 +530,28 @@ def test_every_trailer_bit_of_a_gzip_stream(amd, orc):
         buf = bytearray(g); buf[bit >> 3] ^= 1 << (bit & 7); buf = bytes(buf)
         assert _gz(amd, buf) == _noneify(orc.gzip_decode(buf)), bit
     assert n == 384
+
+
+def test_small_gzip_stream_cut_everywhere_and_flipped_everywhere(amd, orc):
+    """A three-member gzip stream of 0.6 KB (a name, a BGZF member, a header CRC; dynamic, fixed and stored blocks): cut at
+    every byte, and every third bit flipped -- header, payload, trailer alike.  Verdict and bytes are the oracle's, with and
+    without verification."""
+    from archive_amd import errors
+    a, b, c = streams.text(900, 71), streams.text(300, 72), bytes(range(200))
+    g = streams.gz_member(a, name=b"first") + streams.bgzf_member(b, level=1) + streams.gz_member(c, level=0, hcrc=True)
+    cases = [g[:cut] for cut in range(len(g) + 1)]
+    for bit in range(0, len(g) * 8, 3):
+        m = bytearray(g); m[bit >> 3] ^= 1 << (bit & 7); cases.append(bytes(m))
+    seen = set()
+    for i, buf in enumerate(cases):
+        for verify in (False, True):
+            want = _noneify(orc.gzip_decode(buf, verify=verify))
+            if want[0] == 3:
+                want = (3, None)
+            try:
+                got = _gz(amd, buf, verify=verify)
+            except errors.ReferenceWouldHang:
+                got = (3, None)
+            assert got == want, (i, len(buf), verify, got[0], want[0])
+            seen.add(want[0])
+    assert {0, 1, 2} <= seen, seen
