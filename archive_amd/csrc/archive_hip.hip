@@ -22,6 +22,7 @@
 #include "common.hpp"
 #include "gzip_index.hpp"
 #include "bzip2_kernels.hpp"
+#include "bzip2_chain.hpp"
 #include "checksum_kernels.hpp"
 #include "deflate_kernels.hpp"
 #include "inflate_par.hpp"
@@ -1329,7 +1330,7 @@ int32_t zlib_stream_device(const u8 *host_in, const u8 *d_in, u64 n, u64 pos, bo
 // ------------------------------------------------------------------------------------------
 extern "C" {
 
-uint32_t ahip_abi_version(void) { return (2u << 16) | 2u; }
+uint32_t ahip_abi_version(void) { return (2u << 16) | 3u; }
 
 const char *ahip_last_error(void) { return g_err.c_str(); }
 
@@ -1393,6 +1394,8 @@ struct BzShard {
   bool saw_eos = false;  // met the end-of-stream block
   u32 eos_stored = 0;
   bool stopped = false;  // the stream ended inside this shard (end-of-stream block, clean end of input, or a verdict)
+  u64 from = ~0ull;      // in: start the chain at this candidate instead of the range's first (the merge's second try)
+  u64 first = 0, next = 0;  // out: the candidate this shard's chain started at / expects next (>= the range's end unless stopped)
 };
 static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, int32_t verify, u8 *d_out, size_t out_cap,
                                  size_t *out_len, BzShard *sh = nullptr) {
@@ -1423,12 +1426,26 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
   if (ncand) HIP_TRY(hipMemcpy(cands.data(), dcand.p, (size_t)ncand * sizeof(BzCand), hipMemcpyDeviceToHost));
   std::sort(cands.begin(), cands.end(), [](const BzCand &a, const BzCand &b) { return a.bit < b.bit; });
   // the first block type is read at bit 32; anything else there is "Invalid Block Signature"
+  // the stream's seven bytes from bit >> 3 on (zeros beyond the end): what _readBlockType reads where no magic starts
+  auto peek = [&](u64 bit, u8 *b7) {
+    const u64 p = bit >> 3;
+    if (p < in_len) (void)hipMemcpy(b7, d_in + p, (size_t)std::min<u64>(7, in_len - p), hipMemcpyDeviceToHost);
+  };
   if (ncand == 0 || cands[0].bit != 32) {
     if (sh) sh->stopped = true;
-    return in_len * 8 < 32 + 48 ? AHIP_RANGE : AHIP_FALSE;
+    u8 b7[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    peek(32, b7);
+    return bz_no_magic_verdict(32, in_len, b7);
   }
-  const size_t c_lo = sh ? (size_t)((u64)ncand * sh->index / sh->count) : 0, c_hi = sh ? (size_t)((u64)ncand * (sh->index + 1) / sh->count) : ncand;
-  if (c_lo >= c_hi) return AHIP_OK;  // (more shards than blocks)
+  size_t c_lo = sh ? (size_t)((u64)ncand * sh->index / sh->count) : 0;
+  const size_t c_hi = sh ? (size_t)((u64)ncand * (sh->index + 1) / sh->count) : ncand;
+  if (sh) {
+    // (the chain of the shards in front may end somewhere else than at this shard's first candidate -- a false magic
+    //  inside a block's data on the boundary: the merge then runs this shard again from where the chain really stands)
+    if (sh->from != ~0ull) c_lo = (size_t)sh->from;
+    sh->first = c_lo; sh->next = c_lo;
+  }
+  if (c_lo >= c_hi) return AHIP_OK;  // (more shards than blocks, or the chain has stepped over this shard's range)
   HIP_TRY(hipMemcpy(dcand.p, cands.data(), (size_t)ncand * sizeof(BzCand), hipMemcpyHostToDevice));
   const u64 nblock_max = 100000ull * (u64)level;
   const u64 wstride = nblock_max / BZ_G + 2;
@@ -1510,17 +1527,11 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
   static thread_local DevBuf dwq;  // the XCDs' work queues, one set for each of the two walks
   HIP_TRY(dwq.reserve(64));
   static thread_local DevBuf ddir;
-  // chain state (decodeStream's loop)
-  u64 total = 0;        // bytes placed so far
-  u64 keep = 0;         // bytes that count (a CRC mismatch stops the stream behind the block it was found in)
-  int32_t verdict = AHIP_OK;
-  bool saw_eos = false, stopped = false, crc_stop = false, over_cap = false;
-  u32 eos_stored = 0, combined = 0;
-  size_t next = c_lo;   // candidate the chain expects next
-  u64 folded = 0;       // block CRCs folded into `combined`
-  for (size_t c0 = c_lo; c0 < c_hi && !stopped && next < c_hi; c0 += batch) {
-    if (next >= c0 + batch) continue;  // the chain has already stepped over this whole batch (false magics inside data)
-    const u32 nb = (u32)std::min<size_t>(batch, c_hi - c0);
+  // chain state (decodeStream's loop: bzip2_chain.hpp drives the two phases below batch by batch)
+  BzChain ch;
+  bool over_cap = false;
+  // the counting passes of the candidates [c0, c0 + nb): everything but the placement of the bytes
+  auto decode_batch = [&](size_t c0, u32 nb, std::vector<BzResult> &res) -> int32_t {
     const BzCand *dc = dcand.as<BzCand>() + c0;
     // phase 1: the Huffman side of every block (one wave each) -> symbol streams; what the symbols mean by chunks
     const u64 bit0 = cands[c0].bit, bit1 = c0 + nb < ncand ? cands[c0 + nb].bit : (u64)in_len * 8;
@@ -1559,13 +1570,15 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
                            dj50.as<u16>(), bit0, tstride, gstart, gcount, ress);
         hipLaunchKernelGGL(bz_decode_groups, dim3(cdiv(BZ_MAX_SELECTORS, 256), n), dim3(256), 0, s, d_in, (u64)in_len, tabs, sels, gstart, gcount,
                            syms, ress);
-        hipLaunchKernelGGL(bz_decode_block, dim3(n), dim3(64), 0, s, d_in, (u64)in_len, dcs, n, syms, list0, sels, ress, 1u);
+        hipLaunchKernelGGL(bz_decode_block, dim3(n), dim3(64), 0, s, d_in, (u64)in_len, dcs, n, syms, list0, sels, ress, 1u, tabs);
       } else {
-        hipLaunchKernelGGL(bz_decode_block, dim3(n), dim3(64), 0, s, d_in, (u64)in_len, dcs, n, syms, list0, sels, ress, 0u);
+        hipLaunchKernelGGL(bz_decode_block, dim3(n), dim3(64), 0, s, d_in, (u64)in_len, dcs, n, syms, list0, sels, ress, 0u, tabs);
       }
       hipLaunchKernelGGL(bz_mtf_lanes<false>, dim3(BZ_CHUNKS, n), dim3(64), 0, s, syms, ress, (u32)level, chunks, perms, lists, choff, b8, pperms, pcounts);
       hipLaunchKernelGGL(bz_mtf_scan, dim3(n), dim3(64), 0, s, ress, dcs, n, (u32)level, chunks, perms, list0, lists, choff);
       hipLaunchKernelGGL(bz_mtf_lanes<true>, dim3(BZ_CHUNKS, n), dim3(64), 0, s, syms, ress, (u32)level, chunks, perms, lists, choff, b8, pperms, pcounts);
+      // damaged blocks in which _getMtfVal fails: the reference goes on with -1 as a symbol -- its own loop, one lane each
+      hipLaunchKernelGGL(bz_block_exact, dim3(n), dim3(64), 0, s, d_in, (u64)in_len, n, tabs, list0, sels, ress, b8, (u32)level);
       u32 *thist = dthist.as<u32>() + (size_t)b0 * BZ_TINV_WAVES * 256;
       hipLaunchKernelGGL(bz_tinv_hist, dim3(BZ_TINV_PARTS, n), dim3(1024), 0, s, tts, b8, (u32)level, dcs, ress, thist);  // (dpre: the bytes before the walk, the walk's output after it)
       hipLaunchKernelGGL(bz_tinv_cursors, dim3(n), dim3(256), 0, s, dcs, ress, thist);
@@ -1583,74 +1596,37 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
     // blocks the parallel path handed back (BZ_ST_SERIAL): the reference loop, counting only (no slab)
     hipLaunchKernelGGL(bz_unbwt, dim3(cdiv(nb, 64)), dim3(64), 0, st, dtt.as<u32>(), (u32)level, nb, dc, (u8 *)nullptr, (u64)0,
                        dres.as<BzResult>(), dcrc.as<u32>(), (const u64 *)nullptr, (u8 *)nullptr);
-    std::vector<BzResult> res(nb);
     HIP_TRY(hipMemcpy(res.data(), dres.p, (size_t)nb * sizeof(BzResult), hipMemcpyDeviceToHost));
     HIP_TRY(hipGetLastError());
-    // Sizes are known here; block CRCs only after the expansion, so the walk is done for placement first and the
-    // verdict (first CRC mismatch stops the stream, its bytes already written) afterwards.
-    struct Placed { u32 cand; u64 off, len; };
-    std::vector<Placed> placed;
-    while (next < c0 + nb) {
-      const size_t i = next;
-      const BzResult &r = res[i - c0];
-      if (cands[i].kind == 2) {  // end of stream: combined CRC, then decodeStream returns true
-        if (r.status == BZ_ST_RANGE) verdict = AHIP_RANGE;
-        else { saw_eos = true; eos_stored = r.stored_crc; }
-        stopped = true;
-        break;
-      }
-      if (r.status == BZ_ST_RANGE) { verdict = AHIP_RANGE; stopped = true; break; }
-      if (r.status == BZ_ST_UNSUPPORTED) return fail(AHIP_E_UNSUPPORTED, "randomised bzip2 block");
-      if (r.status != BZ_ST_OK && r.status != BZ_ST_OVERFLOW) { verdict = AHIP_FALSE; stopped = true; break; }
-      placed.push_back({(u32)(i - c0), total, r.out_len});
-      total += r.out_len;
-      // next block type is read at r.end_bit
-      if ((r.end_bit + 7) / 8 >= in_len) { stopped = true; break; }  // while (!input.isEOS): clean end without an end-of-stream block
-      size_t j = i + 1;
-      while (j < ncand && cands[j].bit < r.end_bit) ++j;
-      if (j >= ncand || cands[j].bit != r.end_bit) {
-        // not a block magic there: _readBlockType returns -1 (or runs off the end)
-        verdict = (r.end_bit + 48 > (u64)in_len * 8) ? AHIP_RANGE : AHIP_FALSE;
-        stopped = true;
-        break;
-      }
-      next = j;
+    return AHIP_OK;
+  };
+  // the bytes of the blocks the chain placed, and the CRCs of the parallel ones
+  auto place_batch = [&](size_t c0, u32 nb, const std::vector<BzPlaced> &placed, const std::vector<BzResult> &, std::vector<BzResult> &res2) -> int32_t {
+    const BzCand *dc = dcand.as<BzCand>() + c0;
+    std::vector<u64> par_off(nb, ~0ull), ser_off(nb, ~0ull);
+    bool any_serial = false;
+    for (const BzPlaced &pl : placed) {
+      if (pl.how == BZ_PL_PARALLEL) par_off[pl.cand] = pl.off;
+      else { ser_off[pl.cand] = pl.off; any_serial = true; }
     }
-    if (verdict == AHIP_RANGE) { if (out_len) *out_len = total; return AHIP_RANGE; }
-    if (total > out_cap) over_cap = true;  // keep walking: the caller is told the full size
-    if (!placed.empty() && !crc_stop && !over_cap) {
-      std::vector<u64> par_off(nb, ~0ull), ser_off(nb, ~0ull);
-      bool any_serial = false;
-      for (const Placed &pl : placed) {
-        if (res[pl.cand].status == BZ_ST_OK) par_off[pl.cand] = pl.off;
-        else { ser_off[pl.cand] = pl.off; any_serial = true; }
-      }
-      HIP_TRY(hipMemcpy(doff.p, par_off.data(), (size_t)nb * 8, hipMemcpyHostToDevice));
-      hipLaunchKernelGGL(bz_rle_expand, dim3(BZ_SPANS / 256, nb), dim3(256), 0, st, (u32)level, dc, dres.as<BzResult>(), dpre.as<u8>(),
-                         dspans.as<BzSpan>(), doff.as<u64>(), d_out);
-      hipLaunchKernelGGL(bz_block_crc, dim3((u32)cdiv(cdiv(nblock_max * 2, CK_SEG), 4), nb), dim3(256), 0, st, dc, dres.as<BzResult>(), doff.as<u64>(),
-                         d_out, dcktab.as<u32>(), dcrc.as<u32>());
-      if (any_serial) {
-        HIP_TRY(ddir.reserve((size_t)nb * 8));
-        HIP_TRY(hipMemcpy(ddir.p, ser_off.data(), (size_t)nb * 8, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(bz_unbwt, dim3(cdiv(nb, 64)), dim3(64), 0, st, dtt.as<u32>(), (u32)level, nb, dc, (u8 *)nullptr, (u64)0,
-                           dres.as<BzResult>(), dcrc.as<u32>(), ddir.as<u64>(), d_out);
-      }
-      std::vector<BzResult> res2(nb);
-      HIP_TRY(hipMemcpy(res2.data(), dres.p, (size_t)nb * sizeof(BzResult), hipMemcpyDeviceToHost));
-      HIP_TRY(hipGetLastError());
-      // verdict: block CRCs in stream order, then (at the end) the combined CRC
-      for (const Placed &pl : placed) {
-        const u32 crc = res[pl.cand].status == BZ_ST_OK ? (res2[pl.cand].crc ^ 0xffffffffu) : res[pl.cand].crc;
-        if (verify && crc != res[pl.cand].stored_crc) {  // the block's bytes were already written
-          verdict = AHIP_FALSE; keep = pl.off + pl.len; saw_eos = false; crc_stop = true; stopped = true;
-          break;
-        }
-        combined = ((combined << 1) | (combined >> 31)) ^ crc;
-        ++folded;
-        keep = pl.off + pl.len;
-      }
+    HIP_TRY(hipMemcpy(doff.p, par_off.data(), (size_t)nb * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(bz_rle_expand, dim3(BZ_SPANS / 256, nb), dim3(256), 0, st, (u32)level, dc, dres.as<BzResult>(), dpre.as<u8>(),
+                       dspans.as<BzSpan>(), doff.as<u64>(), d_out);
+    hipLaunchKernelGGL(bz_block_crc, dim3((u32)cdiv(cdiv(nblock_max * 2, CK_SEG), 4), nb), dim3(256), 0, st, dc, dres.as<BzResult>(), doff.as<u64>(),
+                       d_out, dcktab.as<u32>(), dcrc.as<u32>());
+    if (any_serial) {  // what the serial inverse transform wrote -- also before it failed (BZ_PL_PARTIAL)
+      HIP_TRY(ddir.reserve((size_t)nb * 8));
+      HIP_TRY(hipMemcpy(ddir.p, ser_off.data(), (size_t)nb * 8, hipMemcpyHostToDevice));
+      hipLaunchKernelGGL(bz_unbwt, dim3(cdiv(nb, 64)), dim3(64), 0, st, dtt.as<u32>(), (u32)level, nb, dc, (u8 *)nullptr, (u64)0,
+                         dres.as<BzResult>(), dcrc.as<u32>(), ddir.as<u64>(), d_out);
     }
+    HIP_TRY(hipMemcpy(res2.data(), dres.p, (size_t)nb * sizeof(BzResult), hipMemcpyDeviceToHost));
+    HIP_TRY(hipGetLastError());
+    return AHIP_OK;
+  };
+  {
+    const int32_t rc = bz_chain_run(ch, cands.data(), ncand, c_lo, c_hi, batch, (u64)in_len, verify, (u64)out_cap, &over_cap, decode_batch, place_batch, peek);
+    if (rc < 0) return rc;
   }
   HIP_TRY(hipStreamSynchronize(st));
 #ifdef AHIP_BZ_PROFILE
@@ -1662,14 +1638,23 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
             pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6]);
   }
 #endif
-  if (over_cap) { if (out_len) *out_len = total; return fail(AHIP_E_CAP, "output buffer too small"); }
+  if (over_cap) { if (out_len) *out_len = ch.total; return fail(AHIP_E_CAP, "output buffer too small"); }
+  if (ch.verdict == AHIP_E_UNSUPPORTED) return fail(AHIP_E_UNSUPPORTED, "randomised bzip2 block");
   if (sh) {  // the caller merges the shards: the end-of-stream CRC is checked there
-    sh->nblocks = folded; sh->fold = combined; sh->saw_eos = saw_eos; sh->eos_stored = eos_stored;
-    sh->stopped = stopped || verdict != AHIP_OK;
-  } else
-  if (saw_eos && verify && eos_stored != combined && verdict == AHIP_OK) verdict = AHIP_FALSE;
-  if (out_len) *out_len = crc_stop ? keep : total;
-  return verdict;
+    sh->nblocks = ch.folded; sh->fold = ch.combined; sh->saw_eos = ch.saw_eos; sh->eos_stored = ch.eos_stored;
+    sh->stopped = ch.stopped || ch.verdict != AHIP_OK;
+    sh->next = ch.next;
+    BzChain part = ch;
+    part.saw_eos = false;
+    u64 n = 0;
+    const int32_t v = bz_chain_finish(part, verify, &n);
+    if (out_len) *out_len = (size_t)n;
+    return v;
+  }
+  u64 n = 0;
+  const int32_t v = bz_chain_finish(ch, verify, &n);
+  if (out_len) *out_len = (size_t)n;
+  return v;
 }
 
 int32_t ahip_bzip2_decode_device(const void *d_in, size_t in_len, int32_t verify, void *d_out, size_t out_cap,
@@ -2194,6 +2179,7 @@ struct Worker {
   }
   void submit(std::function<void()> f) {
     std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return !has_job; });  // (one job at a time: never replace a closure the worker is still running)
     job = std::move(f); has_job = true; done = false;
     cv.notify_all();
   }
@@ -2387,6 +2373,8 @@ int32_t ahip_init_devices(uint64_t device_mask) {
 }
 
 static int32_t g_last_shards = 1;
+static std::atomic<int32_t> g_bz_reruns{0};  // shards of ahip_bzip2_decode_shards run a second time (tests)
+int32_t ahip_debug_bz_reruns(void) { return g_bz_reruns.load(); }
 int32_t ahip_debug_last_shards(void) { return g_last_shards; }
 
 // ---- device-resident shards on several GPUs + the size exchange ----
@@ -2521,22 +2509,26 @@ static bool shard_workers(uint32_t n_shards, const int32_t *devices, int cur, st
 // and the workers run side by side.  The workers are this call's until they are done (g_shards_mu); g_mu is let go
 // meanwhile -- the shards run in the workers' own thread-local contexts, nothing of the process-wide state g_mu guards
 // is touched -- and taken again afterwards.
+// `only` != ~0u: just that shard (a sharded call that runs one of its shards a second time).
 static void run_shards(uint32_t n_shards, const std::vector<int> &wk, const std::function<void(u32)> &run_shard,
-                       std::unique_lock<std::recursive_mutex> &lk) {
+                       std::unique_lock<std::recursive_mutex> &lk, u32 only = ~0u) {
   if (g_workers.empty()) {
-    for (u32 s = 0; s < n_shards; ++s) run_shard(s);
+    for (u32 s = 0; s < n_shards; ++s) if (only == ~0u || s == only) run_shard(s);
     return;
   }
   std::unique_lock<std::mutex> use(g_shards_mu);
   std::vector<Worker *> ws;
   for (auto &w : g_workers) ws.push_back(w.get());
   lk.unlock();
+  std::vector<Worker *> busy;
   for (size_t w = 0; w < ws.size(); ++w) {
     std::vector<u32> mine;
-    for (u32 s = 0; s < n_shards; ++s) if (wk[s] == (int)w) mine.push_back(s);
+    for (u32 s = 0; s < n_shards; ++s) if (wk[s] == (int)w && (only == ~0u || s == only)) mine.push_back(s);
+    if (mine.empty()) continue;
     ws[w]->submit([mine, &run_shard] { for (u32 s : mine) run_shard(s); });
+    busy.push_back(ws[w]);
   }
-  for (Worker *w : ws) w->wait();
+  for (Worker *w : busy) w->wait();
   use.unlock();
   lk.lock();
 }
@@ -2598,10 +2590,12 @@ int32_t ahip_bzip2_decode_shards(uint32_t n_shards, const int32_t *devices, cons
   std::vector<std::string> errs(n_shards);
   std::vector<size_t> got(n_shards, 0);
   std::vector<BzShard> shs(n_shards);
+  std::vector<u64> from(n_shards, ~0ull);
   std::function<void(u32)> run_shard = [&](u32 s) {
     u8 hdr[4] = {0, 0, 0, 0};
     if (in_len && hipMemcpy(hdr, d_in[s], in_len < 4 ? in_len : 4, hipMemcpyDeviceToHost) != hipSuccess) { rcs[s] = AHIP_E_DEVICE; errs[s] = "header read-back"; return; }
-    shs[s].index = s; shs[s].count = n_shards;
+    shs[s] = BzShard{};
+    shs[s].index = s; shs[s].count = n_shards; shs[s].from = from[s];
     rcs[s] = bzip2_device_impl(hdr, (const u8 *)d_in[s], in_len, verify, (u8 *)d_out[s], out_cap[s], &got[s], &shs[s]);
     if (rcs[s] < 0) errs[s] = g_err;
   };
@@ -2610,8 +2604,19 @@ int32_t ahip_bzip2_decode_shards(uint32_t n_shards, const int32_t *devices, cons
   int32_t worst = AHIP_OK;
   bool ended = false, saw_eos = false;
   u32 combined = 0, eos_stored = 0;
+  u64 stands = ~0ull;  // the candidate the chain of the shards so far expects next
   for (u32 s = 0; s < n_shards; ++s) {
     if (ended) { got[s] = 0; if (status) status[s] = AHIP_OK; out_len[s] = 0; continue; }
+    // Shard s started blindly at candidate K s / n.  The scan also lists false magics inside blocks' data, which the
+    // chain steps over: when the shards in front end somewhere else (a false magic on the boundary), what this shard
+    // decoded began at a non-block -- it is run again from where the chain really stands, like decodeStream would.
+    if (s > 0 && stands != ~0ull && rcs[s] != AHIP_E_DEVICE && shs[s].first != stands) {
+      from[s] = stands;
+      got[s] = 0;
+      run_shards(n_shards, wk, run_shard, lk, s);
+      g_bz_reruns++;
+    }
+    stands = shs[s].next;
     out_len[s] = got[s];
     if (status) status[s] = rcs[s];
     const u32 r = (u32)(shs[s].nblocks & 31);
@@ -2673,7 +2678,13 @@ int32_t ahip_gzip_decode(const uint8_t *in, size_t in_len, int32_t verify, int32
   if (rc != AHIP_OK) return rc;
   g_last_shards = 1;
   // (several devices: streams without size hints are partitioned too, after a sizing pass on this thread's device)
-  if (!raw && !g_workers.empty() && gzip_decode_sharded(g_workers, 1, in, in_len, verify, out, out_cap, out_len, &rc, true)) { g_last_shards = (int32_t)g_workers.size(); return rc; }
+  // (the device workers may be a *_shards call's right now -- that call has let go of g_mu while its shards run, see
+  //  run_shards -- and a Worker holds ONE job: whoever uses g_workers owns g_shards_mu.  Busy: this stream is decoded on
+  //  the calling thread's device, same bytes.)
+  if (!raw && !g_workers.empty()) {
+    std::unique_lock<std::mutex> use(g_shards_mu, std::try_to_lock);
+    if (use.owns_lock() && gzip_decode_sharded(g_workers, 1, in, in_len, verify, out, out_cap, out_len, &rc, true)) { g_last_shards = (int32_t)g_workers.size(); return rc; }
+  }
   // one device: a large stream of BGZF members is cut into slices whose upload / decode / download overlap
   if (!raw && g_workers.empty() && in_len >= (32u << 20) && ensure_pipe() &&
       gzip_decode_sharded(g_pipe, 4, in, in_len, verify, out, out_cap, out_len, &rc, false)) { g_last_shards = (int32_t)g_pipe.size(); return rc; }

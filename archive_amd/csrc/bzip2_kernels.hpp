@@ -44,6 +44,7 @@ namespace ahip {
 constexpr u32 BZ_MAX_SELECTORS = 18002;
 constexpr u32 BZ_ST_OK = 0, BZ_ST_FALSE = 1, BZ_ST_RANGE = 2, BZ_ST_OVERFLOW = 16, BZ_ST_UNSUPPORTED = 17, BZ_ST_SERIAL = 18;
 constexpr u32 BZ_ST_HUFF_SERIAL = 19;  // between kernels only: the position-parallel Huffman pass hands the block to the serial one
+constexpr u32 BZ_ST_NEG = 20;          // between kernels only: _getMtfVal returned -1 inside the symbol loop -> bz_block_exact
 constexpr u32 BZ_G = 16;       // splitter stride of the list ranking (see bz_walk: short sublists keep a block's walk inside one L2)
 constexpr u32 BZ_SPANS = 1024;  // run-length spans per block
 #ifndef AHIP_BZ_HANDOUT
@@ -295,7 +296,7 @@ AHIP_DEVINL u64 bz_selectors_wave(const u8 *__restrict__ in, u64 n, u64 bit0, u3
 
 // one wave per candidate block (a device function: tests/emu/bzip2_emu.cc runs it on the CPU wave emulation)
 // syms: room for BZ_SYM_CAP symbols; list0: the block's initial MTF list (256 bytes, seqToUnseq applied)
-// exp != nullptr: stop in front of the symbol stream and leave the tables there (BzTables)
+// exp != nullptr: leave the tables there (BzTables); syms == nullptr: stop in front of the symbol stream
 AHIP_DEVINL void bz_decode_block_wave(BzLds &L, const u8 *__restrict__ in, u64 n, const BzCand cand,
                                       u16 *__restrict__ syms, u8 *__restrict__ list0, u8 *__restrict__ sel, BzResult &out,
                                       const u32 lane, BzTables *__restrict__ exp = nullptr) {
@@ -482,7 +483,7 @@ AHIP_DEVINL void bz_decode_block_wave(BzLds &L, const u8 *__restrict__ in, u64 n
       }
       if (lane < 6) exp->min_len[lane] = L.min_len[lane];
       if (lane == 0) { exp->ngroups = ngroups; exp->nsel = nsel; exp->eob = num_in_use + 1; exp->pad = 0; exp->sym_bit = b.bit; }
-      break;
+      if (!syms) break;  // (bz_header: tables only; the serial wave leaves them for bz_block_exact and goes on)
     }
     // ---- the symbol loop ----
     // Only the Huffman side is serial here: a code's position is the end of the one before.  The 256 bit positions
@@ -664,7 +665,7 @@ AHIP_DEVINL void bz_decode_block_wave(BzLds &L, const u8 *__restrict__ in, u64 n
     b.fault = stop == 3;
     const bool bad = stop == 2;
     if (b.fault) { status = BZ_ST_RANGE; break; }
-    if (bad) { status = BZ_ST_FALSE; break; }
+    if (bad) { status = BZ_ST_NEG; break; }  // a failing _getMtfVal: the reference does NOT stop there (bz_block_exact_lane)
   } while (0);
 
   // what the symbols mean, and everything behind that, are separate launches (bz_mtf_scan sets nblock and the final status)
@@ -928,7 +929,7 @@ AHIP_DEVINL void bz_decode_group(const TB &T, u32 eob, const u8 *__restrict__ in
       }
       if (fault) { status = BZ_ST_RANGE; break; }
       const i32 idx = ok ? (i32)(w32 >> (32 - zn)) - T.base[t][zn] : -1;
-      if (idx < 0 || idx >= 258) { status = BZ_ST_FALSE; break; }
+      if (idx < 0 || idx >= 258) { status = BZ_ST_NEG; break; }  // a failing _getMtfVal: bz_block_exact_lane goes on like the reference
       if ((u32)T.perm[t][idx] == eob) { status = BZ_ST_OK; pos += (u32)zn; break; }
       break;  // (cannot happen: a code after all)
     }
@@ -1242,7 +1243,7 @@ struct BzScanLds { u8 cur[256], nxt[256]; };
 AHIP_DEVINL void bz_mtf_scan_wave(BzScanLds &S, BzResult &R, u32 nblock_max, const BzChunk *__restrict__ chunks,
                                   const u8 *__restrict__ perms, const u8 *__restrict__ list0, u8 *__restrict__ lists,
                                   u32 *__restrict__ offs, const u32 lane) {
-  if (R.nsyms == 0 && R.status != BZ_ST_OK) return;  // nothing was decoded (header trouble, end-of-stream marker)
+  if (R.nsyms == 0 && R.status != BZ_ST_OK) return;  // nothing was decoded (header trouble, end-of-stream marker, BZ_ST_NEG at once)
   for (u32 i = lane; i < 256; i += 64) S.cur[i] = list0[i];
   wave_sync();
   u64 running = 0;
@@ -1258,6 +1259,7 @@ AHIP_DEVINL void bz_mtf_scan_wave(BzScanLds &S, BzResult &R, u32 nblock_max, con
     wave_sync();
   }
   // every error of the list / run side comes before the one the Huffman side stopped at, and reads as `false`
+  // (BZ_ST_NEG stays: the reference goes on behind a failing _getMtfVal, and so does bz_block_exact)
   u32 status = R.status;
   if (bad || running > nblock_max) status = BZ_ST_FALSE;
   if (status == BZ_ST_OK && R.pad_orig_ptr >= running) status = BZ_ST_FALSE;
@@ -1265,19 +1267,143 @@ AHIP_DEVINL void bz_mtf_scan_wave(BzScanLds &S, BzResult &R, u32 nblock_max, con
   R.nblock = status == BZ_ST_OK ? (u32)running : 0u;
 }
 
+// ---- blocks whose _getMtfVal fails: the reference's own loop, symbol by symbol ----
+// _getMtfVal returns -1 when the selectors run out, when a code is longer than 20 bits or when its index lies outside the
+// alphabet (bzip2_decoder.dart:735, :753, :766) -- and only its FIRST result is checked (:271).  Inside the loop (:304,
+// :385) the reference goes on with -1 as a symbol: nn = -2 takes the short-list branch, reads _mtfa[_mtfbase[0] - 2]
+// (the array is fresh, zero-filled, for every block; below the list it holds zeros, or what the list left there before
+// its last rebuild), shifts nothing, makes that byte the front of the list, stores it, and decodes on from wherever the
+// bit reader stands -- until an end-of-block symbol, nblockMAX (`false`), the end of the input or index -1 (RangeError).
+// What such a block makes depends on the physical layout of the 4096-byte array, so this is the reference loop itself,
+// one lane, for exactly those (damaged) blocks: BZ_ST_NEG -> status, nblock, end bit and the block's bytes in b8.
+// mtfa: 4096 bytes of scratch.  sel / list0 (= seqToUnseq, zeros behind the symbols in use) as bz_header left them.
+AHIP_DEVINL void bz_block_exact_lane(const BzTables &T, const u8 *__restrict__ sel, const u8 *__restrict__ list0, const u8 *__restrict__ in,
+                                     u64 n, u32 nblock_max, u8 *__restrict__ mtfa, u8 *__restrict__ b8, BzResult &R) {
+  BzBits b{in, n, 0, false, 0, 0, 0};
+  bz_seek(b, T.sym_bit);
+  const i32 nsel = (i32)T.nsel, eob = (i32)T.eob;
+  i32 group_no = -1, group_pos = 0, gsel = 0, gmin = 0;
+  auto get = [&]() -> i32 {  // _getMtfVal, :732-772
+    if (group_pos == 0) {
+      group_no++;
+      if (group_no >= nsel) return -1;
+      group_pos = 50;
+      gsel = sel[group_no];
+      gmin = T.min_len[gsel];
+    }
+    group_pos--;
+    i32 zn = gmin;
+    i32 zvec = (i32)bz_bits(b, (u32)zn);
+    for (;;) {
+      if (zn > 20) return -1;
+      if (zvec <= T.limit[gsel][zn]) break;
+      zn++;
+      zvec = (zvec << 1) | (i32)bz_bits(b, 1);
+    }
+    const i32 idx = zvec - T.base[gsel][zn];
+    if (idx < 0 || idx >= 258) return -1;
+    return (i32)T.perm[gsel][idx];
+  };
+  i32 mtfbase[16];
+  for (u32 i = 0; i < 4096; ++i) mtfa[i] = 0;
+  {
+    i32 kk = 4095;
+    for (i32 ii = 15; ii >= 0; ii--) {
+      for (i32 jj = 15; jj >= 0; jj--) { mtfa[kk] = (u8)(ii * 16 + jj); kk--; }
+      mtfbase[ii] = kk + 1;
+    }
+  }
+  u32 nblock = 0, status = BZ_ST_OK;
+  i32 next_sym = get();
+  if (b.fault) status = BZ_ST_RANGE;
+  else if (next_sym < 0) status = BZ_ST_FALSE;
+  while (status == BZ_ST_OK) {
+    if (next_sym == eob) break;
+    if (next_sym == 0 || next_sym == 1) {
+      i32 es = -1, N = 1;
+      do {
+        if (N >= 2 * 1024 * 1024) { status = BZ_ST_FALSE; break; }
+        es += next_sym == 0 ? N : 2 * N;
+        N *= 2;
+        next_sym = get();
+        if (b.fault) { status = BZ_ST_RANGE; break; }
+      } while (next_sym == 0 || next_sym == 1);
+      if (status != BZ_ST_OK) break;
+      es++;
+      const u8 uc = list0[mtfa[mtfbase[0]]];
+      if ((u64)nblock + (u64)es > nblock_max) { status = BZ_ST_FALSE; break; }
+      for (i32 k = 0; k < es; ++k) b8[nblock++] = uc;
+      continue;
+    }
+    if (nblock >= nblock_max) { status = BZ_ST_FALSE; break; }
+    i32 nn = next_sym - 1;  // (-2 for the symbol -1)
+    u8 uc;
+    if (nn < 16) {
+      const i32 pp = mtfbase[0];
+      if (pp + nn < 0) { status = BZ_ST_RANGE; break; }  // Uint8List[-1]
+      uc = mtfa[pp + nn];
+      while (nn > 0) { mtfa[pp + nn] = mtfa[pp + nn - 1]; nn--; }
+      mtfa[pp] = uc;
+    } else {
+      i32 lno = nn / 16;
+      const i32 off = nn % 16;
+      i32 pp = mtfbase[lno] + off;
+      uc = mtfa[pp];
+      while (pp > mtfbase[lno]) { mtfa[pp] = mtfa[pp - 1]; pp--; }
+      mtfbase[lno]++;
+      while (lno > 0) {
+        mtfbase[lno]--;
+        mtfa[mtfbase[lno]] = mtfa[mtfbase[lno - 1] + 15];
+        lno--;
+      }
+      mtfbase[0]--;
+      mtfa[mtfbase[0]] = uc;
+      if (mtfbase[0] == 0) {
+        i32 kk = 4095;
+        for (i32 ii = 15; ii >= 0; ii--) {
+          for (i32 jj = 15; jj >= 0; jj--) { mtfa[kk] = mtfa[mtfbase[ii] + jj]; kk--; }
+          mtfbase[ii] = kk + 1;
+        }
+      }
+    }
+    b8[nblock++] = list0[uc];
+    next_sym = get();
+    if (b.fault) { status = BZ_ST_RANGE; break; }
+  }
+  if (status == BZ_ST_OK && R.pad_orig_ptr >= nblock) status = BZ_ST_FALSE;  // (origPtr, :392; the count checks :399-432 cannot fail)
+  R.status = status;
+  R.nblock = status == BZ_ST_OK ? nblock : 0u;
+  R.end_bit = b.bit;
+}
+
 #ifndef AHIP_HOST_EMU
 // only_serial: just the blocks the position-parallel pass handed back (BZ_ST_HUFF_SERIAL)
 __global__ __launch_bounds__(64) void bz_decode_block(const u8 *__restrict__ in, u64 n, const BzCand *__restrict__ cands,
                                                       u32 ncand, u16 *__restrict__ syms_all, u8 *__restrict__ list0_all,
-                                                      u8 *__restrict__ sel_all, BzResult *__restrict__ results, u32 only_serial) {
+                                                      u8 *__restrict__ sel_all, BzResult *__restrict__ results, u32 only_serial,
+                                                      BzTables *__restrict__ tables) {
   __shared__ BzLds L;
   const u32 blk = blockIdx.x, lane = threadIdx.x;
   if (blk >= ncand) return;
   if (only_serial && results[blk].status != BZ_ST_HUFF_SERIAL) return;
   BzResult R;
   bz_decode_block_wave(L, in, n, cands[blk], syms_all + (u64)blk * BZ_SYM_CAP, list0_all + (u64)blk * 256,
-                       sel_all + (u64)blk * BZ_MAX_SELECTORS, R, lane);
+                       sel_all + (u64)blk * BZ_MAX_SELECTORS, R, lane, tables + blk);  // (the tables too: bz_block_exact may need them)
   if (lane == 0) results[blk] = R;
+}
+// one workgroup per candidate; only the blocks marked BZ_ST_NEG do anything (damaged input), one lane of them
+__global__ __launch_bounds__(64) void bz_block_exact(const u8 *__restrict__ in, u64 n, u32 ncand, const BzTables *__restrict__ tables,
+                                                     const u8 *__restrict__ list0_all, const u8 *__restrict__ sel_all,
+                                                     BzResult *__restrict__ results, u8 *__restrict__ b8_all, u32 block_size100k) {
+  __shared__ u8 mtfa[4096];
+  const u32 blk = blockIdx.x;
+  if (blk >= ncand || results[blk].status != BZ_ST_NEG) return;
+  if (threadIdx.x != 0) return;
+  const u32 nblock_max = 100000u * block_size100k;
+  BzResult R = results[blk];
+  bz_block_exact_lane(tables[blk], sel_all + (u64)blk * BZ_MAX_SELECTORS, list0_all + (u64)blk * 256, in, n, nblock_max, mtfa,
+                      b8_all + (u64)blk * nblock_max, R);
+  results[blk] = R;
 }
 // bz_header: the block headers and tables for the position-parallel pass (one wave per candidate)
 __global__ __launch_bounds__(64) void bz_header(const u8 *__restrict__ in, u64 n, const BzCand *__restrict__ cands, u32 ncand,
@@ -1321,7 +1447,7 @@ __global__ __launch_bounds__(512) void bz_group_starts(const u8 *__restrict__ in
                  found, marked, threadIdx.x, blockDim.x);
   if (threadIdx.x == 0) {
     gcount[blk] = marked == 1 ? found : 0u;
-    if (marked != 1) { results[blk].status = marked == 0 ? BZ_ST_FALSE : BZ_ST_HUFF_SERIAL; results[blk].nsyms = 0; }
+    if (marked != 1) { results[blk].status = marked == 0 ? BZ_ST_NEG : BZ_ST_HUFF_SERIAL; results[blk].nsyms = 0; }  // (out of selectors: _getMtfVal's first -1)
   }
 }
 // grid (ceil(BZ_MAX_SELECTORS / 256), blocks): one thread per group
@@ -1468,24 +1594,15 @@ __global__ __launch_bounds__(1024) void bz_tinv_scatter(u32 *__restrict__ tt_all
   }
 }
 
+#endif  // AHIP_HOST_EMU (the serial inverse transform below also runs on the host: tests/emu/bzip2_chain_emu.cc)
+
 // ---- phase 3 (own launch): inverse BWT + un-RLE + CRC, one lane per block ----
-// direct_off == nullptr: every decoded block goes to its slab (a block that outgrows the slab keeps
-// counting and reports BZ_ST_OVERFLOW with its true size).  direct_off != nullptr: second pass for
-// exactly those blocks, written straight to direct_out + direct_off[blk].
-__global__ __launch_bounds__(64) void bz_unbwt(const u32 *__restrict__ tt_all, u32 block_size100k, u32 ncand,
-                                               const BzCand *__restrict__ cands, u8 *__restrict__ slabs, u64 slab_cap,
-                                               BzResult *__restrict__ results, const u32 *__restrict__ crc_table,
-                                               const u64 *__restrict__ direct_off, u8 *__restrict__ direct_out) {
-  const u32 blk = blockIdx.x * 64 + threadIdx.x;
-  if (blk >= ncand) return;
-  if (cands[blk].kind != 0) return;
-  if (direct_off) { if (direct_off[blk] == ~0ull) return; }
-  else if (results[blk].status != BZ_ST_SERIAL) return;
-  const u32 nblock_max = 100000u * block_size100k;
-  const u32 *tt = tt_all + (u64)blk * nblock_max;
-  u8 *out = direct_off ? direct_out + direct_off[blk] : slabs + (u64)blk * slab_cap;
-  if (direct_off) slab_cap = ~0ull;
-  const u32 nblock = results[blk].nblock, orig_ptr = results[blk].pad_orig_ptr;
+// bzip2_decoder.dart:610-727 restated 1:1 (the reference writes its bytes as it goes and may fail AFTER writing:
+// `cNBlockUsed > sSaveNBlockPP` behind a run whose count byte lay beyond the block's data, :612-631 -- those bytes stay
+// in the output, the verdict is `false`; the host chain places them: bzip2_chain.hpp).  out_cap: bytes beyond it are
+// counted, not written (BZ_ST_OVERFLOW).
+AHIP_DEVINL void bz_unbwt_block(const u32 *__restrict__ tt, u32 nblock_max, u32 nblock, u32 orig_ptr, u8 *__restrict__ out, u64 out_cap,
+                                const u32 *__restrict__ crc_table, u32 &status_out, u64 &olen_out, u32 &crc_out) {
   u32 crc = 0xffffffffu;
   u64 olen = 0;
   u32 status = BZ_ST_OK;
@@ -1494,7 +1611,7 @@ __global__ __launch_bounds__(64) void bz_unbwt(const u32 *__restrict__ tt_all, u
   const u32 save_pp = nblock + 1;
 #define BZ_EMIT(ch)                                                     \
   do {                                                                  \
-    if (olen < slab_cap) out[olen] = (u8)(ch); else status = BZ_ST_OVERFLOW; \
+    if (olen < out_cap) out[olen] = (u8)(ch); else status = BZ_ST_OVERFLOW; \
     olen++;                                                             \
     crc = (crc << 8) ^ crc_table[((crc >> 24) & 0xff) ^ ((ch) & 0xff)]; \
   } while (0)
@@ -1535,12 +1652,37 @@ __global__ __launch_bounds__(64) void bz_unbwt(const u32 *__restrict__ tt_all, u
     }
   }
 fin:
+#undef BZ_EMIT
+#undef BZ_STEP
+  status_out = status; olen_out = olen; crc_out = crc ^ 0xffffffffu;
+}
+
+#ifndef AHIP_HOST_EMU
+// direct_off == nullptr: the blocks the parallel path handed back (BZ_ST_SERIAL) are walked COUNTING only (slab_cap 0:
+// a block with bytes reports BZ_ST_OVERFLOW and its true size; one that fails behind its bytes BZ_ST_FALSE and the bytes
+// it had written).  direct_off != nullptr: second pass for exactly the blocks the chain placed, written straight to
+// direct_out + direct_off[blk] (what a failing block wrote before it failed included).
+__global__ __launch_bounds__(64) void bz_unbwt(const u32 *__restrict__ tt_all, u32 block_size100k, u32 ncand,
+                                               const BzCand *__restrict__ cands, u8 *__restrict__ slabs, u64 slab_cap,
+                                               BzResult *__restrict__ results, const u32 *__restrict__ crc_table,
+                                               const u64 *__restrict__ direct_off, u8 *__restrict__ direct_out) {
+  const u32 blk = blockIdx.x * 64 + threadIdx.x;
+  if (blk >= ncand) return;
+  if (cands[blk].kind != 0) return;
+  if (direct_off) { if (direct_off[blk] == ~0ull) return; }
+  else if (results[blk].status != BZ_ST_SERIAL) return;
+  const u32 nblock_max = 100000u * block_size100k;
+  const u32 *tt = tt_all + (u64)blk * nblock_max;
+  u8 *out = direct_off ? direct_out + direct_off[blk] : slabs + (u64)blk * slab_cap;
+  if (direct_off) slab_cap = ~0ull;
+  u32 status, crc;
+  u64 olen;
+  bz_unbwt_block(tt, nblock_max, results[blk].nblock, results[blk].pad_orig_ptr, out, slab_cap, crc_table, status, olen, crc);
   if (direct_off) return;  // sizes and CRC were established by the first pass
   results[blk].status = status;
   results[blk].out_len = olen;
-  results[blk].crc = crc ^ 0xffffffffu;
+  results[blk].crc = crc;
 }
-
 // ---- phase 3 (parallel): list-ranked inverse BWT ----
 // Splitter s < S sits at index s * BZ_G; splitter S is the chain head p0 = tt[origPtr] >> 8.
 struct BzWalk { u32 next, len; };

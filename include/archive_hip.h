@@ -59,7 +59,8 @@ void ahip_shutdown(void);
 const char *ahip_last_error(void);
 /* ABI version of this header (major << 16 | minor). */
 uint32_t ahip_abi_version(void);  /* 2.1: + ahip_gzip_decode_shards, ahip_gzip_encode_device, ahip_zlib_encode_device;
-                                    * 2.2: + ahip_deflate_shards, ahip_bzip2_decode_shards, ahip_debug_last_chunks */
+                                    * 2.2: + ahip_deflate_shards, ahip_bzip2_decode_shards, ahip_debug_last_chunks;
+                                    * 2.3: + ahip_debug_bz_reruns */
 
 /* ---- Inflate: host-pointer entry points (what dart:ffi binds) ---- */
 
@@ -136,6 +137,9 @@ int32_t ahip_deflate_shards(uint32_t n_shards, const int32_t *devices, const voi
 int32_t ahip_bzip2_decode_shards(uint32_t n_shards, const int32_t *devices, const void *const *d_in, size_t in_len,
                                  int32_t verify, void *const *d_out, const size_t *out_cap, size_t *out_len,
                                  uint64_t *offsets, int32_t *status);
+/* Diagnostics: shards ahip_bzip2_decode_shards has decoded a second time, process-wide -- the chain of the shards in front
+ * ended somewhere else than at the shard's first candidate (a false block magic inside a block's data on the boundary). */
+int32_t ahip_debug_bz_reruns(void);
 /* Diagnostics: chunks the calling thread's last long stream (one DEFLATE stream of >= 2 MiB: ahip_inflate_raw, a zlib
  * stream, a long gzip member) was decoded in by the many-waves path; 0 = it went to the one-wave path. */
 int32_t ahip_debug_last_chunks(void);

@@ -141,6 +141,12 @@ static int get_mtf_val(bz_t *s) {
 /* -1 = data error (reference returns -1); otherwise the block CRC (not finalised) via *crc_out */
 static int read_compressed(bz_t *s, uint32_t *crc_out) {
   bitreader_t *br = &s->br;
+  /* The reference allocates these afresh -- zero-filled -- for EVERY block (_selectorMtf/_selector :155-156, _len :193-196,
+   * _limit/_base/_perm :221-229, _seqToUnseq :817; only _tt lives as long as the stream, :42): a damaged block whose code
+   * indexes _perm beyond the symbols its tables hold reads 0 there, never what the block before it left behind. */
+  memset(s->selector, 0, sizeof s->selector); memset(s->selector_mtf, 0, sizeof s->selector_mtf);
+  memset(s->len, 0, sizeof s->len); memset(s->limit, 0, sizeof s->limit); memset(s->base, 0, sizeof s->base);
+  memset(s->perm, 0, sizeof s->perm); memset(s->min_lens, 0, sizeof s->min_lens); memset(s->seq_to_unseq, 0, sizeof s->seq_to_unseq);
   int randomized = (int)br_bits(br, 1);
   int32_t orig_ptr = (int32_t)br_bits(br, 8);
   orig_ptr = (orig_ptr << 8) | (int32_t)br_bits(br, 8);
@@ -204,6 +210,7 @@ static int read_compressed(bz_t *s, uint32_t *crc_out) {
   int eob = s->num_in_use + 1;
   int nblock_max = 100000 * s->block_size100k;
   memset(s->unzftab, 0, sizeof s->unzftab);
+  memset(s->mtfa, 0, sizeof s->mtfa); /* _mtfa = Uint8List(mtfaSize), :255 */
   {
     int kk = MTFA_SIZE - 1;
     for (int ii = 256 / MTFL_SIZE - 1; ii >= 0; ii--) {
@@ -240,9 +247,16 @@ static int read_compressed(bz_t *s, uint32_t *crc_out) {
     }
     if (nblock >= nblock_max) return -1;
     {
+      /* next_sym may be -1 here: _getMtfVal's failures (out of selectors, a code longer than 20 bits, an index outside
+       * the alphabet: :735, :753, :766) are NOT checked by the loop (:304, :385 -- only the very first call is, :271).
+       * The reference goes on with -1 as a symbol: nn = -2 takes the short-list branch, reads _mtfa[_mtfbase[0] - 2]
+       * (whatever that cell of the freshly allocated array holds: zero unless this block's list has been there), shifts
+       * nothing, makes that byte the front of the list, stores it, and decodes on from wherever the bit reader stands --
+       * until an end-of-block symbol, nblockMAX (`false`), the end of the input or a negative index (RangeError). */
       int nn = next_sym - 1;
       if (nn < MTFL_SIZE) {
         int pp = s->mtfbase[0];
+        if (pp + nn < 0) { br->fault = 1; return -1; } /* Uint8List[-1]: RangeError */
         uc = s->mtfa[pp + nn];
         while (nn > 0) { s->mtfa[pp + nn] = s->mtfa[pp + nn - 1]; nn--; }
         s->mtfa[pp] = (uint8_t)uc;
@@ -270,8 +284,7 @@ static int read_compressed(bz_t *s, uint32_t *crc_out) {
     }
     s->unzftab[s->seq_to_unseq[uc]]++;
     s->tt[nblock++] = s->seq_to_unseq[uc];
-    next_sym = get_mtf_val(s);
-    if (next_sym < 0) return -1; /* the reference would loop on -1 as a symbol; -1 - 1 indexes mtfa[-2]: RangeError */
+    next_sym = get_mtf_val(s); /* (not checked: see above) */
   }
   if (orig_ptr < 0 || orig_ptr >= nblock) return -1;
   for (int i = 0; i <= 255; i++) if (s->unzftab[i] < 0 || s->unzftab[i] > nblock) return -1;
@@ -345,6 +358,47 @@ static int read_block_type(bz_t *s) {
     if (!eos && !compressed) return -1;
   }
   return compressed ? 0 : 2;
+}
+
+/* ONE candidate block of a stream on its own -- what the chain test (tests/emu/bzip2_chain_emu.cc) feeds the product's
+ * host chain with instead of the GPU's per-block verdicts: the bit reader is put at `bit` (any bit position), then
+ * _readBlockType, the stored CRC and, for a compressed block, _readCompressed run exactly as decodeStream runs them
+ * (bzip2_decoder.dart:47-58, :70-75).  kind: 0 compressed, 2 end of stream, -1 no magic.  Returns ORC_OK / ORC_FALSE
+ * (bytes written before the failure are in out[0, *out_len)) / ORC_RANGE / ORC_CAP; 17 = the randomised flag is set (the
+ * product reports that as unsupported before anything else of the block). */
+int orc_bzip2_block(const uint8_t *in, size_t n, uint64_t bit, int level, uint8_t *out, size_t cap, uint64_t *end_bit,
+                    size_t *out_len, uint32_t *crc_out, uint32_t *stored_out, int *kind_out) {
+  if (!g_crc_ready) crc_init();
+  bz_t *s = (bz_t *)calloc(1, sizeof(bz_t));
+  if (!s) return ORC_CAP;
+  int st = ORC_OK;
+  s->br.p = in; s->br.n = n; s->out = out; s->out_cap = cap;
+  s->br.pos = (size_t)(bit >> 3);
+  if (bit & 7) { s->br.buf = br_byte_raw(&s->br); s->br.bitpos = 8 - (int)(bit & 7); }
+  s->block_size100k = level;
+  s->tt = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(level * 100000 + 1));
+  uint32_t crc = 0, stored = 0;
+  int type = read_block_type(s);
+  *kind_out = type;
+  if (s->br.fault) { st = ORC_RANGE; goto done; }
+  if (type < 0) { st = ORC_FALSE; goto done; }
+  for (int k = 0; k < 4; ++k) stored = (stored << 8) | br_bits(&s->br, 8);
+  if (s->br.fault) { st = ORC_RANGE; goto done; }
+  if (type == 0) {
+    bitreader_t look = s->br;
+    if (br_bits(&look, 1) == 1 && !look.fault) { st = 17; goto done; }
+    int r = read_compressed(s, &crc);
+    if (s->br.fault) st = ORC_RANGE;
+    else if (s->cap_fault) st = ORC_CAP;
+    else if (r < 0) st = ORC_FALSE;
+    crc ^= 0xffffffffu;
+  }
+done:
+  *end_bit = (uint64_t)s->br.pos * 8 - (uint64_t)s->br.bitpos;
+  *out_len = s->out_len; *crc_out = crc; *stored_out = stored;
+  free(s->tt);
+  free(s);
+  return st;
 }
 
 /* BZip2Decoder().decodeBytes(data, verify) */

@@ -39,6 +39,8 @@ def lib():
         L.orc_adler32.argtypes = [u8p, ctypes.c_size_t, ctypes.c_uint32]
         L.orc_adler32.restype = ctypes.c_uint32
         L.orc_bzip2_decode.argtypes = [u8p, ctypes.c_size_t, ctypes.c_int, u8p, ctypes.c_size_t, szp]
+        L.orc_bzip2_block.argtypes = [u8p, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_int, u8p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64), szp,
+                                      ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_int)]
         L.orc_deflate_raw.argtypes = [u8p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, u8p, ctypes.c_size_t, szp,
                                       ctypes.POINTER(ctypes.c_uint32)]
         L.orc_gzip_encode.argtypes = [u8p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint32, u8p, ctypes.c_size_t, szp]
@@ -141,3 +143,28 @@ def bzip2_decode(data, verify=False, cap=None):
         return lib().orc_bzip2_decode(ctypes.addressof(buf), n, int(verify), ctypes.addressof(out), cap, ctypes.byref(olen)), None
     st, o, _ = _run(fn, data, (), cap if cap is not None else max(1 << 16, 64 * len(bytes(data))))
     return st, o
+
+
+def bzip2_block(data, bit, level, cap=None):
+    """ONE candidate block of a bzip2 stream, read from bit position `bit` the way decodeStream reads it (block type,
+    stored CRC, _readCompressed) -> dict(status, kind, end_bit, out, crc, stored).  status 17 = randomised flag set."""
+    buf, n = _inbuf(data)
+    cap = cap if cap is not None else level * 100000 * 52 + 1024
+    out = ctypes.create_string_buffer(cap)
+    end, olen = ctypes.c_uint64(0), ctypes.c_size_t(0)
+    crc, stored, kind = ctypes.c_uint32(0), ctypes.c_uint32(0), ctypes.c_int(0)
+    st = lib().orc_bzip2_block(ctypes.addressof(buf), n, bit, level, ctypes.addressof(out), cap, ctypes.byref(end), ctypes.byref(olen),
+                               ctypes.byref(crc), ctypes.byref(stored), ctypes.byref(kind))
+    return dict(status=st, kind=kind.value, end_bit=end.value, out=out.raw[:olen.value], crc=crc.value, stored=stored.value)
+
+
+def bzip2_block_bits(data):
+    """Bit positions of the blocks of a VALID stream, the end-of-stream marker's last."""
+    level = data[3] - 0x30
+    bits = [32]
+    while True:
+        r = bzip2_block(data, bits[-1], level)
+        assert r["status"] == 0, r["status"]
+        if r["kind"] == 2:
+            return bits
+        bits.append(r["end_bit"])

@@ -85,7 +85,7 @@ int main(int argc, char **argv) {
       uint32_t found = 0, marked = 0;
       bz_walk_groups(WL, &T, sel2.data(), lim, j50.data(), bit0, tstride, gstart.data(), found, marked, 0, 1);
       BzGroupEnd end{};
-      if (marked == 0) { end.status = BZ_ST_FALSE; end.nsyms = R.nsyms; end.end_bit = R.end_bit; }  // out of selectors: `false`, whatever was decoded
+      if (marked == 0) { end.status = BZ_ST_NEG; end.nsyms = R.nsyms; end.end_bit = R.end_bit; }  // out of selectors: _getMtfVal's -1 (bz_block_exact goes on from there like the reference)
       else if (marked == 2 && damaged_ok) { printf("bzip2 emu agree: block %zu handed to the serial wave by the walk (it ran into the end of the block's bits)\n", blocks); return 0; }
       else if (marked != 1 || found == 0) { printf("block %zu: walk found %u groups, marked %u\n", blocks, found, marked); return 1; }
       else for (uint32_t g = 0; g < found; ++g) bz_decode_group(T, T.eob, in, n, T.sym_bit, g, gstart[g], sel2[g], g + 1 == found, syms2.data(), end);

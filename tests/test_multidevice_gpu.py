@@ -331,6 +331,128 @@ def test_sharded_deflate_and_bzip2(native_built, monkeypatch):
                 assert got == bytes(ref_out[:ref_n.value].cpu().numpy()), name
             if name == "clean":
                 assert got == text and min(out_len) > 0
+        # ---- a false block magic on a shard boundary ----
+        # The magic scan lists EVERY bit position that holds the 48 bits, also inside a block's data, and shard s starts
+        # blindly at candidate K s / n.  A magic planted in the second block's data (at a spot where that block still decodes
+        # and still ends where it did: found with the oracle's block function) becomes candidate 2 of 7 -- the first one of
+        # shard 1 of 3.  decodeStream never looks there (the chain steps from block to block); neither must the shards: the
+        # merge sees that shard 0's chain ends at candidate 3 and runs shard 1 again from there.
+        from oracle import pyoracle as orc
+        text2 = streams.text(450000, 8) + bytes(range(256)) * 100
+        clean = bz2.compress(text2, 1)
+        starts = orc.bzip2_block_bits(clean)
+        assert len(starts) == 6                               # five blocks + the end-of-stream marker
+        big, nb = int.from_bytes(clean, "big"), len(clean) * 8
+        planted = None
+        for bit in range(starts[1] + 2000, starts[2] - 100, 7):
+            sh = nb - bit - 48
+            cand = ((big & ~(((1 << 48) - 1) << sh)) | (0x314159265359 << sh)).to_bytes(len(clean), "big")
+            r = orc.bzip2_block(cand, starts[1], 1)
+            if r["status"] == 0 and r["end_bit"] == starts[2]:
+                planted = cand
+                break
+        assert planted is not None
+        for verify in (0, 1):
+            cap = len(text2) + 200000
+            one = torch.from_numpy(np.frombuffer(planted, dtype=np.uint8).copy()).cuda()
+            ref_out = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+            ref_n = ctypes.c_size_t()
+            ref_rc = L.ahip_bzip2_decode_device(one.data_ptr(), len(planted), verify, ref_out.data_ptr(), cap, ctypes.byref(ref_n), None)
+            st, want = orc.bzip2_decode(planted, verify=bool(verify), cap=cap)
+            assert ref_rc == st and bytes(ref_out[:ref_n.value].cpu().numpy()) == want
+            n = 3
+            copies = [one.clone() for _ in range(n)]
+            d_outs = [torch.zeros(cap, dtype=torch.uint8, device="cuda") for _ in range(n)]
+            arr_dev = (ctypes.c_int32 * n)(*([0] * n))
+            arr_in = (ctypes.c_void_p * n)(*[t.data_ptr() for t in copies])
+            arr_out = (ctypes.c_void_p * n)(*[t.data_ptr() for t in d_outs])
+            arr_cap = (ctypes.c_size_t * n)(*([cap] * n))
+            out_len = (ctypes.c_size_t * n)()
+            offsets = (ctypes.c_uint64 * (n + 1))()
+            status = (ctypes.c_int32 * n)()
+            before = L.ahip_debug_bz_reruns()
+            rc = L.ahip_bzip2_decode_shards(n, arr_dev, arr_in, len(planted), verify, arr_out, arr_cap, out_len, offsets, status)
+            assert rc == st, (verify, rc, st, N.last_error())
+            assert L.ahip_debug_bz_reruns() == before + 1     # shard 1 began at the planted magic and was run again
+            got = b"".join(bytes(d_outs[s][:out_len[s]].cpu().numpy()) for s in range(n))
+            assert got == want and offsets[n] == len(got), verify
+    finally:
+        monkeypatch.delenv("AHIP_FAKE_DEVICES")
+        assert L.ahip_init_devices(1) == 0 and L.ahip_device_count() == 1
+
+
+def test_shards_call_and_host_decode_from_two_threads(native_built, monkeypatch):
+    """A *_shards call lets go of the library's lock while its shards run on the device workers (other threads may use the
+    library meanwhile) -- and ahip_gzip_decode, which fans a BGZF stream out over the SAME workers, must not hand them a
+    second job then: it takes the one-context path while they are busy.  Two threads, many rounds, every result checked."""
+    import ctypes
+    import threading
+    import numpy as np
+    import torch
+    import archive_amd
+    from archive_amd import _native as N
+    from tools import corpus
+    L = N.lib()
+    assert L.ahip_init(0) == 0
+    monkeypatch.setenv("AHIP_FAKE_DEVICES", "3")
+    assert L.ahip_init_devices(1) == 0, N.last_error()
+    try:
+        comp, plain = corpus.make_gzip(n_members=192, want_plain=True)      # 12 MiB out: large enough to be fanned out
+        comp, plain = bytes(comp), bytes(plain)
+        # the shards call's input: the same members cut in three
+        sizes = []
+        pos = 0
+        while pos < len(comp):
+            bs = comp[pos + 16] | (comp[pos + 17] << 8)
+            sizes.append(bs + 1)
+            pos += bs + 1
+        from archive_amd.sharding import partition_members
+        parts = partition_members(sizes, 3)
+        offs = [0]
+        for v in sizes:
+            offs.append(offs[-1] + v)
+        n = 3
+        src = np.frombuffer(comp, dtype=np.uint8)
+        d_ins = [torch.from_numpy(src[offs[lo]:offs[hi]].copy()).cuda() for lo, hi in parts]
+        lens = [offs[hi] - offs[lo] for lo, hi in parts]
+        cap = len(plain)
+        errors_seen = []
+
+        def shards_loop():
+            try:
+                for _ in range(12):
+                    d_outs = [torch.zeros(cap, dtype=torch.uint8, device="cuda") for _ in range(n)]
+                    arr_dev = (ctypes.c_int32 * n)(*([0] * n))
+                    arr_in = (ctypes.c_void_p * n)(*[t.data_ptr() for t in d_ins])
+                    arr_len = (ctypes.c_size_t * n)(*lens)
+                    arr_out = (ctypes.c_void_p * n)(*[t.data_ptr() for t in d_outs])
+                    arr_cap = (ctypes.c_size_t * n)(*([cap] * n))
+                    out_len = (ctypes.c_size_t * n)()
+                    offsets = (ctypes.c_uint64 * (n + 1))()
+                    status = (ctypes.c_int32 * n)()
+                    rc = L.ahip_gzip_decode_shards(n, arr_dev, arr_in, arr_len, arr_out, arr_cap, out_len, offsets, status)
+                    got = b"".join(bytes(d_outs[s][:out_len[s]].cpu().numpy()) for s in range(n))
+                    if rc != 0 or got != plain:
+                        errors_seen.append(("shards", rc, len(got)))
+            except Exception as e:  # noqa: BLE001
+                errors_seen.append(("shards", repr(e)))
+
+        def host_loop():
+            try:
+                for _ in range(12):
+                    out = archive_amd.GZipDecoder().decode_bytes(comp)
+                    if out != plain:
+                        errors_seen.append(("host", len(out)))
+            except Exception as e:  # noqa: BLE001
+                errors_seen.append(("host", repr(e)))
+
+        ts = [threading.Thread(target=shards_loop), threading.Thread(target=host_loop)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout=300)
+        assert not any(t.is_alive() for t in ts), "deadlock"
+        assert not errors_seen, errors_seen[:3]
     finally:
         monkeypatch.delenv("AHIP_FAKE_DEVICES")
         assert L.ahip_init_devices(1) == 0 and L.ahip_device_count() == 1
