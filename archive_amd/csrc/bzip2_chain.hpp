@@ -1,7 +1,7 @@
 // bzip2_chain.hpp -- the loop of BZip2Decoder.decodeStream (ref: lib/src/codecs/bzip2_decoder.dart:46-87) restated over
 // per-block verdicts.  HOST ONLY, no HIP: archive_hip.hip drives it between the kernel phases of a batch of blocks, and
-// tests/emu/bzip2_chain_emu.cc drives the very same functions on the CPU (per-block results from the oracle's block
-// function or from the wave emulation of the device code) against the oracle's whole-stream decoder.
+// tests/emu/bzip2_chain_emu.cc drives the very same functions on the CPU (per-block results from a CPU restatement of
+// the reference's block loop or from the wave emulation of the device code) against a whole-stream CPU decoder.
 //
 // The reference reads block after block from ONE bit reader:
 //   _readBlockType (:90-111)  six bytes, one at a time: a byte that matches neither magic is `false` AT ONCE (even when
