@@ -133,11 +133,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+        # the bare command `python bench.py --gpus N`: start the N ranks ourselves, one process per GPU, exactly the way the
+        # driver does it (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...)
+        sys.exit(launch_ranks(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print("bench.py: --gpus %d needs `python -m torch.distributed.run --nproc-per-node %d`" % (args.gpus, args.gpus),
-                  file=sys.stderr)
-            sys.exit(2)
+        print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     dev_index = 0 if args.one_device else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -268,7 +270,7 @@ def main():
         line = {
             "metric": "Inflate GB/s (uncompressed out) on multi-member gzip",
             "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(step_ms, 4), "higher_is_better": True, "scaling": "weak" if world == 1 else "strong",
+            "ms_per_step": round(step_ms, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "ONE stream of %d gzip members x %d B %s text (%s), zlib level 6%s" % (
                 args.members, args.member_bytes, args.kind, "BGZF BC subfield" if not args.no_bc else "no BC",
@@ -317,6 +319,22 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def launch_ranks(n):
+    """Re-run this command line under torch.distributed.run with n local ranks (rendezvous on 127.0.0.1, a free port);
+    rank 0's JSON line goes to our stdout, the exit code is the launcher's."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def weak_scaling(args, L, N, corpus, dist, torch, np, dev, cdev, sh, rank, world, kind, seed, threads, decode_loop):

@@ -83,14 +83,10 @@ def test_two_ranks_on_one_device_gloo(native_built):
     ONE device, the collectives on CPU tensors (gloo) -- the headline is the strong-scaled ONE stream (partitioned on compressed
     bytes, size exchange every step, shard CRCs combined over GF(2)); the weak leg (every rank its own members) rides along."""
     import json
-    import socket
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--one-device",
+    # The BARE command, no launcher in front of it: bench.py starts its own ranks (bench.launch_ranks -> torch.distributed.run
+    # on 127.0.0.1 and a free port) -- the form `python bench.py --gpus N` takes when a driver runs it like the N = 1 line.
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--one-device",
                         "--steps", "2", "--warmup", "1", "--members", "2048", "--cpu-seconds", "0"],
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
