@@ -21,7 +21,7 @@ EXPORTS = [
     "ahip_bzip2_decode", "ahip_bzip2_decode_device", "ahip_crc32_device", "ahip_adler32_device", "ahip_inflate_batch", "ahip_inflate_batch_device", "ahip_deflate_raw", "ahip_gzip_encode", "ahip_zlib_encode", "ahip_deflate_raw_device", "ahip_deflate_bound",
     "ahip_crc32", "ahip_adler32", "ahip_decode_bound",
     "ahip_gzip_decode_shards", "ahip_debug_last_exchange", "ahip_gzip_encode_device", "ahip_zlib_encode_device",
-    "ahip_debug_last_chunks", "ahip_deflate_shards", "ahip_bzip2_decode_shards", "ahip_debug_bz_reruns",
+    "ahip_debug_last_chunks", "ahip_deflate_shards", "ahip_bzip2_decode_shards", "ahip_debug_bz_reruns", "ahip_last_consumed",
 ]
 
 _lib = None
@@ -85,6 +85,7 @@ def lib():
     L.ahip_bzip2_decode_shards.argtypes = [u32, vp, vp, sz, i32, vp, vp, vp, vp, vp]; L.ahip_bzip2_decode_shards.restype = i32
     L.ahip_debug_last_exchange.argtypes = []; L.ahip_debug_last_exchange.restype = i32
     L.ahip_debug_bz_reruns.argtypes = []; L.ahip_debug_bz_reruns.restype = i32
+    L.ahip_last_consumed.argtypes = []; L.ahip_last_consumed.restype = sz
     L.ahip_gzip_encode_device.argtypes = [vp, sz, i32, i32, u32, vp, sz, szp, vp]; L.ahip_gzip_encode_device.restype = i32
     L.ahip_zlib_encode_device.argtypes = [vp, sz, i32, i32, vp, sz, szp, vp]; L.ahip_zlib_encode_device.restype = i32
     L.ahip_crc32.argtypes = [vp, sz, u32]; L.ahip_crc32.restype = u32

@@ -83,6 +83,7 @@ class ZLibDecoder:
         st, out = _call_growing(
             lambda o, cap, olen: N.lib().ahip_zlib_decode(buf, n, int(verify), int(raw), o, cap, olen), n)
         self.last_status = st
+        self.input_position = N.lib().ahip_last_consumed()  # where decodeStream leaves its InputStream
         return out
 
     def decode_stream(self, input_bytes, output, verify=False, raw=False):
@@ -104,6 +105,7 @@ class GZipDecoder:
         st, out = _call_growing(
             lambda o, cap, olen: N.lib().ahip_gzip_decode(buf, n, int(verify), int(raw), o, cap, olen), n)
         self.last_status = st
+        self.input_position = N.lib().ahip_last_consumed()  # where decodeStream leaves its InputStream
         return out
 
     def decode_stream(self, input_bytes, output, verify=False, raw=False):

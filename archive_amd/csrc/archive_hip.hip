@@ -1245,6 +1245,11 @@ int32_t inflate_one_wave(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap,
   return AHIP_OK;
 }
 
+// Where the reference's InputStream stands after the last decode call of this thread (ahip_last_consumed): decodeStream
+// CONSUMES its input -- all of it when it returns true; on `false` it stops where the check that failed left the reader
+// (_zlib_decoder_web.dart:53-99), and callers that go on reading the stream must find it there.
+static thread_local u64 g_consumed = 0;
+
 int32_t member_status_to_abi(u32 ms) {
   switch (ms) {
     case MS_OK: case MS_EOS: return AHIP_OK;
@@ -1262,6 +1267,7 @@ int32_t member_status_to_abi(u32 ms) {
 //  host_in: host copy of the input (headers/trailers are read there).
 int32_t zlib_stream_device(const u8 *host_in, const u8 *d_in, u64 n, u64 pos, bool big_endian, int verify, int raw,
                            DevBuf &outbuf, u64 *committed_io, hipStream_t st) {
+#define ZRET(code) do { g_consumed = pos; return (code); } while (0)
   u64 committed = *committed_io;
   bool have = false;
   u64 buf_len = 0;
@@ -1271,11 +1277,13 @@ int32_t zlib_stream_device(const u8 *host_in, const u8 *d_in, u64 n, u64 pos, bo
       if (pos + 2 > n) return AHIP_RANGE;
       u32 cmf = host_in[pos], flg = host_in[pos + 1];
       pos += 2;
-      if ((cmf & 8) != 8) { *committed_io = committed; return AHIP_FALSE; }
-      if (((cmf * 256) + flg) % 31 != 0) { *committed_io = committed; return AHIP_FALSE; }
-      if ((flg & 32) >> 5) {
+      if ((cmf & 8) != 8) { *committed_io = committed; ZRET(AHIP_FALSE); }
+      if (((cmf * 256) + flg) % 31 != 0) { *committed_io = committed; ZRET(AHIP_FALSE); }
+      if ((flg & 32) >> 5) {  // readUint32() of the dictionary id, then `false`
         *committed_io = committed;
-        return (pos + 4 > n) ? AHIP_RANGE : AHIP_FALSE;
+        if (pos + 4 > n) return AHIP_RANGE;
+        pos += 4;
+        ZRET(AHIP_FALSE);
       }
     }
     if (have) committed += buf_len;
@@ -1314,13 +1322,14 @@ int32_t zlib_stream_device(const u8 *host_in, const u8 *d_in, u64 n, u64 pos, bo
         u32 got = 0;
         rc = adler32_device_impl(outbuf.as<u8>() + committed, buf_len, 1, &got, st);
         if (rc != AHIP_OK) return rc;
-        if (got != want) { *committed_io = committed; return AHIP_FALSE; }
+        if (got != want) { *committed_io = committed; ZRET(AHIP_FALSE); }
       }
     }
   }
   if (have) committed += buf_len;
   *committed_io = committed;
-  return AHIP_OK;
+  ZRET(AHIP_OK);
+#undef ZRET
 }
 
 }  // namespace
@@ -1333,6 +1342,8 @@ extern "C" {
 uint32_t ahip_abi_version(void) { return (2u << 16) | 3u; }
 
 const char *ahip_last_error(void) { return g_err.c_str(); }
+
+size_t ahip_last_consumed(void) { return (size_t)g_consumed; }
 
 int32_t ahip_init(int32_t device) {
   std::lock_guard<std::recursive_mutex> lk(g_mu);
@@ -1654,6 +1665,8 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
   u64 n = 0;
   const int32_t v = bz_chain_finish(ch, verify, &n);
   if (out_len) *out_len = (size_t)n;
+  // (what the bit reader has pulled from the InputStream when decodeStream returns true: whole bytes)
+  g_consumed = std::min<u64>((u64)in_len, (ch.end_bit + 7) / 8);
   return v;
 }
 
@@ -2072,6 +2085,7 @@ static int32_t gzip_decode_impl(const u8 *host_in, const u8 *d_in, size_t in_len
   if (pl.sum.range_error) return AHIP_RANGE;
   u64 committed = pl.sum.total_out;
   if (out_len) *out_len = committed;
+  g_consumed = in_len;  // (the member loop runs until isEOS)
   if (pl.sum.tail_pos >= in_len) return AHIP_OK;
   // The bytes at tail_pos are not a gzip header: the reference hands the rest of the stream to
   // the zlib decoder (little-endian stream, so its Adler-32 is read byte-swapped).
@@ -2090,7 +2104,7 @@ static int32_t gzip_decode_impl(const u8 *host_in, const u8 *d_in, size_t in_len
     u64 p = pl.sum.tail_pos;
     if (p + 2 > in_len) return AHIP_RANGE;
     u32 cmf = h[p], flg = h[p + 1];
-    if ((cmf & 8) != 8 || ((cmf * 256) + flg) % 31 != 0) return AHIP_FALSE;
+    if ((cmf & 8) != 8 || ((cmf * 256) + flg) % 31 != 0) { g_consumed = p + 2; return AHIP_FALSE; }
   }
   if (!out_is_growable) {
     // fixed caller buffer: decode the tail into scratch, then append what fits
@@ -2322,6 +2336,7 @@ bool gzip_decode_sharded(std::vector<std::unique_ptr<Worker>> &set, size_t per, 
     if (rcs[q] != AHIP_OK || got[q] != o_off[q + 1] - o_off[q]) return false;  // lying ISIZE, damaged member, a reference into another slice: exact path
   if (out_len) *out_len = o_off[S];
   *rc_out = AHIP_OK;
+  g_consumed = in_len;
   return true;
 }
 // contexts on the current device for the host-pointer pipeline (lazily, once)
@@ -2722,6 +2737,7 @@ int32_t ahip_inflate_raw(const uint8_t *in, size_t in_len, uint8_t *out, size_t 
   if (rc != AHIP_OK) return rc;
   if (out_len) *out_len = r.out_len;
   if (consumed) *consumed = r.end_pos;
+  g_consumed = r.end_pos;
   int32_t st = member_status_to_abi(r.status);
   if (st < 0 || st == AHIP_RANGE || st == AHIP_HANG) return st;
   if (r.out_len > out_cap) return fail(AHIP_E_CAP, "output buffer too small");

@@ -34,6 +34,7 @@ struct BzChain {
   u32 eos_stored = 0, combined = 0;
   size_t next = 0;       // candidate the chain expects next
   u64 folded = 0;        // block CRCs folded into `combined`
+  u64 end_bit = 32;      // where the bit reader stands behind the last block (or end-of-stream marker) the chain has read
 };
 
 // What _readBlockType makes of bit position `bit` when NO magic starts there.  `bytes` = the stream's bytes from bit >> 3
@@ -64,7 +65,7 @@ inline void bz_chain_walk(BzChain &ch, const BzCand *cands, size_t ncand, size_t
     const BzResult &r = res[i - c0];
     if (cands[i].kind == 2) {  // end of stream: combined CRC, then decodeStream returns true
       if (r.status == BZ_ST_RANGE) ch.verdict = 2;
-      else { ch.saw_eos = true; ch.eos_stored = r.stored_crc; }
+      else { ch.saw_eos = true; ch.eos_stored = r.stored_crc; ch.end_bit = r.end_bit; }
       ch.stopped = true;
       break;
     }
@@ -79,6 +80,7 @@ inline void bz_chain_walk(BzChain &ch, const BzCand *cands, size_t ncand, size_t
     if (r.status != BZ_ST_OK && r.status != BZ_ST_OVERFLOW) { ch.verdict = 1; ch.stopped = true; break; }
     placed.push_back({(u32)(i - c0), ch.total, r.out_len, r.status == BZ_ST_OK ? BZ_PL_PARALLEL : BZ_PL_SERIAL});
     ch.total += r.out_len;
+    ch.end_bit = r.end_bit;
     // the next block type is read at r.end_bit
     if ((r.end_bit + 7) / 8 >= in_len) { ch.stopped = true; break; }  // while (!input.isEOS): clean end without an end-of-stream block
     size_t j = i + 1;

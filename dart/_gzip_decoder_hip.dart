@@ -24,9 +24,10 @@ class _GZipDecoderHip extends ZLibDecoderBase {
     final hip = ArchiveHip.instance;
     final data = input.toUint8List();  // what is left of the stream, from its current position
     output.writeBytes(hip.gzipDecode(data, verify: verify, raw: raw));
-    // The reference's decodeStream CONSUMES the stream (it reads member after member until isEOS, or hands the rest to
-    // the zlib decoder, which reads to where it stops): callers that go on reading `input` must find it there.
-    input.skip(data.length);
+    // The reference's decodeStream CONSUMES the stream: all of it when it returns true; on `false` it stands where the
+    // failing check left it (two header bytes in, behind a dictionary id, behind a wrong Adler-32:
+    // _zlib_decoder_web.dart:53-99).  Callers that go on reading `input` must find it exactly there.
+    input.skip(hip.lastStreamPosition);
     return hip.lastStatus == ArchiveHip.ok;
   }
 }

@@ -91,6 +91,7 @@ class ArchiveHip {
   late final _BoundSizeDart _deflateBound =
       _lib.lookupFunction<_BoundSizeNative, _BoundSizeDart>('ahip_deflate_bound');
   late final _BzDart _bzip2 = _lib.lookupFunction<_BzNative, _BzDart>('ahip_bzip2_decode');
+  late final int Function() _lastConsumed = _lib.lookupFunction<Size Function(), int Function()>('ahip_last_consumed');
   late final int Function(int) _init =
       _lib.lookupFunction<Int32 Function(Int32), int Function(int)>('ahip_init');
   late final Pointer<Utf8> Function() _lastError =
@@ -131,6 +132,7 @@ class ArchiveHip {
           if (rc == rangeError) throw RangeError('archive_hip: read past the end of the input');
           if (rc < 0 || rc == wouldHang) throw StateError('archive_hip $rc: ${_lastError().toDartString()}');
           lastStatus = rc;
+          lastStreamPosition = _lastConsumed();
           return Uint8List.fromList(out.asTypedList(outLen.value));
         } finally {
           malloc.free(out);
@@ -144,6 +146,11 @@ class ArchiveHip {
   }
 
   int lastStatus = 0;
+
+  /// Bytes of the input the reference's decodeStream would have consumed in the last gzipDecode / zlibDecode /
+  /// bzip2Decode: all of them when it returns true; on `false` the position its failing check left the InputStream at
+  /// (ahip_last_consumed; _zlib_decoder_web.dart:53-99).
+  int lastStreamPosition = 0;
 
   /// Bytes of the input the last [inflateRaw] consumed (the reference InputStream's position afterwards).
   int lastConsumed = 0;

@@ -60,7 +60,7 @@ const char *ahip_last_error(void);
 /* ABI version of this header (major << 16 | minor). */
 uint32_t ahip_abi_version(void);  /* 2.1: + ahip_gzip_decode_shards, ahip_gzip_encode_device, ahip_zlib_encode_device;
                                     * 2.2: + ahip_deflate_shards, ahip_bzip2_decode_shards, ahip_debug_last_chunks;
-                                    * 2.3: + ahip_debug_bz_reruns */
+                                    * 2.3: + ahip_debug_bz_reruns, ahip_last_consumed */
 
 /* ---- Inflate: host-pointer entry points (what dart:ffi binds) ---- */
 
@@ -79,6 +79,15 @@ int32_t ahip_gzip_decode(const uint8_t *in, size_t in_len, int32_t verify, int32
  * Multi-member zlib with the reference's deferred-flush behaviour; Adler-32 big-endian. */
 int32_t ahip_zlib_decode(const uint8_t *in, size_t in_len, int32_t verify, int32_t raw,
                          uint8_t *out, size_t out_cap, size_t *out_len);
+
+/* Where the reference's InputStream stands after the calling thread's last ahip_gzip_decode / ahip_zlib_decode /
+ * ahip_inflate_raw -- what `decodeStream(input, output)` has consumed of `input`: everything when it returned true; on `false`
+ * the position the failing check left the reader at (ref: _zlib_decoder_web.dart:53-99: two header bytes, + 4 for a
+ * preset-dictionary id, behind the Adler-32 that did not match; _gzip_decoder_web.dart:31-37 rewinds to the start of what
+ * is not a gzip header before it hands over).  After ahip_bzip2_decode returning AHIP_OK: the bytes its bit reader has pulled
+ * (the end-of-stream marker's CRC included, rounded up to a byte).  Undefined after AHIP_RANGE / an AHIP_E_* code, and after
+ * a bzip2 AHIP_FALSE (the reference stops wherever its bit reader stood inside the damaged block). */
+size_t ahip_last_consumed(void);
 
 /* Size the decoded output is expected to have, so that a caller can allocate once: for a gzip stream whose members all
  * carry a BGZF `BC` subfield (or that is one member) the sum of the ISIZE trailers; 0 = unknown (zlib / raw input, members

@@ -340,6 +340,10 @@ static int gz_header(istream_t *in) {
 static int zlib_stream(tables_t *T, istream_t *in, ostream_t *out, int verify, int raw);
 uint32_t orc_adler32(const uint8_t *p, size_t n, uint32_t adler);
 
+/* where the last orc_gzip_decode / orc_zlib_decode of this thread left its InputStream (what decodeStream consumed) */
+static __thread size_t g_last_pos = 0;
+size_t orc_last_position(void) { return g_last_pos; }
+
 /* _GZipDecoder.decodeStream */
 int orc_gzip_decode(const uint8_t *in, size_t n, int verify, int raw, uint8_t *out, size_t cap, size_t *out_len) {
   istream_t is = {in, n, 0, 0, 0};
@@ -364,6 +368,7 @@ int orc_gzip_decode(const uint8_t *in, size_t n, int verify, int raw, uint8_t *o
   }
   free(T);
   if (out_len) *out_len = os.len;
+  g_last_pos = is.pos;
   return st;
 }
 
@@ -413,6 +418,7 @@ int orc_zlib_decode(const uint8_t *in, size_t n, int verify, int raw, uint8_t *o
   int st = zlib_stream(T, &is, &os, verify, raw);
   free(T);
   if (out_len) *out_len = os.len;
+  g_last_pos = is.pos;
   return st;
 }
 

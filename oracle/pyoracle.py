@@ -39,6 +39,8 @@ def lib():
         L.orc_adler32.argtypes = [u8p, ctypes.c_size_t, ctypes.c_uint32]
         L.orc_adler32.restype = ctypes.c_uint32
         L.orc_bzip2_decode.argtypes = [u8p, ctypes.c_size_t, ctypes.c_int, u8p, ctypes.c_size_t, szp]
+        L.orc_last_position.argtypes = []
+        L.orc_last_position.restype = ctypes.c_size_t
         L.orc_bzip2_block.argtypes = [u8p, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_int, u8p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64), szp,
                                       ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_int)]
         L.orc_deflate_raw.argtypes = [u8p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, u8p, ctypes.c_size_t, szp,
@@ -89,6 +91,11 @@ def zlib_decode(data, verify=False, raw=False, cap=None):
         return lib().orc_zlib_decode(ctypes.addressof(buf), n, int(verify), int(raw), ctypes.addressof(out), cap, ctypes.byref(olen)), None
     st, o, _ = _run(fn, data, (), cap)
     return st, o
+
+
+def last_position():
+    """where the calling thread's last gzip_decode / zlib_decode left the reference's InputStream"""
+    return lib().orc_last_position()
 
 
 def crc32(data, crc=0):

@@ -112,3 +112,13 @@ def test_dart_bindings_match_the_header():
                   "void addBytes(List<int> bytes)", "int addStream(InputStream buffer)", "int get level", "int crc32", "int total",
                   "static const defaultCompression = 6", "static const bestCompression = 9", "static const bestSpeed = 1", "static const none = 0"]:
         assert piece in deflate, piece
+    # BZip2Decoder with the reference's two methods and their signatures (bzip2_decoder.dart:12-21)
+    bz = open(os.path.join(dart_dir, "bzip2_decoder_hip.dart")).read()
+    for piece in ["class BZip2Decoder", "Uint8List decodeBytes(List<int> data, {bool verify = false})",
+                  "bool decodeStream(InputStream input, OutputStream output, {bool verify = false})", "bzip2Decode(data, verify: verify)"]:
+        assert piece in bz, piece
+    # the decoders' decodeStream leaves the InputStream where the reference does (ahip_last_consumed), not at its end
+    assert "ahip_last_consumed" in [s_ for _, s_ in looked_up]
+    for f in ("_gzip_decoder_hip.dart", "_zlib_decoder_hip.dart"):
+        src = open(os.path.join(dart_dir, f)).read()
+        assert "input.skip(hip.lastStreamPosition)" in src and "input.skip(data.length)" not in src, f

@@ -36,12 +36,14 @@ def chain():
                                  ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_uint32)]
     L.bzchain_decode.restype = ctypes.c_int
 
+    big = ctypes.create_string_buffer(6 << 20)       # (a damaged level-1 block makes up to 5.2 MB of runs)
+
     def run(buf, verify, batch=64, mode=0, cap=None):
-        cap = (6 << 20) if cap is None else cap      # (a damaged level-1 block makes up to 5.2 MB of runs)
-        out = ctypes.create_string_buffer(max(cap, 1))
+        out = big if cap is None else ctypes.create_string_buffer(max(cap, 1))
+        cap = len(big) if cap is None else cap
         olen, seen = ctypes.c_size_t(0), ctypes.c_uint32(0)
         st = L.bzchain_decode(bytes(buf), len(buf), int(verify), batch, mode, ctypes.addressof(out), cap, ctypes.byref(olen), ctypes.byref(seen))
-        return st, (out.raw[:olen.value] if st in (0, 1) else olen.value), seen.value
+        return st, (ctypes.string_at(out, olen.value) if st in (0, 1) else olen.value), seen.value
     return run
 
 
@@ -77,22 +79,22 @@ def test_two_block_stream_flipped_everywhere(chain):
     bits = list(range(0, len(c) * 8, 37))
     partial = 0
     n = 0
-    for bit in bits:
+    whole = chain(c, False)[1]
+    for k, bit in enumerate(bits):
         buf = bytearray(c); buf[bit >> 3] ^= 0x80 >> (bit & 7); buf = bytes(buf)
         for verify in (False, True):
             st, out = _expect(orc, buf, verify)
-            for batch in (1, 64):
-                got = chain(buf, verify, batch)
-                if got[0] == -3:       # the obsolete randomised mode: not a verdict
-                    continue
-                assert got[0] == st and (st == 2 or got[1] == out), (bit, verify, batch, got[0], st, len(out))
-                n += 1
+            batch = 1 if (k + verify) % 2 else 64      # (batches of one candidate and of all of them, in turn)
+            got = chain(buf, verify, batch)
+            if got[0] == -3:       # the obsolete randomised mode: not a verdict
+                continue
+            assert got[0] == st and (st == 2 or got[1] == out), (bit, verify, batch, got[0], st, len(out))
+            n += 1
             if st == 1 and not verify and len(out) > 0:
                 # did the last block the reference touched fail behind its own bytes?
-                whole = chain(c, False)[1]
                 if out != whole[:len(out)] or len(out) not in (0, len(whole)):
                     partial += 1
-    assert n > 12000
+    assert n > 6000
     assert partial > 0
 
 

@@ -41,11 +41,15 @@ def _raw(amd, data):
         return 3, None, None
 
 
+_last_pos = [None]  # input position after the last _gz / _zl call that returned bytes (what decodeStream consumed)
+
+
 def _gz(amd, data, **kw):
     from archive_amd import errors
     d = amd.GZipDecoder()
     try:
         out = d.decode_bytes(data, **kw)
+        _last_pos[0] = d.input_position
         return d.last_status, out
     except errors.RangeError:
         return 2, None
@@ -56,6 +60,7 @@ def _zl(amd, data, **kw):
     d = amd.ZLibDecoder()
     try:
         out = d.decode_bytes(data, **kw)
+        _last_pos[0] = d.input_position
         return d.last_status, out
     except errors.RangeError:
         return 2, None
@@ -114,6 +119,8 @@ def test_gzip_framing_matches_oracle(amd, orc):
         except Exception as e:  # keep the case index visible
             raise AssertionError("case %d: %r (oracle %r)" % (i, e, want[0]))
         assert got == want, i
+        if want[0] in (0, 1):  # ... and the InputStream stands where the reference leaves it (decodeStream consumes it)
+            assert _last_pos[0] == orc.last_position(), (i, _last_pos[0], orc.last_position(), len(c))
     assert _gz(amd, zlib.compress(a), verify=True) == _noneify(orc.gzip_decode(zlib.compress(a), verify=True))
 
 
@@ -129,8 +136,15 @@ def test_zlib_framing_matches_oracle(amd, orc):
     bad[-1] ^= 1
     for data, kw in [(za + zb, dict(verify=True)), (za + b"\x00\x00", dict(verify=True)), (za + zb + b"\x01\x02", {}),
                      (bytes(bad), dict(verify=True)), (bytes(bad), {}), (streams.raw_deflate(a), dict(raw=True)),
-                     (za[:-2], {}), (b"", {})]:
-        assert _zl(amd, data, **kw) == _noneify(orc.zlib_decode(data, **kw)), (len(data), kw)
+                     (za[:-2], {}), (b"", {}),
+                     # where `false` leaves the stream: behind the two header bytes (method / FCHECK), behind the dictionary id,
+                     # behind the Adler-32 that did not match
+                     (za + b"\x77\x01" + zb, {}), (za + b"\x78\x02" + zb, {}), (za + b"\x78\x20" + zb, {}), (za + b"\x78\x20\x00", {}),
+                     (b"\x78\xbb" + bytes(9), {})]:
+        want = _noneify(orc.zlib_decode(data, **kw))
+        assert _zl(amd, data, **kw) == want, (len(data), kw)
+        if want[0] in (0, 1):
+            assert _last_pos[0] == orc.last_position(), (len(data), kw, _last_pos[0], orc.last_position())
 
 
 def test_bsize_or_isize_lies_are_caught(amd, orc):
