@@ -180,7 +180,7 @@ __global__ __launch_bounds__(64, AHIP_RES_MIN_WAVES) void inflate_resolve_kernel
       tok_layout(sel.ids ? uniform64(sel.rel[k]) : out_off - group_out0, out_limit, k, toff, cc, doff, dc);
     }
     u32 cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    resolve_member(lds, in, tokens + toff, dir + doff, ndir, out + out_off, cyc, lane);
+    if (!resolve_member(lds, in, tokens + toff, dir + doff, ndir, out + out_off, cyc, lane) && lane == 0) results[m].status = MS_INTERNAL;
 #ifdef AHIP_PROFILE_RES
     if (lane == 0) for (int q = 0; q < 8; ++q) results[m].cyc[q] = cyc[q];
 #endif
@@ -241,7 +241,8 @@ __global__ __launch_bounds__(64) void inflate_late_kernel(const u8 *__restrict__
         u32 cc, dc;
         tok_layout(sel.ids ? uniform64(sel.rel[k]) : d.out_off - group_out0, d.out_limit, k, toff, cc, doff, dc);
         u32 cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        resolve_member(par, in, tokens + toff, dir + doff, (u32)uniform64(results[m].tok_words), out + d.out_off, cyc, lane);
+        if (!resolve_member(par, in, tokens + toff, dir + doff, (u32)uniform64(results[m].tok_words), out + d.out_off, cyc, lane) && lane == 0)
+          results[m].status = MS_INTERNAL;
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");  // the next late member may read these bytes
     }
@@ -400,7 +401,8 @@ static hipError_t scratch_acquire(hipStream_t st) {
 // *gen_out names the scratch contents they are (0: not kept).
 template <bool WRITE>
 hipError_t launch_inflate_group(const u8 *in, u64 n, const MemberDesc *members, u32 first, u32 count, u64 out0, u64 out1,
-                                u8 *out, MemberResult *res, hipStream_t st, const u64 *lay_pos = nullptr, u64 *gen_out = nullptr) {
+                                u8 *out, MemberResult *res, hipStream_t st, const u64 *lay_pos = nullptr, u64 *gen_out = nullptr,
+                                bool skip_late = false) {
   if (gen_out) *gen_out = 0;
   if (!tok_resident) {
     int dev = 0, cus = 0, a = 0, b = 0;
@@ -485,8 +487,13 @@ hipError_t launch_inflate_group(const u8 *in, u64 n, const MemberDesc *members, 
     (void)hipEventElapsedTime(&b, kt[1], kt[2]);
     fprintf(stderr, "[ahip] ktime members %u: tokenize %.3f ms, resolve %.3f ms\n", count, a, b);
   }
-  hipLaunchKernelGGL(inflate_late_kernel<WRITE>, dim3(WRITE ? 1u : SIZING_LATE_WGS), dim3(64), 0, st, in, n, members, first, count, out, (const u32 *)tp,
-                     (const DirEnt *)dp, out0, res, dlate.as<u32>(), dexact.as<u32>(), MemberSel{nullptr, nullptr});
+  // (skip_late, a sizing run only: the over-subscribed candidates stay unsized.  Nearly all of them are FALSE candidates --
+  //  `1f 8b 08` inside compressed data, whose garbage headers are over-subscribed more often than not -- that the member
+  //  chain never reaches, and sizing them with the reference's exact tables was 1.07 ms of every decode of a stream without
+  //  size hints, profiles/r04_nobc_kernel_stats.md.  The chain counts the unsized ones it does reach: plan_build.)
+  if (!skip_late)
+    hipLaunchKernelGGL(inflate_late_kernel<WRITE>, dim3(WRITE ? 1u : SIZING_LATE_WGS), dim3(64), 0, st, in, n, members, first, count, out, (const u32 *)tp,
+                       (const DirEnt *)dp, out0, res, dlate.as<u32>(), dexact.as<u32>(), MemberSel{nullptr, nullptr});
   e = hipEventRecord(scratch_free, st);
   if (e != hipSuccess) return e;
   return hipGetLastError();
@@ -548,7 +555,7 @@ hipError_t launch_inflate_listed(const u8 *in, u64 n, const MemberDesc *members,
 template <bool WRITE>
 hipError_t launch_inflate(const u8 *in, u64 n, const MemberDesc *members, u32 M, u8 *out, MemberResult *res,
                           hipStream_t st, const u64 *host_out_off = nullptr, u64 total_out = 0, const u64 *lay_pos = nullptr,
-                          u64 *gen_out = nullptr, u32 m_begin = 0, u32 m_end = 0xffffffffu) {
+                          u64 *gen_out = nullptr, u32 m_begin = 0, u32 m_end = 0xffffffffu, bool skip_late = false) {
   if (gen_out) *gen_out = 0;
   if (M == 0) return hipSuccess;
   if (m_end > M) m_end = M;
@@ -559,7 +566,7 @@ hipError_t launch_inflate(const u8 *in, u64 n, const MemberDesc *members, u32 M,
   }
   if (!WRITE || !host_out_off) {
     const u64 total = host_out_off ? host_out_off[M] : total_out;
-    return launch_inflate_group<WRITE>(in, n, members, 0, M, 0, total, out, res, st, lay_pos, gen_out);
+    return launch_inflate_group<WRITE>(in, n, members, 0, M, 0, total, out, res, st, lay_pos, gen_out, skip_late);
   }
   u32 first = m_begin;
   while (first < m_end) {
@@ -596,6 +603,7 @@ struct ahip_gzip_plan {
   u64 retok_span = 0;
   u32 K = 0;           // candidates
   bool cands_ready = false;  // cand_pos / hdr hold this stream's candidates (a rebuild with sizes from the data keeps them)
+  bool size_oversub = false; // the sizing run also sizes over-subscribed candidates (inflate_late_kernel<false>): only once the chain met one
   ChainSummary sum{};
   DevBuf tile_counts, tile_offsets, tile_slots, cand_pos, hdr, scratch_u32, members, expect_status, results, sizing_descs,
       sizing_results, dsum, drun, retok_ids, retok_rel, chain_aux, tile_recs, cand_rec;
@@ -721,8 +729,10 @@ int32_t plan_build(ahip_gzip_plan *pl, bool force_sizing, hipStream_t st) {
     }
     // (when the long members cover every candidate the launch below sizes nothing: it then must not take the token
     //  scratch either -- the chunked path has just kept ITS tokens there for the decode proper)
+    // (the late kernel -- exact tables for over-subscribed candidates -- only when a first build found one ON the chain)
     HIP_TRY(launch_inflate<false>(in, n, pl->sizing_descs.as<MemberDesc>(), K, (u8 *)nullptr,
-                                  pl->sizing_results.as<MemberResult>(), st, nullptr, 0, nothing_left ? nullptr : pl->cand_pos.as<u64>(), &pl->tok_gen));
+                                  pl->sizing_results.as<MemberResult>(), st, nullptr, 0, nothing_left ? nullptr : pl->cand_pos.as<u64>(), &pl->tok_gen,
+                                  0, 0xffffffffu, !pl->size_oversub));
     for (auto &mr : measured)
       HIP_TRY(hipMemcpyAsync(pl->sizing_results.as<MemberResult>() + mr.first, &mr.second, sizeof(MemberResult), hipMemcpyHostToDevice, st));
     if (!measured.empty()) HIP_TRY(hipStreamSynchronize(st));
@@ -777,6 +787,12 @@ int32_t plan_build(ahip_gzip_plan *pl, bool force_sizing, hipStream_t st) {
   HIP_TRY(hipMemcpyAsync(&pl->sum, pl->dsum.p, sizeof(ChainSummary), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipGetLastError());
+  if (pl->sized && pl->sum.oversub && !pl->size_oversub) {
+    // an over-subscribed member ON the chain (no encoder writes one; the reference decodes it with its overwritten table):
+    // its size and everything behind it are not known -- size once more, the late kernel in the launch this time
+    pl->size_oversub = true;
+    return plan_build(pl, true, st);
+  }
   if (pl->tok_gen && pl->sum.retok > RETOK_CAP) pl->tok_gen = 0;  // too many to list: the decode tokenizes everything again
   if (pl->tok_gen && pl->sum.retok) {
     // the members tokenized again: ascending, with the running sum of their sizes (where their token areas go)
@@ -1137,6 +1153,10 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
       if (it == cand.end() || *it != r.end_pos || (u32)(it - cand.begin()) <= i) return fail(AHIP_E_DEVICE, "internal: chunk chain broken");
       i = (u32)(it - cand.begin());
     }
+    // Only chunk 0 is WATCHED for references into what earlier gzip members wrote (q8).  A later chunk can reach there too
+    // when chunk 0 made less than a window of output (a small AHIP_SM_CHUNK; 15-bit literal codes): taken as reaching --
+    // the member is then decoded in stream order, after the members in front of it, which is always right.
+    if (hist0 > 0 && g_sm.chain.size() > 1 && g_sm.chain[1].out_off < SM_WINDOW) g_sm.blocks |= MR_REACH;
     g_sm.cand = cand;
     g_sm.total_out = total;
     g_sm.d_in = d_in; g_sm.n = n; g_sm.off = off; g_sm.hist0 = hist0;
@@ -1195,8 +1215,11 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
         return AHIP_OK;
       }
   }
+  static thread_local DevBuf derr;  // chunks whose resolver gave up on a loop bound (cannot happen; if it does: AHIP_E_DEVICE, not wrong bytes)
+  HIP_TRY(derr.reserve(16));
+  HIP_TRY(hipMemsetAsync(derr.p, 0, 4, st));
   hipLaunchKernelGGL(sm_resolve_kernel, dim3(grid), dim3(64), 0, st, d_in, n, dchunks.as<ChunkDesc>(), nch, dsym.as<u16>(), (const u32 *)tp,
-                     (const DirEnt *)sp, dres.as<MemberResult>(), dcand.as<u64>(), nc, kept ? 1u : 0u);
+                     (const DirEnt *)sp, dres.as<MemberResult>(), dcand.as<u64>(), nc, kept ? 1u : 0u, derr.as<u32>());
   {
     static thread_local DevBuf dwsym, dgwin;
     u32 gs = 1;
@@ -1213,9 +1236,12 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
   }
   hipLaunchKernelGGL(sm_translate_kernel, dim3(32, nch), dim3(256), 0, st, dchunks.as<ChunkDesc>(), dres.as<MemberResult>(), dsym.as<u16>(),
                      dwin.as<u8>(), d_out, (const u8 *)d_out - SM_WINDOW, hist0);
+  u32 res_err = 0;
+  HIP_TRY(hipMemcpyAsync(&res_err, derr.p, 4, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipGetLastError());
   g_sm.valid = false;
+  if (res_err) return fail(AHIP_E_DEVICE, "internal: the chunk resolver ran into its loop bound");
   *handled = true;
   g_last_chunks = (int32_t)nch;
   if (dbg) fprintf(stderr, "[ahip] sm: write pass %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
@@ -1511,7 +1537,8 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
     if (batch <= 1) return fail(AHIP_E_DEVICE, std::string("bzip2 work memory: ") + hipGetErrorString(e));
     batch = (batch + 1) / 2;
   }
-  {
+  static thread_local bool crc_tables_up = false;  // (this context's copy of the MSB-first CRC tables: uploaded once)
+  if (!crc_tables_up || !dcrc.p) {
     u32 table[256 + 64];
     for (u32 i = 0; i < 256; ++i) {
       u32 c = i << 24;
@@ -1527,6 +1554,7 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
     for (int k = 0; k < 64; ++k) { table[256 + k] = pw; pw = mulmod(pw, pw); }
     HIP_TRY(dcrc.reserve(sizeof(table)));
     HIP_TRY(hipMemcpy(dcrc.p, table, sizeof(table), hipMemcpyHostToDevice));
+    crc_tables_up = true;
   }
   static thread_local DevBuf dcktab, dckacc;  // the reflected CRC's tables (bz_block_crc mirrors it)
   HIP_TRY(ck_prepare(dcktab, dckacc));

@@ -32,6 +32,8 @@ enum : u32 {
                     // the member with the reference's own overwritten single-level table
   MS_CHUNK_END = 19, // chunked single-stream decode: stopped at the next chunk's first block (end_pos is a BIT position)
   MS_TOKFULL = 20,  // internal: the member's token area / run directory overflowed; the byte-writing serial kernel redoes it
+  MS_INTERNAL = 21, // a kernel's own invariant did not hold (a loop bound that "cannot" be reached was reached): never silent --
+                    // the host reports AHIP_E_DEVICE
 };
 
 struct MemberDesc {

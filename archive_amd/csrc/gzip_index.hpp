@@ -45,7 +45,8 @@ struct ChainSummary {
   u32 unknown;       // candidates whose size is not known yet (valid after gz_parse_headers)
   u32 stopped_unknown; // the chain reached a member of unknown size: a sizing run is needed
   u32 retok;         // members on the chain that carry HF_RETOK
-  u32 pad;
+  u32 oversub;       // members on the chain a sizing run left UNSIZED: over-subscribed code lengths (MS_OVERSUB), which only the
+                     // late kernel's exact tables decode -- the plan then sizes once more with that kernel in the launch
 };
 
 // 16-bit mask of candidate positions base+0 .. base+15
@@ -545,6 +546,7 @@ __global__ __launch_bounds__(1024) void gz_chain_emit(const u64 *cand_pos, const
       if (!(h.flags & (HF_BC | HF_SIZED | HF_RANGE))) sum->stopped_unknown = 1;
     }
     if (h.flags & HF_RANGE) atomicOr(&sum->range_error, 1u);
+    if ((h.flags & HF_SIZED) && h.status == MS_OVERSUB) atomicAdd(&sum->oversub, 1u);
   }
   if (blockIdx.x == gridDim.x - 1 && tid == 0) {
     const bool first_ok = K > 0 && cand_pos[0] == start;

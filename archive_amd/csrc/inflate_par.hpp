@@ -937,8 +937,10 @@ AHIP_DEVINL void deposit16_sym(u16 *dp, u32 len, u64 w0, u64 w1, u64 w2, u64 w3)
 //            their own source or straddling the window start are copied by the whole wave when they are the first
 //            pending one (everything in front of their destination is final then).  Then the window goes to HBM with
 //            16-byte stores.
+// Returns false when a chunk could not be finished within its loop bound (cannot happen -- see process() -- but a bound that
+// fires must not drop tokens silently: the caller turns it into MS_INTERNAL).
 template <typename E>
-AHIP_DEVINL void resolve_member(ResLdsT<E> &P, const u8 *in, const u32 *area, const DirEnt *dir, u32 ndir, E *out_base, u32 *cyc,
+AHIP_DEVINL bool resolve_member(ResLdsT<E> &P, const u8 *in, const u32 *area, const DirEnt *dir, u32 ndir, E *out_base, u32 *cyc,
                                 int lane) {
   constexpr bool MARK = sizeof(E) == 2;
   constexpr u32 EPV = 16 / sizeof(E);        // elements per 16-byte vector
@@ -1120,6 +1122,7 @@ AHIP_DEVINL void resolve_member(ResLdsT<E> &P, const u8 *in, const u32 *area, co
     u32 wrel0; i32 cend; u64 inbm;  // (uniform) the window position it was classified against; end of the chunk's output rel. borg; ballot(inb)
   };
   u32 de = 0;
+  bool all_done = true;
   while (de < ndir) {
     RTICK(r_l0);
     const u32 ei = de + (u32)lane;
@@ -1196,13 +1199,17 @@ AHIP_DEVINL void resolve_member(ResLdsT<E> &P, const u8 *in, const u32 *area, co
     auto process = [&](Ck &c) {
       RSTAT(1, 1);
       u64 rem = c.inbm;
-      for (u32 guard = 0; guard < 300; ++guard) {  // (a pass after a flush always takes at least one token: never spins)
+      // (a pass after a flush always takes at least one token -- the window starts at its first byte then and a token is at
+      //  most 258 bytes --, so 64 passes and as many flushes are the most a chunk can need; the bound only keeps a broken
+      //  invariant from spinning, and reaching it is reported, not swallowed)
+      for (u32 guard = 0; guard < 300; ++guard) {
         if (rem) rem = pass(c, rem);
         if (!rem && wfill < WIN_FLUSH) break;
         flush();
         wrel = (u32)(wpos - borg);
         // sources that were fetched ahead stay valid (flushed output never changes); everything else is looked at again
       }
+      if (rem) all_done = false;
     };
     if (nplain == 0) {
       // ---- a special entry at the head of the look ----
@@ -1328,6 +1335,7 @@ AHIP_DEVINL void resolve_member(ResLdsT<E> &P, const u8 *in, const u32 *area, co
   if (wfill) flush();
   RTICK(r_end);
   RACC(7, r_begin, r_end);
+  return all_done;
 }
 
 }  // namespace ahip

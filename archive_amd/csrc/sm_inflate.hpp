@@ -324,7 +324,7 @@ __global__ __launch_bounds__(64) void sm_tokenize_kernel(const u8 *__restrict__ 
 __global__ __launch_bounds__(64) void sm_resolve_kernel(const u8 *__restrict__ in, u64 in_len, const ChunkDesc *__restrict__ chunks,
                                                        u32 n_chunks, u16 *sym, const u32 *__restrict__ tokens,
                                                        const DirEnt *__restrict__ dir, const MemberResult *__restrict__ results,
-                                                       const u64 *__restrict__ cand_bits, u32 n_cand, u32 lay_in) {
+                                                       const u64 *__restrict__ cand_bits, u32 n_cand, u32 lay_in, u32 *__restrict__ err) {
   __shared__ ResLdsT<u16> lds;
   const int lane = threadIdx.x;
   for (u32 k = blockIdx.x; k < n_chunks; k += gridDim.x) {
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(64) void sm_resolve_kernel(const u8 *__restrict__ i
     if (lay_in) sm_layout_in(cand_bits, n_cand, in_len, uniform(chunks[k].pad), toff, cc, doff, dc);
     else tok_layout(out_off, out_limit, k, toff, cc, doff, dc);
     u32 cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    resolve_member<u16>(lds, in, tokens + toff, dir + doff, ndir, sym + out_off, cyc, lane);
+    if (!resolve_member<u16>(lds, in, tokens + toff, dir + doff, ndir, sym + out_off, cyc, lane) && lane == 0) atomicAdd(err, 1u);  // (never silent)
   }
 }
 
