@@ -70,49 +70,18 @@ AHIP_DEVINL u32 wrap_item(u32 x) { return x >= (u32)ITEMS ? x - (u32)ITEMS : x; 
 // The decode step works on a STEP WORD: literal (0x8000 | byte) << 16 (negative), match len << 16 | dist
 // (len <= 258, dist <= 32768); anything else is not negative and has a zero distance field.
 constexpr u32 TK_LIT = 0x80000000u;  // | byte << 16
-// What is RECORDED is a SEQUENCE token of two words (LZ4's idea: the literals in front of a match travel with it) -- the
-// resolver spends its instructions per token, and on text a third of the symbols are literals, nearly all of them in
-// groups of one to three between two matches:
-//   x = end << 16 | payload
-//         end      the low 16 bits of the output bytes the token's RUN has produced up to and including this token -- the
-//                  recording lane counts them anyway; a token's length is end - (end of the token before it), its output
-//                  offset is the run's offset (directory) + the end before it;
-//         payload  dist - 1 (< 0x8000) for literals + MATCH; REC_LIT | n for a token of n = 1..4 literals and nothing else
-//                  (a fourth literal in a row, or the literals a run ends with);
-//   y = the literals, pushed in from below as they were decoded (the LAST one in the low byte); in a match token a
-//       sentinel 1 sits above them, so y = 1 means "no literals" and their number is (31 - clz(y)) / 8.
-// The match's length is the token's length minus its literals.  (What the fold costs the decode step: a shift-or per
-// literal, a compare, two selects and the wider store -- which a third of the steps no longer execute.)
+// What is RECORDED per token is  end << 16 | payload:
+//   end      the low 16 bits of the output bytes the token's RUN has produced up to and including this token -- the
+//            recording lane counts them anyway; a token's length is end - (end of the token before it), its output
+//            offset is the run's offset (directory) + the end before it;
+//   payload  0x8000 | byte for a literal, dist - 1 (< 0x8000) for a match.
 constexpr u32 REC_LIT = 0x8000u;
-constexpr u32 TOK_WORDS = 2;  // words per recorded token
-// The literals a recording lane is holding back for the match behind them: 1 (the sentinel) when there are none.
-struct SeqFold { u32 lits; };
-constexpr u32 FOLD_EMPTY = 1u, FOLD_FULL = 1u << 24;  // three literals are held when lits >= FOLD_FULL
-// One decoded symbol (a step word: literal / match) into the fold; true = a token (x, y) is complete.  end_bytes = the run's
-// output up to and including this symbol.  Straight-line on the device (selects).
-AHIP_DEVINL bool seq_feed(SeqFold &f, u32 step_word, u32 end_bytes, u32 &x, u32 &y) {
+AHIP_DEVINL u32 rec_word(u32 end_bytes, u32 step_word) {
   const bool lit = (i32)step_word < 0;
-  const u32 pushed = (f.lits << 8) | ((step_word >> 16) & 0xffu);
-  const bool out = !lit || f.lits >= FOLD_FULL;  // a match, or the fourth literal in a row (the sentinel drops out of `pushed`)
-  x = (end_bytes << 16) | (lit ? (REC_LIT | 4u) : ((step_word & 0xffffu) - 1u));
-  y = lit ? pushed : f.lits;
-  f.lits = out ? FOLD_EMPTY : pushed;
-  return out;
+  return (end_bytes << 16) | (lit ? (step_word >> 16) : (step_word & 0xffffu) - 1u);
 }
-// what a run ends with: the literals still held back, as a token of their own (false: none)
-AHIP_DEVINL bool seq_flush(SeqFold &f, u32 end_bytes, u32 &x, u32 &y) {
-  const bool out = f.lits != FOLD_EMPTY;
-  const u32 n = f.lits >= FOLD_FULL ? 3u : (f.lits >= (1u << 16) ? 2u : 1u);
-  x = (end_bytes << 16) | REC_LIT | n;
-  y = f.lits;  // (the sentinel above the n bytes is ignored by the reader)
-  f.lits = FOLD_EMPTY;
-  return out;
-}
-// what the resolver makes of a token: how many literals, and the literals in output order (the first one in the low byte)
-AHIP_DEVINL u32 seq_nlit(u32 x, u32 y) { return (x & REC_LIT) ? (x & 7u) : ((31u - (u32)__builtin_clz(y | 1u)) >> 3); }
-AHIP_DEVINL u32 seq_lits(u32 y, u32 n) { return n ? __builtin_bswap32(y) >> (8u * (4u - n)) : 0u; }
 // Run directory entry (16 bytes, stream order):
-//   x  word offset of the run's first token in the member's token area (even: tokens are two words, 8-byte aligned)
+//   x  word offset of the run's first token in the member's token area
 //   y  tokens of the run (DF_CNT) | flags
 //   z,w  output offset of the run's first byte, relative to the member's own first byte (64 bits)
 // DF_BIG: `end` may wrap inside the run (it produced more than 65535 bytes, or the serial decoder wrote it): lengths
@@ -165,8 +134,8 @@ struct TokSink {
 };
 // member k of a launch group whose output starts out_rel bytes into the group's output
 AHIP_DEVINL void tok_layout(u64 out_rel, u64 out_limit, u32 k, u64 &tok_off, u32 &col_cap, u64 &dir_off, u32 &dir_cap) {
-  tok_off = ((out_rel * 3) / 2 + (u64)k * 1024) & ~1ull;           // (tokens are 8-byte records)
-  col_cap = (u32)(((out_limit * 3) / 2 + 1023) / 64) & ~1u;
+  tok_off = (out_rel * 3) / 2 + (u64)k * 1024;
+  col_cap = (u32)(((out_limit * 3) / 2 + 1023) / 64);
   dir_off = out_rel / 16 + (u64)k * 64;
   dir_cap = (u32)(out_limit / 16 + 63);
 }
@@ -270,7 +239,7 @@ AHIP_DEVINL void sink_close(TokSink &k, u32 &colreg, int lane, u64 out_rel) {  /
   if (k.spos > k.srun) {
     if (k.ndir < k.dir_cap) {
       const u64 base = out_rel - k.sbytes;
-      if (lane == 0) k.dir[k.ndir] = make_uint4(k.srun, ((k.spos - k.srun) / TOK_WORDS) | DF_BIG, (u32)base, (u32)(base >> 32));
+      if (lane == 0) k.dir[k.ndir] = make_uint4(k.srun, (k.spos - k.srun) | DF_BIG, (u32)base, (u32)(base >> 32));
       k.ndir++;
     } else k.full = true;
   }
@@ -299,17 +268,12 @@ AHIP_DEVINL bool sink_room(TokSink &k, u32 &colreg, u32 words, int lane, u64 out
 }
 // one token: `step_word` as the decode step makes it (literal / match), `adv` the bytes it produces; out_rel = the
 // output offset in FRONT of it
-// (the serial writer does not fold: a literal is a token of one literal, a match a token without literals)
 AHIP_DEVINL void sink_put(TokSink &k, u32 &colreg, u32 step_word, u32 adv, int lane, u64 out_rel) {
   if (!k.area || k.full) return;
-  if (!sink_room(k, colreg, TOK_WORDS, lane, out_rel)) return;
+  if (!sink_room(k, colreg, 1, lane, out_rel)) return;
   k.sbytes += adv;
-  if (lane == 0) {
-    const bool lit = (i32)step_word < 0;
-    k.area[k.spos] = (k.sbytes << 16) | (lit ? (REC_LIT | 1u) : ((step_word & 0xffffu) - 1u));
-    k.area[k.spos + 1] = lit ? ((step_word >> 16) & 0xffu) : FOLD_EMPTY;  // (a match token's sentinel: no literals)
-  }
-  k.spos += TOK_WORDS;
+  if (lane == 0) k.area[k.spos] = rec_word(k.sbytes, step_word);
+  k.spos += 1;
 }
 
 // Serial decode of one Huffman block that EMITS tokens instead of writing bytes: the checked path
@@ -484,7 +448,6 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
     // lane state: ms = mode<<28 | item (mode 0 idle, 1 SPEC, 2 RUN)
     u32 ms = 0, bound = 0, start = 0, endp = 0, fl = 0, nbytes = 0, row0 = 0, myslot = 0;  // myslot: scoreboard slot of the lane's item
     u32 rowctr = colreg;  // words this lane has recorded into its column of the token area
-    SeqFold fold{FOLD_EMPTY};  // the literals the lane's run is holding back for the match behind them
     i32 need = 0;
     LaneBits d{0, 0, 0, 0, 2, 0};
     u32 *const col = sink.area + (u32)lane * sink.col_cap;  // this lane's column of the member's token area
@@ -587,7 +550,7 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
         wave_sync();
       }
       // a recording lane must not run out of column: the serial decoder takes over with what all columns have left
-      if (emit && !finishing && __any(rowctr + TOK_WORDS * ((u32)STEPS + 1) > sink.col_cap)) {  // (+ 1: the literals a run ends with)
+      if (emit && !finishing && __any(rowctr + (u32)STEPS > sink.col_cap)) {
         if (sink.sizing) { sink.full = true; give_up_tokens = true; stop_serial = true; }
         else { st.fallbacks++; st.dbg |= 32; stop_serial = true; }
       }
@@ -656,7 +619,7 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
             ms = (take_c ? 1u << 28 : 2u << 28) | s_new;
             myslot = slot_new;
             bound = (s_new + 1) * SUB;
-            start = st_new; endp = st_new; fl = 0; nbytes = 0; need = 0; row0 = rowctr; fold.lits = FOLD_EMPTY;
+            start = st_new; endp = st_new; fl = 0; nbytes = 0; need = 0; row0 = rowctr;
             // (the unit starts inside its item or, a repair / predicted start, less than 64 bits behind its end)
             lb_init(d, P.inbuf, st_new, wrap_ring(slot_new * (u32)SUB_DW + ((st_new - s_new * SUB) >> 5)));
             if (take_b) P.fa[slot_new] = 1u << 30;  // in flight
@@ -695,13 +658,11 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
             const i32 req = (i32)(t & 0xffff) - (i32)nbytes;  // (a literal has no distance: never positive)
             need = req > need ? req : need;
             nbytes += lit ? 1u : (t >> 16);
-            if (ms >> 29) {  // a recording run: literals wait for their match (three at most; a fourth takes them along)
-              u32 tx, ty;
-              if (seq_feed(fold, t, nbytes, tx, ty)) {
-                if (emit) *(uint2 *)(col + rowctr) = make_uint2(tx, ty);
-                rowctr += TOK_WORDS;
-              }
-            }
+#ifdef AHIP_ABL_NO_TOKSTORE  // dev ablation: what the token stores cost
+            if (ms >> 29) rowctr += 1;
+#else
+            if (ms >> 29) { if (emit) col[rowctr] = rec_word(nbytes, t); rowctr += 1; }
+#endif
           }
         }
         ++g;
@@ -723,15 +684,8 @@ AHIP_DEVINL u32 huffman_block_tokenize(WaveLds &L, TokLds &P, BitCursor &b, OutC
               const u32 nslot = wrap_item(myslot + 1);
               if (usable && (P.fa[nslot] >> 30) == 0u) P.fa[nslot] = (3u << 30) | (endp - bnd);
             } else {
-              {  // the literals the run ends with
-                u32 tx, ty;
-                if (seq_flush(fold, nbytes, tx, ty)) {
-                  if (emit) *(uint2 *)(col + rowctr) = make_uint2(tx, ty);
-                  rowctr += TOK_WORDS;
-                }
-              }
               P.fb[myslot] = row0;
-              P.fc[myslot] = nbytes | ((((rowctr - row0) / TOK_WORDS) & 0xfffu) << 20);
+              P.fc[myslot] = nbytes | (((rowctr - row0) & 0xfffu) << 20);
               P.need[myslot] = (u16)need;
               P.fa[myslot] = (2u << 30) | (fl << 28) | ((u32)lane << 22) | ((start - s * SUB) << 12) | (endp - s * SUB);
             }
@@ -1058,30 +1012,12 @@ AHIP_DEVINL bool resolve_member(ResLdsT<E> &P, const u8 *in, const u32 *area, co
       if (len <= 16) deposit16(dp, len, w0, w1);
     }
   };
-  // The literals of a token: n of the bytes in `w` (the first one in the low byte).  In front of a match (n <= 3) one store of
-  // four elements does it: what lies behind the literals is the lane's own match (>= 3 long), written afterwards -- now, or
-  // at the flush, its bytes marked pending until then.  A token of literals only stores exactly its 1..4.
-  auto store_lits = [&](E *dp, u32 w, u32 n, bool only) {
-    if constexpr (MARK) {
-      const u64 e = (u64)(w & 0xffu) | ((u64)(w & 0xff00u) << 8) | ((u64)(w & 0xff0000u) << 16) | ((u64)(w & 0xff000000u) << 24);  // bytes -> 16-bit symbols
-      if (!only) ((unaligned_u64 *)dp)->v = e & 0x0000ffffffffffffull;
-      else if (n == 4) ((unaligned_u64 *)dp)->v = e;
-      else {
-        if (n & 2) ((unaligned_u32 *)dp)->v = (u32)e;
-        if (n & 1) ((unaligned_u16 *)(dp + (n & 2)))->v = (u16)(e >> (16 * (n & 2)));
-      }
-    } else {
-      if (!only) ((unaligned_u32 *)dp)->v = w & 0x00ffffffu;
-      else if (n == 4) ((unaligned_u32 *)dp)->v = w;
-      else {
-        if (n & 2) ((unaligned_u16 *)dp)->v = (u16)w;
-        if (n & 1) dp[n & 2] = (u8)(w >> (8 * (n & 2)));
-      }
-    }
-  };
   // 16 (bytes: 16 + the last 16) source elements of a match whose source is flushed output at window index so (< 0);
   // symbols in front of the chunk are made up: markers count upwards like the bytes they stand for
   auto fetch = [&](i32 so, u32 len, u64 &w0, u64 &w1, u64 &w2, u64 &w3) {
+#ifdef AHIP_ABL_NO_FETCH  // dev ablation (wrong bytes): what the global source fetches cost
+    w0 = w1 = w2 = w3 = (u64)so + len; return;
+#endif
     if constexpr (MARK) {
       const i64 ab = (i64)wpos + so;
       if (ab < 0) {
@@ -1092,7 +1028,11 @@ AHIP_DEVINL bool resolve_member(ResLdsT<E> &P, const u8 *in, const u32 *area, co
         w0 = load_u64_unaligned(sp); w1 = load_u64_unaligned(sp + 8); w2 = load_u64_unaligned(sp + 16); w3 = load_u64_unaligned(sp + 24);
       }
     } else {
+#ifdef AHIP_ABL_FETCH_NEAR  // dev ablation (wrong bytes): every source fetch from the member's first 4 KiB -- L2 hits only
+      const u8 *sp = (const u8 *)(out_base + ((wpos + so) & 4095));
+#else
       const u8 *sp = (const u8 *)(out_base + wpos + so);
+#endif
       w0 = load_u64_unaligned(sp);
       w1 = load_u64_unaligned(sp + 8);
       if (len > 16) { w2 = load_u64_unaligned(sp + len - 16); w3 = load_u64_unaligned(sp + len - 8); }
@@ -1111,6 +1051,9 @@ AHIP_DEVINL bool resolve_member(ResLdsT<E> &P, const u8 *in, const u32 *area, co
     return g;
   };
   auto resolve_pending = [&]() {
+#ifdef AHIP_ABL_NO_ROUNDS  // dev ablation (wrong bytes; tools/ablate.py): what the rounds cost
+    npend = 0; return;
+#endif
     RTICK(r_r0);
     E *const ob = P.obuf + A;
     wave_sync();
@@ -1170,6 +1113,7 @@ AHIP_DEVINL bool resolve_member(ResLdsT<E> &P, const u8 *in, const u32 *area, co
     E *g = out_base + wpos;
     u32 head = (EPV - A) & (EPV - 1);
     if (head > wfill) head = wfill;
+#ifndef AHIP_ABL_NO_FLUSH  // dev ablation (wrong bytes): what writing the window out costs
     if ((u32)lane < head) g[lane] = P.obuf[A + lane];
     const u32 body = (wfill - head) & ~(EPV - 1);
     const uint4 *src = (const uint4 *)(P.obuf + A + head);
@@ -1177,6 +1121,7 @@ AHIP_DEVINL bool resolve_member(ResLdsT<E> &P, const u8 *in, const u32 *area, co
     for (u32 i = lane; i < body / EPV; i += 64) dst[i] = src[i];
     const u32 tail0 = head + body;
     if (tail0 + lane < wfill) g[tail0 + lane] = P.obuf[A + tail0 + lane];
+#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // later matches read this output back
     wave_sync();
     wpos += wfill;
@@ -1185,9 +1130,9 @@ AHIP_DEVINL bool resolve_member(ResLdsT<E> &P, const u8 *in, const u32 *area, co
     RTICK(r_f1);
     RACC(6, r_f0, r_f1);
   };
-  struct Tok { u32 t, u; i32 base; bool first, inb; u32 nin; };  // a chunk's tokens as loaded: the two words, run offset (rel. borg); nin = lanes in the look
+  struct Tok { u32 t; i32 base; bool first, inb; u32 nin; };  // a chunk's tokens as loaded: word, run offset (rel. borg); nin = lanes in the look
   struct Ck {  // ... decoded
-    u32 t, u, len; i32 ob;  // len: literals + match; ob = output offset of the token's first byte rel. borg
+    u32 t, len; i32 ob;  // ob = output offset rel. borg
     bool inb, pre, gc;   // pre: the source bytes are in w0..w3; gc: classified "deposit now" when prepared
     u64 w0, w1, w2, w3;
     u32 wrel0; i32 cend; u64 inbm;  // (uniform) the window position it was classified against; end of the chunk's output rel. borg; ballot(inb)
@@ -1209,18 +1154,15 @@ AHIP_DEVINL bool resolve_member(ResLdsT<E> &P, const u8 *in, const u32 *area, co
     //      returns the rest (the caller flushes and comes back) ----
     auto pass = [&](Ck &c, u64 rem) -> u64 {
       RTICK(r_p0);
-      const bool lit = (c.t & REC_LIT) != 0;  // literals only
-      const u32 nlit = c.inb ? seq_nlit(c.t, c.u) : 0u;
-      const u32 mlen = c.len - nlit;     // the match's length (0: none)
+      const bool lit = (c.t & REC_LIT) != 0;
       const u32 dist = (c.t & 0x7fffu) + 1u;
       const bool isM = c.inb && !lit;
-      const i32 wo = c.ob - (i32)wrel;   // window index of the token's first byte: its literals, then the match
-      const i32 wm = wo + (i32)nlit;     // ... of the match's destination
-      const i32 so = wm - (i32)dist;     // window index of the source (negative: flushed output)
+      const i32 wo = c.ob - (i32)wrel;  // window index of the destination
+      const i32 so = wo - (i32)dist;    // window index of the source (negative: flushed output)
       // A match is deposited right here when deposit_now() says so; everything else is deferred to the flush.
       bool Gc = c.gc;  // as classified when the chunk was prepared ...
       RSTAT(2, 1);
-      if (wrel != c.wrel0) { RSTAT(10, 1); Gc = deposit_now(isM, mlen, dist, so); }  // ... unless the window has moved since
+      if (wrel != c.wrel0) { RSTAT(10, 1); Gc = deposit_now(isM, c.len, dist, so); }  // ... unless the window has moved since
       const bool defer_ = isM && !Gc;
       bool fit = c.inb;
       const bool whole = rem == c.inbm && (u32)(c.cend - (i32)wrel) <= WIN_CAP && npend + 64 <= PEND_CAP;
@@ -1237,7 +1179,7 @@ AHIP_DEVINL bool resolve_member(ResLdsT<E> &P, const u8 *in, const u32 *area, co
       const u64 fm = __ballot(fit);
       if (!fm) return rem;
       E *const ob = P.obuf + A;
-      if (fit && nlit) store_lits(ob + wo, seq_lits(c.u, nlit), nlit, lit);
+      if (fit && lit) ob[wo] = (E)(u8)c.t;
       const bool G = fit && Gc;
       const bool D = fit && defer_;
       // flushed sources that were not fetched ahead (the window was flushed after the chunk was prepared): fetched
@@ -1246,20 +1188,26 @@ AHIP_DEVINL bool resolve_member(ResLdsT<E> &P, const u8 *in, const u32 *area, co
       if (wrel != c.wrel0 && __any(late)) {
         RSTAT(4, 1);
         if (late) {
-          fetch(so, mlen, c.w0, c.w1, c.w2, c.w3);
+          fetch(so, c.len, c.w0, c.w1, c.w2, c.w3);
           c.pre = true;
         }
         AHIP_PIN(c.w0); AHIP_PIN(c.w1); AHIP_PIN(c.w2); AHIP_PIN(c.w3);
       }
-      if (G) store_match(ob + wm, mlen, c.w0, c.w1, c.w2, c.w3);
+#ifndef AHIP_ABL_NO_DEPOSIT  // dev ablation (wrong bytes): what the deposits of fetched matches cost
+      if (G) store_match(ob + wo, c.len, c.w0, c.w1, c.w2, c.w3);
+#endif
       const u64 dm = __ballot(D);
 #ifdef AHIP_RES_STATS
-      { const u64 gm_ = __ballot(G); u32 nl_; (void)wave_excl_sum(fit ? nlit : 0u, nl_); RSTAT(5, __popcll(dm)); RSTAT(11, __popcll(gm_)); RSTAT(12, nl_); }
+      { const u64 gm_ = __ballot(G), lm_ = __ballot(fit && lit); RSTAT(5, __popcll(dm)); RSTAT(11, __popcll(gm_)); RSTAT(12, __popcll(lm_)); }
 #endif
+#ifdef AHIP_ABL_NO_DEFER  // dev ablation (wrong bytes): what the deferral bookkeeping (list + marks) and the rounds cost together
+      if (false) {
+#else
       if (dm) {
+#endif
         if (D) {
-          P.plist[npend + (u32)__popcll(dm & ((1ull << lane) - 1))] = make_uint2((u32)wm | (mlen << 16), dist);
-          mark((u32)wm, mlen, true);
+          P.plist[npend + (u32)__popcll(dm & ((1ull << lane) - 1))] = make_uint2((u32)wo | (c.len << 16), dist);
+          mark((u32)wo, c.len, true);
         }
         npend += (u32)__popcll(dm);
       }
@@ -1304,8 +1252,7 @@ AHIP_DEVINL bool resolve_member(ResLdsT<E> &P, const u8 *in, const u32 *area, co
         for (u32 c0 = 0; c0 < cnt; c0 += 64) {
           Ck c;
           c.inb = c0 + (u32)lane < cnt;
-          const uint2 tv = c.inb ? *(const uint2 *)(area + x + TOK_WORDS * (c0 + lane)) : make_uint2(0u, 0u);
-          c.t = tv.x; c.u = tv.y;
+          c.t = c.inb ? area[x + c0 + lane] : 0u;
           const u32 end = c.t >> 16;
           u32 pe = lane_prev(end);
           pe = lane == 0 ? carry_end : pe;
@@ -1340,7 +1287,7 @@ AHIP_DEVINL bool resolve_member(ResLdsT<E> &P, const u8 *in, const u32 *area, co
     for (u32 i = lane; i < LOOK_TOK / 32 + 4; i += 64) P.rbits[i] = 0;
     wave_sync();
     if (rmine) {
-      P.rtab[lane] = make_uint2(dv.x - TOK_WORDS * ts, (u32)rb);
+      P.rtab[lane] = make_uint2(dv.x - ts, (u32)rb);
       atomicOr(&P.rbits[ts >> 5], 1u << (ts & 31));
     }
     wave_sync();
@@ -1362,8 +1309,8 @@ AHIP_DEVINL bool resolve_member(ResLdsT<E> &P, const u8 *in, const u32 *area, co
       q.first = (bits >> lane) & 1;
       const uint2 e = P.rtab[r & 63u];
       q.base = (i32)e.y;
-      const uint2 tv = *(const uint2 *)(area + (q.inb ? e.x + TOK_WORDS * idx : 0u));  // (no branch around the load and no use of it
-      q.t = tv.x; q.u = tv.y;              //  here: it stays in flight; lanes outside the look read some token, which `inb` keeps anyone from using)
+      q.t = area[q.inb ? e.x + idx : 0u];  // (no branch around the load and no use of it here: it stays in flight; lanes
+                                           //  outside the look read some token, which `inb` keeps anyone from using)
       RTICK(r_g1);
       RACC(1, r_g0, r_g1);
       return q;
@@ -1372,7 +1319,7 @@ AHIP_DEVINL bool resolve_member(ResLdsT<E> &P, const u8 *in, const u32 *area, co
     auto prep = [&](const Tok &q) -> Ck {
       RTICK(r_q0);
       Ck c;
-      c.t = q.t; c.u = q.u;
+      c.t = q.t;
       c.inb = q.inb;
       const u32 end = q.t >> 16;
       u32 pe = lane_prev(end);
@@ -1382,17 +1329,15 @@ AHIP_DEVINL bool resolve_member(ResLdsT<E> &P, const u8 *in, const u32 *area, co
       c.len = q.inb ? end - pe : 0u;
       c.ob = q.base + (i32)pe;
       const bool lit = (q.t & REC_LIT) != 0;
-      const u32 nlit = seq_nlit(q.t, q.u);
-      const u32 mlen = c.len - (q.inb ? nlit : 0u);
       const u32 dist = (q.t & 0x7fffu) + 1u;
-      const i32 so = c.ob + (i32)nlit - (i32)wrel - (i32)dist;  // against the window as it is NOW: what is flushed stays flushed
-      c.gc = deposit_now(q.inb && !lit, mlen, dist, so);
+      const i32 so = c.ob - (i32)wrel - (i32)dist;  // against the window as it is NOW: what is flushed stays flushed
+      c.gc = deposit_now(q.inb && !lit, c.len, dist, so);
       c.pre = c.gc;
       c.wrel0 = wrel;
       c.inbm = q.nin >= 64 ? ~0ull : (1ull << q.nin) - 1;
       c.cend = (i32)lane_bcast((u32)c.ob + c.len, (int)q.nin - 1);
       c.w0 = c.w1 = c.w2 = c.w3 = 0;  // (also ends the live range of the previous chunk's registers)
-      if (c.pre) fetch(so, mlen, c.w0, c.w1, c.w2, c.w3);
+      if (c.pre) fetch(so, c.len, c.w0, c.w1, c.w2, c.w3);
       RTICK(r_q1);
       RACC(2, r_q0, r_q1);
       return c;

@@ -51,7 +51,7 @@ int main(int argc, char **argv) {
   fseek(f, 0, SEEK_END); n_ = ftell(f); fseek(f, 0, SEEK_SET);
   std::vector<uint8_t> buf(n_ + 64, 0); if (fread(buf.data(), 1, n_, f) != n_) return 2; in_ = buf.data();
   std::vector<uint8_t> out, ref;
-  size_t pos = 0, members = 0; uint64_t toks_total = 0, stored_recs = 0, runs_total = 0, markers_total = 0, seq_tokens = 0;
+  size_t pos = 0, members = 0; uint64_t toks_total = 0, stored_recs = 0, runs_total = 0, markers_total = 0;
   while (pos + 18 <= n_ && in_[pos] == 0x1f && in_[pos + 1] == 0x8b) {
     int flg = in_[pos + 3]; size_t q = pos + 10;
     if (flg & 4) q += 2 + in_[q] + 256 * in_[q + 1];
@@ -125,7 +125,7 @@ int main(int argc, char **argv) {
       while (ri < rec_at.size() && rec_at[ri] < t) ++ri;
       if (ri < rec_at.size() && rec_at[ri] == t) {  // stored block
         const uint32_t len = tok[t] & 0xffffu;
-        area.resize(area.size() + 2 * ((seed >> 4) % 4), 0xdeadbeefu);
+        area.resize(area.size() + (seed >> 4) % 7, 0xdeadbeefu);
         dir.push_back(make_uint4((unsigned)area.size(), len | DF_STORED, (unsigned)opos, (unsigned)(opos >> 32)));
         area.push_back(tok[t + 1]); area.push_back(tok[t + 2]);
         opos += len; t += 3;
@@ -133,25 +133,16 @@ int main(int argc, char **argv) {
       }
       size_t want = 1 + (seed >> 8) % ((seed >> 28) == 0 ? 400 : 90), end = t + want < tok.size() ? t + want : tok.size();
       if (ri < rec_at.size() && rec_at[ri] < end) end = rec_at[ri];
-      area.resize(area.size() + 2 * ((seed >> 4) % 4), 0xdeadbeefu);  // a gap (tokens are two words, 8-byte aligned)
+      area.resize(area.size() + (seed >> 4) % 7, 0xdeadbeefu);  // a gap
       const size_t a0 = area.size();
       uint64_t bytes = 0;
-      // sequence tokens like the flow tokenizer folds them (<= 3 literals travel with the match behind them, a fourth makes a
-      // token of four, a run ends with a token of what is left) -- or, for one run in four, the way the serial writer emits:
-      // every symbol a token of its own
-      const bool unfolded = ((seed >> 12) & 3) == 0;
-      SeqFold fold{FOLD_EMPTY};
-      u32 tx, ty;
       for (size_t i = t; i < end; ++i) {
         const uint32_t w = tok[i];
         bytes += (int32_t)w < 0 ? 1u : (w >> 16);
-        if (seq_feed(fold, w, (u32)bytes, tx, ty)) { area.push_back(tx); area.push_back(ty); }
-        else if (unfolded && seq_flush(fold, (u32)bytes, tx, ty)) { area.push_back(tx); area.push_back(ty); }
+        area.push_back(rec_word((u32)bytes, w));
       }
-      if (seq_flush(fold, (u32)bytes, tx, ty)) { area.push_back(tx); area.push_back(ty); }
       const bool big = bytes > 0xffffu || ((seed >> 20) & 7) == 0;
-      dir.push_back(make_uint4((unsigned)a0, (unsigned)((area.size() - a0) / 2) | (big ? DF_BIG : 0u), (unsigned)opos, (unsigned)(opos >> 32)));
-      seq_tokens += (area.size() - a0) / 2;
+      dir.push_back(make_uint4((unsigned)a0, (unsigned)(end - t) | (big ? DF_BIG : 0u), (unsigned)opos, (unsigned)(opos >> 32)));
       opos += bytes;
       t = end;
     }
@@ -179,7 +170,7 @@ int main(int argc, char **argv) {
   }
   const char *what = sizeof(Elem) == 2 ? "token-centric resolver, 16-bit symbols" : "token-centric resolver";
   if (sizeof(Elem) == 2) printf("markers checked: %llu\n", (unsigned long long)markers_total);
-  printf("resolver emu ok [%s]: %zu members, %zu bytes, %llu symbols as %llu sequence tokens in %llu runs, %llu stored records\n", what, members, ref.size(),
-         (unsigned long long)toks_total, (unsigned long long)seq_tokens, (unsigned long long)runs_total, (unsigned long long)stored_recs);
+  printf("resolver emu ok [%s]: %zu members, %zu bytes, %llu token words in %llu runs, %llu stored records\n", what, members, ref.size(),
+         (unsigned long long)toks_total, (unsigned long long)runs_total, (unsigned long long)stored_recs);
   return members ? 0 : 7;
 }
