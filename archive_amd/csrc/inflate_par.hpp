@@ -1073,11 +1073,21 @@ AHIP_DEVINL bool resolve_member(ResLdsT<E> &P, const u8 *in, const u32 *area, co
         const u64 pend = __ballot(pl);
         if (!pend) break;
         RSTAT(8, 1);
-        // marks over the source, and the source bytes themselves, in one LDS round trip
-        const u32 m0 = P.pmap[sa >> 5], m1 = P.pmap[(sa >> 5) + 1];
-        const u8 *sb = (const u8 *)(ob + sa), *sb2 = MARK ? sb + 16 : (const u8 *)(ob + sa2);  // symbols: one piece of 32 bytes
-        const u64 w0 = ((const unaligned_u64 *)sb)->v, w1 = ((const unaligned_u64 *)(sb + 8))->v;
-        const u64 w2 = ((const unaligned_u64 *)sb2)->v, w3 = ((const unaligned_u64 *)(sb2 + 8))->v;
+        // marks over the source, and the source bytes themselves, in one LDS round trip -- by the lanes that still wait
+        // only: the resolver's deferred side is bound by LDS cycles (SQ_LDS_IDX_ACTIVE 78 % of the kernel, three fifths of
+        // them in these rounds, profiles/r05_experiments.md), a round serves nine lanes on average, and an unaligned
+        // 8-byte access costs its cycles per ACTIVE lane
+        u32 m0 = ~0u, m1 = ~0u;
+        u64 w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+#ifndef AHIP_ROUNDS_ALL_LANES
+        if (pl && simple)
+#endif
+        {
+          m0 = P.pmap[sa >> 5]; m1 = P.pmap[(sa >> 5) + 1];
+          const u8 *sb = (const u8 *)(ob + sa), *sb2 = MARK ? sb + 16 : (const u8 *)(ob + sa2);  // symbols: one piece of 32 bytes
+          w0 = ((const unaligned_u64 *)sb)->v; w1 = ((const unaligned_u64 *)(sb + 8))->v;
+          w2 = ((const unaligned_u64 *)sb2)->v; w3 = ((const unaligned_u64 *)(sb2 + 8))->v;
+        }
         const u64 marks = ((((u64)m1 << 32) | m0) >> (sa & 31)) & lmask;
         const bool act = pl && simple && marks == 0;
         const int f = __builtin_ctzll(pend);
