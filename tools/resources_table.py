@@ -12,7 +12,7 @@ import sys
 
 def demangle(names):
     try:
-        out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
+        out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
         return [o if o else n for o, n in zip(out, names)]
     except Exception:
         return names
