@@ -1,31 +1,43 @@
-// deflate_kernels.hpp -- DEFLATE encoder on gfx950 (first correct version).
+// deflate_kernels.hpp -- DEFLATE encoder on gfx950.
 //
 // The reference encoder (/root/reference/lib/src/codecs/zlib/deflate.dart) is one sequential
 // pass: hash-chain LZ77 with lazy matching (_deflateSlow :997-1118, _longestMatch :1120-1206),
 // a symbol buffer (_trTally :531-568) and per-block Huffman coding (_trFlushBlock :747-807,
 // _buildTree :2656, _compressBlock :571-614, _sendBits :487-499).  Its output bytes are not pinned
 // by any reference test; what must hold is (a) the stream inflates to the input through the
-// reference's Inflate and (b) the size stays within a stated tolerance of the reference's.
+// reference's Inflate and (b) the size stays within a stated tolerance of the reference's
+// (<= + 5 % on the benchmark corpora at levels 1 / 6 / 9).
 //
 // Here the input is cut into independent 32 KiB chunks (each may still reference the 32 KiB of
 // raw input before it) and every chunk becomes one DEFLATE block, closed -- except the last --
 // by an empty stored block so that it ends on a byte boundary (the Z_SYNC_FLUSH marker the
 // reference itself emits through _trStoredBlock(0, 0, false), deflate.dart:219):
 //
-//   D1 deflate_match_kernel   one workgroup per chunk.  Sliding window (36 KiB ring) and a 4-way bucketed
-//                             hash of 4-byte strings in LDS; positions are processed 256 at a time
-//                             (probe, then insert), so every probe sees exactly the strings before
-//                             its own sub-block.  Best (len, dist) per position goes to scratch.
+//   D1 deflate_match_kernel   persistent workgroups (one per CU at levels 4-9: 1 024 threads and the CU's whole LDS),
+//                             each taking a run of consecutive chunks.  The sliding window is a 36 KiB ring in LDS;
+//                             the reference's hash-chain DEPTH (128 / 4 096 candidates) is replaced by CONTEXT: a
+//                             4-way bucketed hash of 4-byte strings (the four most recent occurrences) plus one-way
+//                             tables keyed by the hash of the 8- and of the 16-byte string at the position.  A step
+//                             probes, then inserts, one position per thread; all seven candidates are verified and
+//                             extended together, 8 bytes per LDS round trip, to 32 bytes (ties go on to nice_length).
+//                             Insertion is an LDS atomicMax on a key that orders positions (the lowest position of
+//                             the youngest step wins): two encodes of the same input are byte-identical.  The tables
+//                             are carried from chunk to chunk (the window of chunk c + 1 is the window of chunk c moved
+//                             on by 32 KiB).  Best (len, dist) per position goes to scratch.
 //   D2 deflate_parse_kernel   one wave per chunk follows the reference's one-step lazy rule as the
 //                             orbit of position 0 (scalar hops over a 64-position block) and writes
-//                             the token list.
+//                             the token list; a capped match the parse lands on is extended by the whole wave.
 //   D3 deflate_encode_kernel  one workgroup per chunk: symbol histogram (LDS atomics), zlib's
 //                             heap Huffman construction with the 15/7-bit limit (restated from
-//                             deflate.dart:2567-2784, run by one lane), dynamic header, then the
+//                             deflate.dart:2567-2784, run by one lane), the dynamic header's code-length
+//                             tokens by the whole workgroup (df_cl_tokens: what the reference's run-length state
+//                             machine makes of a run of L equal lengths is a closed form), then the block's
 //                             tokens 256 at a time: workgroup prefix sum of code lengths -> bit
 //                             offsets -> atomicOr into the LDS output image.  A chunk that does
 //                             not shrink is emitted as a stored block.
 //   D4 deflate_concat_kernel  exclusive scan of chunk sizes (host) -> byte-granular gather.
+// Measured (config 3, 1 GiB of log text, level 6): 36 ms = 29.8 GB/s in, match 23.1 / parse 6.3 / encode 6.4 ms
+// (profiles/r04_df_kernel_stats.md; unchanged in round 5).
 #pragma once
 #include "common.hpp"
 
@@ -33,12 +45,12 @@ namespace ahip {
 
 constexpr u32 DF_CHUNK = 32768;          // bytes per chunk = one DEFLATE block
 constexpr u32 DF_SLAB = DF_CHUNK + 512;  // per-chunk output slab (a stored block needs CHUNK + 5 + flush)
-// Hash table shape per level group (the reference's level table, deflate.dart:1253-1272, trades chain
-// depth for speed; here the knob is how many window positions the LDS table can index -- measured on the
-// benchmark text, compressed size follows the ENTRY COUNT, not the associativity):
-//   levels 1-3: 4096 x 2 ( 8 K entries, 16 KiB, three workgroups per CU)   fastest
-//   levels 4-6: 4096 x 4 (16 K entries, 32 KiB, two workgroups per CU)
-//   levels 7-9: 8192 x 4 (32 K entries, 64 KiB, one workgroup per CU)      every window position indexed
+// Table shapes per level group (the reference's level table, deflate.dart:1253-1272, trades chain depth for speed; here
+// the knob is what the LDS tables can index -- compressed size follows the ENTRY COUNT and the context length, not the
+// associativity).  The instances archive_hip.hip launches (deflate_match_kernel<HASH_BITS, WAYS, LA, LB, SUB>):
+//   levels 1-3: 4 096 buckets x 2 ways, no long-context tables, 256 positions a step (three workgroups per CU)
+//   levels 4-7: 8 192 x 4 + 16 384 / 8 192 entries keyed by the 8- / 16-byte string, 1 024 positions a step (one workgroup per CU)
+//   levels 8-9: the same tables, 512 positions a step (closer candidates are seen; AHIP_DF_SUB512=1 selects it for all levels)
 constexpr u32 DF_MINLEN = 4;             // 4-byte hash: 3-byte matches are not searched
 constexpr u32 DF_EMPTY = 0;              // a table slot nobody wrote
 #ifndef AHIP_DF_CAP

@@ -22,7 +22,8 @@ def _binary(variant):
     deps = [src, os.path.join(ROOT, "tests", "emu", "wave_emu.hpp")] + [os.path.join(ROOT, "archive_amd", "csrc", f)
                                                                         for f in ("common.hpp", "inflate_wave.hpp", "inflate_par.hpp")]
     if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps):
-        cmd = ["g++", "-std=c++17", "-O2", "-pthread", "-o", exe, src] + (["-DAHIP_TOKEN_RESOLVER"] if variant == "tokres" else [])
+        # ("all_lanes": the rounds of the resolver read for every lane, as before round 5 -- the masked reads must change nothing)
+        cmd = ["g++", "-std=c++17", "-O2", "-pthread", "-o", exe, src] + (["-DAHIP_ROUNDS_ALL_LANES"] if variant == "all_lanes" else [])
         subprocess.check_call(cmd)
     return exe
 
@@ -43,7 +44,7 @@ def _parts():
     ]
 
 
-@pytest.mark.parametrize("variant", ["production", "tokres"])
+@pytest.mark.parametrize("variant", ["production", "all_lanes"])
 def test_device_path_on_the_cpu(tmp_path, variant):
     exe = _binary(variant)
     parts = _parts()
