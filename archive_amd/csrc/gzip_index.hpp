@@ -466,6 +466,12 @@ __global__ __launch_bounds__(1024) void gz_chain_fix(const u64 *cand_pos, u32 K,
     for (u32 r = 0; r < n_skip; ++r)
       for (u32 i = skip_lo[r] + tid; i < skip_hi[r]; i += 1024) reach[i] = 0;
   } else {
+    // (the first build of a stream WITHOUT size hints: no member's end is known, every candidate is an "exception" and the
+    //  chain stops at candidate 0 -- nothing to double over; 0.29 ms of every such decode, profiles/r04_nobc_kernel_stats.md)
+    if (nxt[0] >= K) {
+      for (u32 i = tid; i <= K; i += 1024) reach[i] = (i == 0) ? 1u : 0u;
+      return;
+    }
     for (u32 i = tid; i <= K; i += 1024) { jmp[i] = nxt[i]; reach[i] = (i == 0) ? 1u : 0u; }
     if (tid == 0) jmp2[K] = K;
     __syncthreads();
