@@ -131,3 +131,27 @@ def test_oracle_large_multimember():
     st, out = orc.gzip_decode(bytes(comp), cap=len(plain) + 16)
     assert st == 0 and out == bytes(plain)
     assert gzip.decompress(bytes(comp)) == bytes(plain)
+
+
+def test_stream_position_after_decodestream():
+    """Where decodeStream leaves its InputStream (what ahip_last_consumed is held against on the GPU): all of it when it
+    returns true; on `false` where the failing check stood -- two header bytes in (method / FCHECK), behind the four bytes of
+    a dictionary id, behind the Adler-32 that did not match (_zlib_decoder_web.dart:53-99); the gzip decoder rewinds to the
+    start of what is not a gzip header before it hands over to the zlib one (_gzip_decoder_web.dart:31-37)."""
+    import zlib
+
+    from oracle import pyoracle as orc
+    from tests import streams
+    a, b = streams.text(3000, 3), streams.text(4000, 4)
+    za, zb = zlib.compress(a), zlib.compress(b)
+    assert orc.zlib_decode(za + zb, verify=True) == (0, a + b) and orc.last_position() == len(za + zb)
+    assert orc.zlib_decode(za + b"\x77\x01" + zb)[0] == 1 and orc.last_position() == len(za) + 2      # method
+    assert orc.zlib_decode(za + b"\x78\x02" + zb)[0] == 1 and orc.last_position() == len(za) + 2      # FCHECK
+    assert orc.zlib_decode(za + b"\x78\x20" + zb)[0] == 1 and orc.last_position() == len(za) + 6      # FDICT: + readUint32
+    bad = bytearray(za + zb)
+    bad[len(za) - 1] ^= 1                                                                           # first member's Adler-32
+    assert orc.zlib_decode(bytes(bad), verify=True)[0] == 1 and orc.last_position() == len(za)
+    g = streams.gz_member(a) + streams.gz_member(b)
+    assert orc.gzip_decode(g) == (0, a + b) and orc.last_position() == len(g)
+    assert orc.gzip_decode(g + b"junk")[0] == 1 and orc.last_position() == len(g) + 2                 # zlib fallback: `ju` is no header
+    assert orc.gzip_decode(g + za)[0] == 0 and orc.last_position() == len(g) + len(za)               # ... a zlib stream behind gzip members is decoded
