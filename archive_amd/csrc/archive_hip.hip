@@ -1026,6 +1026,11 @@ static int32_t adler32_device_impl(const u8 *d, size_t n, u32 adler0, u32 *out, 
 }
 
 // ---- one long stream on many waves (sm_inflate.hpp) ----
+static u32 sm_translate_blocks() {  // workgroups per chunk of sm_translate_kernel (AHIP_SM_TBLOCKS: tuning)
+  static u32 v = 0;
+  if (!v) { const char *e = getenv("AHIP_SM_TBLOCKS"); v = e && atoi(e) > 0 ? (u32)atoi(e) : 4u; }
+  return v;
+}
 u64 sm_min_bytes() {
   static u64 v = 0;
   if (!v) { const char *e = getenv("AHIP_SM_MIN"); v = e && atoll(e) > 0 ? (u64)atoll(e) : (2ull << 20); }
@@ -1234,7 +1239,7 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
     hipLaunchKernelGGL(sm_windows_apply, dim3(8, nch), dim3(256), 0, st, gs, dwsym.as<u16>(), dgwin.as<u8>(), dwin.as<u8>(),
                        (const u8 *)d_out - SM_WINDOW, hist0);
   }
-  hipLaunchKernelGGL(sm_translate_kernel, dim3(32, nch), dim3(256), 0, st, dchunks.as<ChunkDesc>(), dres.as<MemberResult>(), dsym.as<u16>(),
+  hipLaunchKernelGGL(sm_translate_kernel, dim3(sm_translate_blocks(), nch), dim3(256), 0, st, dchunks.as<ChunkDesc>(), dres.as<MemberResult>(), dsym.as<u16>(),
                      dwin.as<u8>(), d_out, (const u8 *)d_out - SM_WINDOW, hist0);
   u32 res_err = 0;
   HIP_TRY(hipMemcpyAsync(&res_err, derr.p, 4, hipMemcpyDeviceToHost, st));
@@ -1833,8 +1838,8 @@ static int32_t deflate_device_impl(const u8 *d_in, size_t n, int level, int wind
     double s[8] = {0};
     for (u32 c = 0; c < P.chunks; ++c) for (int k = 0; k < 8; ++k) s[k] += pc[(size_t)c * 8 + k] * 16.0;
     fprintf(stderr, "[ahip] match kernel cycles per chunk (wave 0): pre-sync %.0f  barriers+insert %.0f  verify %.0f  compare %.0f  "
-            "post-sync total %.0f  search loop %.0f\n", s[0] / P.chunks, s[1] / P.chunks, s[2] / P.chunks, s[3] / P.chunks,
-            s[4] / P.chunks, s[5] / P.chunks);
+            "post-sync total %.0f  search loop %.0f  (compare, first pass alone %.0f)\n", s[0] / P.chunks, s[1] / P.chunks, s[2] / P.chunks, s[3] / P.chunks,
+            s[4] / P.chunks, s[5] / P.chunks, s[6] / P.chunks);
   }
 #endif
   hipLaunchKernelGGL(deflate_parse_kernel, dim3(P.chunks), dim3(64), 0, st, d_in, P, b_match.as<u32>(), b_tok.as<u32>(),

@@ -121,29 +121,80 @@ AHIP_DEVINL u64 df_rd8(const u32 *ring, u32 r) {
 #endif
 // Lengths of up to NW candidate matches at once.  rc[k] = ring offset of candidate k (alive[k]: there is one;
 // a bucket-mate that does not even share 4 bytes ends with len < 4).  The candidates advance together, 8 bytes per round, so one
-// round costs ONE LDS round trip for all of them -- the kernel is bound by dependent LDS latency (two waves
-// per SIMD), not by LDS bandwidth.
+// round costs ONE LDS round trip for all of them.  The kernel issues VALU 84 % of the time (profiles/r05_experiments.md section 6)
+// and three quarters of that is this loop, so a round is written for its instruction count: a candidate is a dword-aligned
+// LDS address and a byte shift, both fixed (a round moves every address by 8); "alive" is a lane mask in a register (no
+// branches around the candidates: dead ones compute along, masking them per lane or per candidate with a wave vote was
+// measured slower); the first differing byte of 8 is v_ffbl on the two XORed dwords -- which answers -1 = "none" for
+// equal dwords, so min3 with the bytes that are left needs no compare.  The lengths are what the straightforward loop gives.
+AHIP_DEVINL u32 df_ffbl(u32 x) {  // v_ffbl_b32: index of the lowest set bit, 0xffffffff for 0 (__builtin_ctz(0) is undefined)
+  u32 r;
+  asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+typedef const u32 __attribute__((address_space(3))) *df_lds_u32p;
+#ifndef AHIP_DF_ROUND
+#define AHIP_DF_ROUND 8
+#endif
+constexpr u32 DF_ROUND = AHIP_DF_ROUND;  // bytes compared per round: 8 or 16 (the lengths are the same).  16 halves what is paid per round, but most
+                                         // waves are done after one or two rounds of 8: measured slower (256 MiB of log text, level 6: 8.95 against 8.73 ms)
+static_assert((DF_ROUND == 8 || DF_ROUND == 16) && DF_CAP % DF_ROUND == 0, "compare rounds");
 template <int NW>
 AHIP_DEVINL void df_match_lens(const u32 *ring, const u32 (&rc)[NW], u32 rp, u32 maxl, bool (&alive)[NW], u32 (&len)[NW], u32 l0 = 0) {
-  bool any = false;
+  // LDS byte addresses, made opaque: left to itself the compiler re-adds the ring's LDS offset (beyond a DS instruction's
+  // 16-bit offset field) to every address in every round -- 24 v_add per round for what is one add per candidate
+  const u32 rb = (u32)(uintptr_t)(const __attribute__((address_space(3))) u8 *)ring;
+  constexpr u32 ND = DF_ROUND / 4;  // dwords compared per round
+  u32 ca_[NW], sh[NW], am[NW];
+  u32 anym = 0;
 #pragma unroll
-  for (int k = 0; k < NW; ++k) { if (l0 == 0) len[k] = 0; any |= alive[k]; }  // (maxl >= 4: the position has four bytes to hash)
-  for (u32 l = l0; any; l += 8) {  // the first round doubles as the check that the bucket-mate really shares 4 bytes
-    const u64 pw = df_rd8(ring, rp + l);
-    u64 cw[NW];
+  for (int k = 0; k < NW; ++k) {
+    if (l0 == 0) len[k] = 0;  // (an alive candidate's len is l0 on entry: 0, or the cap its first pass ended on)
+    ca_[k] = rb + (rc[k] & ~3u) + l0;
+    AHIP_PIN(ca_[k]);
+    sh[k] = rc[k] & 3u;
+    am[k] = alive[k] ? ~0u : 0u;
+    anym |= am[k];
+  }
+  u32 pa_ = rb + (rp & ~3u) + l0;
+  AHIP_PIN(pa_);
+  const u32 psh = rp & 3u;
+  for (u32 l = l0, o = 0; anym; l += DF_ROUND, o += DF_ROUND) {  // the first round doubles as the check that the bucket-mate really shares 4 bytes
+    const df_lds_u32p pp = (df_lds_u32p)(pa_ + o);
+    u32 pw[ND + 1], p[ND];
 #pragma unroll
-    for (int k = 0; k < NW; ++k) cw[k] = df_rd8(ring, rc[k] + l);  // dead candidates read too: masking them (per lane, or per candidate with a wave vote) was measured slower
-    any = false;
-    const u32 room = maxl - l;  // > 0
+    for (u32 d = 0; d <= ND; ++d) pw[d] = pp[d];
+    u32 cw[NW][ND + 1];
 #pragma unroll
     for (int k = 0; k < NW; ++k) {
-      const u64 x = cw[k] ^ pw;
-      u32 n = x ? ((u32)__builtin_ctzll(x) >> 3) : 8u;
-      n = n < room ? n : room;
-      if (alive[k]) { len[k] = l + n; alive[k] = n == 8 && room > 8; }
-      any |= alive[k];
+      const df_lds_u32p cp = (df_lds_u32p)(ca_[k] + o);
+#pragma unroll
+      for (u32 d = 0; d <= ND; ++d) cw[k][d] = cp[d];
+    }
+#pragma unroll
+    for (u32 d = 0; d < ND; ++d) p[d] = __builtin_amdgcn_alignbyte(pw[d + 1], pw[d], psh);
+    const u32 room = maxl - l;  // > 0 (maxl >= 4: the position has four bytes to hash)
+    const u32 cap = (room < DF_ROUND ? room : DF_ROUND) * 8 + 7;  // first-difference bit index at which the bytes that count run out
+    const u32 goon = room > DF_ROUND ? ~0u : 0u;
+    anym = 0;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+      u32 t = cap;
+#pragma unroll
+      for (u32 d = 0; d < ND; d += 2) {  // (-1 | 32 stays -1: "these dwords are equal")
+        const u32 f0 = df_ffbl(__builtin_amdgcn_alignbyte(cw[k][d + 1], cw[k][d], sh[k]) ^ p[d]) | (32u * d);
+        const u32 f1 = df_ffbl(__builtin_amdgcn_alignbyte(cw[k][d + 2], cw[k][d + 1], sh[k]) ^ p[d + 1]) | (32u * (d + 1));
+        const u32 m = f0 < f1 ? f0 : f1;
+        t = t < m ? t : m;
+      }
+      const u32 n = (t >> 3) & am[k];  // bytes this round adds: min(equal bytes, DF_ROUND, room), nothing for a finished candidate
+      len[k] += n;
+      am[k] = n == DF_ROUND ? goon : 0u;
+      anym |= am[k];
     }
   }
+#pragma unroll
+  for (int k = 0; k < NW; ++k) alive[k] = am[k] != 0;
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for the wave's outstanding
@@ -321,16 +372,23 @@ __global__ __launch_bounds__(SUB) void deflate_match_kernel(const u8 *__restrict
       constexpr u32 NC = DF_WAYS + 1 + NX;
       u32 rc[NC], dist[NC], len[NC];
       bool alive[NC];
+      // (straight-line: a candidate `dist` back lies `dist` back in the ring too -- one wrap at most, dist < DF_RING -- and
+      //  c < p && dist <= max_dist is one unsigned compare of dist - 1)
 #pragma unroll
       for (u32 k = 0; k < NC; ++k) {
         const u32 c = cand[k] ^ KX;  // key -> position
         dist[k] = p - c;
-        alive[k] = k != DF_WAYS ? (cand[k] != DF_EMPTY && c < p && dist[k] <= P.max_dist) : (cand[k] != DF_EMPTY && c < p && c >= base && dist[k] <= P.max_dist);
-        rc[k] = alive[k] ? rc_of(c) : rp;
+        bool ok = cand[k] != DF_EMPTY && dist[k] - 1u < P.max_dist;
+        if (k == DF_WAYS) ok = ok && c >= base;
+        alive[k] = ok;
+        const u32 back = rp - dist[k], wrapped = back + DF_RING;
+        rc[k] = ok ? (back < wrapped ? back : wrapped) : rp;
       }
       AHIP_TICK(t3);
       AHIP_ACC(pc[2], t2, t3);
       df_match_lens<NC>(ring, rc, rp, maxl, alive, len);
+      AHIP_TICK(t3b);
+      AHIP_ACC(pc[6], t3, t3b);  // (the first pass alone; pc[3] has the tie-break pass as well)
       // Candidates that all reached the cap are told apart by comparing on (to `nice` bytes): the nearest one is not
       // the longest one on repetitive input.  Short periods (a tied candidate closer than the cap) are left alone --
       // the nearest candidate of a run is as good as any, and every position of the run would walk it again.

@@ -339,6 +339,10 @@ __global__ __launch_bounds__(64) void sm_resolve_kernel(const u8 *__restrict__ i
   }
 }
 
+// Workgroup barrier that orders LDS traffic only: __syncthreads() would also wait for the prefetched global loads below
+// (the threads of these kernels talk to each other through LDS alone).
+AHIP_DEVINL void sm_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Windows.  windows[k] = the 32 KiB of output that end with chunk k (bytes; positions before the stream start are
 // unused).  Window k is a function of window k-1 (every element is a byte of chunk k or a look-up into window k-1),
 // and such functions compose, so the chain is cut into groups:
@@ -360,6 +364,8 @@ __global__ __launch_bounds__(1024) void sm_windows_group(const ChunkDesc *__rest
     u16 *cur = W[g & 1];
     const u64 off = chunks[k].out_off, len = results[k].out_len;
     // window element j = output position (end - 32768 + j) of the stream; all loads first, they are independent
+    // (issuing the next chunk's loads ahead as sm_windows_link does was measured slower here: the loads are conditional,
+    //  and 64 symbols in registers per thread spill at 1 024 threads)
     u32 s[PER];
 #pragma unroll
     for (u32 u = 0; u < PER; ++u) {
@@ -389,17 +395,29 @@ __global__ __launch_bounds__(1024) void sm_windows_link(u32 n_chunks, u32 group_
   const u32 tid = threadIdx.x, n_groups = (n_chunks + group_size - 1) / group_size;
   for (u32 j = tid; j < SM_WINDOW; j += 1024) W[1][j] = sm_hist_byte(hist_win, hist0, j);
   __syncthreads();
+  constexpr u32 PER = SM_WINDOW / 1024;
+  u32 s[PER], sn[PER];  // (the symbols of group g + 1 are on their way while group g is looked up: see sm_windows_group)
+  auto last_of = [&](u32 g) -> u32 { return (g + 1) * group_size - 1 < n_chunks ? (g + 1) * group_size - 1 : n_chunks - 1; };
+  auto request = [&](u32 g, u32 (&r)[PER]) {
+    const u16 *ws = wsym + (u64)last_of(g) * SM_WINDOW;
+#pragma unroll
+    for (u32 u = 0; u < PER; ++u) r[u] = ws[tid + u * 1024];
+  };
+  if (n_groups) request(0, sn);
   for (u32 g = 0; g < n_groups; ++g) {
-    const u32 last = (g + 1) * group_size - 1 < n_chunks ? (g + 1) * group_size - 1 : n_chunks - 1;
     const u8 *prev = W[(g + 1) & 1];
     u8 *cur = W[g & 1];
-    for (u32 j = tid; j < SM_WINDOW; j += 1024) {
-      const u32 s = wsym[(u64)last * SM_WINDOW + j];
-      const u8 v = s < SYM_MARK ? (u8)s : prev[s - SYM_MARK];
+#pragma unroll
+    for (u32 u = 0; u < PER; ++u) s[u] = sn[u];
+    if (g + 1 < n_groups) request(g + 1, sn);
+#pragma unroll
+    for (u32 u = 0; u < PER; ++u) {
+      const u32 j = tid + u * 1024;
+      const u8 v = s[u] < SYM_MARK ? (u8)s[u] : prev[s[u] - SYM_MARK];
       cur[j] = v;
       gwin[(u64)g * SM_WINDOW + j] = v;
     }
-    __syncthreads();
+    sm_lds_barrier();
   }
 }
 __global__ __launch_bounds__(256) void sm_windows_apply(u32 group_size, const u16 *__restrict__ wsym, const u8 *__restrict__ gwin,
@@ -412,16 +430,56 @@ __global__ __launch_bounds__(256) void sm_windows_apply(u32 group_size, const u1
   }
 }
 
-// symbols -> bytes, every chunk with the window of the chunk before it
+// symbols -> bytes, every chunk with the window of the chunk before it.  Eight symbols a thread and step: one 16-byte load
+// (the symbol array is the library's own: aligned; the vectors start where the chunk's offset reaches a multiple of 8),
+// one 8-byte store (the output is the caller's pointer: whatever alignment it has).  The window look-ups are what the
+// kernel's time goes to -- scattered byte reads, 64 different lines an instruction: each workgroup copies the window into
+// LDS first (a few workgroups per chunk: the copy is a quarter of what the workgroup then translates) and looks up there.
+// (A byte per thread and step, look-ups in global memory: 0.58 ms for 256 MiB; vectors alone: 0.51.)
 __global__ __launch_bounds__(256) void sm_translate_kernel(const ChunkDesc *__restrict__ chunks, const MemberResult *__restrict__ results,
                                                            const u16 *__restrict__ sym, const u8 *__restrict__ windows,
                                                            u8 *__restrict__ out, const u8 *hist_win, u32 hist0) {
+  __shared__ u8 W[SM_WINDOW] __attribute__((aligned(16)));
   const u32 k = blockIdx.y;
   const u64 off = chunks[k].out_off, len = results[k].out_len;
   const u8 *w = k ? windows + (u64)(k - 1) * SM_WINDOW : nullptr;  // chunk 0: the window in front of the stream
-  for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < len; i += (u64)gridDim.x * 256) {
-    const u32 s = sym[off + i];
-    out[off + i] = s < SYM_MARK ? (u8)s : (w ? w[s - SYM_MARK] : sm_hist_byte(hist_win, hist0, s - SYM_MARK));
+  auto byte_of = [&](u32 s) -> u32 { return s < SYM_MARK ? (s & 0xffu) : (u32)(w ? w[s - SYM_MARK] : sm_hist_byte(hist_win, hist0, s - SYM_MARK)); };
+  u64 head = (8 - (off & 7)) & 7;
+  head = head < len ? head : len;
+  const u64 nvec = (len - head) >> 3, tail0 = head + (nvec << 3);
+  if ((u64)blockIdx.x * 256 >= nvec && blockIdx.x) return;  // (nothing for this workgroup: not even the copy)
+  if (w) {
+    for (u32 i = threadIdx.x; i < SM_WINDOW / 16; i += 256) ((uint4 *)W)[i] = ((const uint4 *)w)[i];
+    __syncthreads();
+  }
+  if (blockIdx.x == 0) {  // the elements in front of the first and behind the last whole vector
+    const u32 t = threadIdx.x;
+    if (t < head) out[off + t] = (u8)byte_of(sym[off + t]);
+    if (t >= 8 && tail0 + (t - 8) < len) out[off + tail0 + (t - 8)] = (u8)byte_of(sym[off + tail0 + (t - 8)]);
+  }
+  const uint4 *sv = (const uint4 *)(sym + off + head);
+  u8 *ov = out + off + head;
+  for (u64 v = (u64)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (u64)gridDim.x * 256) {
+    const uint4 q = sv[v];
+    const u32 x[4] = {q.x, q.y, q.z, q.w};
+    u32 b[8];
+#pragma unroll
+    for (u32 e = 0; e < 4; ++e) { b[2 * e] = x[e] & 0xffffu; b[2 * e + 1] = x[e] >> 16; }
+    if (((q.x | q.y | q.z | q.w) & (SYM_MARK * 0x10001u)) != 0) {  // (SYM_MARK is the symbols' top bit)
+      if (w) {  // eight look-ups, all on their way before the first is used (a byte value looks up W[byte]: harmless)
+        u32 g[8];
+#pragma unroll
+        for (u32 e = 0; e < 8; ++e) g[e] = W[b[e] & (SM_WINDOW - 1)];
+#pragma unroll
+        for (u32 e = 0; e < 8; ++e) b[e] = b[e] < SYM_MARK ? b[e] : g[e];
+      } else {
+#pragma unroll
+        for (u32 e = 0; e < 8; ++e) b[e] = byte_of(b[e]);
+      }
+    }
+    const u64 lo = (b[0] & 0xffu) | ((b[1] & 0xffu) << 8) | ((b[2] & 0xffu) << 16) | (b[3] << 24);
+    const u64 hi = (b[4] & 0xffu) | ((b[5] & 0xffu) << 8) | ((b[6] & 0xffu) << 16) | (b[7] << 24);
+    ((unaligned_u64 *)(ov + (v << 3)))->v = lo | (hi << 32);
   }
 }
 
