@@ -430,21 +430,40 @@ __global__ __launch_bounds__(SUB) void deflate_match_kernel(const u8 *__restrict
 // (one-step lazy rule), so every position has a well-defined "next position"; the parse is the orbit of
 // position 0.  64 positions at a time: the lanes compute step and token, a scalar loop hops through the
 // block with v_readlane, and the visited lanes write their tokens compacted.
-// true length (<= maxl) of a match known to hold for DF_CAP bytes: one wave-wide step, 4 bytes per lane
-AHIP_DEVINL u32 df_extend(const u8 *a, u32 dist, u32 maxl, u32 lane) {
-  const u32 o = DF_CAP + 4 * lane;
-  const u8 *src = a - dist;  // (a[x - dist] with unsigned x would wrap)
-  u32 same = 4, nb = 0;
-  if (o < maxl) {
-    nb = maxl - o < 4 ? maxl - o : 4;
-    same = nb;
-    for (u32 k = nb; k-- > 0;)
-      if (a[o + k] != src[o + k]) same = k;
+// true length (<= maxl) of a match known to hold for DF_CAP bytes: one wave-wide step, 4 bytes per lane.
+// df_same4: how many of the nb (<= 4) bytes at a and at s are the same from the front (a dword each when all four count);
+// df_extend_len: the length that follows from every lane's count.
+AHIP_DEVINL u32 df_same4(const u8 *a, const u8 *s, u32 nb) {
+  if (nb == 4) {
+    const u32 x = load_u32_unaligned(a) ^ load_u32_unaligned(s);
+    return x ? (u32)__builtin_ctz(x) >> 3 : 4u;
   }
-  const u64 stop = __ballot(o < maxl && same < 4);  // a mismatch, or the end of the allowed range, inside this lane
+  u32 same = nb;
+  for (u32 k = nb; k-- > 0;)
+    if (a[k] != s[k]) same = k;
+  return same;
+}
+AHIP_DEVINL u32 df_extend_len(u32 same, bool in_range, u32 maxl) {
+  const u64 stop = __ballot(in_range && same < 4);  // a mismatch, or the end of the allowed range, inside this lane
   if (!stop) return maxl;
   const int f = __ffsll((long long)stop) - 1;
   return DF_CAP + 4 * (u32)f + lane_bcast(same, f);
+}
+AHIP_DEVINL u32 df_extend(const u8 *a, u32 dist, u32 maxl, u32 lane) {
+  const u32 o = DF_CAP + 4 * lane;
+  u32 same = 4;
+  if (o < maxl) same = df_same4(a + o, a + o - dist, maxl - o < 4 ? maxl - o : 4);  // (a - dist + o: a[x - dist] with unsigned x would wrap)
+  return df_extend_len(same, o < maxl, maxl);
+}
+// the match at a (dist0 back) and the one at a + 1 (dist1 back) together: their loads are on the way at the same time --
+// the parse waits for global memory here, and a position it lands on inside a long match has a long match behind it
+AHIP_DEVINL void df_extend2(const u8 *a, u32 dist0, u32 maxl0, u32 dist1, u32 maxl1, u32 lane, u32 &L0, u32 &L1) {
+  const u32 o = DF_CAP + 4 * lane;
+  u32 same0 = 4, same1 = 4;
+  if (o < maxl0) same0 = df_same4(a + o, a + o - dist0, maxl0 - o < 4 ? maxl0 - o : 4);
+  if (o < maxl1) same1 = df_same4(a + 1 + o, a + 1 + o - dist1, maxl1 - o < 4 ? maxl1 - o : 4);
+  L0 = df_extend_len(same0, o < maxl0, maxl0);
+  L1 = df_extend_len(same1, o < maxl1, maxl1);
 }
 
 __global__ __launch_bounds__(64) void deflate_parse_kernel(const u8 *__restrict__ in, DeflateParams P,
@@ -458,16 +477,23 @@ __global__ __launch_bounds__(64) void deflate_parse_kernel(const u8 *__restrict_
   u32 k = 0, pos = 0;
   if (!P.store) {
     const u64 below = (1ull << lane) - 1;
+    // a block's matches and bytes are asked for one block ahead (the wave does nothing but wait for them otherwise: 512
+    // blocks a chunk, a trip to memory each); the match at i + 1 is the neighbour lane's, or lane 0's of the block ahead
+    u32 m_next = lane < clen ? match[cstart + lane] : 0u;
+    u32 b_next = lane < clen ? (u32)in[cstart + lane] : 0u;
     for (u32 base = 0; base < clen; base += 64) {
       const u32 i = base + lane;
       const bool inb = i < clen;
-      const u32 m = inb ? match[cstart + i] : 0u;
-      const u32 m1 = (i + 1 < clen) ? match[cstart + i + 1] : 0u;
+      const u32 m = m_next, byte = b_next;
+      m_next = i + 64 < clen ? match[cstart + i + 64] : 0u;
+      b_next = i + 64 < clen ? (u32)in[cstart + i + 64] : 0u;
+      const u32 up = lane_gather(m, (lane + 1) & 63), first_ahead = lane_bcast(m_next, 0);
+      const u32 m1 = lane == 63 ? first_ahead : up;  // (0 behind the chunk's end: m_next is)
       const u32 l = m >> 16;  // <= min(DF_CAP, clen - i) by construction
       bool is_match = inb && l >= DF_MINLEN;
       if (is_match && P.lazy && (m1 >> 16) > l) is_match = false;  // a longer match starts at the next byte
       u32 step = is_match ? l : 1u;
-      u32 token = is_match ? m : (0x80000000u | (inb ? (u32)in[cstart + i] : 0u));
+      u32 token = is_match ? m : (0x80000000u | byte);
       const bool capped = inb && l >= DF_CAP;  // true length unknown: settled when (if) the parse lands here
       u64 visited = 0;
       const u64 cap_mask = __ballot(capped);
@@ -480,16 +506,18 @@ __global__ __launch_bounds__(64) void deflate_parse_kernel(const u8 *__restrict_
           const u8 *a = in + cstart + pos;
           const u32 rem = clen - pos;
           const u32 d0 = lane_bcast(m, (int)j) & 0xffff;
-          const u32 L0 = df_extend(a, d0, rem < P.max_cmp ? rem : P.max_cmp, lane);
+          const u32 max0 = rem < P.max_cmp ? rem : P.max_cmp;
+          u32 L0;
           bool take = true;
           if (P.lazy && pos + 1 < clen) {
             const u32 mm1 = lane_bcast(m1, (int)j);
             u32 L1 = mm1 >> 16;
-            if (L1 >= DF_CAP) L1 = df_extend(a + 1, mm1 & 0xffff, (rem - 1) < P.max_cmp ? (rem - 1) : P.max_cmp, lane);
+            if (L1 >= DF_CAP) df_extend2(a, d0, max0, mm1 & 0xffff, (rem - 1) < P.max_cmp ? (rem - 1) : P.max_cmp, lane, L0, L1);
+            else L0 = df_extend(a, d0, max0, lane);
             take = !(L1 > L0);
-          }
+          } else L0 = df_extend(a, d0, max0, lane);
           st = take ? L0 : 1u;
-          if (lane == j) token = take ? ((L0 << 16) | d0) : (0x80000000u | (u32)a[0]);
+          if (lane == j) token = take ? ((L0 << 16) | d0) : (0x80000000u | byte);
         }
         pos += st;
       }
