@@ -543,9 +543,11 @@ struct EncLds {
   int t_maxcode;
   u32 opt_len;
   u32 wsum[4];
+  u32 wsum2[2][4];  // the token rounds' bit counts per wave, two sets taking turns
   u32 run_bits;
   u16 cl_tok[DF_LCODES + DF_DCODES + 8];  // the code lengths of both trees as run-length tokens: symbol | extra value << 5
   u16 cl_pos[320];                          // df_cl_tokens: tokens in front of the run that starts at i
+  u64 cl_start[5];                          //               bit i: a run of equal lengths starts at i (or i is the end)
   u32 cl_ntok;
   u32 cl_freq[32];                          // how often each of the 19 code-length symbols occurs among them
   u32 obuf[DF_SLAB / 4];
@@ -628,6 +630,9 @@ __device__ inline void df_build_tree_wg(EncLds &E, u16 *tree, int elems, int max
     }
   }
   // ---- two-queue merge: leaves 0..m-1 (sorted), internal nodes m..2m-2 in creation (= weight) order ----
+  // (one lane, a dependent LDS read per take.  Wave 0 running the loop as scalar code with 64 weights of either queue in a
+  //  register across its lanes -- v_readlane for the heads, nothing read from LDS in the steady state -- was measured SLOWER:
+  //  98 K cycles per chunk for the literal/length tree against 80 K; the loop turns into two dozen scalar branches a step)
   if (tid == 0) {
     u32 *iw = E.iw;
     u16 *par = E.par;
@@ -722,11 +727,21 @@ __device__ inline void df_cl_tokens(EncLds &E, const u16 *tree, int max_code, u3
   const int n = max_code + 1;
   const u32 base = E.cl_ntok;
   __syncthreads();
+  // where the runs start, a bit each (and one at n): a run's length is the distance to the next bit -- a lane counting
+  // along its run (up to 138 dependent LDS reads, twice per run) was 57 K of the kernel's 336 K cycles per chunk
+  for (int i = (int)tid; i < 320; i += 256) {  // (whole waves: tid < 64 come round twice)
+    const bool st = i == n || (i < n && (i == 0 || tree[i * 2 + 1] != tree[(i - 1) * 2 + 1]));
+    const u64 bm = __ballot(st);
+    if ((tid & 63) == 0) E.cl_start[i >> 6] = bm;
+  }
+  __syncthreads();
   // tokens of the run that starts at i (0 elsewhere)
   auto run_tokens = [&](int i, int &L) -> u32 {
     const u32 v = tree[i * 2 + 1];
-    L = 1;
-    while (i + L < n && tree[(i + L) * 2 + 1] == v) ++L;
+    u32 w = (u32)i >> 6;
+    u64 mk = E.cl_start[w] & ~((2ull << (i & 63)) - 1);  // starts behind i in its word
+    while (!mk) mk = E.cl_start[++w];                     // (the bit at n <= 286 ends the search)
+    L = (int)(w * 64 + (u32)__builtin_ctzll(mk)) - i;
     if (v != 0) {
       const int first = L < 7 ? L : 7;
       u32 t = first < 4 ? (u32)first : 2u;
@@ -886,19 +901,12 @@ __global__ __launch_bounds__(256) void deflate_encode_kernel(const u8 *__restric
     }
     AHIP_TICK(e2);
     // ---- exact size first: a chunk that does not shrink (or would not fit the LDS image) is stored ----
+    // (from the histograms, like the reference's opt_len, deflate.dart:2567-2648: a symbol costs its code length plus its
+    //  extra bits however often it occurs -- a second pass over the tokens was 37 K of the kernel's 336 K cycles per chunk)
     {
       u32 mybits = 0;
-      for (u32 i = tid; i < nt; i += 256) {
-        const u32 v = t[i];
-        if (v >> 31) mybits += E.ltree[(v & 0xff) * 2 + 1];
-        else {
-          u32 c, xb, xv;
-          df_len_code(v >> 16, c, xb, xv);
-          mybits += E.ltree[(257 + c) * 2 + 1] + xb;
-          df_dist_code(v & 0xffff, c, xb, xv);
-          mybits += E.dtree[c * 2 + 1] + xb;
-        }
-      }
+      for (u32 i = tid; i < 286; i += 256) mybits += E.fl[i] * ((u32)E.ltree[i * 2 + 1] + (i >= 257 ? (u32)k_extra_lbits[i - 257] : 0u));
+      if (tid < 30) mybits += E.fd[tid] * ((u32)E.dtree[tid * 2 + 1] + (u32)k_extra_dbits[tid]);
       if (tid == 0) E.opt_len = 0;
       __syncthreads();
       atomicAdd(&E.opt_len, mybits);
@@ -912,13 +920,17 @@ __global__ __launch_bounds__(256) void deflate_encode_kernel(const u8 *__restric
                     pc[4] = (u32)((e1a - e1) >> 4); pc[5] = (u32)((e1c - e1b) >> 4); pc[6] = (u32)((e1d - e1c) >> 4); pc[7] = (u32)((e2 - e1d) >> 4); }
 #endif
     if (!stored) {
-    // ---- tokens, 256 per round ----
-    for (u32 base = 0; base < nt; base += 256) {
+    // ---- tokens, 256 per round: the next round's token is asked for before this one's is worked on, and ONE barrier a
+    //      round (the waves' bit counts alternate between two sets of slots; everybody keeps the running offset) ----
+    u32 run = E.run_bits;
+    u32 v_next = tid < nt ? t[tid] : 0u;
+    for (u32 base = 0, par = 0; base < nt; base += 256, par ^= 1) {
       const u32 i = base + tid;
+      const u32 v = v_next;
+      v_next = i + 256 < nt ? t[i + 256] : 0u;
       u64 bits = 0;
       u32 nb = 0;
       if (i < nt) {
-        const u32 v = t[i];
         if (v >> 31) {
           const u32 s = v & 0xff;
           bits = E.ltree[s * 2];
@@ -935,10 +947,11 @@ __global__ __launch_bounds__(256) void deflate_encode_kernel(const u8 *__restric
         }
       }
       const u32 inc = wave_incl_sum(nb);
-      if (lane == 63) E.wsum[wave] = inc;
+      if (lane == 63) E.wsum2[par][wave] = inc;
       __syncthreads();
-      u32 off = E.run_bits + inc - nb;
-      for (u32 w = 0; w < wave; ++w) off += E.wsum[w];
+      u32 off = run + inc - nb;
+      for (u32 w = 0; w < wave; ++w) off += E.wsum2[par][w];
+      run += E.wsum2[par][0] + E.wsum2[par][1] + E.wsum2[par][2] + E.wsum2[par][3];
       if (nb) {
         const u32 wi = off >> 5, s = off & 31;
         const u64 lo = bits << s;
@@ -946,10 +959,9 @@ __global__ __launch_bounds__(256) void deflate_encode_kernel(const u8 *__restric
         if ((u32)(lo >> 32)) atomicOr(&E.obuf[wi + 1], (u32)(lo >> 32));
         if (s && (bits >> (64 - s))) atomicOr(&E.obuf[wi + 2], (u32)(bits >> (64 - s)));
       }
-      __syncthreads();
-      if (tid == 0) E.run_bits += E.wsum[0] + E.wsum[1] + E.wsum[2] + E.wsum[3];
-      __syncthreads();
     }
+    __syncthreads();  // (the last round's bits are in the image)
+    if (tid == 0) E.run_bits = run;
     // ---- end of block, then the byte-aligning empty stored block (not after the last chunk) ----
     if (tid == 0) {
       DfBits b{E.obuf, E.run_bits};
