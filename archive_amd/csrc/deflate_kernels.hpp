@@ -543,14 +543,14 @@ struct EncLds {
   int t_maxcode;
   u32 opt_len;
   u32 wsum[4];
-  u32 wsum2[2][4];  // the token rounds' bit counts per wave, two sets taking turns
+  u32 wsum2[2][8];  // the token rounds' bit counts per wave and half, two sets taking turns
   u32 run_bits;
   u16 cl_tok[DF_LCODES + DF_DCODES + 8];  // the code lengths of both trees as run-length tokens: symbol | extra value << 5
   u16 cl_pos[320];                          // df_cl_tokens: tokens in front of the run that starts at i
   u64 cl_start[5];                          //               bit i: a run of equal lengths starts at i (or i is the end)
   u32 cl_ntok;
   u32 cl_freq[32];                          // how often each of the 19 code-length symbols occurs among them
-  u32 obuf[DF_SLAB / 4];
+  u32 obuf[DF_SLAB / 4] __attribute__((aligned(16)));
 };
 
 __device__ const u8 k_extra_lbits[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
@@ -810,23 +810,31 @@ __global__ __launch_bounds__(256) void deflate_encode_kernel(const u8 *__restric
   const u32 *t = tok + cstart;
   u8 *slab = slabs + (u64)chunk * DF_SLAB;
   AHIP_TICK(e0);
-  for (u32 i = tid; i < DF_SLAB / 4; i += 256) E.obuf[i] = 0;
+  static_assert(DF_SLAB % 16 == 0, "the output image is cleared 16 bytes at a time");
+  for (u32 i = tid; i < DF_SLAB / 16; i += 256) ((uint4 *)E.obuf)[i] = make_uint4(0u, 0u, 0u, 0u);
   for (u32 i = tid; i < 288; i += 256) E.fl[i] = 0;
   if (tid < 32) { E.fd[tid] = 0; E.cl_freq[tid] = 0; }
   __syncthreads();
   bool stored = P.store != 0;
   u32 total_bits = 0;
   if (!stored) {
-    // ---- histogram ----
-    for (u32 i = tid; i < nt; i += 256) {
-      const u32 v = t[i];
-      if (v >> 31) atomicAdd(&E.fl[v & 0xff], 1u);
-      else {
-        u32 c, xb, xv;
-        df_len_code(v >> 16, c, xb, xv);
-        atomicAdd(&E.fl[257 + c], 1u);
-        df_dist_code(v & 0xffff, c, xb, xv);
-        atomicAdd(&E.fd[c], 1u);
+    // ---- histogram (four tokens a thread on their way at a time) ----
+    for (u32 i = tid; i < nt; i += 1024) {
+      u32 v4[4];
+#pragma unroll
+      for (u32 u = 0; u < 4; ++u) v4[u] = i + 256 * u < nt ? t[i + 256 * u] : 0u;
+#pragma unroll
+      for (u32 u = 0; u < 4; ++u) {
+        const u32 v = v4[u];
+        if (i + 256 * u >= nt) continue;
+        if (v >> 31) atomicAdd(&E.fl[v & 0xff], 1u);
+        else {
+          u32 c, xb, xv;
+          df_len_code(v >> 16, c, xb, xv);
+          atomicAdd(&E.fl[257 + c], 1u);
+          df_dist_code(v & 0xffff, c, xb, xv);
+          atomicAdd(&E.fd[c], 1u);
+        }
       }
     }
     __syncthreads();
@@ -920,45 +928,57 @@ __global__ __launch_bounds__(256) void deflate_encode_kernel(const u8 *__restric
                     pc[4] = (u32)((e1a - e1) >> 4); pc[5] = (u32)((e1c - e1b) >> 4); pc[6] = (u32)((e1d - e1c) >> 4); pc[7] = (u32)((e2 - e1d) >> 4); }
 #endif
     if (!stored) {
-    // ---- tokens, 256 per round: the next round's token is asked for before this one's is worked on, and ONE barrier a
-    //      round (the waves' bit counts alternate between two sets of slots; everybody keeps the running offset) ----
+    // ---- tokens, 512 per round (two halves of 256, a token of each per thread): the next round's tokens are asked for before
+    //      this one's are worked on, and ONE barrier a round (the waves' bit counts alternate between two sets of slots;
+    //      everybody keeps the running offset) ----
+    auto token_bits = [&](u32 v, u64 &bits, u32 &nb) {
+      if (v >> 31) {
+        const u32 s = v & 0xff;
+        bits = E.ltree[s * 2];
+        nb = E.ltree[s * 2 + 1];
+      } else {
+        u32 c, xb, xv;
+        df_len_code(v >> 16, c, xb, xv);
+        bits = E.ltree[(257 + c) * 2];
+        nb = E.ltree[(257 + c) * 2 + 1];
+        bits |= (u64)xv << nb; nb += xb;
+        df_dist_code(v & 0xffff, c, xb, xv);
+        bits |= (u64)E.dtree[c * 2] << nb; nb += E.dtree[c * 2 + 1];
+        bits |= (u64)xv << nb; nb += xb;
+      }
+    };
+    auto deposit = [&](u32 off, u64 bits, u32 nb) {
+      if (!nb) return;
+      const u32 wi = off >> 5, s = off & 31;
+      const u64 lo = bits << s;
+      atomicOr(&E.obuf[wi], (u32)lo);
+      if ((u32)(lo >> 32)) atomicOr(&E.obuf[wi + 1], (u32)(lo >> 32));
+      if (s && (bits >> (64 - s))) atomicOr(&E.obuf[wi + 2], (u32)(bits >> (64 - s)));
+    };
     u32 run = E.run_bits;
-    u32 v_next = tid < nt ? t[tid] : 0u;
-    for (u32 base = 0, par = 0; base < nt; base += 256, par ^= 1) {
-      const u32 i = base + tid;
-      const u32 v = v_next;
-      v_next = i + 256 < nt ? t[i + 256] : 0u;
-      u64 bits = 0;
-      u32 nb = 0;
-      if (i < nt) {
-        if (v >> 31) {
-          const u32 s = v & 0xff;
-          bits = E.ltree[s * 2];
-          nb = E.ltree[s * 2 + 1];
-        } else {
-          u32 c, xb, xv;
-          df_len_code(v >> 16, c, xb, xv);
-          bits = E.ltree[(257 + c) * 2];
-          nb = E.ltree[(257 + c) * 2 + 1];
-          bits |= (u64)xv << nb; nb += xb;
-          df_dist_code(v & 0xffff, c, xb, xv);
-          bits |= (u64)E.dtree[c * 2] << nb; nb += E.dtree[c * 2 + 1];
-          bits |= (u64)xv << nb; nb += xb;
-        }
-      }
-      const u32 inc = wave_incl_sum(nb);
-      if (lane == 63) E.wsum2[par][wave] = inc;
+    u32 va_next = tid < nt ? t[tid] : 0u, vb_next = tid + 256 < nt ? t[tid + 256] : 0u;
+    for (u32 base = 0, par = 0; base < nt; base += 512, par ^= 1) {
+      const u32 ia = base + tid, ib = ia + 256;
+      const u32 va = va_next, vb = vb_next;
+      va_next = ia + 512 < nt ? t[ia + 512] : 0u;
+      vb_next = ib + 512 < nt ? t[ib + 512] : 0u;
+      u64 bits_a = 0, bits_b = 0;
+      u32 nb_a = 0, nb_b = 0;
+      if (ia < nt) token_bits(va, bits_a, nb_a);
+      if (ib < nt) token_bits(vb, bits_b, nb_b);
+      const u32 inc_a = wave_incl_sum(nb_a), inc_b = wave_incl_sum(nb_b);
+      if (lane == 63) { E.wsum2[par][wave] = inc_a; E.wsum2[par][4 + wave] = inc_b; }
       __syncthreads();
-      u32 off = run + inc - nb;
-      for (u32 w = 0; w < wave; ++w) off += E.wsum2[par][w];
-      run += E.wsum2[par][0] + E.wsum2[par][1] + E.wsum2[par][2] + E.wsum2[par][3];
-      if (nb) {
-        const u32 wi = off >> 5, s = off & 31;
-        const u64 lo = bits << s;
-        atomicOr(&E.obuf[wi], (u32)lo);
-        if ((u32)(lo >> 32)) atomicOr(&E.obuf[wi + 1], (u32)(lo >> 32));
-        if (s && (bits >> (64 - s))) atomicOr(&E.obuf[wi + 2], (u32)(bits >> (64 - s)));
-      }
+      u32 ws[8];
+#pragma unroll
+      for (u32 w = 0; w < 8; ++w) ws[w] = E.wsum2[par][w];
+      u32 off_a = run + inc_a - nb_a, off_b = run + ws[0] + ws[1] + ws[2] + ws[3] + inc_b - nb_b;
+#pragma unroll
+      for (u32 w = 0; w < 4; ++w) { off_a += w < wave ? ws[w] : 0u; off_b += w < wave ? ws[4 + w] : 0u; }
+#pragma unroll
+      for (u32 w = 0; w < 8; ++w) run += ws[w];
+      deposit(off_a, bits_a, nb_a);
+      deposit(off_b, bits_b, nb_b);
     }
     __syncthreads();  // (the last round's bits are in the image)
     if (tid == 0) E.run_bits = run;
