@@ -434,6 +434,9 @@ __global__ __launch_bounds__(SUB) void deflate_match_kernel(const u8 *__restrict
 // df_same4: how many of the nb (<= 4) bytes at a and at s are the same from the front (a dword each when all four count);
 // df_extend_len: the length that follows from every lane's count.
 AHIP_DEVINL u32 df_same4(const u8 *a, const u8 *s, u32 nb) {
+#ifdef AHIP_ABL_NO_EXTEND  // dev ablation (wrong bytes): what the parse's trips to memory cost
+  return nb;
+#endif
   if (nb == 4) {
     const u32 x = load_u32_unaligned(a) ^ load_u32_unaligned(s);
     return x ? (u32)__builtin_ctz(x) >> 3 : 4u;
@@ -457,6 +460,9 @@ AHIP_DEVINL u32 df_extend(const u8 *a, u32 dist, u32 maxl, u32 lane) {
 }
 // the match at a (dist0 back) and the one at a + 1 (dist1 back) together: their loads are on the way at the same time --
 // the parse waits for global memory here, and a position it lands on inside a long match has a long match behind it
+// (Extending, block by block, the FIRST position of every run of capped matches with one distance and counting down from it
+//  for the others -- no memory access left in the hop loop -- gave the same bytes and was SLOWER, 5.0 against 4.15 ms per GiB:
+//  most such runs lie inside a match the parse takes and are never landed on.)
 AHIP_DEVINL void df_extend2(const u8 *a, u32 dist0, u32 maxl0, u32 dist1, u32 maxl1, u32 lane, u32 &L0, u32 &L1) {
   const u32 o = DF_CAP + 4 * lane;
   u32 same0 = 4, same1 = 4;
@@ -477,18 +483,20 @@ __global__ __launch_bounds__(64) void deflate_parse_kernel(const u8 *__restrict_
   u32 k = 0, pos = 0;
   if (!P.store) {
     const u64 below = (1ull << lane) - 1;
-    // a block's matches and bytes are asked for one block ahead (the wave does nothing but wait for them otherwise: 512
-    // blocks a chunk, a trip to memory each); the match at i + 1 is the neighbour lane's, or lane 0's of the block ahead
+    // 63 positions a block: lane 63 only looks ahead (it is lane 0 of the next block), so the match at i + 1 is always the
+    // neighbour lane's.  A block's matches and bytes are asked for one block ahead and not touched before the next round:
+    // the wave does nothing but wait for them otherwise -- 512 blocks a chunk, a trip to memory each.  (Taking lane 63's
+    // neighbour from the block ahead made every round wait for the loads it had just issued.)
+    constexpr u32 STRIDE = 63;
     u32 m_next = lane < clen ? match[cstart + lane] : 0u;
     u32 b_next = lane < clen ? (u32)in[cstart + lane] : 0u;
-    for (u32 base = 0; base < clen; base += 64) {
+    for (u32 base = 0; base < clen; base += STRIDE) {
       const u32 i = base + lane;
-      const bool inb = i < clen;
+      const bool inb = i < clen && lane < STRIDE;
       const u32 m = m_next, byte = b_next;
-      m_next = i + 64 < clen ? match[cstart + i + 64] : 0u;
-      b_next = i + 64 < clen ? (u32)in[cstart + i + 64] : 0u;
-      const u32 up = lane_gather(m, (lane + 1) & 63), first_ahead = lane_bcast(m_next, 0);
-      const u32 m1 = lane == 63 ? first_ahead : up;  // (0 behind the chunk's end: m_next is)
+      m_next = i + STRIDE < clen ? match[cstart + i + STRIDE] : 0u;
+      b_next = i + STRIDE < clen ? (u32)in[cstart + i + STRIDE] : 0u;
+      const u32 m1 = lane_gather(m, (lane + 1) & 63);  // (0 behind the chunk's end: m is; lane 63 is not used)
       const u32 l = m >> 16;  // <= min(DF_CAP, clen - i) by construction
       bool is_match = inb && l >= DF_MINLEN;
       if (is_match && P.lazy && (m1 >> 16) > l) is_match = false;  // a longer match starts at the next byte
@@ -497,7 +505,7 @@ __global__ __launch_bounds__(64) void deflate_parse_kernel(const u8 *__restrict_
       const bool capped = inb && l >= DF_CAP;  // true length unknown: settled when (if) the parse lands here
       u64 visited = 0;
       const u64 cap_mask = __ballot(capped);
-      const u32 lim = base + 64 < clen ? base + 64 : clen;
+      const u32 lim = base + STRIDE < clen ? base + STRIDE : clen;
       while (pos < lim) {
         const u32 j = pos - base;
         visited |= 1ull << j;
@@ -616,7 +624,8 @@ __device__ inline void df_build_tree_wg(EncLds &E, u16 *tree, int elems, int max
   __syncthreads();
   const int m = (int)E.t_m;
   max_code_out = E.t_maxcode;
-  // ---- bitonic sort, ascending ----
+  // ---- bitonic sort, ascending (passes with j <= 64 stay inside the 128 keys a wave owns; giving only the others the
+  //      workgroup's barrier changed nothing: the tree's time is the serial merge below) ----
   for (u32 k = 2; k <= (u32)NP; k <<= 1) {
     for (u32 j = k >> 1; j > 0; j >>= 1) {
       for (u32 t = tid; t < (u32)NP / 2; t += 256) {
