@@ -1236,7 +1236,7 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
                        dsym.as<u16>(), dwsym.as<u16>());
     // (the window in front of the stream: the hist0 bytes that end right in front of d_out -- already final, see plan_run)
     hipLaunchKernelGGL(sm_windows_link, dim3(1), dim3(1024), 0, st, nch, gs, dwsym.as<u16>(), dgwin.as<u8>(), (const u8 *)d_out - SM_WINDOW, hist0);
-    hipLaunchKernelGGL(sm_windows_apply, dim3(8, nch), dim3(256), 0, st, gs, dwsym.as<u16>(), dgwin.as<u8>(), dwin.as<u8>(),
+    hipLaunchKernelGGL(sm_windows_apply, dim3(nch), dim3(1024), 0, st, gs, dwsym.as<u16>(), dgwin.as<u8>(), dwin.as<u8>(),
                        (const u8 *)d_out - SM_WINDOW, hist0);
   }
   hipLaunchKernelGGL(sm_translate_kernel, dim3(sm_translate_blocks(), nch), dim3(256), 0, st, dchunks.as<ChunkDesc>(), dres.as<MemberResult>(), dsym.as<u16>(),

@@ -420,13 +420,35 @@ __global__ __launch_bounds__(1024) void sm_windows_link(u32 n_chunks, u32 group_
     sm_lds_barrier();
   }
 }
-__global__ __launch_bounds__(256) void sm_windows_apply(u32 group_size, const u16 *__restrict__ wsym, const u8 *__restrict__ gwin,
-                                                        u8 *__restrict__ windows, const u8 *hist_win, u32 hist0) {
-  const u32 k = blockIdx.y, g = k / group_size;
+// (one workgroup per chunk; the group's input window is copied into LDS first -- the look-ups are scattered byte reads, see
+//  sm_translate_kernel)
+__global__ __launch_bounds__(1024) void sm_windows_apply(u32 group_size, const u16 *__restrict__ wsym, const u8 *__restrict__ gwin,
+                                                         u8 *__restrict__ windows, const u8 *hist_win, u32 hist0) {
+  __shared__ u8 W[SM_WINDOW] __attribute__((aligned(16)));
+  const u32 k = blockIdx.x, g = k / group_size, tid = threadIdx.x;
   const u8 *in_win = g ? gwin + (u64)(g - 1) * SM_WINDOW : nullptr;
-  for (u32 j = blockIdx.x * 256 + threadIdx.x; j < SM_WINDOW; j += gridDim.x * 256) {
-    const u32 s = wsym[(u64)k * SM_WINDOW + j];
-    windows[(u64)k * SM_WINDOW + j] = s < SYM_MARK ? (u8)s : (in_win ? in_win[s - SYM_MARK] : sm_hist_byte(hist_win, hist0, s - SYM_MARK));
+  // this chunk's symbols, eight a thread and step (on their way while the window is copied)
+  constexpr u32 PER = SM_WINDOW / 8 / 1024;  // 4
+  uint4 q[PER];
+#pragma unroll
+  for (u32 u = 0; u < PER; ++u) q[u] = ((const uint4 *)(wsym + (u64)k * SM_WINDOW))[tid + u * 1024];
+  if (in_win) for (u32 i = tid; i < SM_WINDOW / 16; i += 1024) ((uint4 *)W)[i] = ((const uint4 *)in_win)[i];
+  else for (u32 i = tid; i < SM_WINDOW; i += 1024) W[i] = sm_hist_byte(hist_win, hist0, i);
+  __syncthreads();
+#pragma unroll
+  for (u32 u = 0; u < PER; ++u) {
+    const u32 x[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+    u32 b[8];
+#pragma unroll
+    for (u32 e = 0; e < 4; ++e) { b[2 * e] = x[e] & 0xffffu; b[2 * e + 1] = x[e] >> 16; }
+    u32 gth[8];
+#pragma unroll
+    for (u32 e = 0; e < 8; ++e) gth[e] = W[b[e] & (SM_WINDOW - 1)];
+#pragma unroll
+    for (u32 e = 0; e < 8; ++e) b[e] = b[e] < SYM_MARK ? b[e] : gth[e];
+    const u64 lo = (b[0] & 0xffu) | ((b[1] & 0xffu) << 8) | ((b[2] & 0xffu) << 16) | (b[3] << 24);
+    const u64 hi = (b[4] & 0xffu) | ((b[5] & 0xffu) << 8) | ((b[6] & 0xffu) << 16) | (b[7] << 24);
+    ((u64 *)(windows + (u64)k * SM_WINDOW))[tid + u * 1024] = lo | (hi << 32);
   }
 }
 

@@ -177,6 +177,12 @@ def request_traffic(rnd, bench_line, js):
                     % (stage_r / 1e9, stage_w / 1e9, (stage_r + stage_w) / 1e9, algo / 1e9, (stage_r + stage_w) / algo))
 
 
+def side_only(rnd):
+    """only the side profiles that exist under gpurun_out/ (tools/run_final_prof.sh, tools/run_side_prof.sh)"""
+    side_profile(rnd, "df", "Deflate level 6, 1 GiB log text (config 3)", "python tests/perf/deflate_stats.py 1024")
+    side_profile(rnd, "sm", "Inflate of ONE 256 MiB gzip member of wiki-like text (config 2a)", "python tools/sm_check.py 256 wiki")
+
+
 def main():
     rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
     os.makedirs(PROF, exist_ok=True)
