@@ -36,8 +36,8 @@
 //                             offsets -> atomicOr into the LDS output image.  A chunk that does
 //                             not shrink is emitted as a stored block.
 //   D4 deflate_concat_kernel  exclusive scan of chunk sizes (host) -> byte-granular gather.
-// Measured (config 3, 1 GiB of log text, level 6): 36 ms = 29.8 GB/s in, match 23.1 / parse 6.3 / encode 6.4 ms
-// (profiles/r04_df_kernel_stats.md; unchanged in round 5).
+// Measured (config 3, 1 GiB of log text, level 6): 27.7 ms = 38.8 GB/s in, match 19.4 / parse 4.2 / encode 4.0 ms
+// (profiles/r05_df_kernel_stats.md; round 4: 36 ms, 23.1 / 6.3 / 6.4 -- same bytes out).
 #pragma once
 #include "common.hpp"
 
