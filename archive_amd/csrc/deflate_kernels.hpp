@@ -506,13 +506,35 @@ __global__ __launch_bounds__(64) void deflate_parse_kernel(const u8 *__restrict_
       u64 visited = 0;
       const u64 cap_mask = __ballot(capped);
       const u32 lim = base + STRIDE < clen ? base + STRIDE : clen;
-      // (a run of literals as ONE hop -- ctz over a mask of the certain literals -- gave the same bytes and was slower, 5.5 against
-      //  4.2 ms per GiB: a second branch per hop costs more than the hops it saves)
-      while (pos < lim) {
-        const u32 j = pos - base;
-        visited |= 1ull << j;
-        u32 st = lane_bcast(step, (int)j);
-        if ((cap_mask >> j) & 1) {
+      // Which positions the parse visits = the orbit of its entry position under "next position".  Followed hop by hop (a scalar
+      // loop of ~ 12 instructions a hop, ~ 12 hops a block) that was the kernel's time: it is bound by instruction issue at its 8
+      // waves per SIMD (no memory access left in the loop: an ablation without the extends costs the same).  Wave-wide instead:
+      // with J = "the lane I hop to" (a capped match and the block's end hop to themselves), the set S of visited lanes grows
+      // by S |= J^(2^k)(S) for k = 0 .. 5 -- the positions after t < 2^(k+1) hops are those after t' < 2^k hops and those 2^k
+      // hops further -- one ds_permute (lanes of S send a 1 to their target) and one ds_bpermute (J doubled) a round.
+      // (A run of literals as ONE hop of the scalar loop gave the same bytes and was slower, 5.5 against 4.2 ms per GiB.)
+      const bool absorb = !inb || capped;  // (lanes behind the block's or the chunk's end are not positions of this block)
+      while (pos < lim) {  // once; once more behind every capped match the parse lands on
+        const u32 entry = pos - base;
+        u32 J = absorb ? lane : (lane + step < 63u ? lane + step : 63u);
+        u32 S = lane == entry ? 1u : 0u;
+#pragma unroll
+        for (u32 r = 0; r < 6; ++r) {
+          const u32 got = (u32)__builtin_amdgcn_ds_permute((int)((S ? J : entry) << 2), 1);  // (everybody else re-marks the entry)
+          S |= got;
+          if (r < 5) J = lane_gather(J, J);
+        }
+        const u64 hit = __ballot(S != 0);
+        const u64 vis = hit & ~__ballot(absorb);
+        const u64 cap_hit = hit & cap_mask;  // the capped match the orbit ends on, if it does
+        visited |= vis;
+        if (!cap_hit) {  // left the block: behind the last position visited
+          const int jl = 63 - __builtin_clzll(vis);
+          pos = base + (u32)jl + lane_bcast(step, jl);
+        } else {
+          const u32 j = (u32)__builtin_ctzll(cap_hit);
+          visited |= 1ull << j;
+          pos = base + j;
           const u8 *a = in + cstart + pos;
           const u32 rem = clen - pos;
           const u32 d0 = lane_bcast(m, (int)j) & 0xffff;
@@ -526,10 +548,9 @@ __global__ __launch_bounds__(64) void deflate_parse_kernel(const u8 *__restrict_
             else L0 = df_extend(a, d0, max0, lane);
             take = !(L1 > L0);
           } else L0 = df_extend(a, d0, max0, lane);
-          st = take ? L0 : 1u;
           if (lane == j) token = take ? ((L0 << 16) | d0) : (0x80000000u | byte);
+          pos += take ? L0 : 1u;
         }
-        pos += st;
       }
       if ((visited >> lane) & 1) t[k + (u32)__popcll(visited & below)] = token;
       k += (u32)__popcll(visited);
