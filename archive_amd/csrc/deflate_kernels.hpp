@@ -25,8 +25,9 @@
 //                             are carried from chunk to chunk (the window of chunk c + 1 is the window of chunk c moved
 //                             on by 32 KiB).  Best (len, dist) per position goes to scratch.
 //   D2 deflate_parse_kernel   one wave per chunk follows the reference's one-step lazy rule as the
-//                             orbit of position 0 (scalar hops over a 64-position block) and writes
-//                             the token list; a capped match the parse lands on is extended by the whole wave.
+//                             orbit of position 0 (63 positions a block, the visited ones found wave-wide by
+//                             pointer doubling) and writes the token list; a capped match the parse lands on is
+//                             extended by the whole wave.
 //   D3 deflate_encode_kernel  one workgroup per chunk: symbol histogram (LDS atomics), zlib's
 //                             heap Huffman construction with the 15/7-bit limit (restated from
 //                             deflate.dart:2567-2784, run by one lane), the dynamic header's code-length
@@ -36,7 +37,7 @@
 //                             offsets -> atomicOr into the LDS output image.  A chunk that does
 //                             not shrink is emitted as a stored block.
 //   D4 deflate_concat_kernel  exclusive scan of chunk sizes (host) -> byte-granular gather.
-// Measured (config 3, 1 GiB of log text, level 6): 27.7 ms = 38.8 GB/s in, match 19.4 / parse 4.2 / encode 4.0 ms
+// Measured (config 3, 1 GiB of log text, level 6): 26.0 ms = 41.2 GB/s in, match 19.4 / parse 2.6 / encode 4.0 ms
 // (profiles/r05_df_kernel_stats.md; round 4: 36 ms, 23.1 / 6.3 / 6.4 -- same bytes out).
 #pragma once
 #include "common.hpp"
