@@ -149,6 +149,9 @@ AHIP_DEVINL u64 sm_find_wave(SmFindLds &S, const u8 *__restrict__ in, u64 in_len
   u64 found = ~0ull;
   u32 qn = 0;
   u64 slab_byte = ~0ull;  // stream byte of slab[0] (a multiple of 4)
+  // (Where the finder's time goes, ablation builds on a 64 MiB member: 0.70 ms; 0.155 with this check compiled out -- and then
+  //  every wave scans its whole part --, 0.06 without filter 1 as well.  Settling the queue slab by slab with the header's bits
+  //  read from the slab in LDS instead of global memory was slower, 0.82 ms: the calls cost, not their memory accesses.)
   auto second = [&]() {  // sm_header_plausible on the first <= SM_SECOND queued positions; lowest position first
     const u32 nb = qn < SM_SECOND ? qn : SM_SECOND;
     bool pass = false;
