@@ -1096,9 +1096,10 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
       std::vector<u64> pc((size_t)n_chunks * SPLIT * 4);
       HIP_TRY(hipMemcpy(pc.data(), dcand.p, pc.size() * 8, hipMemcpyDeviceToHost));
       const size_t nn = (size_t)n_chunks * SPLIT, wgs = (size_t)(n_chunks - 1) * SPLIT;
-      double a = 0, b = 0, c = 0;
-      for (size_t i = 0; i < wgs; ++i) { a += (double)pc[nn + i]; b += (double)pc[2 * nn + i]; c += (double)pc[3 * nn + i]; }
-      fprintf(stderr, "[ahip] sm find: cycles per workgroup: staging %.0f  first filter %.0f  second filter %.0f\n", a / wgs, b / wgs, c / wgs);
+      double a = 0, b = 0, c = 0, d = 0;
+      size_t busy = 0;
+      for (size_t i = 0; i < wgs; ++i) { a += (double)pc[nn + i]; b += (double)pc[2 * nn + i]; c += (double)(pc[3 * nn + i] & 0xffffffffull); d += (double)(pc[3 * nn + i] >> 32); busy += pc[nn + i] != 0; }
+      fprintf(stderr, "[ahip] sm find: per workgroup (%zu of %zu called the header check): calls %.2f  candidates %.1f  cycles in it %.0f of %.0f\n", busy, wgs, a / wgs, b / wgs, c / wgs, d / wgs);
     }
 #endif
     std::vector<u64> found((size_t)n_chunks * SPLIT);

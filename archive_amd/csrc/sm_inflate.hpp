@@ -59,19 +59,57 @@ AHIP_DEVINL bool sm_header_plausible(const u8 *in, u64 in_len, u64 q, u8 *tab /*
   const u64 w = sm_bits64(in, in_len, q + 17);
   // position of symbol s in the transmitted order 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
   const u8 inv[19] = {3, 17, 15, 13, 11, 9, 7, 5, 4, 6, 8, 10, 12, 14, 16, 18, 0, 1, 2};
-  u32 code = 0;
-  for (u32 bl = 1; bl <= 7; ++bl) {
+  // The code-length code, canonical, WITHOUT a look-up table: how many codes of each length (cnt), the first code of each
+  // length (first) and where its symbols start in the list of symbols sorted by (length, symbol) (offs) -- 8-bit fields of a
+  // u64 each; the caller's first filter has made sure the code is complete, so a code fits 7 bits and a first code 8 -- and
+  // that list in this lane's 128 bytes.  A symbol is then decoded by comparing the next 1 .. 7 bits with the lengths' code
+  // ranges.  (A 128-entry table per candidate -- seven passes over the 19 symbols, each code replicated 2^(7 - len) times in
+  // loops whose trip count is the longest of the 32 lanes' -- was what a call of this function cost; nearly every candidate
+  // dies within a few symbols, and the calls are four fifths of the finder.)
+  u64 cnt = 0;
+#pragma unroll
+  for (u32 sym = 0; sym < 19; ++sym) {
+    const u32 l = inv[sym] < ncl ? (u32)(w >> (3 * inv[sym])) & 7 : 0u;
+    cnt += 1ull << (8 * l);
+  }
+  cnt &= ~0xffull;  // (length 0 = not used)
+  u64 first = 0, offs = 0;
+  {
+    u32 code = 0, at = 0;
+#pragma unroll
+    for (u32 bl = 1; bl <= 7; ++bl) {
+      const u32 before = bl > 1 ? (u32)(cnt >> (8 * (bl - 1))) & 0xffu : 0u;
+      code = (code + before) << 1;
+      at += before;
+      first |= (u64)(code & 0xffu) << (8 * bl);
+      offs |= (u64)at << (8 * bl);
+    }
+  }
+  {
+    u64 put = offs;  // field l: where the next symbol of length l goes
 #pragma unroll
     for (u32 sym = 0; sym < 19; ++sym) {
       const u32 l = inv[sym] < ncl ? (u32)(w >> (3 * inv[sym])) & 7 : 0u;
-      if (l == bl) {
-        const u32 rev = __brev(code) >> (32 - bl);
-        for (u32 j = rev; j < 128; j += 1u << bl) tab[j] = (u8)((bl << 5) | sym);
-        ++code;
-      }
+      if (l) { tab[(u32)(put >> (8 * l)) & 0xffu] = (u8)sym; put += 1ull << (8 * l); }
     }
-    code <<= 1;
   }
+  // (The header's bits come from global memory, 64 at a time.  Fetching its first 96 bytes into this lane's LDS at once changed
+  //  nothing -- a call of this function takes ~ 80 us, 1.2 calls per searching wave, and it is the serial decode of the ONE true
+  //  header among the candidates that the call waits for: ~ 150 dependent steps on a wave with two or three neighbours per SIMD.)
+  // length and symbol of the code in the low bits of `bits` (0: none -- cannot happen with a complete code)
+  auto decode = [&](u32 bits, u32 &sym) -> u32 {
+    const u32 r = __brev(bits) >> 25;  // the next seven bits, the first one read on top: a code of length l is r >> (7 - l)
+    u32 len = 0, idx = 0;
+#pragma unroll
+    for (u32 l = 7; l >= 1; --l) {  // (downwards: the shortest length that fits is the one that stays)
+      const u32 c = (r >> (7 - l)) - ((u32)(first >> (8 * l)) & 0xffu);
+      const bool hit = c < ((u32)(cnt >> (8 * l)) & 0xffu);
+      len = hit ? l : len;
+      idx = hit ? ((u32)(offs >> (8 * l)) & 0xffu) + c : idx;
+    }
+    sym = len ? tab[idx] : 0u;
+    return len;
+  };
   const u32 total = hlit + hdist;
   const u64 end_bits = in_len * 8;
   u64 pos = q + 17 + 3 * ncl;
@@ -80,9 +118,8 @@ AHIP_DEVINL bool sm_header_plausible(const u8 *in, u64 in_len, u64 q, u8 *tab /*
   bool eob = false;
   while (idx < total) {
     if (have < 16) { if (pos + 16 > end_bits) return false; buf = sm_bits64(in, in_len, pos); have = 64; }
-    const u32 e = tab[(u32)buf & 127];
-    u32 len = e >> 5;
-    const u32 sym = e & 31;
+    u32 sym;
+    u32 len = decode((u32)buf & 127u, sym);
     if (len == 0) return false;
     u32 rep = 1, val = sym;
     if (sym >= 16) {
@@ -127,7 +164,7 @@ constexpr u32 SM_SLAB = 2048, SM_STEP = 2048;  // bytes per slab; bit positions 
 //  and the kernel is latency-bound.)
 constexpr u32 SM_SECOND = 32;  // candidates the second filter takes at a time (a 128-byte table each)
 struct SmFindLds {
-  u8 cl_tab[SM_SECOND][128];
+  u8 cl_tab[SM_SECOND][128];  // per candidate of a second-filter call: its symbols sorted by code length (19 bytes used)
   u64 queue[128];
   u8 kraft4[4096];  // sum of 128 >> len over four 3-bit code-length fields (len 0 counts nothing), saturated at 255
   u32 slab[(SM_SLAB + 64) / 4];
@@ -137,7 +174,7 @@ struct SmFindLds {
 // The host keeps the first find behind a cut, so a wave searching a LATER part of the same cut gives up as soon as an
 // earlier part has one (its own find could not be used): about half of the finder's work on text.
 AHIP_DEVINL u64 sm_find_wave(SmFindLds &S, const u8 *__restrict__ in, u64 in_len, u64 q0, u64 q1, const int lane,
-                             u32 *first_part = nullptr, u32 part = 0) {
+                             u32 *first_part = nullptr, u32 part = 0, u64 *stats = nullptr) {
   for (u32 i = lane; i < 4096; i += 64) {
     u32 t = 0;
     for (u32 f = 0; f < 4; ++f) { const u32 l = (i >> (3 * f)) & 7; t += l ? (128u >> l) : 0u; }
@@ -154,6 +191,9 @@ AHIP_DEVINL u64 sm_find_wave(SmFindLds &S, const u8 *__restrict__ in, u64 in_len
   //  read from the slab in LDS instead of global memory was slower, 0.82 ms: the calls cost, not their memory accesses.)
   auto second = [&]() {  // sm_header_plausible on the first <= SM_SECOND queued positions; lowest position first
     const u32 nb = qn < SM_SECOND ? qn : SM_SECOND;
+#ifdef AHIP_PROFILE
+    const u64 t_in = __builtin_amdgcn_s_memtime();
+#endif
     bool pass = false;
     if ((u32)lane < nb) pass = sm_header_plausible(in, in_len, S.queue[lane], S.cl_tab[lane]);
     const u64 pm = __ballot(pass);
@@ -165,6 +205,9 @@ AHIP_DEVINL u64 sm_find_wave(SmFindLds &S, const u8 *__restrict__ in, u64 in_len
     if ((u32)lane + 64 + nb < qn) S.queue[lane + 64] = m1;
     qn -= nb;
     wave_sync();
+#ifdef AHIP_PROFILE
+    if (stats && lane == 0) { stats[0] += 1; stats[1] += nb; stats[2] += __builtin_amdgcn_s_memtime() - t_in; }
+#endif
   };
   for (u64 base = q0 & ~31ull; found == ~0ull && base < q1; base += SM_STEP) {
     if (first_part && uniform(__atomic_load_n(first_part, __ATOMIC_RELAXED)) < part) return ~0ull;
@@ -273,7 +316,18 @@ __global__ __launch_bounds__(64) void sm_find_kernel(const u8 *__restrict__ in, 
   const u64 part_bits = chunk_bytes * 8 / split;
   const u64 q0 = (data_start + (u64)k * chunk_bytes) * 8 + part * part_bits;
   u32 *first_part = (u32 *)(cand + (u64)n_chunks * split * 4) + k;  // (behind the finds and the profile slots; set to "none" by the host)
+#ifdef AHIP_PROFILE
+  __shared__ u64 stats[4];
+  if (lane < 4) stats[lane] = 0;
+  const u64 t_all = __builtin_amdgcn_s_memtime();
+  const u64 found = sm_find_wave(S, in, in_len, q0, q0 + part_bits, lane, first_part, part, stats);
+  if (lane == 0) {  // per workgroup behind the finds: calls of the header check, candidates it took, its cycles (the host prints means)
+    const u64 nn = (u64)n_chunks * split;
+    cand[nn + blockIdx.x] = stats[0]; cand[2 * nn + blockIdx.x] = stats[1]; cand[3 * nn + blockIdx.x] = stats[2] | ((__builtin_amdgcn_s_memtime() - t_all) << 32);
+  }
+#else
   const u64 found = sm_find_wave(S, in, in_len, q0, q0 + part_bits, lane, first_part, part);
+#endif
   if (lane == 0) {
     cand[(u64)k * split + part] = found;
     if (found != ~0ull) atomicMin(first_part, part);
