@@ -26,6 +26,7 @@
 #include "checksum_kernels.hpp"
 #include "deflate_kernels.hpp"
 #include "inflate_par.hpp"
+#include "inflate_res_wg.hpp"
 #include "sm_inflate.hpp"
 
 using namespace ahip;
@@ -184,6 +185,121 @@ __global__ __launch_bounds__(64, AHIP_RES_MIN_WAVES) void inflate_resolve_kernel
 #ifdef AHIP_PROFILE_RES
     if (lane == 0) for (int q = 0; q < 8; ++q) results[m].cyc[q] = cyc[q];
 #endif
+  }
+}
+
+// The resolver as a workgroup per member (inflate_res_wg.hpp): WG_WAVES waves share one LDS ring that holds DEFLATE's whole
+// reach, so no back-reference goes to global memory.  Same arguments, same member hand-out (one counter step per
+// WORKGROUP) and same skips as inflate_resolve_kernel, which stays for the late kernel's members and the A/B switch
+// AHIP_RES_WG=0.
+union ResWgKernelLds {
+  ResWgLds wg;
+  ResLds one;  // a member of 2 GiB and more (positions are 32-bit here): the one-wave resolver, wave 0 alone
+};
+// What a workgroup needs to know of a member before it can start: handed from wave 0 to the others through LDS.
+struct WgMember {
+  u32 k;           // index in the launch (>= n_members: nothing left)
+  u32 m;           // member
+  u32 ndir;        // runs in its directory; 0xffffffff: not for this kernel (late kernel, re-tokenized, long member)
+  u32 big;         // produced >= 2 GiB
+  u64 out_off, toff, doff;
+};
+// With four members per CU nothing hides a member's start-up -- the hand-out counter, its descriptor, its verdict, then
+// its directory and its first tokens are four dependent round trips to memory --, so the hand-out runs TWO members ahead:
+// while member k is resolved, wave 0 holds the counter's answer for the member after next and has the descriptor and the
+// verdict of the next one on their way.
+template <bool KEPT>
+__global__ __launch_bounds__(WG_THREADS) void inflate_resolve_wg_kernel(const u8 *__restrict__ in,
+                                                            const MemberDesc *__restrict__ members, u32 first_member,
+                                                            u32 n_members, u8 *out, const u32 *__restrict__ tokens,
+                                                            const DirEnt *__restrict__ dir, u64 group_out0,
+                                                            MemberResult *__restrict__ results, InLayout lay,
+                                                            const MemberResult *__restrict__ sized, MemberSel sel,
+                                                            u32 *__restrict__ next) {
+  __shared__ ResWgKernelLds lds;
+  __shared__ WgMember hand;
+  const int lane = threadIdx.x & 63, wave = (int)uniform(threadIdx.x >> 6);
+  // raw loads of a member's start-up data (wave 0; every lane loads the same words) ...
+  struct Raw { u32 k, m; u64 out_off, out_limit, in_off, tok_words, out_len; u32 status, blocks, pad; };
+  auto ask = [&](u32 k) -> Raw {
+    Raw r{};
+    r.k = k;
+    if (k >= n_members) return r;
+    r.m = sel.ids ? sel.ids[k] : first_member + k;
+    const MemberDesc &d = members[r.m];
+    r.out_off = d.out_off; r.out_limit = d.out_limit; r.in_off = d.in_off; r.pad = d.pad;
+    const MemberResult &v = KEPT ? sized[r.pad] : results[r.m];
+    r.status = v.status; r.blocks = v.blocks; r.tok_words = v.tok_words; r.out_len = v.out_len;
+    return r;
+  };
+  // ... and what follows from them
+  auto post = [&](const Raw &r) {
+    WgMember h{};
+    h.k = uniform(r.k);
+    if (h.k < n_members) {
+      h.m = uniform(r.m);
+      h.out_off = uniform64(r.out_off);
+      const u64 out_limit = uniform64(r.out_limit);
+      const u32 status = uniform(r.status), blocks = uniform(r.blocks);
+      h.ndir = (u32)uniform64(r.tok_words);
+      h.big = uniform64(r.out_len) >= (1ull << 31);
+      u32 cc, dc;
+      if (KEPT) {  // the tokens of the sizing run
+        const u32 c = uniform(r.pad);
+        if (status != MS_OK || (blocks & MR_FAR)) h.ndir = 0xffffffffu;  // HF_RETOK: tokenized again, afterwards
+        else {
+          if (lane == 0) results[h.m] = sized[c];
+          if (uniform64(r.in_off) >= lay.in_len) h.ndir = 0xffffffffu;  // a long member: decoded by many waves, elsewhere
+        }
+        in_layout(lay, c, h.toff, cc, h.doff, dc);
+      } else {
+        if (status == MS_TOKFULL || status == MS_OVERSUB || (blocks & MR_FAR)) h.ndir = 0xffffffffu;  // inflate_late_kernel
+        tok_layout(sel.ids ? uniform64(sel.rel[h.k]) : h.out_off - group_out0, out_limit, h.k, h.toff, cc, h.doff, dc);
+      }
+    }
+    if (lane == 0) hand = h;
+  };
+  u32 k2 = 0;  // (thread 0) the counter's answer for the member after next
+  Raw nxt{};
+  if (wave == 0) {
+    u32 k0 = 0, k1 = 0;
+    if (lane == 0) { k0 = atomicAdd(next, 1u); k1 = atomicAdd(next, 1u); k2 = atomicAdd(next, 1u); }
+    k0 = uniform(k0); k1 = uniform(k1);
+    post(ask(k0));
+    nxt = ask(k1);
+  }
+  __syncthreads();
+  for (;;) {
+    const WgMember h = hand;
+    if (uniform(h.k) >= n_members) break;
+    const u32 m = uniform(h.m), ndir = uniform(h.ndir);
+    __syncthreads();  // (everybody has read the hand-out)
+    if (ndir != 0xffffffffu) {
+      const u64 out_off = uniform64(h.out_off), toff = uniform64(h.toff), doff = uniform64(h.doff);
+      bool ok;
+      if (uniform(h.big)) {
+        ok = true;
+        u32 cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (wave == 0) ok = resolve_member(lds.one, in, tokens + toff, dir + doff, ndir, out + out_off, cyc, lane);
+        __syncthreads();
+      } else {
+#ifdef AHIP_PROFILE_RES
+        u32 cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        ok = resolve_member_wg(lds.wg, in, tokens + toff, dir + doff, ndir, out + out_off, wave, lane, cyc);
+        if (lane == 0) for (int q = 0; q < 8; ++q) if (q < 7 || wave == 0) atomicAdd(&results[m].cyc[q], cyc[q]);  // (phases summed over the waves)
+#else
+        ok = resolve_member_wg(lds.wg, in, tokens + toff, dir + doff, ndir, out + out_off, wave, lane);
+#endif
+      }
+      if (!ok && lane == 0) results[m].status = MS_INTERNAL;
+    }
+    if (wave == 0) {
+      post(nxt);                        // the next member's data has been here for a while
+      const u32 kn = uniform(k2);
+      if (lane == 0) k2 = atomicAdd(next, 1u);
+      nxt = ask(kn);
+    }
+    __syncthreads();
   }
 }
 
@@ -360,6 +476,15 @@ hipError_t tokens_reserve(size_t bytes, void **p) {
 
 inline u32 cdiv(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
 
+// AHIP_RES_WG=1: the resolver as a workgroup per member with DEFLATE's whole reach in one LDS ring (inflate_res_wg.hpp) instead of
+// the one-wave-per-member kernel.  Bit-exact and without a single far fetch (resolver reads 53 -> 5 GB per decode), but 10.6 ms
+// against 7.8 on the benchmark stream: an unaligned DS access costs one LDS cycle per active lane, and with the history in LDS
+// every match pays that twice (profiles/r06_experiments.md section 1).  Kept selectable, measured, not the default.
+bool use_res_wg() {
+  static int v = -1;
+  if (v < 0) { const char *e = getenv("AHIP_RES_WG"); v = (e && e[0] == '1') ? 1 : 0; }
+  return v == 1;
+}
 bool use_serial_kernel() {
   static int v = -1;
   if (v < 0) { const char *e = getenv("AHIP_SERIAL"); v = (e && e[0] == '1') ? 1 : 0; }
@@ -412,7 +537,8 @@ hipError_t launch_inflate_group(const u8 *in, u64 n, const MemberDesc *members, 
     if (e != hipSuccess) return e;
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, inflate_tokenize_kernel<false>, 64, 0);
     if (e != hipSuccess) return e;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, inflate_resolve_kernel<false>, 64, 0);
+    if (use_res_wg()) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, inflate_resolve_wg_kernel<false>, (int)WG_THREADS, 0);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, inflate_resolve_kernel<false>, 64, 0);
     if (e != hipSuccess) return e;
     // (the number the runtime reports is sometimes one workgroup per CU more than the hardware grants -- MI355X_MICROARCH.md,
     // "Residency"; members are handed out by a counter, so the surplus workgroups just find nothing left to do)
@@ -475,9 +601,14 @@ hipError_t launch_inflate_group(const u8 *in, u64 n, const MemberDesc *members, 
   if (ktime) (void)hipEventRecord(kt[1], st);
   if (WRITE) {
     const u32 grid2 = count < (u32)res_resident ? count : (u32)res_resident;
-    hipLaunchKernelGGL(inflate_resolve_kernel<false>, dim3(grid2), dim3(64), 0, st, in, members, first, count, out,
-                       (const u32 *)tp, (const DirEnt *)dp, out0, res, InLayout{nullptr, 0, n}, (const MemberResult *)nullptr,
-                       MemberSel{nullptr, nullptr}, dlate.as<u32>() + 2);
+    if (use_res_wg())
+      hipLaunchKernelGGL(inflate_resolve_wg_kernel<false>, dim3(grid2), dim3(WG_THREADS), 0, st, in, members, first, count, out,
+                         (const u32 *)tp, (const DirEnt *)dp, out0, res, InLayout{nullptr, 0, n}, (const MemberResult *)nullptr,
+                         MemberSel{nullptr, nullptr}, dlate.as<u32>() + 2);
+    else
+      hipLaunchKernelGGL(inflate_resolve_kernel<false>, dim3(grid2), dim3(64), 0, st, in, members, first, count, out,
+                         (const u32 *)tp, (const DirEnt *)dp, out0, res, InLayout{nullptr, 0, n}, (const MemberResult *)nullptr,
+                         MemberSel{nullptr, nullptr}, dlate.as<u32>() + 2);
   }
   if (ktime) {
     (void)hipEventRecord(kt[2], st);
@@ -511,9 +642,14 @@ hipError_t launch_resolve_kept(const u8 *in, u64 n, const MemberDesc *members, u
   if (e != hipSuccess) return e;
   e = hipMemsetAsync(g_late.p, 0, 64, st);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(inflate_resolve_kernel<true>, dim3(grid), dim3(64), 0, st, in, members, 0u, M, out, (const u32 *)g_tokens.p,
-                     (const DirEnt *)g_scratch.p, (u64)0, res, InLayout{cand_pos, K, n}, sized, MemberSel{nullptr, nullptr},
-                     g_late.as<u32>() + 2);
+  if (use_res_wg())
+    hipLaunchKernelGGL(inflate_resolve_wg_kernel<true>, dim3(grid), dim3(WG_THREADS), 0, st, in, members, 0u, M, out, (const u32 *)g_tokens.p,
+                       (const DirEnt *)g_scratch.p, (u64)0, res, InLayout{cand_pos, K, n}, sized, MemberSel{nullptr, nullptr},
+                       g_late.as<u32>() + 2);
+  else
+    hipLaunchKernelGGL(inflate_resolve_kernel<true>, dim3(grid), dim3(64), 0, st, in, members, 0u, M, out, (const u32 *)g_tokens.p,
+                       (const DirEnt *)g_scratch.p, (u64)0, res, InLayout{cand_pos, K, n}, sized, MemberSel{nullptr, nullptr},
+                       g_late.as<u32>() + 2);
   e = hipEventRecord(scratch_free, st);
   if (e != hipSuccess) return e;
   return hipGetLastError();
@@ -539,9 +675,14 @@ hipError_t launch_inflate_listed(const u8 *in, u64 n, const MemberDesc *members,
   const u32 r1 = tok_resident > 0 ? (u32)tok_resident : 2048u, r2 = res_resident > 0 ? (u32)res_resident : 4096u;
   hipLaunchKernelGGL(inflate_tokenize_kernel<false>, dim3(count < r1 ? count : r1), dim3(64), 0, st, in, n, members, 0u, count,
                      g_tokens2.as<u32>(), g_scratch2.as<DirEnt>(), (u64)0, res, g_late.as<u32>(), InLayout{nullptr, 0, n}, sel);
-  hipLaunchKernelGGL(inflate_resolve_kernel<false>, dim3(count < r2 ? count : r2), dim3(64), 0, st, in, members, 0u, count, out,
-                     (const u32 *)g_tokens2.p, (const DirEnt *)g_scratch2.p, (u64)0, res, InLayout{nullptr, 0, n},
-                     (const MemberResult *)nullptr, sel, g_late.as<u32>() + 2);
+  if (use_res_wg())
+    hipLaunchKernelGGL(inflate_resolve_wg_kernel<false>, dim3(count < r2 ? count : r2), dim3(WG_THREADS), 0, st, in, members, 0u, count, out,
+                       (const u32 *)g_tokens2.p, (const DirEnt *)g_scratch2.p, (u64)0, res, InLayout{nullptr, 0, n},
+                       (const MemberResult *)nullptr, sel, g_late.as<u32>() + 2);
+  else
+    hipLaunchKernelGGL(inflate_resolve_kernel<false>, dim3(count < r2 ? count : r2), dim3(64), 0, st, in, members, 0u, count, out,
+                       (const u32 *)g_tokens2.p, (const DirEnt *)g_scratch2.p, (u64)0, res, InLayout{nullptr, 0, n},
+                       (const MemberResult *)nullptr, sel, g_late.as<u32>() + 2);
   hipLaunchKernelGGL(inflate_late_kernel<true>, dim3(1), dim3(64), 0, st, in, n, members, 0u, count, out, (const u32 *)g_tokens2.p,
                      (const DirEnt *)g_scratch2.p, (u64)0, res, g_late.as<u32>(), g_exact.as<u32>(), sel);
   e = hipEventRecord(scratch_free, st);

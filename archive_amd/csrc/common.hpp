@@ -119,6 +119,18 @@ struct MemberResult {
 #define AHIP_ACC(slot, t0, t1) do { } while (0)
 #endif
 
+// A word in LDS that one wave of a workgroup writes and the others poll (the frontier of the workgroup-per-member
+// resolver).  The CU's LDS executes the DS instructions of all its waves in one order and a wave's own in issue order, so
+// "data, then the word" by the writer and "the word, then data" by a reader need no hardware wait -- only the compiler must
+// keep the order (wave_sync() on both sides).  In the CPU emulation lanes are threads: acquire / release.
+#ifdef AHIP_HOST_EMU
+#define AHIP_LDS_POLL(p) __atomic_load_n((p), __ATOMIC_ACQUIRE)
+#define AHIP_LDS_POST(p, v) __atomic_store_n((p), (v), __ATOMIC_RELEASE)
+#else
+#define AHIP_LDS_POLL(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define AHIP_LDS_POST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#endif
+
 // Compiler-level ordering point for cross-lane traffic through LDS/global inside ONE wave.
 // The hardware already executes a wave's DS (and vector-memory) instructions in issue order;
 // this only stops hipcc from moving accesses across it.

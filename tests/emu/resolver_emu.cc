@@ -4,8 +4,13 @@
 //
 //   g++ -std=c++17 -O2 -pthread -o resolver_emu tests/emu/resolver_emu.cc
 //   resolver_emu <file of concatenated gzip members> [seed]
+//   -DEMU_WG: the workgroup-per-member resolver (inflate_res_wg.hpp): WG_WAVES x 64 threads, one LDS ring
 #define AHIP_HOST_EMU 1
+#ifdef EMU_WG
+#include "../../archive_amd/csrc/inflate_res_wg.hpp"
+#else
 #include "../../archive_amd/csrc/inflate_par.hpp"
+#endif
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
@@ -42,7 +47,12 @@ typedef u16 Elem;
 #else
 typedef u8 Elem;
 #endif
+#ifdef EMU_WG
+static ResWgLds PW;               // the workgroup's LDS
+static wave_emu::Ctx wave_ctx[8];  // a context per wave
+#else
 static ResLdsT<Elem> P;  // the wave's LDS
+#endif
 
 int main(int argc, char **argv) {
   if (argc < 2) return 2;
@@ -148,12 +158,31 @@ int main(int argc, char **argv) {
     }
     runs_total += dir.size(); toks_total += tok.size();
     const size_t produced = ref.size() - out0 - front;
-    std::vector<Elem> eout(produced + 64, (Elem)0xEE);
+    // (the output starts at every alignment in turn: the ring goes out in 16-byte units aligned in global memory)
+    const size_t mis = members % 16;
+    std::vector<Elem> ebuf(produced + 64 + 16 + 32, (Elem)0xEE);
+    Elem *eout_p = (Elem *)(((uintptr_t)ebuf.data() + 15) & ~(uintptr_t)15) + mis;
     u32 cyc_all[64][8] = {};
     std::vector<std::thread> th;
-    for (int l = 0; l < 64; ++l)
-      th.emplace_back([&, l]() { wave_emu::lane = l; resolve_member<Elem>(P, in_, area.data(), dir.data(), (u32)dir.size(), eout.data(), cyc_all[l], l); });
+#ifdef EMU_WG
+    wave_emu::wg_threads = (int)WG_THREADS;
+    bool ok_all[WG_THREADS];
+    for (int t = 0; t < (int)WG_THREADS; ++t)
+      th.emplace_back([&, t]() {
+        wave_emu::lane = t & 63; wave_emu::wave = t >> 6; wave_emu::cur = &wave_ctx[t >> 6];
+        ok_all[t] = resolve_member_wg(PW, in_, area.data(), dir.data(), (u32)dir.size(), eout_p, t >> 6, t & 63);
+      });
     for (auto &x : th) x.join();
+    for (int t = 0; t < (int)WG_THREADS; ++t) if (!ok_all[t]) { printf("LOOP BOUND reached in member %zu (thread %d)\n", members, t); return 1; }
+    // nothing in front of the member's first byte or behind its last one may have been touched
+    for (size_t i = 0; i < mis; ++i) if (eout_p[-(ptrdiff_t)(i + 1)] != (Elem)0xEE) { printf("WRITE IN FRONT of member %zu\n", members); return 1; }
+    for (size_t i = 0; i < 32; ++i) if (eout_p[produced + i] != (Elem)0xEE) { printf("WRITE BEHIND member %zu (+%zu)\n", members, i); return 1; }
+#else
+    for (int l = 0; l < 64; ++l)
+      th.emplace_back([&, l]() { wave_emu::lane = l; resolve_member<Elem>(P, in_, area.data(), dir.data(), (u32)dir.size(), eout_p, cyc_all[l], l); });
+    for (auto &x : th) x.join();
+#endif
+    const Elem *eout = eout_p;
     const uint8_t *want = ref.data() + out0 + front;
     for (size_t i = 0; i < produced; ++i) {
       uint32_t v = eout[i];
@@ -163,12 +192,33 @@ int main(int argc, char **argv) {
         v = ref[out0 + (size_t)at];
         markers_total++;
       }
-      if (v != want[i]) { printf("MISMATCH in member %zu at element %zu of %zu (got %02x want %02x)\n", members, i, produced, v, want[i]); return 1; }
+      if (v != want[i]) {
+        printf("MISMATCH in member %zu at element %zu of %zu (got %02x want %02x)\n", members, i, produced, v, want[i]);
+        // which directory entry / token makes that byte
+        uint64_t o = 0;
+        for (size_t e = 0; e < dir.size(); ++e) {
+          const uint32_t cnt = dir[e].y & DF_CNT;
+          if (dir[e].y & DF_STORED) { if (i < o + cnt) { printf("  stored entry %zu at %llu + %u\n", e, (unsigned long long)o, cnt); break; } o += cnt; continue; }
+          uint32_t pe = 0; bool hit = false;
+          for (uint32_t k = 0; k < cnt; ++k) {
+            const uint32_t w = area[dir[e].x + k], len = ((w >> 16) - pe) & 0xffffu;
+            if (i < o + len) { printf("  entry %zu (%s, %u tokens, starts at %llu) token %u: at %llu, %u bytes, %s %u\n", e, (dir[e].y & DF_BIG) ? "BIG" : "plain", cnt, (unsigned long long)dir[e].z, k,
+                                      (unsigned long long)o, len, (w & REC_LIT) ? "literal" : "distance", (w & REC_LIT) ? (w & 0xff) : (w & 0x7fff) + 1); hit = true; break; }
+            o += len; pe = w >> 16;
+          }
+          if (hit) break;
+        }
+        return 1;
+      }
     }
     members++;
     pos = (size_t)((p + 7) >> 3) + 8;
   }
+#ifdef EMU_WG
+  const char *what = "workgroup-per-member resolver";
+#else
   const char *what = sizeof(Elem) == 2 ? "token-centric resolver, 16-bit symbols" : "token-centric resolver";
+#endif
   if (sizeof(Elem) == 2) printf("markers checked: %llu\n", (unsigned long long)markers_total);
   printf("resolver emu ok [%s]: %zu members, %zu bytes, %llu token words in %llu runs, %llu stored records\n", what, members, ref.size(),
          (unsigned long long)toks_total, (unsigned long long)runs_total, (unsigned long long)stored_recs);

@@ -29,23 +29,31 @@ struct Ctx {
   uint64_t slot[W];
 };
 inline Ctx ctx;
-inline void barrier() {
-  const int ph = ctx.phase.load(std::memory_order_acquire);
-  if (ctx.arrived.fetch_add(1, std::memory_order_acq_rel) == W - 1) {
-    ctx.arrived.store(0, std::memory_order_relaxed);
-    ctx.phase.store(ph + 1, std::memory_order_release);
+// A WORKGROUP of several waves (the workgroup-per-member resolver): every wave has a context of its own (a thread's
+// `cur` points at its wave's), the workgroup barrier counts all of its threads.
+inline thread_local Ctx *cur = &ctx;
+inline thread_local int wave = 0;
+inline void barrier_on(Ctx &c, int n) {
+  const int ph = c.phase.load(std::memory_order_acquire);
+  if (c.arrived.fetch_add(1, std::memory_order_acq_rel) == n - 1) {
+    c.arrived.store(0, std::memory_order_relaxed);
+    c.phase.store(ph + 1, std::memory_order_release);
   } else {
     int spins = 0;
-    while (ctx.phase.load(std::memory_order_acquire) == ph)
+    while (c.phase.load(std::memory_order_acquire) == ph)
       if (++spins > 64) std::this_thread::yield();  // fewer cores than lanes
   }
 }
+inline void barrier() { barrier_on(*cur, W); }
+inline Ctx wg_ctx;
+inline int wg_threads = W;
+inline void wg_barrier() { barrier_on(wg_ctx, wg_threads); }
 // publish v, let f look at all 64 values, leave together
 template <class F>
 inline auto exchange(uint64_t v, F f) -> decltype(f((const uint64_t *)nullptr)) {
-  ctx.slot[lane] = v;
+  cur->slot[lane] = v;
   barrier();
-  auto r = f((const uint64_t *)ctx.slot);
+  auto r = f((const uint64_t *)cur->slot);
   barrier();
   return r;
 }
@@ -60,6 +68,9 @@ static inline unsigned __brev(unsigned v) { unsigned r = 0; for (int i = 0; i < 
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 static inline void __builtin_amdgcn_wave_barrier() { wave_emu::barrier(); }
 static inline unsigned long long __builtin_amdgcn_s_memtime() { return 0; }
+static inline void __builtin_amdgcn_s_sleep(int) { std::this_thread::yield(); }
+static inline void __syncthreads() { wave_emu::wg_barrier(); }
+static inline unsigned atomicAdd(unsigned *p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_ACQ_REL); }
 static inline int __builtin_amdgcn_readlane(int v, int src) {
   return wave_emu::exchange((uint32_t)v, [src](const uint64_t *s) { return (int)(uint32_t)s[src & 63]; });
 }

@@ -222,6 +222,44 @@ print("groups ok")
     assert r.returncode == 0 and "groups ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_workgroup_resolver_is_bit_exact(native_built):
+    """The resolver as a workgroup per member (inflate_res_wg.hpp, AHIP_RES_WG=1; the library reads the switch once, so a
+    fresh process): DEFLATE's whole reach in one LDS ring shared by four waves, chunks completing in stream order.  Members
+    of the benchmark's kind against their plain text; streams without size hints (the kept tokens of the sizing run); every
+    valid stream shape of tests/streams.py against the oracle -- zeros (a chunk of 64 matches is 16 KiB: token by token), periods
+    shorter than a match, stored blocks, members of a few bytes; many members so that every output alignment occurs."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, zlib, random
+sys.path.insert(0, %r)
+import archive_amd
+from tests import streams
+from tools import corpus
+comp, plain = corpus.make_gzip(n_members=200, want_plain=True)
+assert archive_amd.GZipDecoder().decode_bytes(bytes(comp)) == bytes(plain)
+comp, plain = corpus.make_gzip(n_members=70, want_plain=True, bc=False)      # no size hints: resolved from the sizing run's tokens
+assert archive_amd.GZipDecoder().decode_bytes(bytes(comp)) == bytes(plain)
+rnd = random.Random(3)
+noise = bytes(rnd.getrandbits(8) for _ in range(70000))
+parts = [bytes(200000), b"abc" * 40000, b"0123456789" * 7000, noise, streams.text(150000, 4), b"", b"x", b"xy" * 3,
+         (streams.text(5000, 4) + noise[:3000]) * 9, bytes(range(256)) * 300, streams.text(66000, 5)]
+for lv in (0, 1, 6, 9):
+    g = b"".join(streams.gz_member(p, level=lv) for p in parts)
+    assert archive_amd.GZipDecoder().decode_bytes(g) == b"".join(parts), lv
+from oracle import pyoracle
+for name, raw in streams.valid_raw_streams():
+    z = archive_amd.Inflate(raw)
+    assert (z.status, z.get_bytes(), z.input_position) == pyoracle.inflate_raw(raw), name
+odd = [streams.text(1 + 37 * i, i) for i in range(300)]                        # ragged members: every output alignment
+assert archive_amd.GZipDecoder().decode_bytes(b"".join(streams.bgzf_member(p) for p in odd)) == b"".join(odd)
+print("wg resolver ok")
+''' % ROOT
+    env = dict(os.environ, AHIP_RES_WG="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "wg resolver ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_device_resident_plan_api(amd):
     import torch
     from archive_amd import _native as N

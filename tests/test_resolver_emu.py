@@ -25,12 +25,18 @@ def _binary(variant):
     exe = os.path.join(BUILD, "resolver_emu_" + variant.replace("+", "_"))
     src = os.path.join(ROOT, "tests", "emu", "resolver_emu.cc")
     deps = [src, os.path.join(ROOT, "tests", "emu", "wave_emu.hpp")] + [os.path.join(ROOT, "archive_amd", "csrc", f)
-                                                                        for f in ("common.hpp", "inflate_wave.hpp", "inflate_par.hpp")]
+                                                                        for f in ("common.hpp", "inflate_wave.hpp", "inflate_par.hpp", "inflate_res_wg.hpp")]
     if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps):
         flags = {"production": [], "small_window": ["-DAHIP_WIN_CAP=1024", "-DAHIP_WIN_KEEP=400"],
                  "big_window": ["-DAHIP_WIN_CAP=8192", "-DAHIP_WIN_KEEP=2048"],
                  "small_pending": ["-DAHIP_WIN_CAP=8192", "-DAHIP_WIN_KEEP=512", "-DAHIP_PEND_CAP=128"],
-                 "symbols": ["-DEMU_SYM"], "symbols_small_window": ["-DEMU_SYM", "-DAHIP_WIN_CAP=1024", "-DAHIP_WIN_KEEP=400"]}[variant]
+                 "symbols": ["-DEMU_SYM"], "symbols_small_window": ["-DEMU_SYM", "-DAHIP_WIN_CAP=1024", "-DAHIP_WIN_KEEP=400"],
+                 # the workgroup-per-member resolver (inflate_res_wg.hpp): production geometry (4 waves, 36 KiB ring); one wave
+                 # (no chunk ever waits: logic without races); three waves on a ring with 1 KiB of room (chunks wait for room
+                 # all the time, the ring wraps at another place); eight waves
+                 "wg": ["-DEMU_WG"], "wg_one_wave": ["-DEMU_WG", "-DAHIP_WG_WAVES=1"],
+                 "wg_tight_ring": ["-DEMU_WG", "-DAHIP_WG_WAVES=3", "-DAHIP_WG_RING=33856"],
+                 "wg_eight_waves": ["-DEMU_WG", "-DAHIP_WG_WAVES=8", "-DAHIP_WG_RING=40960"]}[variant]
         cmd = ["g++", "-std=c++17", "-O2", "-pthread", "-o", exe, src] + flags
         subprocess.check_call(cmd)
     return exe
@@ -75,3 +81,24 @@ def test_resolver_device_code_on_the_cpu(tmp_path, variant):
         assert "resolver emu ok" in r.stdout and "%d members, %d bytes" % (members, total) in r.stdout, r.stdout
         if variant.startswith("symbols"):
             assert int(r.stdout.split("markers checked:")[1].split()[0]) > 1000, r.stdout
+
+
+@pytest.mark.parametrize("variant", ["wg", "wg_one_wave", "wg_tight_ring", "wg_eight_waves"])
+def test_workgroup_resolver_on_the_cpu(tmp_path, variant):
+    """The workgroup-per-member resolver (archive_amd/csrc/inflate_res_wg.hpp: several waves, one LDS ring that holds
+    DEFLATE's whole reach, chunks completing in stream order through a frontier word in LDS) with every wave as 64 host
+    threads.  The same corpus and run cuts as above, the output placed at every alignment in turn (the ring goes out in
+    16-byte units aligned in global memory; nothing in front of the member or behind it may be touched), plus members of the
+    benchmark's kind: 64 KiB of log text wrap the 36 KiB ring."""
+    exe = _binary(variant)
+    blob, total, members = _corpus()
+    log = b"".join(streams.gz_member(streams.text(65536, 40 + i), level=6) for i in range(3))
+    path, path2 = tmp_path / "members.gz", tmp_path / "log.gz"
+    path.write_bytes(blob)
+    path2.write_bytes(log)
+    for seed in (1, 2):
+        r = subprocess.run([exe, str(path), str(seed)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "resolver emu ok [workgroup-per-member resolver]" in r.stdout and "%d members, %d bytes" % (members, total) in r.stdout, r.stdout
+    r = subprocess.run([exe, str(path2), "3"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "3 members, 196608 bytes" in r.stdout, r.stdout + r.stderr

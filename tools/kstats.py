@@ -46,6 +46,8 @@ if cyc.sum() > 0:
     tot = cyc.sum()
     if os.environ.get("AHIP_KSTATS_RES"):  # a -DAHIP_PROFILE_RES build: the resolver's phases
         names = ["res look setup", "res gather", "res prep", "res classify+lit+late", "res rounds", "res hard", "res flush", "res whole member"]
+        if os.environ.get("AHIP_KSTATS_RES") == "wg":  # the workgroup-per-member resolver: phases summed over its waves, [7] wave 0's whole member
+            names = ["wg look setup+barriers", "wg gather+prep", "wg wait for room", "wg literals+early", "wg wait chunk in front", "wg late rounds", "wg publish+flush", "wg whole member (wave 0)"]
         tot = cyc[7]
     print("cycles per member: total %.0f" % tot)
     for nme, c in zip(names, cyc):
