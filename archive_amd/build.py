@@ -36,7 +36,11 @@ def compiler_changed(lib=None):
     info = lib + ".buildinfo"
     if not (os.path.exists(lib) and os.path.exists(info)):
         return False
-    return open(info).read().strip() != _compiler_id(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"))
+    # (no compiler at hand, or a library from before the compiler was recorded: the prebuilt library is what there is)
+    have, cur = open(info).read().strip(), _compiler_id(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"))
+    if cur == "unknown" or have.startswith("unknown"):
+        return False
+    return have != cur
 
 
 def build(force=False, verbose=False, profile=False, defines=()):

@@ -1585,12 +1585,16 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
                                  size_t *out_len, BzShard *sh = nullptr) {
   if (out_len) *out_len = 0;
   // BZh + level, read through the bit reader: fewer than 4 bytes is a RangeError in the reference
+  // (ahip_last_consumed: the reference's reader has pulled the bytes it compared, `||` stops at the first that differs --
+  //  bzip2_decoder.dart:29-41; never the position a previous call of this thread left)
+  g_consumed = 0;
   if (in_len < 4) {
-    for (size_t i = 0; i < in_len && i < 3; ++i) if (in[i] != "BZh"[i]) return AHIP_FALSE;
+    for (size_t i = 0; i < in_len && i < 3; ++i) if (in[i] != "BZh"[i]) { g_consumed = i + 1; return AHIP_FALSE; }
     return AHIP_RANGE;
   }
-  if (in[0] != 'B' || in[1] != 'Z' || in[2] != 'h') return AHIP_FALSE;
+  for (size_t i = 0; i < 3; ++i) if (in[i] != "BZh"[i]) { g_consumed = i + 1; return AHIP_FALSE; }
   const int level = (int)in[3] - 0x30;
+  g_consumed = 4;
   if (level < 0 || level > 9) return AHIP_FALSE;
   if (in_len == 4) return AHIP_OK;  // while (!input.isEOS) never runs
   if (level == 0) return AHIP_FALSE;  // zero-sized tt: the first symbol already fails nblock >= nblockMAX
@@ -2343,7 +2347,10 @@ struct Worker {
   std::mutex mu;
   std::condition_variable cv;
   std::function<void()> job;
-  bool has_job = false, done = false, quit = false;
+  bool has_job = false, quit = false;
+  // every job has a number; wait() is for the job the CALLING thread submitted last (a second submitter -- nothing in the
+  // library does that today: callers hold g_mu or g_shards_mu -- neither resets the first one's completion nor is woken by it)
+  u64 submitted = 0, completed = 0;
   void loop() {
     (void)hipSetDevice(device);
     tl_free_bufs_at_exit = true;  // din / dout / token scratch / ... of this context go back to the device when the thread ends
@@ -2358,7 +2365,7 @@ struct Worker {
       lk.unlock();
       job();
       lk.lock();
-      has_job = false; done = true;
+      has_job = false; ++completed;
       cv.notify_all();
     }
     for (auto &b : g_pool) (void)hipFree(b.p);  // this thread's pool
@@ -2369,12 +2376,20 @@ struct Worker {
   void submit(std::function<void()> f) {
     std::unique_lock<std::mutex> lk(mu);
     cv.wait(lk, [&] { return !has_job; });  // (one job at a time: never replace a closure the worker is still running)
-    job = std::move(f); has_job = true; done = false;
+    job = std::move(f); has_job = true;
+    my_ticket() = ++submitted;
     cv.notify_all();
   }
   void wait() {
     std::unique_lock<std::mutex> lk(mu);
-    cv.wait(lk, [&] { return done; });
+    const u64 t = my_ticket();
+    cv.wait(lk, [&] { return completed >= t; });
+  }
+  u64 &my_ticket() {  // (per calling thread and worker)
+    static thread_local std::vector<std::pair<const Worker *, u64>> mine;
+    for (auto &e : mine) if (e.first == this) return e.second;
+    mine.push_back({this, 0});
+    return mine.back().second;
   }
 };
 std::vector<std::unique_ptr<Worker>> g_workers;  // guarded by g_mu; the set does not change while g_shards_mu is held

@@ -26,6 +26,8 @@ constexpr u32 HF_BC = 1;     // size known from the BC subfield
 constexpr u32 HF_RANGE = 2;  // header runs past the end of the input: RangeError in the reference
 constexpr u32 HF_SIZED = 4;  // next_pos/size come from a sizing run
 constexpr u32 HF_RETOK = 8;  // ... whose tokens cannot serve the decode proper (error, q8 reach, full token area, late path)
+constexpr u32 HF_RANGE_SIZED = 16;  // HF_RANGE set by gz_apply_sizing (the member's trailer runs past the input), not by the header parse:
+                                    // a second sizing pass (plan_build's size_oversub rebuild) looks at such a member again
 
 struct GzHeader {
   u64 payload_off;  // first DEFLATE byte
@@ -373,14 +375,14 @@ __global__ __launch_bounds__(256) void gz_apply_sizing(GzHeader *hdr, u32 K, con
   u32 i = blockIdx.x * 256 + threadIdx.x;
   if (i >= K) return;
   GzHeader h = hdr[i];
-  if (h.flags & HF_RANGE) return;
+  if ((h.flags & HF_RANGE) && !(h.flags & HF_RANGE_SIZED)) return;  // the header itself runs past the input
   MemberResult r = res[i];
-  h.flags = (h.flags & ~(HF_BC | HF_RETOK)) | HF_SIZED;
+  h.flags = (h.flags & ~(HF_BC | HF_RETOK | HF_RANGE | HF_RANGE_SIZED)) | HF_SIZED;
   if (r.status != MS_OK || (r.blocks & MR_FAR)) h.flags |= HF_RETOK;
   h.size = r.out_len;
   h.status = r.status;
   h.next_pos = r.end_pos + 8;  // CRC32 + ISIZE are read unconditionally (:40-41)
-  if (h.next_pos > n) { h.flags |= HF_RANGE; h.next_pos = n; }
+  if (h.next_pos > n) { h.flags |= HF_RANGE | HF_RANGE_SIZED; h.next_pos = n; }
   hdr[i] = h;
 }
 

@@ -17,7 +17,7 @@ from .codecs import BZip2Decoder, GZipDecoder, _as_buffer
 # what Dart's String.trim() removes (the reference trims every header string, tar_file.dart:233-238)
 _DART_WS = "".join(map(chr, list(range(0x09, 0x0E)) + [0x20, 0x85, 0xA0, 0x1680] + list(range(0x2000, 0x200B)) +
                        [0x2028, 0x2029, 0x202F, 0x205F, 0x3000, 0xFEFF]))
-_PAX_RECORD = re.compile(r"(\d+) (\w+)=(.*)", re.ASCII)  # tar_decoder.dart:9
+_PAX_RECORD = re.compile(r"(\d+) (\w+)=([^\n\r\u2028\u2029]*)", re.ASCII)  # tar_decoder.dart:9 (Dart's `.` stops at \n, \r, U+2028, U+2029)
 
 NORMAL_FILE, HARD_LINK, SYMBOLIC_LINK, DIRECTORY = "0", "1", "2", "5"
 

@@ -497,6 +497,41 @@ def extras(args, L, N, corpus, torch, np, dev, sh, comp, d_in, out_bytes, decode
     except AssertionError as e:
         res["config4_host_pointers"] = {"error": str(e)}
 
+    try:  # config 4's kind of member compressed by the REFERENCE's own Deflate (the oracle's restatement, level 6, with its
+        # 8 192-symbol block truncation, deflate.dart:549-562: more and shorter blocks per member than zlib's) -- what a Dart user's
+        # own GZipEncoder output looks like to this decoder.  4 096 members; the oracle only makes the input here.
+        import struct
+        from concurrent.futures import ThreadPoolExecutor
+        from oracle import pyoracle
+        n_or, mb = 4096, 65536
+        plain = np.empty(n_or * mb, dtype=np.uint8)
+        for c in range(n_or * mb >> 20):
+            corpus.lib().corpus_log_text(1234, c * 16, plain[c << 20:].ctypes.data, 1 << 20)
+
+        def member(i):
+            d = plain[i * mb:(i + 1) * mb].tobytes()
+            body, crc = pyoracle.deflate_raw(d, 6, True)
+            total = 18 + len(body) + 8
+            assert total <= 65536
+            return bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0]) + struct.pack("<H", total - 1) + body + struct.pack("<II", crc, mb), body[0] & 1
+        pyoracle.lib()
+        with ThreadPoolExecutor(min(64, os.cpu_count() or 1)) as ex:
+            made = list(ex.map(member, range(n_or)))
+        c7 = np.frombuffer(b"".join(m for m, _ in made), dtype=np.uint8)
+        d7 = torch.from_numpy(c7.copy()).to(dev)
+        o7 = torch.empty(n_or * mb + 64, dtype=torch.uint8, device=dev)
+        el, km, _ = decode_loop(d7, o7, n_or * mb, 5, 2, False)
+        got = ctypes.c_uint32()
+        L.ahip_crc32_device(o7.data_ptr(), n_or * mb, 0, ctypes.byref(got), None)
+        res["config4_reference_deflate_4096_members"] = {
+            "value": round(n_or * mb * 5 / el / 1e9, 2), "unit": "GB/s out", "ms": round(el / 5 * 1e3, 3), "kernel_ms": round(km, 3),
+            "ratio": round(n_or * mb / len(c7), 4), "members_whose_first_block_is_not_their_last": int(sum(1 for _, f in made if not f)),
+            "hbm_frac": frac(len(c7), n_or * mb, km * 1e-3), "crc_ok": bool(got.value == zlib.crc32(plain.tobytes())),
+            "what": "4 096 x 64 KiB of log text compressed by the oracle's restatement of the reference's Deflate (level 6, block truncation on) instead of zlib"}
+        del d7, o7, plain
+    except (AssertionError, SystemExit) as e:
+        res["config4_reference_deflate_4096_members"] = {"error": str(e)}
+
     try:  # config 2b: 4 096 members of wiki-like text
         c3, _ = corpus.make_gzip(kind=corpus.WIKI, seed=8, n_members=4096, member_bytes=65536, level=6, bc=True, threads=os.cpu_count() or 1)
         d3 = torch.from_numpy(c3).to(dev)
