@@ -127,6 +127,9 @@ class BZip2Decoder:
         st, out = _call_growing(lambda o, cap, olen: N.lib().ahip_bzip2_decode(buf, n, int(verify), o, cap, olen), n,
                                 hint=8 * n + 1024)
         self.last_status = st
+        # where decodeStream leaves its InputStream -- true: behind the last block or marker it read; false: where the failing
+        # check stood (the bytes its Bz2BitReader had pulled, bzip2/bz2_bit_reader.dart:12-44)
+        self.input_position = N.lib().ahip_last_consumed()
         return out
 
     def decode_stream(self, input_bytes, output, verify=False):

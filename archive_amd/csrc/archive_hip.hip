@@ -1623,7 +1623,10 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
     if (sh) sh->stopped = true;
     u8 b7[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     peek(32, b7);
-    return bz_no_magic_verdict(32, in_len, b7);
+    u64 sb = 32;
+    const int32_t v0 = bz_no_magic_verdict(32, in_len, b7, &sb);
+    g_consumed = std::min<u64>((u64)in_len, (sb + 7) / 8);
+    return v0;
   }
   size_t c_lo = sh ? (size_t)((u64)ncand * sh->index / sh->count) : 0;
   const size_t c_hi = sh ? (size_t)((u64)ncand * (sh->index + 1) / sh->count) : ncand;
@@ -1819,6 +1822,16 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
     if (rc < 0) return rc;
   }
   HIP_TRY(hipStreamSynchronize(st));
+  if (ch.verdict == 1 && !ch.crc_stop && ch.fail_cand != ~(size_t)0) {
+    // decodeStream returned false inside a block: where did its reader stand?  (bz_fail_cursor; the batch's tables are still there)
+    static thread_local DevBuf dcur;
+    HIP_TRY(dcur.reserve(8));
+    hipLaunchKernelGGL(bz_fail_cursor, dim3(1), dim3(64), 0, st, d_in, (u64)in_len, (u32)(ch.fail_cand - ch.fail_c0), dtab.as<BzTables>(),
+                       dlist0.as<u8>(), dsel.as<u8>(), dres.as<BzResult>(), (u32)level, dcur.as<u64>());
+    u64 cur = 0;
+    HIP_TRY(hipMemcpy(&cur, dcur.p, 8, hipMemcpyDeviceToHost));
+    if (cur) ch.fail_bit = cur;
+  }
 #ifdef AHIP_BZ_PROFILE
   {
     unsigned long long pr[8] = {0}, zero[8] = {0};
@@ -1841,11 +1854,12 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
     if (out_len) *out_len = (size_t)n;
     return v;
   }
-  u64 n = 0;
-  const int32_t v = bz_chain_finish(ch, verify, &n);
+  u64 n = 0, sb = 0;
+  const int32_t v = bz_chain_finish(ch, verify, &n, &sb);
   if (out_len) *out_len = (size_t)n;
-  // (what the bit reader has pulled from the InputStream when decodeStream returns true: whole bytes)
-  g_consumed = std::min<u64>((u64)in_len, (ch.end_bit + 7) / 8);
+  // (what the bit reader has pulled from the InputStream when decodeStream returns -- true: behind the last block or marker;
+  //  false: where the failing check stood -- whole bytes, bz2_bit_reader.dart:12-44)
+  g_consumed = std::min<u64>((u64)in_len, (sb + 7) / 8);
   return v;
 }
 

@@ -35,11 +35,17 @@ struct BzChain {
   size_t next = 0;       // candidate the chain expects next
   u64 folded = 0;        // block CRCs folded into `combined`
   u64 end_bit = 32;      // where the bit reader stands behind the last block (or end-of-stream marker) the chain has read
+  size_t fail_cand = ~(size_t)0, fail_c0 = 0;  // the candidate whose own failure ended the stream (and its batch's first): its
+                         // result's end_bit is where the header stopped or the block ended -- a failure inside the symbol loop
+                         // is located by the caller (bz_fail_cursor) and put into fail_bit
+  u64 fail_bit = 0;      // ... and where it stood when decodeStream returned false (bz_chain_finish: the reader has pulled
+                         // ceil(fail_bit / 8) bytes from its InputStream, bz2_bit_reader.dart:12-44)
 };
 
 // What _readBlockType makes of bit position `bit` when NO magic starts there.  `bytes` = the stream's bytes from bit >> 3
-// on (at least 7, zeros beyond the end).
-inline int32_t bz_no_magic_verdict(u64 bit, u64 in_len, const u8 *bytes) {
+// on (at least 7, zeros beyond the end).  *stop_bit: where the reader stands when it returns -1 (behind the first byte
+// that fits neither magic).
+inline int32_t bz_no_magic_verdict(u64 bit, u64 in_len, const u8 *bytes, u64 *stop_bit = nullptr) {
   static const u8 cm[6] = {0x31, 0x41, 0x59, 0x26, 0x53, 0x59}, em[6] = {0x17, 0x72, 0x45, 0x38, 0x50, 0x90};
   const u32 sh = (u32)(bit & 7);
   bool eos = true, comp = true;
@@ -48,8 +54,9 @@ inline int32_t bz_no_magic_verdict(u64 bit, u64 in_len, const u8 *bytes) {
     const u32 b = (((u32)bytes[i] << 8 | bytes[i + 1]) >> (8 - sh)) & 0xff;
     if (b != cm[i]) comp = false;
     if (b != em[i]) eos = false;
-    if (!eos && !comp) return 1;  // AHIP_FALSE
+    if (!eos && !comp) { if (stop_bit) *stop_bit = bit + 8 * (u64)(i + 1); return 1; }  // AHIP_FALSE
   }
+  if (stop_bit) *stop_bit = bit + 48;
   return 1;  // (a magic after all: the scan lists every one, so this is not reached)
 }
 
@@ -74,10 +81,10 @@ inline void bz_chain_walk(BzChain &ch, const BzCand *cands, size_t ncand, size_t
     if (r.status == BZ_ST_FALSE && r.out_len > 0) {  // _readCompressed wrote, then returned -1
       placed.push_back({(u32)(i - c0), ch.total, r.out_len, BZ_PL_PARTIAL});
       ch.total += r.out_len;
-      ch.verdict = 1; ch.stopped = true;
+      ch.verdict = 1; ch.stopped = true; ch.fail_bit = r.end_bit;  // (it failed in the inverse transform: behind the block)
       break;
     }
-    if (r.status != BZ_ST_OK && r.status != BZ_ST_OVERFLOW) { ch.verdict = 1; ch.stopped = true; break; }
+    if (r.status != BZ_ST_OK && r.status != BZ_ST_OVERFLOW) { ch.verdict = 1; ch.stopped = true; ch.fail_bit = r.end_bit; ch.fail_cand = i; ch.fail_c0 = c0; break; }
     placed.push_back({(u32)(i - c0), ch.total, r.out_len, r.status == BZ_ST_OK ? BZ_PL_PARALLEL : BZ_PL_SERIAL});
     ch.total += r.out_len;
     ch.end_bit = r.end_bit;
@@ -88,7 +95,7 @@ inline void bz_chain_walk(BzChain &ch, const BzCand *cands, size_t ncand, size_t
     if (j >= ncand || cands[j].bit != r.end_bit) {
       u8 b7[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       peek(r.end_bit, b7);
-      ch.verdict = bz_no_magic_verdict(r.end_bit, in_len, b7);
+      ch.verdict = bz_no_magic_verdict(r.end_bit, in_len, b7, &ch.fail_bit);
       ch.stopped = true;
       break;
     }
@@ -103,6 +110,7 @@ inline void bz_chain_crcs(BzChain &ch, const std::vector<BzPlaced> &placed, cons
     const u32 crc = pl.how == BZ_PL_PARALLEL ? (res2[pl.cand].crc ^ 0xffffffffu) : res[pl.cand].crc;
     if (verify && crc != res[pl.cand].stored_crc) {  // the block's bytes were already written
       ch.verdict = 1; ch.keep = pl.off + pl.len; ch.saw_eos = false; ch.crc_stop = true; ch.stopped = true;
+      ch.fail_bit = res[pl.cand].end_bit;  // (the CRC is compared when _readCompressed has returned: behind the block)
       break;
     }
     ch.combined = ((ch.combined << 1) | (ch.combined >> 31)) ^ crc;
@@ -145,10 +153,14 @@ inline int32_t bz_chain_run(BzChain &ch, const BzCand *cands, size_t ncand, size
 }
 
 // decodeStream's return value and the bytes that count, once the chain has stopped (or run out of candidates)
-inline int32_t bz_chain_finish(const BzChain &ch, int32_t verify, u64 *out_len) {
+// *stop_bit: where the reference's bit reader stands then (true: behind the last block or marker it read; false: where the
+// failing check stood)
+inline int32_t bz_chain_finish(const BzChain &ch, int32_t verify, u64 *out_len, u64 *stop_bit = nullptr) {
   int32_t v = ch.verdict;
-  if (v == 0 && ch.saw_eos && verify && ch.eos_stored != ch.combined) v = 1;
+  u64 sb = v == 1 ? ch.fail_bit : ch.end_bit;
+  if (v == 0 && ch.saw_eos && verify && ch.eos_stored != ch.combined) { v = 1; sb = ch.end_bit; }  // (behind the marker's CRC)
   if (out_len) *out_len = ch.crc_stop ? ch.keep : ch.total;
+  if (stop_bit) *stop_bit = sb;
   return v;
 }
 

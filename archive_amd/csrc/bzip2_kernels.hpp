@@ -310,6 +310,7 @@ AHIP_DEVINL void bz_decode_block_wave(BzLds &L, const u8 *__restrict__ in, u64 n
   bz_seek(b, cand.bit + 48);
   u32 status = BZ_ST_OK;
   u32 orig_ptr = 0;
+  if (exp && lane == 0) exp->sym_bit = 0;  // (nonzero only behind a header that held: bz_fail_cursor looks)
   if (cand.kind != 0) {  // end-of-stream marker: just the combined CRC
     u32 c = bz_bits(b, 16);
     c = (c << 16) | bz_bits(b, 16);
@@ -358,6 +359,7 @@ AHIP_DEVINL void bz_decode_block_wave(BzLds &L, const u8 *__restrict__ in, u64 n
         while (bzf_bits(fo, 1, lane) && !fo.fault) { if (++j >= ngroups) { bad = true; break; } }
       }
       status = (bad && !fo.fault) ? BZ_ST_FALSE : BZ_ST_RANGE;
+      b.bit = fo.bit;  // (where the reader stands: behind the bit that made the number too large)
       break;
     }
     // selectors and code lengths: ~30 000 bits read a few at a time -- from the stream held in registers (64 dwords a
@@ -384,7 +386,7 @@ AHIP_DEVINL void bz_decode_block_wave(BzLds &L, const u8 *__restrict__ in, u64 n
         }
         const u32 j = top == 0xffffffffu ? 32u : (u32)__builtin_clz(~top);  // the unary number: ones up to a zero
         if (j >= ngroups) {  // the reference reads them one by one: the ngroups-th one is the error -- if the input lasts that long
-          if (f.bit + ngroups > f.nbits) f.fault = true; else bad = true;
+          if (f.bit + ngroups > f.nbits) f.fault = true; else { bad = true; f.bit += ngroups; }  // (the reader stands behind that bit)
           break;
         }
         if (f.bit + j + 1 > f.nbits) { f.fault = true; break; }
@@ -395,7 +397,7 @@ AHIP_DEVINL void bz_decode_block_wave(BzLds &L, const u8 *__restrict__ in, u64 n
         if (lane == 0) sel[i] = (u8)v;
       }
       if (f.fault) { status = BZ_ST_RANGE; break; }
-      if (bad) { status = BZ_ST_FALSE; break; }
+      if (bad) { status = BZ_ST_FALSE; b.bit = f.bit; break; }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // lane 0's selector stores -> every lane's loads
       wave_sync();
     }
@@ -415,7 +417,7 @@ AHIP_DEVINL void bz_decode_block_wave(BzLds &L, const u8 *__restrict__ in, u64 n
         }
       }
       if (f.fault) { status = BZ_ST_RANGE; break; }
-      if (bad) { status = BZ_ST_FALSE; break; }
+      if (bad) { status = BZ_ST_FALSE; b.bit = f.bit; break; }  // (behind the last bit of the length that left 1 .. 20)
     }
     b.bit = f.bit;
     // (the reference's tables are fresh, zero-filled arrays for every block: a damaged code can index perm past its symbols)
@@ -1280,6 +1282,7 @@ AHIP_DEVINL void bz_mtf_scan_wave(BzScanLds &S, BzResult &R, u32 nblock_max, con
 // What such a block makes depends on the physical layout of the 4096-byte array, so this is the reference loop itself,
 // one lane, for exactly those (damaged) blocks: BZ_ST_NEG -> status, nblock, end bit and the block's bytes in b8.
 // mtfa: 4096 bytes of scratch.  sel / list0 (= seqToUnseq, zeros behind the symbols in use) as bz_header left them.
+// b8 == nullptr: nothing is written (bz_fail_cursor: only where the reader stands when the loop ends is wanted).
 AHIP_DEVINL void bz_block_exact_lane(const BzTables &T, const u8 *__restrict__ sel, const u8 *__restrict__ list0, const u8 *__restrict__ in,
                                      u64 n, u32 nblock_max, u8 *__restrict__ mtfa, u8 *__restrict__ b8, BzResult &R) {
   BzBits b{in, n, 0, false, 0, 0, 0};
@@ -1335,7 +1338,8 @@ AHIP_DEVINL void bz_block_exact_lane(const BzTables &T, const u8 *__restrict__ s
       es++;
       const u8 uc = list0[mtfa[mtfbase[0]]];
       if ((u64)nblock + (u64)es > nblock_max) { status = BZ_ST_FALSE; break; }
-      for (i32 k = 0; k < es; ++k) b8[nblock++] = uc;
+      if (b8) for (i32 k = 0; k < es; ++k) b8[nblock + k] = uc;
+      nblock += (u32)es;
       continue;
     }
     if (nblock >= nblock_max) { status = BZ_ST_FALSE; break; }
@@ -1369,7 +1373,8 @@ AHIP_DEVINL void bz_block_exact_lane(const BzTables &T, const u8 *__restrict__ s
         }
       }
     }
-    b8[nblock++] = list0[uc];
+    if (b8) b8[nblock] = list0[uc];
+    nblock++;
     next_sym = get();
     if (b.fault) { status = BZ_ST_RANGE; break; }
   }
@@ -1407,6 +1412,23 @@ __global__ __launch_bounds__(64) void bz_block_exact(const u8 *__restrict__ in, 
   bz_block_exact_lane(tables[blk], sel_all + (u64)blk * BZ_MAX_SELECTORS, list0_all + (u64)blk * 256, in, n, nblock_max, mtfa,
                       b8_all + (u64)blk * nblock_max, R);
   results[blk] = R;
+}
+// Where the reference's bit reader stands when _readCompressed gives up on block `blk` somewhere in its symbol loop (the
+// stream position decodeStream leaves behind, ahip_last_consumed): the position-parallel passes know THAT a block fails
+// there -- the list outgrowing the block, :292-326 -- not at which bit, so the reference's own loop is run once more, one
+// lane, nothing written.  Only for the one block a damaged stream stops at, and only when its header held (sym_bit != 0:
+// a header that fails knows its own bit, BzResult::end_bit).  *cursor = 0: no answer.
+__global__ __launch_bounds__(64) void bz_fail_cursor(const u8 *__restrict__ in, u64 n, u32 blk, const BzTables *__restrict__ tables,
+                                                     const u8 *__restrict__ list0_all, const u8 *__restrict__ sel_all,
+                                                     const BzResult *__restrict__ results, u32 block_size100k, u64 *__restrict__ cursor) {
+  __shared__ u8 mtfa[4096];
+  if (threadIdx.x != 0) return;
+  *cursor = 0;
+  if (tables[blk].sym_bit == 0) return;
+  BzResult R = results[blk];
+  bz_block_exact_lane(tables[blk], sel_all + (u64)blk * BZ_MAX_SELECTORS, list0_all + (u64)blk * 256, in, n, 100000u * block_size100k, mtfa,
+                      (u8 *)nullptr, R);
+  *cursor = R.end_bit;
 }
 // bz_header: the block headers and tables for the position-parallel pass (one wave per candidate)
 __global__ __launch_bounds__(64) void bz_header(const u8 *__restrict__ in, u64 n, const BzCand *__restrict__ cands, u32 ncand,

@@ -22,15 +22,14 @@ class BZip2Decoder {
     final hip = ArchiveHip.instance;
     final data = input.toUint8List();  // what is left of the stream, from its current position
     output.writeBytes(hip.bzip2Decode(data, verify: verify));
+    // the reference's bit reader has pulled exactly these bytes (bzip2/bz2_bit_reader.dart:12-44): up to the end of the
+    // end-of-stream block's CRC on `true`; on `false` up to the check that failed -- the signature, a block magic, a block's
+    // CRC under [verify], or wherever _readCompressed gave up inside a damaged block (ahip_last_consumed)
+    input.skip(hip.lastStreamPosition);
     if (hip.lastStatus == ArchiveHip.ok) {
-      // the reference's bit reader has pulled exactly the bytes up to the end of the end-of-stream block's CRC
-      input.skip(hip.lastStreamPosition);
       output.flush();
       return true;
     }
-    // `false`: the reference's reader stands wherever it stopped inside the damaged block; that position is not
-    // reproduced -- the stream is left at its end (a caller cannot resume a bzip2 stream behind a bad block anyway)
-    input.skip(data.length);
     return false;
   }
 }

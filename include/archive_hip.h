@@ -84,9 +84,13 @@ int32_t ahip_zlib_decode(const uint8_t *in, size_t in_len, int32_t verify, int32
  * ahip_inflate_raw -- what `decodeStream(input, output)` has consumed of `input`: everything when it returned true; on `false`
  * the position the failing check left the reader at (ref: _zlib_decoder_web.dart:53-99: two header bytes, + 4 for a
  * preset-dictionary id, behind the Adler-32 that did not match; _gzip_decoder_web.dart:31-37 rewinds to the start of what
- * is not a gzip header before it hands over).  After ahip_bzip2_decode returning AHIP_OK: the bytes its bit reader has pulled
- * (the end-of-stream marker's CRC included, rounded up to a byte).  Undefined after AHIP_RANGE / an AHIP_E_* code, and after
- * a bzip2 AHIP_FALSE (the reference stops wherever its bit reader stood inside the damaged block). */
+ * is not a gzip header before it hands over).  After ahip_bzip2_decode: the bytes the reference's bit reader has pulled
+ * (ref: bzip2/bz2_bit_reader.dart:12-44 -- whole bytes, rounded up) -- AHIP_OK: behind the end-of-stream marker's CRC (or the
+ * last block when the input ends without one); AHIP_FALSE: where the check that failed stood -- the signature byte that
+ * differs, the first byte that fits neither block magic (bzip2_decoder.dart:90-111), behind a block whose CRC `verify`
+ * rejects, and inside a damaged block wherever _readCompressed gave up (bzip2_decoder.dart:113-730: the header's own bit; in
+ * the symbol loop the reference's loop is run once more for that one block to find it).  Undefined after AHIP_RANGE / an
+ * AHIP_E_* code. */
 size_t ahip_last_consumed(void);
 
 /* Size the decoded output is expected to have, so that a caller can allocate once: for a gzip stream whose members all

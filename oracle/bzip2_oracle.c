@@ -401,6 +401,11 @@ done:
   return st;
 }
 
+/* where decodeStream left its InputStream (the bytes its Bz2BitReader had pulled, bz2_bit_reader.dart:12-44) in the last
+ * orc_bzip2_decode() of this thread */
+static __thread size_t g_bz_last_pos;
+size_t orc_bzip2_last_position(void) { return g_bz_last_pos; }
+
 /* BZip2Decoder().decodeBytes(data, verify) */
 int orc_bzip2_decode(const uint8_t *in, size_t n, int verify, uint8_t *out, size_t cap, size_t *out_len) {
   if (!g_crc_ready) crc_init();
@@ -445,6 +450,7 @@ int orc_bzip2_decode(const uint8_t *in, size_t n, int verify, uint8_t *out, size
 done:
   if (s->br.fault && st == ORC_OK) st = ORC_RANGE;
   if (out_len) *out_len = s->out_len;
+  g_bz_last_pos = s->br.pos < n ? s->br.pos : n;
   free(s->tt);
   free(s);
   return st;

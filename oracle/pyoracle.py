@@ -152,6 +152,14 @@ def bzip2_decode(data, verify=False, cap=None):
     return st, o
 
 
+def bzip2_last_position():
+    """where BZip2Decoder.decodeStream left its InputStream in the last bzip2_decode() of this thread"""
+    L = lib()
+    L.orc_bzip2_last_position.argtypes = []
+    L.orc_bzip2_last_position.restype = ctypes.c_size_t
+    return L.orc_bzip2_last_position()
+
+
 def bzip2_block(data, bit, level, cap=None):
     """ONE candidate block of a bzip2 stream, read from bit position `bit` the way decodeStream reads it (block type,
     stored CRC, _readCompressed) -> dict(status, kind, end_bit, out, crc, stored).  status 17 = randomised flag set."""

@@ -80,7 +80,16 @@ BzResult device_block(const u8 *in, size_t n, const BzCand &c, u32 level, Block 
     bz_block_exact_lane(T, sel.data(), list0.data(), in, n, nmax, mtfa.data(), b8.data(), R);
     ++g_exact_blocks;
   }
-  if (R.status != BZ_ST_OK) return R;
+  // bz_fail_cursor (the product runs it for the one block the chain stops at): where the reference's reader stands when its
+  // symbol loop gives up -- its own loop once more, nothing written; a header that failed knows its own bit
+  auto fail_cursor = [&]() {
+    if (R.status != BZ_ST_FALSE || T.sym_bit == 0) return;
+    std::vector<u8> mtfa(4096);
+    BzResult r2 = R;
+    bz_block_exact_lane(T, sel.data(), list0.data(), in, n, nmax, mtfa.data(), (u8 *)nullptr, r2);
+    R.end_bit = r2.end_bit;
+  };
+  if (R.status != BZ_ST_OK) { fail_cursor(); return R; }
   // T^-1 the plain way (bzip2_decoder.dart:406-439; bz_tinv_* on the device)
   blk.tt.assign((size_t)nmax + 64, 0);
   u32 cf[257] = {0};
@@ -92,6 +101,7 @@ BzResult device_block(const u8 *in, size_t n, const BzCand &c, u32 level, Block 
   u32 st, crc; u64 olen;
   bz_unbwt_block(blk.tt.data(), nmax, blk.nblock, blk.orig_ptr, (u8 *)nullptr, 0, g_crc_table, st, olen, crc);
   R.status = st; R.out_len = olen; R.crc = crc;
+  if (R.out_len == 0) fail_cursor();
   return R;
 }
 }  // namespace
@@ -101,18 +111,23 @@ extern "C" u32 bzchain_exact_blocks() { return g_exact_blocks; }
 // status: AHIP_OK 0 / AHIP_FALSE 1 / AHIP_RANGE 2 / AHIP_E_CAP -1 / AHIP_E_UNSUPPORTED -3; *out_len as ahip_bzip2_decode
 // reports it.  batch: candidates per batch.  *blocks_seen (may be NULL): per-block decodes that ran (nothing behind the
 // end of the chain must be touched beyond its batch).
+// what ahip_last_consumed() reports after the call (the product's g_consumed, worked out the same way)
+static u64 g_pos;
+extern "C" size_t bzchain_last_consumed(void) { return (size_t)g_pos; }
 extern "C" int bzchain_decode(const u8 *in_raw, size_t n, int verify, u32 batch, int mode, u8 *out, size_t cap, size_t *out_len, u32 *blocks_seen) {
   if (out_len) *out_len = 0;
   if (blocks_seen) *blocks_seen = 0;
   static bool once = (crc_init(), true);
   (void)once;
   // the header outcomes of bzip2_device_impl
+  g_pos = 0;
   if (n < 4) {
-    for (size_t i = 0; i < n && i < 3; ++i) if (in_raw[i] != "BZh"[i]) return 1;
+    for (size_t i = 0; i < n && i < 3; ++i) if (in_raw[i] != "BZh"[i]) { g_pos = i + 1; return 1; }
     return 2;
   }
-  if (in_raw[0] != 'B' || in_raw[1] != 'Z' || in_raw[2] != 'h') return 1;
+  for (size_t i = 0; i < 3; ++i) if (in_raw[i] != "BZh"[i]) { g_pos = i + 1; return 1; }
   const int level = (int)in_raw[3] - 0x30;
+  g_pos = 4;
   if (level < 0 || level > 9) return 1;
   if (n == 4) return 0;
   if (level == 0) return 1;
@@ -136,7 +151,10 @@ extern "C" int bzchain_decode(const u8 *in_raw, size_t n, int verify, u32 batch,
   if (ncand == 0 || cands[0].bit != 32) {
     u8 b7[8] = {0};
     peek(32, b7);
-    return bz_no_magic_verdict(32, n, b7);
+    u64 sb = 32;
+    const int32_t v0 = bz_no_magic_verdict(32, n, b7, &sb);
+    g_pos = std::min<u64>((u64)n, (sb + 7) / 8);
+    return v0;
   }
   std::vector<Block> blocks;  // of the current batch
   u32 seen = 0;
@@ -186,8 +204,9 @@ extern "C" int bzchain_decode(const u8 *in_raw, size_t n, int verify, u32 batch,
   if (rc < 0) return rc;
   if (over_cap) { if (out_len) *out_len = ch.total; return -1; }
   if (ch.verdict == -3) return -3;
-  u64 got = 0;
-  const int32_t v = bz_chain_finish(ch, verify, &got);
+  u64 got = 0, sb = 0;
+  const int32_t v = bz_chain_finish(ch, verify, &got, &sb);
   if (out_len) *out_len = (size_t)got;
+  g_pos = std::min<u64>((u64)n, (sb + 7) / 8);
   return v;
 }

@@ -119,6 +119,6 @@ def test_dart_bindings_match_the_header():
         assert piece in bz, piece
     # the decoders' decodeStream leaves the InputStream where the reference does (ahip_last_consumed), not at its end
     assert "ahip_last_consumed" in [s_ for _, s_ in looked_up]
-    for f in ("_gzip_decoder_hip.dart", "_zlib_decoder_hip.dart"):
+    for f in ("_gzip_decoder_hip.dart", "_zlib_decoder_hip.dart", "bzip2_decoder_hip.dart"):
         src = open(os.path.join(dart_dir, f)).read()
         assert "input.skip(hip.lastStreamPosition)" in src and "input.skip(data.length)" not in src, f

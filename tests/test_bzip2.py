@@ -162,10 +162,13 @@ def test_gpu_damage_in_header_and_selectors(native_built):
     data = streams.text(24000, 4) + bytes(rnd.getrandbits(8) for _ in range(6000)) + bytes(500) + streams.text(9000, 6)
     c = bz2.compress(data, 9)
 
+    pos = [None]
+
     def run(buf, verify):
         d = archive_amd.BZip2Decoder()
         try:
             out = d.decode_bytes(buf, verify=verify)
+            pos[0] = d.input_position
             return d.last_status, out
         except errors.RangeError:
             return 2, None
@@ -183,8 +186,11 @@ def test_gpu_damage_in_header_and_selectors(native_built):
     for i, buf in enumerate(cases):
         for verify in (False, True):
             st, out = orc.bzip2_decode(buf, verify=verify)
+            opos = orc.bzip2_last_position()
             got = run(buf, verify)
             assert got == ((2, None) if st == 2 else (st, out)), (i, verify, got[0], st)
+            if st in (0, 1):   # where the reader stood -- behind the stream, or at the check that failed (ahip_last_consumed)
+                assert pos[0] == opos, (i, verify, st, pos[0], opos)
             seen.add(st)
     assert {0, 1, 2} <= seen, seen  # decoded all the same (the damage hit nothing that is checked), `false`, RangeError
 
@@ -220,10 +226,13 @@ def test_gpu_small_stream_flipped_everywhere(native_built):
     starts = orc.bzip2_block_bits(c)    # [first block, second block, end-of-stream marker]
     assert len(starts) == 3
 
+    pos = [None]
+
     def run(buf, verify):
         d = archive_amd.BZip2Decoder()
         try:
             out = d.decode_bytes(buf, verify=verify)
+            pos[0] = d.input_position
             return d.last_status, out
         except errors.RangeError:
             return 2, None
@@ -243,6 +252,8 @@ def test_gpu_small_stream_flipped_everywhere(native_built):
                 continue
             st, out = orc.bzip2_decode(buf, verify=verify)
             assert got == ((2, None) if st == 2 else (st, out)), (bit, verify, got[0], st)
+            if st in (0, 1):   # where decodeStream leaves its InputStream, `true` or `false` (ahip_last_consumed)
+                assert pos[0] == orc.bzip2_last_position(), (bit, verify, st, pos[0], orc.bzip2_last_position())
             n += 1
     assert n > 600
 

@@ -35,6 +35,8 @@ def chain():
     L.bzchain_decode.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p,
                                  ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_uint32)]
     L.bzchain_decode.restype = ctypes.c_int
+    L.bzchain_last_consumed.argtypes = []
+    L.bzchain_last_consumed.restype = ctypes.c_size_t
 
     big = ctypes.create_string_buffer(6 << 20)       # (a damaged level-1 block makes up to 5.2 MB of runs)
 
@@ -43,12 +45,14 @@ def chain():
         cap = len(big) if cap is None else cap
         olen, seen = ctypes.c_size_t(0), ctypes.c_uint32(0)
         st = L.bzchain_decode(bytes(buf), len(buf), int(verify), batch, mode, ctypes.addressof(out), cap, ctypes.byref(olen), ctypes.byref(seen))
+        run.position = L.bzchain_last_consumed()   # what ahip_last_consumed() reports after the call
         return st, (ctypes.string_at(out, olen.value) if st in (0, 1) else olen.value), seen.value
     return run
 
 
 def _expect(orc, buf, verify):
     st, out = orc.bzip2_decode(buf, verify=verify)
+    _expect.position = orc.bzip2_last_position()   # where decodeStream left its InputStream
     return st, out
 
 
@@ -68,6 +72,8 @@ def test_valid_and_malformed_streams(chain):
             st, out = _expect(orc, buf, verify)
             got = chain(buf, verify, 2)
             assert got[0] == st and (st == 2 or got[1] == out), (name, verify, got[0], st)
+            if st in (0, 1):   # (a RangeError leaves no position)
+                assert chain.position == _expect.position, (name, verify, st, chain.position, _expect.position)
 
 
 def test_two_block_stream_flipped_everywhere(chain):
@@ -89,6 +95,8 @@ def test_two_block_stream_flipped_everywhere(chain):
             if got[0] == -3:       # the obsolete randomised mode: not a verdict
                 continue
             assert got[0] == st and (st == 2 or got[1] == out), (bit, verify, batch, got[0], st, len(out))
+            if st in (0, 1):   # the InputStream's position after decodeStream, `true` or `false` (bz2_bit_reader.dart:12-44)
+                assert chain.position == _expect.position, (bit, verify, batch, st, chain.position, _expect.position)
             n += 1
             if st == 1 and not verify and len(out) > 0:
                 # did the last block the reference touched fail behind its own bytes?
@@ -169,6 +177,8 @@ def test_device_code_on_the_wave_emulation_feeds_the_chain(chain):
         if got[0] == -3:
             continue
         assert got[0] == st and (st == 2 or got[1] == out), (t, got[0], st)
+        if st in (0, 1):
+            assert chain.position == _expect.position, (t, bit, st, chain.position, _expect.position)
 
 
 def test_a_failing_getmtfval_is_not_the_end_of_the_block(chain):
@@ -191,6 +201,8 @@ def test_a_failing_getmtfval_is_not_the_end_of_the_block(chain):
         if got[0] == -3:
             continue
         assert got[0] == st and (st == 2 or got[1] == out), (bit, got[0], st)
+        if st in (0, 1):
+            assert chain.position == _expect.position, (bit, st, chain.position, _expect.position)
         seen.add(st)
     assert seen == {0, 1, 2}
     rnd = random.Random(12)
@@ -201,3 +213,5 @@ def test_a_failing_getmtfval_is_not_the_end_of_the_block(chain):
         if got[0] == -3:
             continue
         assert got[0] == st and (st == 2 or got[1] == out), (bit, got[0], st)
+        if st in (0, 1):
+            assert chain.position == _expect.position, (bit, st, chain.position, _expect.position)
