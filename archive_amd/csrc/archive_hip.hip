@@ -1198,6 +1198,22 @@ struct SmPlan {  // what the sizing pass learned, kept for the write pass of the
 static thread_local SmPlan g_sm;
 static thread_local int32_t g_last_chunks = 0;  // chunks of this thread's last long stream (ahip_debug_last_chunks)
 
+// AHIP_SM_COUNTER=0: the chunk kernels take their chunks by the grid's stride instead of a device counter
+static bool sm_use_counter() {
+  static int v = -1;
+  if (v < 0) { const char *e = getenv("AHIP_SM_COUNTER"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v == 1;
+}
+// a zeroed counter for the next chunk-kernel launch on `st` (nullptr: stride)
+static thread_local DevBuf g_sm_ctr;
+static hipError_t sm_counter(hipStream_t st, u32 slot, u32 **out) {
+  *out = nullptr;
+  if (!sm_use_counter()) return hipSuccess;
+  hipError_t e = g_sm_ctr.reserve(256);
+  if (e != hipSuccess) return e;
+  *out = g_sm_ctr.as<u32>() + 16 * slot;  // (a slot per launch site: a launch never shares its counter with one still in flight)
+  return hipMemsetAsync(*out, 0, 4, st);
+}
 static int sm_resident_waves() {
   static int v = 0;
   if (!v) {
@@ -1275,8 +1291,10 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
           scratch_reserve(((size_t)(n / 32) + (size_t)nc * 64 + 64) * DIR_BYTES, &ksp) == hipSuccess) kept_gen = g_tok_gen;
       else { ktp = nullptr; ksp = nullptr; }
     }
+    u32 *ctr0 = nullptr;
+    HIP_TRY(sm_counter(st, 0, &ctr0));
     hipLaunchKernelGGL(sm_tokenize_kernel, dim3(grid), dim3(64), 0, st, d_in, n, dchunks.as<ChunkDesc>(), nc, dcand.as<u64>(), nc,
-                       (u32 *)ktp, (DirEnt *)ksp, dres.as<MemberResult>(), kept_gen ? 1u : 0u);
+                       (u32 *)ktp, (DirEnt *)ksp, dres.as<MemberResult>(), kept_gen ? 1u : 0u, ctr0);
     std::vector<MemberResult> rs(nc);
     HIP_TRY(hipMemcpyAsync(rs.data(), dres.p, (size_t)nc * sizeof(MemberResult), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -1348,8 +1366,10 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
   } else {
     HIP_TRY(tokens_reserve(((size_t)(total * 3 / 2) + (size_t)nch * 1024 + 64) * 4, &tp));
     HIP_TRY(scratch_reserve(((size_t)(total / 16) + (size_t)nch * 64 + 64) * DIR_BYTES, &sp));
+    u32 *ctr1 = nullptr;
+    HIP_TRY(sm_counter(st, 1, &ctr1));
     hipLaunchKernelGGL(sm_tokenize_kernel, dim3(grid), dim3(64), 0, st, d_in, n, dchunks.as<ChunkDesc>(), nch, dcand.as<u64>(), nc,
-                       (u32 *)tp, (DirEnt *)sp, dres.as<MemberResult>(), 0u);
+                       (u32 *)tp, (DirEnt *)sp, dres.as<MemberResult>(), 0u, ctr1);
     std::vector<MemberResult> rs(nch);
     HIP_TRY(hipMemcpyAsync(rs.data(), dres.p, (size_t)nch * sizeof(MemberResult), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -1365,8 +1385,10 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
   static thread_local DevBuf derr;  // chunks whose resolver gave up on a loop bound (cannot happen; if it does: AHIP_E_DEVICE, not wrong bytes)
   HIP_TRY(derr.reserve(16));
   HIP_TRY(hipMemsetAsync(derr.p, 0, 4, st));
+  u32 *ctr2 = nullptr;
+  HIP_TRY(sm_counter(st, 2, &ctr2));
   hipLaunchKernelGGL(sm_resolve_kernel, dim3(grid), dim3(64), 0, st, d_in, n, dchunks.as<ChunkDesc>(), nch, dsym.as<u16>(), (const u32 *)tp,
-                     (const DirEnt *)sp, dres.as<MemberResult>(), dcand.as<u64>(), nc, kept ? 1u : 0u, derr.as<u32>());
+                     (const DirEnt *)sp, dres.as<MemberResult>(), dcand.as<u64>(), nc, kept ? 1u : 0u, derr.as<u32>(), ctr2);
   {
     static thread_local DevBuf dwsym, dgwin;
     u32 gs = 1;

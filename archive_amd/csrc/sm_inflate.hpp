@@ -343,6 +343,14 @@ AHIP_DEVINL void sm_layout_in(const u64 *cand_bits, u32 n_cand, u64 in_len, u32 
   const u64 p1 = c + 1 < n_cand ? (uniform64(cand_bits[c + 1]) >> 3) + 1 : in_len;
   tok_layout_in(p0, p1 > p0 ? p1 - p0 : 0, c, toff, col_cap, doff, dir_cap);
 }
+// The next chunk of a workgroup: the next value of a device counter (lane 0's atomicAdd, like next_member of the member
+// kernels), or -- next == nullptr -- what the grid's stride says (`strided`).
+AHIP_DEVINL u32 sm_next_chunk(u32 *next, u32 strided, int lane) {
+  if (!next) return strided;
+  u32 k = 0;
+  if (lane == 0) k = atomicAdd(next, 1u);
+  return uniform(k);
+}
 // the tokenizer on chunks (persistent grid like inflate_tokenize_kernel).  lay_in = 0: chunk k's token area / run
 // directory follow tok_layout(out_off, out_limit, k) (exact offsets known); lay_in = 1: a sizing pass over ALL candidates
 // that keeps its tokens, laid out along the input.
@@ -350,10 +358,11 @@ __global__ __launch_bounds__(64) void sm_tokenize_kernel(const u8 *__restrict__ 
                                                         const ChunkDesc *__restrict__ chunks, u32 n_chunks,
                                                         const u64 *__restrict__ cand_bits, u32 n_cand,
                                                         u32 *__restrict__ tokens, DirEnt *__restrict__ dir,
-                                                        MemberResult *__restrict__ results, u32 lay_in) {
+                                                        MemberResult *__restrict__ results, u32 lay_in, u32 *__restrict__ next) {
   __shared__ SmLds lds;
   const int lane = threadIdx.x;
-  for (u32 k = blockIdx.x; k < n_chunks; k += gridDim.x) {
+  // chunks are handed out by a counter like the members of inflate_tokenize_kernel (next != nullptr), or by the grid's stride
+  for (u32 k = sm_next_chunk(next, blockIdx.x, lane); k < n_chunks; k = sm_next_chunk(next, k + gridDim.x, lane)) {
     const ChunkDesc c = chunks[k];
     MemberDesc d;
     d.in_off = uniform64(c.start_bit) >> 3;
@@ -381,10 +390,11 @@ __global__ __launch_bounds__(64) void sm_tokenize_kernel(const u8 *__restrict__ 
 __global__ __launch_bounds__(64) void sm_resolve_kernel(const u8 *__restrict__ in, u64 in_len, const ChunkDesc *__restrict__ chunks,
                                                        u32 n_chunks, u16 *sym, const u32 *__restrict__ tokens,
                                                        const DirEnt *__restrict__ dir, const MemberResult *__restrict__ results,
-                                                       const u64 *__restrict__ cand_bits, u32 n_cand, u32 lay_in, u32 *__restrict__ err) {
+                                                       const u64 *__restrict__ cand_bits, u32 n_cand, u32 lay_in, u32 *__restrict__ err,
+                                                       u32 *__restrict__ next) {
   __shared__ ResLdsT<u16> lds;
   const int lane = threadIdx.x;
-  for (u32 k = blockIdx.x; k < n_chunks; k += gridDim.x) {
+  for (u32 k = sm_next_chunk(next, blockIdx.x, lane); k < n_chunks; k = sm_next_chunk(next, k + gridDim.x, lane)) {
     const u64 out_off = uniform64(chunks[k].out_off), out_limit = uniform64(chunks[k].out_limit);
     const u32 ndir = (u32)uniform64(results[k].tok_words);
     u64 toff, doff;
