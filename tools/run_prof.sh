@@ -6,7 +6,7 @@
 #   7. side profiles: Deflate (config 3), one long member (config 2a), bzip2 (config 5), checksums.
 # tools/prof_summary.py turns gpurun_out/ into the committed profiles/rNN_* summaries.
 set -x
-R=${1:-r04}
+R=${1:-r06}
 MODE=${2:-full}   # "core": only the passes over the bench command (3.-6.), each under a short timeout
 T=200; [ "$MODE" = core ] && T=60
 cd /root/repo
