@@ -1604,7 +1604,9 @@ struct BzShard {
   u64 first = 0, next = 0;  // out: the candidate this shard's chain started at / expects next (>= the range's end unless stopped)
 };
 static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, int32_t verify, u8 *d_out, size_t out_cap,
-                                 size_t *out_len, BzShard *sh = nullptr) {
+                                 size_t *out_len, BzShard *sh = nullptr, hipStream_t st = nullptr) {
+  // (every launch, fill and copy below is ordered on `st` -- the caller's stream, a worker context's own, or the default one;
+  //  the verdicts the host chain needs are read back with copy_on: a copy on `st` that the host waits for)
   if (out_len) *out_len = 0;
   // BZh + level, read through the bit reader: fewer than 4 bytes is a RangeError in the reference
   // (ahip_last_consumed: the reference's reader has pulled the bytes it compared, `||` stops at the first that differs --
@@ -1621,7 +1623,6 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
   if (in_len == 4) return AHIP_OK;  // while (!input.isEOS) never runs
   if (level == 0) return AHIP_FALSE;  // zero-sized tt: the first symbol already fails nblock >= nblockMAX
   static thread_local DevBuf dcand, dcount, dtt, dsel, dres, dcrc, doff;
-  hipStream_t st = nullptr;
   // B0: block / end-of-stream magics at any bit offset
   const u32 cap_c = (u32)(in_len / 32 + 64);
   HIP_TRY(dcand.reserve((size_t)cap_c * sizeof(BzCand)));
@@ -1630,16 +1631,16 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
   hipLaunchKernelGGL(bz_scan_magic, dim3(cdiv(in_len, 256)), dim3(256), 0, st, d_in, (u64)in_len,
                      dcand.as<BzCand>(), dcount.as<u32>(), cap_c);
   u32 ncand = 0;
-  HIP_TRY(hipMemcpy(&ncand, dcount.p, 4, hipMemcpyDeviceToHost));
+  HIP_TRY(copy_on(&ncand, dcount.p, 4, hipMemcpyDeviceToHost, st));
   if (ncand > cap_c) return fail(AHIP_E_UNSUPPORTED, "too many bzip2 block-magic candidates");
   std::vector<BzCand> cands(ncand);
-  if (ncand) HIP_TRY(hipMemcpy(cands.data(), dcand.p, (size_t)ncand * sizeof(BzCand), hipMemcpyDeviceToHost));
+  if (ncand) HIP_TRY(copy_on(cands.data(), dcand.p, (size_t)ncand * sizeof(BzCand), hipMemcpyDeviceToHost, st));
   std::sort(cands.begin(), cands.end(), [](const BzCand &a, const BzCand &b) { return a.bit < b.bit; });
   // the first block type is read at bit 32; anything else there is "Invalid Block Signature"
   // the stream's seven bytes from bit >> 3 on (zeros beyond the end): what _readBlockType reads where no magic starts
   auto peek = [&](u64 bit, u8 *b7) {
     const u64 p = bit >> 3;
-    if (p < in_len) (void)hipMemcpy(b7, d_in + p, (size_t)std::min<u64>(7, in_len - p), hipMemcpyDeviceToHost);
+    if (p < in_len) (void)copy_on(b7, d_in + p, (size_t)std::min<u64>(7, in_len - p), hipMemcpyDeviceToHost, st);
   };
   if (ncand == 0 || cands[0].bit != 32) {
     if (sh) sh->stopped = true;
@@ -1659,7 +1660,7 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
     sh->first = c_lo; sh->next = c_lo;
   }
   if (c_lo >= c_hi) return AHIP_OK;  // (more shards than blocks, or the chain has stepped over this shard's range)
-  HIP_TRY(hipMemcpy(dcand.p, cands.data(), (size_t)ncand * sizeof(BzCand), hipMemcpyHostToDevice));
+  HIP_TRY(copy_on(dcand.p, cands.data(), (size_t)ncand * sizeof(BzCand), hipMemcpyHostToDevice, st));
   const u64 nblock_max = 100000ull * (u64)level;
   const u64 wstride = nblock_max / BZ_G + 2;
   static thread_local DevBuf dpre, dwalk, drank, dspans;
@@ -1729,7 +1730,7 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
     u32 pw = 0x100;  // x^8
     for (int k = 0; k < 64; ++k) { table[256 + k] = pw; pw = mulmod(pw, pw); }
     HIP_TRY(dcrc.reserve(sizeof(table)));
-    HIP_TRY(hipMemcpy(dcrc.p, table, sizeof(table), hipMemcpyHostToDevice));
+    HIP_TRY(copy_on(dcrc.p, table, sizeof(table), hipMemcpyHostToDevice, st));
     crc_tables_up = true;
   }
   static thread_local DevBuf dcktab, dckacc;  // the reflected CRC's tables (bz_block_crc mirrors it)
@@ -1811,7 +1812,7 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
     // blocks the parallel path handed back (BZ_ST_SERIAL): the reference loop, counting only (no slab)
     hipLaunchKernelGGL(bz_unbwt, dim3(cdiv(nb, 64)), dim3(64), 0, st, dtt.as<u32>(), (u32)level, nb, dc, (u8 *)nullptr, (u64)0,
                        dres.as<BzResult>(), dcrc.as<u32>(), (const u64 *)nullptr, (u8 *)nullptr);
-    HIP_TRY(hipMemcpy(res.data(), dres.p, (size_t)nb * sizeof(BzResult), hipMemcpyDeviceToHost));
+    HIP_TRY(copy_on(res.data(), dres.p, (size_t)nb * sizeof(BzResult), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipGetLastError());
     return AHIP_OK;
   };
@@ -1824,18 +1825,18 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
       if (pl.how == BZ_PL_PARALLEL) par_off[pl.cand] = pl.off;
       else { ser_off[pl.cand] = pl.off; any_serial = true; }
     }
-    HIP_TRY(hipMemcpy(doff.p, par_off.data(), (size_t)nb * 8, hipMemcpyHostToDevice));
+    HIP_TRY(copy_on(doff.p, par_off.data(), (size_t)nb * 8, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(bz_rle_expand, dim3(BZ_SPANS / 256, nb), dim3(256), 0, st, (u32)level, dc, dres.as<BzResult>(), dpre.as<u8>(),
                        dspans.as<BzSpan>(), doff.as<u64>(), d_out);
     hipLaunchKernelGGL(bz_block_crc, dim3((u32)cdiv(cdiv(nblock_max * 2, CK_SEG), 4), nb), dim3(256), 0, st, dc, dres.as<BzResult>(), doff.as<u64>(),
                        d_out, dcktab.as<u32>(), dcrc.as<u32>());
     if (any_serial) {  // what the serial inverse transform wrote -- also before it failed (BZ_PL_PARTIAL)
       HIP_TRY(ddir.reserve((size_t)nb * 8));
-      HIP_TRY(hipMemcpy(ddir.p, ser_off.data(), (size_t)nb * 8, hipMemcpyHostToDevice));
+      HIP_TRY(copy_on(ddir.p, ser_off.data(), (size_t)nb * 8, hipMemcpyHostToDevice, st));
       hipLaunchKernelGGL(bz_unbwt, dim3(cdiv(nb, 64)), dim3(64), 0, st, dtt.as<u32>(), (u32)level, nb, dc, (u8 *)nullptr, (u64)0,
                          dres.as<BzResult>(), dcrc.as<u32>(), ddir.as<u64>(), d_out);
     }
-    HIP_TRY(hipMemcpy(res2.data(), dres.p, (size_t)nb * sizeof(BzResult), hipMemcpyDeviceToHost));
+    HIP_TRY(copy_on(res2.data(), dres.p, (size_t)nb * sizeof(BzResult), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipGetLastError());
     return AHIP_OK;
   };
@@ -1851,7 +1852,7 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
     hipLaunchKernelGGL(bz_fail_cursor, dim3(1), dim3(64), 0, st, d_in, (u64)in_len, (u32)(ch.fail_cand - ch.fail_c0), dtab.as<BzTables>(),
                        dlist0.as<u8>(), dsel.as<u8>(), dres.as<BzResult>(), (u32)level, dcur.as<u64>());
     u64 cur = 0;
-    HIP_TRY(hipMemcpy(&cur, dcur.p, 8, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_on(&cur, dcur.p, 8, hipMemcpyDeviceToHost, st));
     if (cur) ch.fail_bit = cur;
   }
 #ifdef AHIP_BZ_PROFILE
@@ -1888,15 +1889,17 @@ static int32_t bzip2_device_impl(const u8 *in, const u8 *d_in, size_t in_len, in
 int32_t ahip_bzip2_decode_device(const void *d_in, size_t in_len, int32_t verify, void *d_out, size_t out_cap,
                                  size_t *out_len, void *stream) {
   std::lock_guard<std::recursive_mutex> lk(g_mu);
-  (void)stream;  // the bzip2 path reads verdicts back between phases: it runs on the default stream
+  // (everything is ordered on the caller's stream; the call still returns with the verdict, i.e. after the stream has caught
+  //  up: the chain of blocks is followed on the host between the kernel phases)
+  hipStream_t st = (hipStream_t)stream;
   if (out_len) *out_len = 0;
   u8 hdr[4] = {0, 0, 0, 0};
   if (in_len >= 4 || in_len > 0) {
     int32_t rc = ensure_init();
     if (rc != AHIP_OK) return rc;
-    HIP_TRY(hipMemcpy(hdr, d_in, in_len < 4 ? in_len : 4, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_on(hdr, d_in, in_len < 4 ? in_len : 4, hipMemcpyDeviceToHost, st));
   }
-  return bzip2_device_impl(hdr, (const u8 *)d_in, in_len, verify, (u8 *)d_out, out_cap, out_len);
+  return bzip2_device_impl(hdr, (const u8 *)d_in, in_len, verify, (u8 *)d_out, out_cap, out_len, nullptr, st);
 }
 
 int32_t ahip_bzip2_decode(const uint8_t *in, size_t in_len, int32_t verify, uint8_t *out, size_t out_cap,
@@ -2834,10 +2837,10 @@ int32_t ahip_bzip2_decode_shards(uint32_t n_shards, const int32_t *devices, cons
   std::vector<u64> from(n_shards, ~0ull);
   std::function<void(u32)> run_shard = [&](u32 s) {
     u8 hdr[4] = {0, 0, 0, 0};
-    if (in_len && hipMemcpy(hdr, d_in[s], in_len < 4 ? in_len : 4, hipMemcpyDeviceToHost) != hipSuccess) { rcs[s] = AHIP_E_DEVICE; errs[s] = "header read-back"; return; }
+    if (in_len && copy_on(hdr, d_in[s], in_len < 4 ? in_len : 4, hipMemcpyDeviceToHost, g_ctx_stream) != hipSuccess) { rcs[s] = AHIP_E_DEVICE; errs[s] = "header read-back"; return; }
     shs[s] = BzShard{};
     shs[s].index = s; shs[s].count = n_shards; shs[s].from = from[s];
-    rcs[s] = bzip2_device_impl(hdr, (const u8 *)d_in[s], in_len, verify, (u8 *)d_out[s], out_cap[s], &got[s], &shs[s]);
+    rcs[s] = bzip2_device_impl(hdr, (const u8 *)d_in[s], in_len, verify, (u8 *)d_out[s], out_cap[s], &got[s], &shs[s], g_ctx_stream);
     if (rcs[s] < 0) errs[s] = g_err;
   };
   run_shards(n_shards, wk, run_shard, lk);

@@ -115,6 +115,24 @@ def test_gpu_device_resident_api(native_built):
     assert N.lib().ahip_bzip2_decode_device(d_in.data_ptr(), d_in.numel(), 1, d_out.data_ptr(), d_out.numel(),
                                             ctypes.byref(olen), None) == 0
     assert olen.value == len(data) and bytes(d_out.cpu().numpy()) == data
+    # ... on the CALLER'S stream (round 6: the argument used to be ignored): the input arrives by an asynchronous copy on a
+    # non-blocking stream of the caller's, with a long kernel queued in front of it -- the decode must wait for both there,
+    # and what the caller queues behind the call on that stream must see the output
+    side = torch.cuda.Stream()
+    pinned = torch.frombuffer(bytearray(comp), dtype=torch.uint8).pin_memory()
+    d_in2 = torch.empty(len(comp), dtype=torch.uint8, device="cuda")
+    d_out2 = torch.zeros(len(data), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        busy = torch.empty(64 << 20, dtype=torch.float32, device="cuda")
+        for _ in range(20):
+            busy.normal_()                      # ~ tens of milliseconds of work in front of the copy
+        d_in2.copy_(pinned, non_blocking=True)
+        assert N.lib().ahip_bzip2_decode_device(d_in2.data_ptr(), d_in2.numel(), 1, d_out2.data_ptr(), d_out2.numel(),
+                                                ctypes.byref(olen), ctypes.c_void_p(side.cuda_stream)) == 0
+        total = d_out2.to(torch.int64).sum()    # queued behind the call on the same stream
+    side.synchronize()
+    assert olen.value == len(data) and int(total.item()) == sum(data) and bytes(d_out2.cpu().numpy()) == data
 
 
 @pytest.mark.gpu

@@ -1,6 +1,6 @@
 """Dev tool (GPU box): a wide sweep of damaged bzip2 streams through the HIP decoder against the oracle -- every 37th bit of
 a two-block level-1 stream, every 101st bit of a level-9 stream with several tables, every cut of a small stream, random
-double flips.  Prints the mismatches (none expected); not part of the test suite (minutes of one-lane inverse transforms).
+double flips.  Status, bytes and -- round 6 -- the stream position after `true` and `false` are held against the oracle.  Prints the mismatches (none expected); not part of the test suite (minutes of one-lane inverse transforms).
 
     python tools/bz_sweep.py [budget seconds]"""
 import bz2
@@ -25,6 +25,7 @@ def run(buf, verify):
     d = archive_amd.BZip2Decoder()
     try:
         out = d.decode_bytes(buf, verify=verify)
+        run.position = d.input_position   # (ahip_last_consumed: where decodeStream leaves its InputStream)
         return d.last_status, out
     except errors.RangeError:
         return 2, None
@@ -67,6 +68,9 @@ for name, s, bits in cases:
         want = (2, None) if st == 2 else (st, out)
         n += 1
         hist[st] = hist.get(st, 0) + 1
+        if got == want and st in (0, 1) and run.position != orc.bzip2_last_position():
+            bad += 1
+            print("POSITION", name, bits, "verify", verify, "status", st, "got", run.position, "want", orc.bzip2_last_position(), flush=True)
         if got != want:
             bad += 1
             print("MISMATCH", name, bits, "verify", verify, "got", got[0], None if got[1] is None else len(got[1]), "want", want[0],
