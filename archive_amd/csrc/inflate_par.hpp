@@ -783,10 +783,10 @@ AHIP_DEVINL void inflate_member(WaveLds &L, HeaderLds &H, TokLds *P, const u8 *i
       AHIP_TICK(t_hm);
       AHIP_ACC(st.cyc[5], t_h0, t_hm);
       if (r == MS_OK) {
-        bool ok = build_decode_table<false>(H.lens, hlit, L.ll, LL_ROOT, L.lld, L.ll_sub, LL_SUB, lane);
+        bool ok = build_decode_table<false>(H.lens, hlit, L.ll, LL_ROOT, L.lld, L.ll_sub, LL_SUB, lane, (u16 *)H.cl);
         AHIP_TICK(t_hn);
         AHIP_ACC(st.cyc[6], t_hm, t_hn);
-        ok &= build_decode_table<true>(H.lens + hlit, hdist, L.dt, D_ROOT, L.dd, L.d_sub, D_SUB, lane);
+        ok &= build_decode_table<true>(H.lens + hlit, hdist, L.dt, D_ROOT, L.dd, L.d_sub, D_SUB, lane, (u16 *)H.cl);
         replayable = ok;
         AHIP_TICK(t_h1);
         AHIP_ACC(st.cyc[0], t_h0, t_h1);

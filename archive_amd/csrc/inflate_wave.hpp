@@ -62,10 +62,12 @@ AHIP_DEVINL u32 dist_entry(u32 sym, u32 len) {
 
 // What the decoders keep of a code next to its tables.
 struct CodeDesc {
-  u16 first[16];   // first canonical code of each length (table build only)
   u32 maxlen;      // reference HuffmanTable.maxCodeLength
   u32 pad;
 };
+// (The first canonical code of each length is needed by the table build alone, indexed by a lane's own code length: it
+//  lives in the header scratch -- HeaderLds::cl, dead once the code lengths are decoded -- not in the tables' LDS, of which
+//  every byte counts: 64 bytes here are what lets 80 items of bitstream ring fit nine LDS granules, inflate_par.hpp.)
 
 // Second-level tables (codes longer than the primary index), one per primary prefix that long codes start with,
 // indexed by the next (longest code under the prefix - root) stream bits.  Sized for every COMPLETE code over the
@@ -154,7 +156,7 @@ AHIP_DEVINL u32 long_lookup(const u32 *sub, u32 e, u32 bits, int root) {
 // Returns false for an over-subscribed set, or one whose second-level tables do not fit (neither reproduced here).
 template <bool IS_DIST>
 AHIP_DEVINL bool build_decode_table(const u8 *lens, int n, u32 *primary, int root, CodeDesc &cd, u32 *sub, u32 sub_cap,
-                                    int lane) {
+                                    int lane, u16 *first_lds) {
   constexpr int CHUNKS = IS_DIST ? 1 : 5;
   u32 mylen[CHUNKS], myrank[CHUNKS];
   u32 cnt[16];
@@ -192,7 +194,7 @@ AHIP_DEVINL bool build_decode_table(const u8 *lens, int n, u32 *primary, int roo
 #pragma unroll
     for (int L = 0; L < 16; ++L)
       if (lane == L) f = first[L];
-    cd.first[lane] = (u16)f;
+    first_lds[lane] = (u16)f;
   }
   if (lane == 0) cd.maxlen = maxlen;
   // default fill: unfilled entries decode as symbol 0 with length 0
@@ -242,7 +244,7 @@ AHIP_DEVINL bool build_decode_table(const u8 *lens, int n, u32 *primary, int roo
     u32 l = mylen[c];
     if (l) {
       u32 s = c * 64 + ln;
-      u32 cde = cd.first[l] + myrank[c];
+      u32 cde = first_lds[l] + myrank[c];
       const u32 e = IS_DIST ? dist_entry(s, l) : litlen_entry(s, l);
       if ((int)l <= root) {
         u32 rev = __brev(cde) >> (32 - l);
