@@ -2390,6 +2390,8 @@ struct Worker {
   // every job has a number; wait() is for the job the CALLING thread submitted last (a second submitter -- nothing in the
   // library does that today: callers hold g_mu or g_shards_mu -- neither resets the first one's completion nor is woken by it)
   u64 submitted = 0, completed = 0;
+  const u64 id = next_worker_id();  // (never reused: a worker that takes a dead one's address does not inherit its tickets)
+  static u64 next_worker_id() { static std::atomic<u64> n{0}; return ++n; }
   void loop() {
     (void)hipSetDevice(device);
     tl_free_bufs_at_exit = true;  // din / dout / token scratch / ... of this context go back to the device when the thread ends
@@ -2425,9 +2427,9 @@ struct Worker {
     cv.wait(lk, [&] { return completed >= t; });
   }
   u64 &my_ticket() {  // (per calling thread and worker)
-    static thread_local std::vector<std::pair<const Worker *, u64>> mine;
-    for (auto &e : mine) if (e.first == this) return e.second;
-    mine.push_back({this, 0});
+    static thread_local std::vector<std::pair<u64, u64>> mine;
+    for (auto &e : mine) if (e.first == id) return e.second;
+    mine.push_back({id, 0});
     return mine.back().second;
   }
 };
