@@ -1987,7 +1987,7 @@ static int32_t deflate_device_impl(const u8 *d_in, size_t n, int level, int wind
   HIP_TRY(b_ntok.reserve((size_t)P.chunks * 4));
   HIP_TRY(b_slabs.reserve((size_t)P.chunks * DF_SLAB));
   HIP_TRY(b_csize.reserve((size_t)P.chunks * 4));
-  HIP_TRY(b_coff.reserve((size_t)P.chunks * 8));
+  HIP_TRY(b_coff.reserve((size_t)P.chunks * 8 + 8));
   if (!P.store)
   {
     // levels 1-3: 4096 x 2 entries, 256 threads, three workgroups per CU.  Levels 4-9: ONE workgroup of 512 threads per
@@ -2043,20 +2043,17 @@ static int32_t deflate_device_impl(const u8 *d_in, size_t n, int level, int wind
             s4[0] / P.chunks, s4[1] / P.chunks, s4[4] / P.chunks, s4[5] / P.chunks, s4[6] / P.chunks, s4[7] / P.chunks, s4[2] / P.chunks, s4[3] / P.chunks);
   }
 #endif
-  std::vector<u32> csize(P.chunks);
-  HIP_TRY(hipMemcpyAsync(csize.data(), b_csize.p, (size_t)P.chunks * 4, hipMemcpyDeviceToHost, st));
+  // sizes -> offsets -> gather, all on the stream; the host reads the total (8 bytes) once at the end
+  hipLaunchKernelGGL(deflate_offsets_kernel, dim3(1), dim3(1024), 0, st, b_csize.as<u32>(), P.chunks, b_coff.as<u64>(),
+                     b_coff.as<u64>() + P.chunks);
+  hipLaunchKernelGGL(deflate_concat_kernel, dim3(P.chunks), dim3(256), 0, st, b_slabs.as<u8>(), b_csize.as<u32>(),
+                     b_coff.as<u64>(), d_out, (u64)cap);
+  u64 total = 0;
+  HIP_TRY(hipMemcpyAsync(&total, b_coff.as<u64>() + P.chunks, 8, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipGetLastError());
-  std::vector<u64> coff(P.chunks);
-  u64 total = 0;
-  for (u32 i = 0; i < P.chunks; ++i) { coff[i] = total; total += csize[i]; }
   if (out_len) *out_len = total;
   if (total > cap) return fail(AHIP_E_CAP, "output buffer too small");
-  HIP_TRY(hipMemcpyAsync(b_coff.p, coff.data(), (size_t)P.chunks * 8, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(deflate_concat_kernel, dim3(P.chunks), dim3(256), 0, st, b_slabs.as<u8>(), b_csize.as<u32>(),
-                     b_coff.as<u64>(), d_out);
-  HIP_TRY(hipStreamSynchronize(st));
-  HIP_TRY(hipGetLastError());
   return AHIP_OK;
 }
 

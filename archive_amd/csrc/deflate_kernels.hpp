@@ -36,7 +36,7 @@
 //                             tokens 256 at a time: workgroup prefix sum of code lengths -> bit
 //                             offsets -> atomicOr into the LDS output image.  A chunk that does
 //                             not shrink is emitted as a stored block.
-//   D4 deflate_concat_kernel  exclusive scan of chunk sizes (host) -> byte-granular gather.
+//   D4 deflate_offsets_kernel + deflate_concat_kernel  exclusive scan of chunk sizes (device) -> byte-granular gather.
 // Measured (config 3, 1 GiB of log text, level 6): 26.0 ms = 41.2 GB/s in, match 19.4 / parse 2.6 / encode 4.0 ms
 // (profiles/r05_df_kernel_stats.md; round 4: 36 ms, 23.1 / 6.3 / 6.4 -- same bytes out).
 #pragma once
@@ -1052,13 +1052,38 @@ __global__ __launch_bounds__(256) void deflate_encode_kernel(const u8 *__restric
   if (tid == 0) csize[chunk] = nbytes;
 }
 
-// D4: gather the chunk slabs into the contiguous output
+// D4a: where every chunk's bytes go -- the exclusive scan of the chunk sizes, on the device (one workgroup: a thread sums a
+// run of consecutive chunks, the workgroup scans the 1 024 sums in LDS), so that the encode, the scan and the gather queue
+// up behind one another without the host in between.  total[0] = the size of the whole stream.
+__global__ __launch_bounds__(1024) void deflate_offsets_kernel(const u32 *__restrict__ csize, u32 chunks, u64 *__restrict__ coff,
+                                                               u64 *__restrict__ total) {
+  __shared__ u64 part[1024];
+  const u32 tid = threadIdx.x, per = (chunks + 1023) / 1024;
+  const u32 lo = min(chunks, tid * per), hi = min(chunks, lo + per);
+  u64 sum = 0;
+  for (u32 i = lo; i < hi; ++i) sum += csize[i];
+  part[tid] = sum;
+  __syncthreads();
+  for (u32 d = 1; d < 1024; d <<= 1) {
+    const u64 add = tid >= d ? part[tid - d] : 0;
+    __syncthreads();
+    part[tid] += add;
+    __syncthreads();
+  }
+  u64 at = part[tid] - sum;
+  for (u32 i = lo; i < hi; ++i) { coff[i] = at; at += csize[i]; }
+  if (tid == 1023) total[0] = part[1023];
+}
+
+// D4: gather the chunk slabs into the contiguous output (nothing is written behind cap: the host reports AHIP_E_CAP from
+// the total)
 __global__ __launch_bounds__(256) void deflate_concat_kernel(const u8 *__restrict__ slabs, const u32 *__restrict__ csize,
-                                                             const u64 *__restrict__ coff, u8 *__restrict__ out) {
+                                                             const u64 *__restrict__ coff, u8 *__restrict__ out, u64 cap) {
   const u32 chunk = blockIdx.x;
   const u8 *src = slabs + (u64)chunk * DF_SLAB;
-  u8 *dst = out + coff[chunk];
   const u32 n = csize[chunk];
+  if (coff[chunk] + n > cap) return;
+  u8 *dst = out + coff[chunk];
   for (u32 i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
 }
 

@@ -176,3 +176,30 @@ def test_sizes_around_every_edge(amd, orc, monkeypatch):
             if n % 5 == 0:
                 assert orc.inflate_raw(a + bytes(4))[:2] == (0, d), n
     monkeypatch.delenv("AHIP_DF_RUNS", raising=False)
+
+
+def test_output_buffer_too_small_is_reported_and_respected(amd):
+    """The chunk offsets are scanned on the device (deflate_offsets_kernel) and the gather runs before the host knows the
+    total: a buffer that is too small must come back as AHIP_E_CAP with the size that IS needed, and no byte behind the
+    capacity the caller gave may have been touched."""
+    import ctypes
+    import torch
+    from archive_amd import _native as N
+    L = N.lib()
+    d = streams.text(32768 * 9 + 77, 21)
+    d_in = torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda()
+    full = torch.zeros(len(d) + 4096, dtype=torch.uint8, device="cuda")
+    olen = ctypes.c_size_t(0)
+    assert L.ahip_deflate_raw_device(d_in.data_ptr(), len(d), 6, 15, full.data_ptr(), full.numel(), ctypes.byref(olen), None) == 0
+    need = olen.value
+    ref = bytes(full[:need].cpu().numpy())
+    assert zlib.decompress(ref, -15) == d
+    for cap in (0, 1, need // 3, need - 1):
+        out = torch.full((need + 256,), 0xA5, dtype=torch.uint8, device="cuda")
+        got = ctypes.c_size_t(0)
+        rc = L.ahip_deflate_raw_device(d_in.data_ptr(), len(d), 6, 15, out.data_ptr(), cap, ctypes.byref(got), None)
+        assert rc == N.AHIP_E_CAP and got.value == need, (cap, rc, got.value)
+        assert bool((out[cap:] == 0xA5).all()), cap
+    out = torch.full((need + 256,), 0xA5, dtype=torch.uint8, device="cuda")
+    assert L.ahip_deflate_raw_device(d_in.data_ptr(), len(d), 6, 15, out.data_ptr(), need, ctypes.byref(olen), None) == 0
+    assert bytes(out[:need].cpu().numpy()) == ref and bool((out[need:] == 0xA5).all())
