@@ -22,6 +22,8 @@ EXPORTS = [
     "ahip_crc32", "ahip_adler32", "ahip_decode_bound",
     "ahip_gzip_decode_shards", "ahip_debug_last_exchange", "ahip_gzip_encode_device", "ahip_zlib_encode_device",
     "ahip_debug_last_chunks", "ahip_deflate_shards", "ahip_bzip2_decode_shards", "ahip_debug_bz_reruns", "ahip_last_consumed",
+    "ahip_stream_split_create", "ahip_stream_split_candidates", "ahip_stream_split_size", "ahip_stream_split_chain", "ahip_stream_split_map_bytes",
+    "ahip_stream_split_resolve", "ahip_stream_split_finish", "ahip_stream_split_destroy", "ahip_debug_stream_split_chain",
 ]
 
 _lib = None
@@ -88,6 +90,16 @@ def lib():
     L.ahip_last_consumed.argtypes = []; L.ahip_last_consumed.restype = sz
     L.ahip_gzip_encode_device.argtypes = [vp, sz, i32, i32, u32, vp, sz, szp, vp]; L.ahip_gzip_encode_device.restype = i32
     L.ahip_zlib_encode_device.argtypes = [vp, sz, i32, i32, vp, sz, szp, vp]; L.ahip_zlib_encode_device.restype = i32
+    i32p, u64p = ctypes.POINTER(i32), ctypes.POINTER(u64)
+    L.ahip_stream_split_create.argtypes = [vp, sz, sz, u32, u32, vp, ctypes.POINTER(vp)]; L.ahip_stream_split_create.restype = i32
+    L.ahip_stream_split_candidates.argtypes = [vp, vp, sz, szp]; L.ahip_stream_split_candidates.restype = i32
+    L.ahip_stream_split_size.argtypes = [vp, vp, sz, vp, sz, i32p]; L.ahip_stream_split_size.restype = i32
+    L.ahip_stream_split_chain.argtypes = [vp, vp, sz, i32p, u64p, u64p, u64p, u64p]; L.ahip_stream_split_chain.restype = i32
+    L.ahip_stream_split_map_bytes.argtypes = []; L.ahip_stream_split_map_bytes.restype = sz
+    L.ahip_stream_split_resolve.argtypes = [vp, vp]; L.ahip_stream_split_resolve.restype = i32
+    L.ahip_stream_split_finish.argtypes = [vp, vp, vp, sz, szp, i32p]; L.ahip_stream_split_finish.restype = i32
+    L.ahip_stream_split_destroy.argtypes = [vp]; L.ahip_stream_split_destroy.restype = None
+    L.ahip_debug_stream_split_chain.argtypes = [vp, vp, sz, u32, u32, vp]; L.ahip_debug_stream_split_chain.restype = i32
     L.ahip_crc32.argtypes = [vp, sz, u32]; L.ahip_crc32.restype = u32
     L.ahip_adler32.argtypes = [vp, sz, u32]; L.ahip_adler32.restype = u32
     _lib = L

@@ -1294,7 +1294,7 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
     u32 *ctr0 = nullptr;
     HIP_TRY(sm_counter(st, 0, &ctr0));
     hipLaunchKernelGGL(sm_tokenize_kernel, dim3(grid), dim3(64), 0, st, d_in, n, dchunks.as<ChunkDesc>(), nc, dcand.as<u64>(), nc,
-                       (u32 *)ktp, (DirEnt *)ksp, dres.as<MemberResult>(), kept_gen ? 1u : 0u, ctr0);
+                       (u32 *)ktp, (DirEnt *)ksp, dres.as<MemberResult>(), kept_gen ? 1u : 0u, ctr0, SmBase{0, 0, 0});
     std::vector<MemberResult> rs(nc);
     HIP_TRY(hipMemcpyAsync(rs.data(), dres.p, (size_t)nc * sizeof(MemberResult), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -1369,7 +1369,7 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
     u32 *ctr1 = nullptr;
     HIP_TRY(sm_counter(st, 1, &ctr1));
     hipLaunchKernelGGL(sm_tokenize_kernel, dim3(grid), dim3(64), 0, st, d_in, n, dchunks.as<ChunkDesc>(), nch, dcand.as<u64>(), nc,
-                       (u32 *)tp, (DirEnt *)sp, dres.as<MemberResult>(), 0u, ctr1);
+                       (u32 *)tp, (DirEnt *)sp, dres.as<MemberResult>(), 0u, ctr1, SmBase{0, 0, 0});
     std::vector<MemberResult> rs(nch);
     HIP_TRY(hipMemcpyAsync(rs.data(), dres.p, (size_t)nch * sizeof(MemberResult), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -1388,7 +1388,7 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
   u32 *ctr2 = nullptr;
   HIP_TRY(sm_counter(st, 2, &ctr2));
   hipLaunchKernelGGL(sm_resolve_kernel, dim3(grid), dim3(64), 0, st, d_in, n, dchunks.as<ChunkDesc>(), nch, dsym.as<u16>(), (const u32 *)tp,
-                     (const DirEnt *)sp, dres.as<MemberResult>(), dcand.as<u64>(), nc, kept ? 1u : 0u, derr.as<u32>(), ctr2);
+                     (const DirEnt *)sp, dres.as<MemberResult>(), dcand.as<u64>(), nc, kept ? 1u : 0u, derr.as<u32>(), ctr2, SmBase{0, 0, 0});
   {
     static thread_local DevBuf dwsym, dgwin;
     u32 gs = 1;
@@ -1399,12 +1399,12 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
     hipLaunchKernelGGL(sm_windows_group, dim3(ng), dim3(1024), 0, st, dchunks.as<ChunkDesc>(), dres.as<MemberResult>(), nch, gs,
                        dsym.as<u16>(), dwsym.as<u16>());
     // (the window in front of the stream: the hist0 bytes that end right in front of d_out -- already final, see plan_run)
-    hipLaunchKernelGGL(sm_windows_link, dim3(1), dim3(1024), 0, st, nch, gs, dwsym.as<u16>(), dgwin.as<u8>(), (const u8 *)d_out - SM_WINDOW, hist0);
+    hipLaunchKernelGGL(sm_windows_link, dim3(1), dim3(1024), 0, st, nch, gs, dwsym.as<u16>(), dgwin.as<u8>(), (const u8 *)d_out - SM_WINDOW, hist0, SM_WINDOW);
     hipLaunchKernelGGL(sm_windows_apply, dim3(nch), dim3(1024), 0, st, gs, dwsym.as<u16>(), dgwin.as<u8>(), dwin.as<u8>(),
-                       (const u8 *)d_out - SM_WINDOW, hist0);
+                       (const u8 *)d_out - SM_WINDOW, hist0, (const u8 *)nullptr);
   }
   hipLaunchKernelGGL(sm_translate_kernel, dim3(sm_translate_blocks(), nch), dim3(256), 0, st, dchunks.as<ChunkDesc>(), dres.as<MemberResult>(), dsym.as<u16>(),
-                     dwin.as<u8>(), d_out, (const u8 *)d_out - SM_WINDOW, hist0);
+                     dwin.as<u8>(), d_out, (const u8 *)d_out - SM_WINDOW, hist0, (const u8 *)nullptr);
   u32 res_err = 0;
   HIP_TRY(hipMemcpyAsync(&res_err, derr.p, 4, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
@@ -1527,14 +1527,256 @@ int32_t zlib_stream_device(const u8 *host_in, const u8 *d_in, u64 n, u64 pos, bo
 #undef ZRET
 }
 
+// ---- ONE long stream decoded by several ranks (the member loop of _gzip_decoder_web.dart:29-55 has
+// nothing to shard when there is one member; inflate.dart:104-156 is one block loop) ----
+// Every rank holds the whole COMPRESSED stream and takes an equal range of its cuts: it finds the block starts behind its
+// own cuts, sizes its own candidates (keeping the tokens), resolves the chunks of the chain that are its own to symbols and
+// composes "the last 32 KiB of my range as a function of the 32 KiB in front of it".  Three things cross between ranks,
+// each as one all-gather done by the caller (archive_amd/sharding.py::ShardedStreamDecoder): the candidate lists, the
+// sizing results (32 B a candidate) and the window maps (64 KiB a rank).  What every rank decides from gathered data it
+// decides alike (the chain); what it learns alone (a chunk that differs from its sizing run) travels in the map's status word.
+constexpr u32 SPLIT_MAP_ELEMS = SM_WINDOW + 32;  // u16 elements of a rank's map in the exchange buffer: the map, then the status word
+struct SplitState {
+  const u8 *d_in = nullptr;
+  u64 n = 0, off = 0, cb = 0;
+  u32 rank = 0, world = 1, n_cuts = 0, k0 = 0, k1 = 0;
+  hipStream_t st = nullptr;
+  bool eligible = false;
+  int phase = 0;               // 0 created, 1 candidates found, 2 sized, 3 chain known, 4 resolved, 5 finished
+  std::vector<u64> own, cand;  // this rank's block starts; everybody's (rank order = stream order)
+  u32 c0 = 0, c1 = 0;          // own == cand[c0 .. c1)
+  u64 byte0 = 0;               // first input byte of the range (token areas are laid out from there)
+  std::vector<MemberResult> own_res, sized;
+  std::vector<ChunkDesc> chain;  // the chunks of the chain this rank owns; out_off counted from base_out
+  u64 base_out = 0, out_len = 0, total_out = 0, end_pos = 0;
+  bool kept = false, have_tokens = false;
+  u32 gs = 1, ng = 0;
+  DevBuf dfind, dcand, dchunks, dres, dsym, dwin, dwsym, dgsym, dgwin, dlink, dtok, ddir, derr, dctr;
+  void release() { for (DevBuf *b : {&dfind, &dcand, &dchunks, &dres, &dsym, &dwin, &dwsym, &dgsym, &dgwin, &dlink, &dtok, &ddir, &derr, &dctr}) b->release(); }
+};
+
+hipError_t split_counter(SplitState *h, u32 slot, u32 **out) {
+  *out = nullptr;
+  if (!sm_use_counter()) return hipSuccess;
+  hipError_t e = h->dctr.reserve(256);
+  if (e != hipSuccess) return e;
+  *out = h->dctr.as<u32>() + 16 * slot;
+  return hipMemsetAsync(*out, 0, 4, h->st);
+}
+
+int32_t split_candidates(SplitState *h) {
+  h->own.clear();
+  if (h->rank == 0) h->own.push_back(h->off * 8);
+  // the cuts K in [max(k0, 1), k1): sm_find_kernel searches cuts 1 .. n - 1 behind `data_start`
+  const u32 K0 = h->k0 > 1 ? h->k0 : 1;
+  if (h->k1 > K0) {
+    static const u32 SPLIT = [] { const char *e = getenv("AHIP_SM_SPLIT"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 64 ? (u32)v : 4u; }();
+    const u32 nloc = h->k1 - K0 + 1;
+    const u64 start = h->off + (u64)(K0 - 1) * h->cb;
+    HIP_TRY(h->dfind.reserve((size_t)nloc * SPLIT * 8 * 4 + (size_t)nloc * 4));
+    HIP_TRY(hipMemsetAsync(h->dfind.as<u64>() + (size_t)nloc * SPLIT * 4, 0xff, (size_t)nloc * 4, h->st));
+    hipLaunchKernelGGL(sm_find_kernel, dim3((nloc - 1) * SPLIT), dim3(64), 0, h->st, h->d_in, h->n, start, h->cb, nloc, SPLIT, h->dfind.as<u64>());
+    std::vector<u64> found((size_t)nloc * SPLIT);
+    HIP_TRY(hipMemcpyAsync(found.data(), h->dfind.p, found.size() * 8, hipMemcpyDeviceToHost, h->st));
+    HIP_TRY(hipStreamSynchronize(h->st));
+    HIP_TRY(hipGetLastError());
+    for (u32 k = 1; k < nloc; ++k)
+      for (u32 part = 0; part < SPLIT; ++part) {
+        const u64 f = found[(size_t)k * SPLIT + part];
+        if (f != ~0ull) { if (h->own.empty() || f > h->own.back()) h->own.push_back(f); break; }
+      }
+  }
+  h->phase = 1;
+  return AHIP_OK;
+}
+
+// everybody's candidates are known: size the own ones.  *handled = false: not a case for the chunked decode (too few block starts)
+int32_t split_size(SplitState *h, const u64 *all, size_t n_all, bool *handled) {
+  *handled = false;
+  for (size_t i = 1; i < n_all; ++i) if (all[i] <= all[i - 1]) return fail(AHIP_E_ARG, "stream split: the gathered block starts are not in stream order");
+  if (n_all == 0 || all[0] != h->off * 8) return fail(AHIP_E_ARG, "stream split: the gathered block starts do not begin with the stream's first bit");
+  h->cand.assign(all, all + n_all);
+  h->c0 = h->own.empty() ? 0 : (u32)(std::lower_bound(h->cand.begin(), h->cand.end(), h->own[0]) - h->cand.begin());
+  h->c1 = h->c0 + (u32)h->own.size();
+  if (h->c1 > n_all || !std::equal(h->own.begin(), h->own.end(), h->cand.begin() + h->c0)) return fail(AHIP_E_ARG, "stream split: this rank's block starts are not in the gathered list");
+  h->own_res.assign(h->own.size(), MemberResult{});
+  h->phase = 2;
+  if (n_all < 4 || n_all > 0x7fffffffu) return AHIP_OK;
+  *handled = true;
+  const u32 nown = (u32)h->own.size(), nc = (u32)n_all;
+  if (!nown) return AHIP_OK;
+  std::vector<ChunkDesc> cd(nown);
+  for (u32 i = 0; i < nown; ++i) cd[i] = ChunkDesc{h->own[i], 0, 1ull << 62, (h->c0 + i) ? SM_WINDOW : 0u, 0};
+  HIP_TRY(h->dcand.reserve((size_t)nc * 8));
+  HIP_TRY(h->dchunks.reserve((size_t)nown * sizeof(ChunkDesc)));
+  HIP_TRY(h->dres.reserve((size_t)nown * sizeof(MemberResult)));
+  HIP_TRY(hipMemcpyAsync(h->dcand.p, h->cand.data(), (size_t)nc * 8, hipMemcpyHostToDevice, h->st));
+  HIP_TRY(hipMemcpyAsync(h->dchunks.p, cd.data(), (size_t)nown * sizeof(ChunkDesc), hipMemcpyHostToDevice, h->st));
+  // the tokens are kept, laid out along the range's input bytes (tok_layout_in, like the sizing pass of sm_inflate)
+  h->byte0 = h->own[0] >> 3;
+  const u64 byte1 = h->c1 < nc ? (h->cand[h->c1] >> 3) + 1 : h->n;
+  const u64 span = byte1 > h->byte0 ? byte1 - h->byte0 : 0;
+  h->have_tokens = false;
+  if (!getenv("AHIP_SM_TWO_PASS") && span <= (4ull << 30) &&
+      h->dtok.reserve(((size_t)span * IN_R + (size_t)nown * IN_PAD + 64) * 4) == hipSuccess &&
+      h->ddir.reserve(((size_t)(span / 32) + (size_t)nown * 64 + 64) * DIR_BYTES) == hipSuccess) h->have_tokens = true;
+  const u32 grid = nown < (u32)sm_resident_waves() ? nown : (u32)sm_resident_waves();
+  u32 *ctr = nullptr;
+  HIP_TRY(split_counter(h, 0, &ctr));
+  hipLaunchKernelGGL(sm_tokenize_kernel, dim3(grid), dim3(64), 0, h->st, h->d_in, h->n, h->dchunks.as<ChunkDesc>(), nown, h->dcand.as<u64>(), nc,
+                     h->have_tokens ? h->dtok.as<u32>() : (u32 *)nullptr, h->have_tokens ? h->ddir.as<DirEnt>() : (DirEnt *)nullptr,
+                     h->dres.as<MemberResult>(), h->have_tokens ? 1u : 0u, ctr, SmBase{h->byte0, h->c0, h->c0});
+  HIP_TRY(hipMemcpyAsync(h->own_res.data(), h->dres.p, (size_t)nown * sizeof(MemberResult), hipMemcpyDeviceToHost, h->st));
+  HIP_TRY(hipStreamSynchronize(h->st));
+  HIP_TRY(hipGetLastError());
+  return AHIP_OK;
+}
+
+// everybody's sizing results are known (4 words a candidate: status, bytes, end position, blocks): follow the chain of
+// ends == starts from the stream's first bit exactly like sm_inflate, keep what is this rank's
+int32_t split_chain(SplitState *h, const u64 *res, size_t n_all, bool *handled) {
+  *handled = false;
+  if (h->phase != 2 || n_all != h->cand.size()) return fail(AHIP_E_ARG, "stream split: results for another candidate list");
+  h->phase = 3;
+  h->chain.clear(); h->sized.clear();
+  h->base_out = 0; h->out_len = 0; h->total_out = 0; h->end_pos = 0;
+  if (n_all < 4) return AHIP_OK;
+  h->kept = h->have_tokens;
+  const bool dbg = getenv("AHIP_DEBUG") != nullptr;
+  u64 total = 0;
+  bool based = false;
+  size_t i = 0;
+  for (;;) {
+    const u64 status = res[4 * i], out_len = res[4 * i + 1], end_pos = res[4 * i + 2], blocks = res[4 * i + 3];
+    const bool mine = i >= h->c0 && i < h->c1;
+    if (!based && i >= h->c0) { h->base_out = total; based = true; }
+    if (mine) {
+      const MemberResult &r = h->own_res[i - h->c0];
+      if (r.status != status || r.out_len != out_len || r.end_pos != end_pos) return fail(AHIP_E_ARG, "stream split: the gathered results differ from this rank's own");
+      h->chain.push_back(ChunkDesc{h->cand[i], total - h->base_out, out_len, (u32)(total < SM_WINDOW ? total : SM_WINDOW), (u32)i});
+      h->sized.push_back(r);
+      if (i && total < SM_WINDOW) h->kept = false;  // sized with a full window in front, has less: tokenize again (see sm_inflate)
+      if (blocks & MR_FAR) h->kept = false;         // its token area did not hold
+      h->out_len += out_len;
+    }
+    total += out_len;
+    if (status == MS_OK) { h->end_pos = end_pos; break; }
+    if (status != MS_CHUNK_END) { if (dbg) fprintf(stderr, "[ahip] stream split: chunk %zu ended with status %llu: not for this path\n", i, (unsigned long long)status); return AHIP_OK; }
+    auto it = std::lower_bound(h->cand.begin(), h->cand.end(), end_pos);
+    if (it == h->cand.end() || *it != end_pos || (size_t)(it - h->cand.begin()) <= i) return fail(AHIP_E_DEVICE, "internal: chunk chain broken");
+    i = (size_t)(it - h->cand.begin());
+  }
+  if (!based) h->base_out = total;
+  h->total_out = total;
+  *handled = true;
+  return AHIP_OK;
+}
+
+// the own chunks -> symbols; the range's window map (+ status word: 1 = fine) -> d_map
+int32_t split_resolve(SplitState *h, u16 *d_map) {
+  if (h->phase != 3) return fail(AHIP_E_ARG, "stream split: resolve before the chain is known");
+  h->phase = 4;
+  const u32 nch = (u32)h->chain.size(), nc = (u32)h->cand.size();
+  u32 ok = 1;
+  h->gs = 1; h->ng = 0;
+  if (nch) {
+    HIP_TRY(h->dsym.reserve((size_t)h->out_len * 2 + 64));
+    HIP_TRY(h->dchunks.reserve((size_t)nch * sizeof(ChunkDesc)));
+    HIP_TRY(h->dres.reserve((size_t)nch * sizeof(MemberResult)));
+    HIP_TRY(hipMemcpyAsync(h->dchunks.p, h->chain.data(), (size_t)nch * sizeof(ChunkDesc), hipMemcpyHostToDevice, h->st));
+    const u32 grid = nch < (u32)sm_resident_waves() ? nch : (u32)sm_resident_waves();
+    const u32 *tp = h->dtok.as<u32>();
+    const DirEnt *sp = h->ddir.as<DirEnt>();
+    if (h->kept) HIP_TRY(hipMemcpyAsync(h->dres.p, h->sized.data(), (size_t)nch * sizeof(MemberResult), hipMemcpyHostToDevice, h->st));
+    else {
+      // exact offsets, exact windows: tokenize the own chunks again (tok_layout on offsets counted from the range's first byte)
+      HIP_TRY(h->dtok.reserve(((size_t)(h->out_len * 3 / 2) + (size_t)nch * 1024 + 64) * 4));
+      HIP_TRY(h->ddir.reserve(((size_t)(h->out_len / 16) + (size_t)nch * 64 + 64) * DIR_BYTES));
+      tp = h->dtok.as<u32>(); sp = h->ddir.as<DirEnt>();
+      u32 *ctr1 = nullptr;
+      HIP_TRY(split_counter(h, 1, &ctr1));
+      hipLaunchKernelGGL(sm_tokenize_kernel, dim3(grid), dim3(64), 0, h->st, h->d_in, h->n, h->dchunks.as<ChunkDesc>(), nch, h->dcand.as<u64>(), nc,
+                         h->dtok.as<u32>(), h->ddir.as<DirEnt>(), h->dres.as<MemberResult>(), 0u, ctr1, SmBase{0, 0, h->chain[0].pad});
+      std::vector<MemberResult> rs(nch);
+      HIP_TRY(hipMemcpyAsync(rs.data(), h->dres.p, (size_t)nch * sizeof(MemberResult), hipMemcpyDeviceToHost, h->st));
+      HIP_TRY(hipStreamSynchronize(h->st));
+      HIP_TRY(hipGetLastError());
+      for (u32 i = 0; i < nch; ++i)
+        if (rs[i].status != h->sized[i].status || rs[i].out_len != h->sized[i].out_len || rs[i].end_pos != h->sized[i].end_pos) ok = 0;
+    }
+    HIP_TRY(h->derr.reserve(16));
+    HIP_TRY(hipMemsetAsync(h->derr.p, 0, 4, h->st));
+    if (ok) {
+      u32 *ctr2 = nullptr;
+      HIP_TRY(split_counter(h, 2, &ctr2));
+      hipLaunchKernelGGL(sm_resolve_kernel, dim3(grid), dim3(64), 0, h->st, h->d_in, h->n, h->dchunks.as<ChunkDesc>(), nch, h->dsym.as<u16>(), tp, sp,
+                         h->dres.as<MemberResult>(), h->dcand.as<u64>(), nc, h->kept ? 1u : 0u, h->derr.as<u32>(), ctr2, SmBase{h->byte0, h->c0, h->c0});
+      while ((u64)h->gs * h->gs < nch) ++h->gs;
+      h->ng = (nch + h->gs - 1) / h->gs;
+      HIP_TRY(h->dwsym.reserve((size_t)nch * SM_WINDOW * 2));
+      hipLaunchKernelGGL(sm_windows_group, dim3(h->ng), dim3(1024), 0, h->st, h->dchunks.as<ChunkDesc>(), h->dres.as<MemberResult>(), nch, h->gs,
+                         h->dsym.as<u16>(), h->dwsym.as<u16>());
+    }
+  }
+  HIP_TRY(h->dgsym.reserve((size_t)(h->ng ? h->ng : 1) * SM_WINDOW * 2));
+  hipLaunchKernelGGL(sm_windows_link_sym, dim3(1), dim3(1024), 0, h->st, ok ? nch : 0u, h->gs, h->dwsym.as<u16>(), h->dgsym.as<u16>());
+  HIP_TRY(hipMemcpyAsync(d_map, h->dgsym.as<u16>() + (size_t)(h->ng && ok ? h->ng - 1 : 0) * SM_WINDOW, (size_t)SM_WINDOW * 2, hipMemcpyDeviceToDevice, h->st));
+  u32 res_err = 0;
+  if (nch) HIP_TRY(hipMemcpyAsync(&res_err, h->derr.p, 4, hipMemcpyDeviceToHost, h->st));
+  HIP_TRY(hipStreamSynchronize(h->st));
+  HIP_TRY(hipGetLastError());
+  if (res_err) return fail(AHIP_E_DEVICE, "internal: the chunk resolver ran into its loop bound");
+  const u32 word[2] = {ok, 0};
+  HIP_TRY(hipMemcpyAsync(d_map + SM_WINDOW, word, 8, hipMemcpyHostToDevice, h->st));
+  HIP_TRY(hipStreamSynchronize(h->st));
+  if (!ok) h->phase = 6;  // nothing left to do here
+  return AHIP_OK;
+}
+
+// everybody's maps are known: the bytes in front of the range, the chunks' windows, the range's bytes
+int32_t split_finish(SplitState *h, const u16 *d_maps, u8 *d_out, size_t out_cap, size_t *out_len, bool *handled) {
+  *handled = false;
+  if (out_len) *out_len = 0;
+  if (h->phase != 4 && h->phase != 6) return fail(AHIP_E_ARG, "stream split: finish before resolve");
+  std::vector<u32> ok(h->world, 0);
+  for (u32 r = 0; r < h->world; ++r) HIP_TRY(hipMemcpyAsync(&ok[r], d_maps + (size_t)r * SPLIT_MAP_ELEMS + SM_WINDOW, 4, hipMemcpyDeviceToHost, h->st));
+  HIP_TRY(hipStreamSynchronize(h->st));
+  for (u32 r = 0; r < h->world; ++r) if (ok[r] != 1) { h->phase = 5; return AHIP_OK; }  // some rank's chunk differs from its sizing run: the caller's exact path
+  if (out_len) *out_len = h->out_len;
+  if (h->out_len > out_cap) return fail(AHIP_E_CAP, "output buffer too small");
+  const u32 nch = (u32)h->chain.size();
+  h->phase = 5;
+  *handled = true;
+  if (!nch) return AHIP_OK;
+  const u8 *entry = nullptr;
+  if (h->rank) {  // the ranks in front, linked in rank order: what their ranges leave behind
+    HIP_TRY(h->dlink.reserve((size_t)h->rank * SM_WINDOW));
+    hipLaunchKernelGGL(sm_windows_link, dim3(1), dim3(1024), 0, h->st, h->rank, 1u, d_maps, h->dlink.as<u8>(), (const u8 *)nullptr, 0u, SPLIT_MAP_ELEMS);
+    entry = h->dlink.as<u8>() + (size_t)(h->rank - 1) * SM_WINDOW;
+  }
+  HIP_TRY(h->dgwin.reserve((size_t)h->ng * SM_WINDOW));
+  HIP_TRY(h->dwin.reserve((size_t)nch * SM_WINDOW));
+  // the groups' last windows (every one a function of the entry window), then every chunk's
+  hipLaunchKernelGGL(sm_windows_apply, dim3(h->ng), dim3(1024), 0, h->st, 0x7fffffffu, h->dgsym.as<u16>(), (const u8 *)nullptr, h->dgwin.as<u8>(),
+                     (const u8 *)nullptr, 0u, entry);
+  hipLaunchKernelGGL(sm_windows_apply, dim3(nch), dim3(1024), 0, h->st, h->gs, h->dwsym.as<u16>(), h->dgwin.as<u8>(), h->dwin.as<u8>(),
+                     (const u8 *)nullptr, 0u, entry);
+  hipLaunchKernelGGL(sm_translate_kernel, dim3(sm_translate_blocks(), nch), dim3(256), 0, h->st, h->dchunks.as<ChunkDesc>(), h->dres.as<MemberResult>(),
+                     h->dsym.as<u16>(), h->dwin.as<u8>(), d_out, (const u8 *)nullptr, 0u, entry);
+  HIP_TRY(hipStreamSynchronize(h->st));
+  HIP_TRY(hipGetLastError());
+  return AHIP_OK;
+}
+
 }  // namespace
+struct ahip_stream_split { SplitState s; };
 
 // ------------------------------------------------------------------------------------------
 // C-ABI
 // ------------------------------------------------------------------------------------------
 extern "C" {
 
-uint32_t ahip_abi_version(void) { return (2u << 16) | 3u; }
+uint32_t ahip_abi_version(void) { return (2u << 16) | 4u; }
 
 const char *ahip_last_error(void) { return g_err.c_str(); }
 
@@ -2265,6 +2507,142 @@ int32_t ahip_debug_plan_results(ahip_gzip_plan *plan, uint32_t *host_words, size
 void ahip_gzip_plan_destroy(ahip_gzip_plan *plan) {
   std::lock_guard<std::recursive_mutex> lk(g_mu);
   delete plan;
+}
+
+// ---- one long stream, several ranks (SplitState above; include/archive_hip.h has the protocol) ----
+int32_t ahip_stream_split_create(const void *d_in, size_t in_len, size_t data_off, uint32_t rank, uint32_t world, void *stream,
+                                 ahip_stream_split **split) {
+  if (!split) return fail(AHIP_E_ARG, "split == NULL");
+  *split = nullptr;
+  if (!world || rank >= world || world > 4096) return fail(AHIP_E_ARG, "stream split: rank / world");
+  if (data_off > in_len) return fail(AHIP_E_ARG, "stream split: data_off behind the input");
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  ahip_stream_split *sp = new ahip_stream_split();
+  SplitState &h = sp->s;
+  h.d_in = (const u8 *)d_in; h.n = in_len; h.off = data_off; h.rank = rank; h.world = world; h.st = (hipStream_t)stream;
+  h.cb = sm_chunk_bytes();
+  const u64 len = in_len - data_off;
+  while ((len + h.cb - 1) / h.cb > 32768) h.cb *= 2;
+  h.n_cuts = (u32)((len + h.cb - 1) / h.cb);
+  h.k0 = (u32)((u64)h.n_cuts * rank / world);
+  h.k1 = (u32)((u64)h.n_cuts * (rank + 1) / world);
+  h.eligible = !getenv("AHIP_NO_SM") && len >= sm_min_bytes() && h.n_cuts >= 4;
+  *split = sp;
+  return AHIP_OK;
+}
+
+int32_t ahip_stream_split_candidates(ahip_stream_split *split, uint64_t *cand, size_t cap, size_t *n) {
+  if (!split || !n) return fail(AHIP_E_ARG, "stream split: NULL argument");
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  SplitState &h = split->s;
+  if (h.phase < 1) {
+    if (h.eligible) {
+      int32_t rc = ensure_init();
+      if (rc != AHIP_OK) return rc;
+      rc = split_candidates(&h);
+      if (rc != AHIP_OK) return rc;
+    } else {
+      h.own.clear();
+      if (h.rank == 0) h.own.push_back(h.off * 8);
+      h.phase = 1;
+    }
+  }
+  *n = h.own.size();
+  if (h.own.size() > cap) return fail(AHIP_E_CAP, "stream split: candidate buffer too small");
+  if (cand) std::copy(h.own.begin(), h.own.end(), cand);
+  return AHIP_OK;
+}
+
+int32_t ahip_stream_split_size(ahip_stream_split *split, const uint64_t *all_cand, size_t n_all, uint64_t *results, size_t cap_words,
+                               int32_t *handled) {
+  if (!split || !all_cand || !handled) return fail(AHIP_E_ARG, "stream split: NULL argument");
+  *handled = 0;
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  SplitState &h = split->s;
+  if (h.phase != 1) return fail(AHIP_E_ARG, "stream split: size before candidates (or twice)");
+  if (cap_words < 4 * h.own.size() || (!results && !h.own.empty())) return fail(AHIP_E_CAP, "stream split: result buffer too small");
+  bool ok = false;
+  int32_t rc = AHIP_OK;
+  if (h.eligible) {
+    rc = ensure_init();
+    if (rc == AHIP_OK) rc = split_size(&h, all_cand, n_all, &ok);
+  } else {
+    h.cand.assign(all_cand, all_cand + n_all);
+    h.own_res.assign(h.own.size(), MemberResult{});
+    h.phase = 2;
+  }
+  if (rc != AHIP_OK) return rc;
+  for (size_t i = 0; i < h.own.size(); ++i) {
+    const MemberResult &r = h.own_res[i];
+    results[4 * i] = r.status; results[4 * i + 1] = r.out_len; results[4 * i + 2] = r.end_pos; results[4 * i + 3] = r.blocks;
+  }
+  *handled = ok ? 1 : 0;
+  return AHIP_OK;
+}
+
+int32_t ahip_stream_split_chain(ahip_stream_split *split, const uint64_t *all_results, size_t n_all, int32_t *handled, uint64_t *rank_off,
+                                uint64_t *rank_len, uint64_t *total_out, uint64_t *end_pos) {
+  if (!split || !all_results || !handled) return fail(AHIP_E_ARG, "stream split: NULL argument");
+  *handled = 0;
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  SplitState &h = split->s;
+  bool ok = false;
+  int32_t rc = split_chain(&h, all_results, n_all, &ok);
+  if (rc != AHIP_OK) return rc;
+  ok = ok && h.eligible;
+  if (rank_off) *rank_off = ok ? h.base_out : 0;
+  if (rank_len) *rank_len = ok ? h.out_len : 0;
+  if (total_out) *total_out = ok ? h.total_out : 0;
+  if (end_pos) *end_pos = ok ? h.end_pos : 0;
+  *handled = ok ? 1 : 0;
+  return AHIP_OK;
+}
+
+size_t ahip_stream_split_map_bytes(void) { return (size_t)SPLIT_MAP_ELEMS * 2; }
+
+// Diagnostics / tests: the chain walk of ahip_stream_split_chain on plain arrays, no device and no handle (a rank that owns
+// the candidates [c0, c1) of `n`).  out[0..5] = handled, slice offset, slice length, total, end position, chunks of the chain
+// that are the rank's.
+int32_t ahip_debug_stream_split_chain(const uint64_t *cand, const uint64_t *results, size_t n, uint32_t c0, uint32_t c1, uint64_t *out) {
+  if (!cand || !results || !out || c0 > c1 || c1 > n) return fail(AHIP_E_ARG, "stream split: bad arguments");
+  SplitState h;
+  h.cand.assign(cand, cand + n);
+  h.c0 = c0; h.c1 = c1;
+  h.own.assign(cand + c0, cand + c1);
+  h.own_res.resize(c1 - c0);
+  for (uint32_t i = c0; i < c1; ++i) { h.own_res[i - c0].status = (u32)results[4 * i]; h.own_res[i - c0].out_len = results[4 * i + 1]; h.own_res[i - c0].end_pos = results[4 * i + 2]; }
+  h.phase = 2;
+  bool ok = false;
+  const int32_t rc = split_chain(&h, results, n, &ok);
+  out[0] = ok ? 1 : 0; out[1] = h.base_out; out[2] = h.out_len; out[3] = h.total_out; out[4] = h.end_pos; out[5] = h.chain.size();
+  return rc;
+}
+
+int32_t ahip_stream_split_resolve(ahip_stream_split *split, void *d_map) {
+  if (!split || !d_map) return fail(AHIP_E_ARG, "stream split: NULL argument");
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  int32_t rc = ensure_init();
+  if (rc != AHIP_OK) return rc;
+  return split_resolve(&split->s, (u16 *)d_map);
+}
+
+int32_t ahip_stream_split_finish(ahip_stream_split *split, const void *d_maps, void *d_out, size_t out_cap, size_t *out_len, int32_t *handled) {
+  if (!split || !d_maps || !handled) return fail(AHIP_E_ARG, "stream split: NULL argument");
+  *handled = 0;
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  int32_t rc = ensure_init();
+  if (rc != AHIP_OK) return rc;
+  bool ok = false;
+  rc = split_finish(&split->s, (const u16 *)d_maps, (u8 *)d_out, out_cap, out_len, &ok);
+  *handled = ok ? 1 : 0;
+  return rc;
+}
+
+void ahip_stream_split_destroy(ahip_stream_split *split) {
+  if (!split) return;
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  split->s.release();
+  delete split;
 }
 
 // Shared body of the gzip entry points.  host_in may be NULL (device API): then a tail that is

@@ -338,10 +338,13 @@ __global__ __launch_bounds__(64) void sm_find_kernel(const u8 *__restrict__ in, 
 #ifndef AHIP_HOST_EMU  // (the emulation only runs the block finder of this file)
 // Token area / run directory of candidate c laid out along the INPUT (tok_layout_in): the sizing pass keeps its tokens
 // there, and the write pass resolves the chunks of the chain straight from them (one tokenizer pass instead of two).
-AHIP_DEVINL void sm_layout_in(const u64 *cand_bits, u32 n_cand, u64 in_len, u32 c, u64 &toff, u32 &col_cap, u64 &doff, u32 &dir_cap) {
+// base: a rank that decodes only a range of the candidates (ahip_stream_split_*) counts input bytes and candidates from the
+// first of its own, so that its areas fill a buffer sized for the range (all zero: the whole stream).
+struct SmBase { u64 byte0; u32 cand0; u32 k0; };  // first byte / first candidate of the range; k0: list entry 0 is entry k0 of the stream's
+AHIP_DEVINL void sm_layout_in(const u64 *cand_bits, u32 n_cand, u64 in_len, u32 c, const SmBase &base, u64 &toff, u32 &col_cap, u64 &doff, u32 &dir_cap) {
   const u64 p0 = uniform64(cand_bits[c]) >> 3;
   const u64 p1 = c + 1 < n_cand ? (uniform64(cand_bits[c + 1]) >> 3) + 1 : in_len;
-  tok_layout_in(p0, p1 > p0 ? p1 - p0 : 0, c, toff, col_cap, doff, dir_cap);
+  tok_layout_in(p0 - base.byte0, p1 > p0 ? p1 - p0 : 0, c - base.cand0, toff, col_cap, doff, dir_cap);
 }
 // The next chunk of a workgroup: the next value of a device counter (lane 0's atomicAdd, like next_member of the member
 // kernels), or -- next == nullptr -- what the grid's stride says (`strided`).
@@ -353,12 +356,14 @@ AHIP_DEVINL u32 sm_next_chunk(u32 *next, u32 strided, int lane) {
 }
 // the tokenizer on chunks (persistent grid like inflate_tokenize_kernel).  lay_in = 0: chunk k's token area / run
 // directory follow tok_layout(out_off, out_limit, k) (exact offsets known); lay_in = 1: a sizing pass over ALL candidates
-// that keeps its tokens, laid out along the input.
+// that keeps its tokens, laid out along the input -- of a rank's range of the candidates (base): list entry k is candidate
+// base.cand0 + k.
 __global__ __launch_bounds__(64) void sm_tokenize_kernel(const u8 *__restrict__ in, u64 in_len,
                                                         const ChunkDesc *__restrict__ chunks, u32 n_chunks,
                                                         const u64 *__restrict__ cand_bits, u32 n_cand,
                                                         u32 *__restrict__ tokens, DirEnt *__restrict__ dir,
-                                                        MemberResult *__restrict__ results, u32 lay_in, u32 *__restrict__ next) {
+                                                        MemberResult *__restrict__ results, u32 lay_in, u32 *__restrict__ next,
+                                                        SmBase base) {
   __shared__ SmLds lds;
   const int lane = threadIdx.x;
   // chunks are handed out by a counter like the members of inflate_tokenize_kernel (next != nullptr), or by the grid's stride
@@ -370,11 +375,11 @@ __global__ __launch_bounds__(64) void sm_tokenize_kernel(const u8 *__restrict__ 
     d.out_limit = uniform64(c.out_limit);
     d.expect_end = POS_UNKNOWN;
     d.in_end = 0;
-    ChunkCtx cx{cand_bits, n_cand, (u32)uniform64(c.start_bit) & 7, uniform(c.hist), k == 0 ? 1u : 0u};  // (chunk 0 = the stream's first bytes)
+    ChunkCtx cx{cand_bits, n_cand, (u32)uniform64(c.start_bit) & 7, uniform(c.hist), k + base.k0 == 0 ? 1u : 0u};  // (chunk 0 = the stream's first bytes)
     TokSink sk{nullptr, 0, nullptr, 0, 0, ~0u, 0, 0, false};
     if (tokens) {
       u64 toff, doff;
-      if (lay_in) { sm_layout_in(cand_bits, n_cand, in_len, k, toff, sk.col_cap, doff, sk.dir_cap); sk.sizing = true; }
+      if (lay_in) { sm_layout_in(cand_bits, n_cand, in_len, k + base.cand0, base, toff, sk.col_cap, doff, sk.dir_cap); sk.sizing = true; }
       else tok_layout(d.out_off, d.out_limit, k, toff, sk.col_cap, doff, sk.dir_cap);
       sk.col_cap = uniform(sk.col_cap);
       sk.dir_cap = uniform(sk.dir_cap);
@@ -391,7 +396,7 @@ __global__ __launch_bounds__(64) void sm_resolve_kernel(const u8 *__restrict__ i
                                                        u32 n_chunks, u16 *sym, const u32 *__restrict__ tokens,
                                                        const DirEnt *__restrict__ dir, const MemberResult *__restrict__ results,
                                                        const u64 *__restrict__ cand_bits, u32 n_cand, u32 lay_in, u32 *__restrict__ err,
-                                                       u32 *__restrict__ next) {
+                                                       u32 *__restrict__ next, SmBase base) {
   __shared__ ResLdsT<u16> lds;
   const int lane = threadIdx.x;
   for (u32 k = sm_next_chunk(next, blockIdx.x, lane); k < n_chunks; k = sm_next_chunk(next, k + gridDim.x, lane)) {
@@ -399,7 +404,7 @@ __global__ __launch_bounds__(64) void sm_resolve_kernel(const u8 *__restrict__ i
     const u32 ndir = (u32)uniform64(results[k].tok_words);
     u64 toff, doff;
     u32 cc, dc;
-    if (lay_in) sm_layout_in(cand_bits, n_cand, in_len, uniform(chunks[k].pad), toff, cc, doff, dc);
+    if (lay_in) sm_layout_in(cand_bits, n_cand, in_len, uniform(chunks[k].pad), base, toff, cc, doff, dc);
     else tok_layout(out_off, out_limit, k, toff, cc, doff, dc);
     u32 cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (!resolve_member<u16>(lds, in, tokens + toff, dir + doff, ndir, sym + out_off, cyc, lane) && lane == 0) atomicAdd(err, 1u);  // (never silent)
@@ -456,8 +461,9 @@ __global__ __launch_bounds__(1024) void sm_windows_group(const ChunkDesc *__rest
 // byte; only its last hist0 elements exist (what EARLIER gzip members wrote into the shared output, quirk q8; 0 for a
 // stream with an output of its own: nothing in front of it is ever referenced)
 AHIP_DEVINL u8 sm_hist_byte(const u8 *hist_win, u32 hist0, u32 j) { return j >= SM_WINDOW - hist0 ? hist_win[j] : (u8)0; }
+// stride: elements from one chunk's symbolic window to the next (SM_WINDOW; more where the maps sit in an exchange buffer)
 __global__ __launch_bounds__(1024) void sm_windows_link(u32 n_chunks, u32 group_size, const u16 *__restrict__ wsym, u8 *__restrict__ gwin,
-                                                        const u8 *hist_win, u32 hist0) {
+                                                        const u8 *hist_win, u32 hist0, u32 stride) {
   __shared__ u8 W[2][SM_WINDOW];
   const u32 tid = threadIdx.x, n_groups = (n_chunks + group_size - 1) / group_size;
   for (u32 j = tid; j < SM_WINDOW; j += 1024) W[1][j] = sm_hist_byte(hist_win, hist0, j);
@@ -466,7 +472,7 @@ __global__ __launch_bounds__(1024) void sm_windows_link(u32 n_chunks, u32 group_
   u32 s[PER], sn[PER];  // (the symbols of group g + 1 are on their way while group g is looked up: see sm_windows_group)
   auto last_of = [&](u32 g) -> u32 { return (g + 1) * group_size - 1 < n_chunks ? (g + 1) * group_size - 1 : n_chunks - 1; };
   auto request = [&](u32 g, u32 (&r)[PER]) {
-    const u16 *ws = wsym + (u64)last_of(g) * SM_WINDOW;
+    const u16 *ws = wsym + (u64)last_of(g) * stride;
 #pragma unroll
     for (u32 u = 0; u < PER; ++u) r[u] = ws[tid + u * 1024];
   };
@@ -487,13 +493,43 @@ __global__ __launch_bounds__(1024) void sm_windows_link(u32 n_chunks, u32 group_
     sm_lds_barrier();
   }
 }
+// The same link on SYMBOLS: gsym[g] = the window at the end of group g as a function of the window in front of group 0 (an
+// element is a byte, or a marker into THAT window).  A rank that decodes a range of one stream's chunks
+// (ahip_stream_split_*) does not know the bytes in front of its range until the ranks have exchanged these maps: its last
+// one, gsym[n_groups - 1], is what it contributes.
+__global__ __launch_bounds__(1024) void sm_windows_link_sym(u32 n_chunks, u32 group_size, const u16 *__restrict__ wsym, u16 *__restrict__ gsym) {
+  __shared__ u16 W[2][SM_WINDOW];
+  const u32 tid = threadIdx.x, n_groups = (n_chunks + group_size - 1) / group_size;
+  for (u32 j = tid; j < SM_WINDOW; j += 1024) W[1][j] = (u16)(SYM_MARK + j);
+  __syncthreads();
+  constexpr u32 PER = SM_WINDOW / 1024;
+  for (u32 g = 0; g < n_groups; ++g) {
+    const u16 *prev = W[(g + 1) & 1];
+    u16 *cur = W[g & 1];
+    const u32 last = (g + 1) * group_size - 1 < n_chunks ? (g + 1) * group_size - 1 : n_chunks - 1;
+    const u16 *ws = wsym + (u64)last * SM_WINDOW;
+    u32 s[PER];
+#pragma unroll
+    for (u32 u = 0; u < PER; ++u) s[u] = ws[tid + u * 1024];
+#pragma unroll
+    for (u32 u = 0; u < PER; ++u) {
+      const u32 j = tid + u * 1024;
+      const u16 v = s[u] < SYM_MARK ? (u16)s[u] : prev[s[u] - SYM_MARK];
+      cur[j] = v;
+      gsym[(u64)g * SM_WINDOW + j] = v;
+    }
+    __syncthreads();
+  }
+  if (n_groups == 0) for (u32 j = tid; j < SM_WINDOW; j += 1024) gsym[j] = (u16)(SYM_MARK + j);  // no chunks: the identity
+}
 // (one workgroup per chunk; the group's input window is copied into LDS first -- the look-ups are scattered byte reads, see
 //  sm_translate_kernel)
+// entry (nullptr: none): the 32 KiB in front of chunk 0 where they are not the stream's history but another rank's output
 __global__ __launch_bounds__(1024) void sm_windows_apply(u32 group_size, const u16 *__restrict__ wsym, const u8 *__restrict__ gwin,
-                                                         u8 *__restrict__ windows, const u8 *hist_win, u32 hist0) {
+                                                         u8 *__restrict__ windows, const u8 *hist_win, u32 hist0, const u8 *__restrict__ entry) {
   __shared__ u8 W[SM_WINDOW] __attribute__((aligned(16)));
   const u32 k = blockIdx.x, g = k / group_size, tid = threadIdx.x;
-  const u8 *in_win = g ? gwin + (u64)(g - 1) * SM_WINDOW : nullptr;
+  const u8 *in_win = g ? gwin + (u64)(g - 1) * SM_WINDOW : entry;
   // this chunk's symbols, eight a thread and step (on their way while the window is copied)
   constexpr u32 PER = SM_WINDOW / 8 / 1024;  // 4
   uint4 q[PER];
@@ -527,11 +563,11 @@ __global__ __launch_bounds__(1024) void sm_windows_apply(u32 group_size, const u
 // (A byte per thread and step, look-ups in global memory: 0.58 ms for 256 MiB; vectors alone: 0.51.)
 __global__ __launch_bounds__(256) void sm_translate_kernel(const ChunkDesc *__restrict__ chunks, const MemberResult *__restrict__ results,
                                                            const u16 *__restrict__ sym, const u8 *__restrict__ windows,
-                                                           u8 *__restrict__ out, const u8 *hist_win, u32 hist0) {
+                                                           u8 *__restrict__ out, const u8 *hist_win, u32 hist0, const u8 *__restrict__ entry) {
   __shared__ u8 W[SM_WINDOW] __attribute__((aligned(16)));
   const u32 k = blockIdx.y;
   const u64 off = chunks[k].out_off, len = results[k].out_len;
-  const u8 *w = k ? windows + (u64)(k - 1) * SM_WINDOW : nullptr;  // chunk 0: the window in front of the stream
+  const u8 *w = k ? windows + (u64)(k - 1) * SM_WINDOW : entry;  // chunk 0: the window in front of the stream (entry: of this rank's range)
   auto byte_of = [&](u32 s) -> u32 { return s < SYM_MARK ? (s & 0xffu) : (u32)(w ? w[s - SYM_MARK] : sm_hist_byte(hist_win, hist0, s - SYM_MARK)); };
   u64 head = (8 - (off & 7)) & 7;
   head = head < len ? head : len;

@@ -9,6 +9,7 @@ concatenation of the shards at those offsets equals `GZipDecoder().decodeBytes(w
 """
 import ctypes
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -143,3 +144,136 @@ class ShardedGZipDecoder:
             L.ahip_gzip_plan_destroy(plan)
         offset, total, _ = exchange_output_offsets(n.value, device=d_in.device, group=group)
         return d_out, n.value, offset, total
+
+
+# ---- ONE long member across ranks (include/archive_hip.h: ahip_stream_split_*) ----
+class StreamSplit:
+    """One rank's part of the chunked decode of ONE long DEFLATE stream: a thin wrapper of the C-ABI handle.  Every rank
+    holds the whole compressed stream (`d_in`, uint8 CUDA tensor; the DEFLATE data starts at byte `data_off`); the phases
+    alternate with three all-gathers the caller performs (ShardedStreamDecoder below; the tests also drive several
+    handles from one process).  The loop it spreads out is the reference's block loop, zlib/inflate.dart:104-156."""
+
+    def __init__(self, d_in, data_off, rank, world, stream=None):
+        self.L = N.lib()
+        self.d_in = d_in  # (kept alive: the handle points into it)
+        self.h = ctypes.c_void_p()
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream) if stream is None and d_in.is_cuda else ctypes.c_void_p(stream)
+        _check(self.L.ahip_stream_split_create(d_in.data_ptr(), d_in.numel(), int(data_off), int(rank), int(world), st, ctypes.byref(self.h)))
+        self.n_own = 0
+
+    def candidates(self):
+        n = ctypes.c_size_t()
+        buf = np.zeros(65536, dtype=np.uint64)
+        _check(self.L.ahip_stream_split_candidates(self.h, buf.ctypes.data, buf.size, ctypes.byref(n)))
+        self.n_own = n.value
+        return buf[:n.value].copy()
+
+    def size(self, all_cand):
+        all_cand = np.ascontiguousarray(all_cand, dtype=np.uint64)
+        res = np.zeros(4 * max(self.n_own, 1), dtype=np.uint64)
+        handled = ctypes.c_int32()
+        _check(self.L.ahip_stream_split_size(self.h, all_cand.ctypes.data, all_cand.size, res.ctypes.data, res.size, ctypes.byref(handled)))
+        return bool(handled.value), res[:4 * self.n_own].copy()
+
+    def chain(self, all_results):
+        all_results = np.ascontiguousarray(all_results, dtype=np.uint64)
+        handled = ctypes.c_int32()
+        off, ln, total, end = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        _check(self.L.ahip_stream_split_chain(self.h, all_results.ctypes.data, all_results.size // 4, ctypes.byref(handled), ctypes.byref(off),
+                                              ctypes.byref(ln), ctypes.byref(total), ctypes.byref(end)))
+        return bool(handled.value), off.value, ln.value, total.value, end.value
+
+    def resolve(self):
+        d_map = torch.empty(self.L.ahip_stream_split_map_bytes(), dtype=torch.uint8, device=self.d_in.device)
+        _check(self.L.ahip_stream_split_resolve(self.h, d_map.data_ptr()))
+        return d_map
+
+    def finish(self, d_maps, d_out):
+        n, handled = ctypes.c_size_t(), ctypes.c_int32()
+        _check(self.L.ahip_stream_split_finish(self.h, d_maps.data_ptr(), d_out.data_ptr(), d_out.numel(), ctypes.byref(n), ctypes.byref(handled)))
+        return bool(handled.value), n.value
+
+    def close(self):
+        if self.h:
+            self.L.ahip_stream_split_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _all_gather_u64(arr, device, group):
+    """Variable-length uint64 lists of all ranks, concatenated in rank order (two all-gathers: the counts, the padded lists)."""
+    arr = np.ascontiguousarray(arr, dtype=np.uint64)
+    if not (dist.is_available() and dist.is_initialized()):
+        return arr
+    world = dist.get_world_size(group)
+    counts = torch.zeros(world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(counts, torch.tensor([arr.size], dtype=torch.int64, device=device), group=group)
+    counts = [int(c) for c in counts.tolist()]
+    width = max(max(counts), 1)
+    mine = torch.zeros(width, dtype=torch.int64, device=device)
+    if arr.size:
+        mine[:arr.size] = torch.from_numpy(arr.view(np.int64)).to(device)
+    everybody = torch.zeros(world * width, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(everybody, mine, group=group)
+    rows = everybody.cpu().numpy().view(np.uint64).reshape(world, width)
+    return np.concatenate([rows[r, :counts[r]] for r in range(world)]) if sum(counts) else np.zeros(0, dtype=np.uint64)
+
+
+class ShardedStreamDecoder:
+    """ONE long DEFLATE stream (a single gzip member, a zlib stream, a raw stream) decoded by all ranks of a process group:
+    every rank passes the whole compressed stream and receives its slice of the output and where it lies.  The collectives run
+    on `collective_device` (default: the stream's device = RCCL under the `nccl` backend; "cpu" for gloo): two gathers of a few
+    words per block start and one of 64 KiB per rank.  Not handled (too short, damaged, ...) = every rank learns so at the same
+    step and rank 0 decodes the stream alone with the exact single-device path; the other ranks' slices are empty."""
+
+    def __init__(self, device_index=None, collective_device=None):
+        self.device_index = torch.cuda.current_device() if device_index is None else device_index
+        self.collective_device = collective_device
+        rc = N.lib().ahip_init(self.device_index)
+        if rc != 0:
+            _check(rc)
+        self.last_handled = None
+
+    def decode(self, d_in, data_off=0, group=None):
+        """Returns (d_out, n, offset, total, end_pos): this rank's n bytes at `offset` of the stream's `total`; end_pos = the
+        reference's stream position behind the DEFLATE data (inflate.dart:104-156), None on the fallback."""
+        on = dist.is_available() and dist.is_initialized()
+        rank = dist.get_rank(group) if on else 0
+        world = dist.get_world_size(group) if on else 1
+        cdev = self.collective_device or d_in.device
+        sp = StreamSplit(d_in, data_off, rank, world)
+        try:
+            all_cand = _all_gather_u64(sp.candidates(), cdev, group)
+            handled, res = sp.size(all_cand)
+            if handled:
+                handled, offset, n, total, end_pos = sp.chain(_all_gather_u64(res, cdev, group))
+            if handled:
+                d_map = sp.resolve()
+                if on:
+                    mine = d_map.to(cdev)
+                    maps = torch.empty(world * mine.numel(), dtype=torch.uint8, device=cdev)
+                    dist.all_gather_into_tensor(maps, mine, group=group)
+                    maps = maps.to(d_in.device)
+                else:
+                    maps = d_map
+                d_out = torch.empty(n + 64, dtype=torch.uint8, device=d_in.device)
+                handled, n = sp.finish(maps, d_out)
+            self.last_handled = handled
+            if handled:
+                return d_out, n, offset, total, end_pos
+        finally:
+            sp.close()
+        # the exact path, on one rank
+        if rank != 0:
+            total = exchange_output_offsets(0, device=cdev, group=group)[1]
+            return torch.empty(0, dtype=torch.uint8, device=d_in.device), 0, total, total, None
+        from .codecs import Inflate
+        out = Inflate(bytes(d_in[data_off:].cpu().numpy())).get_bytes()
+        exchange_output_offsets(len(out), device=cdev, group=group)
+        d_out = torch.frombuffer(bytearray(out), dtype=torch.uint8).to(d_in.device) if out else torch.empty(0, dtype=torch.uint8, device=d_in.device)
+        return d_out, len(out), 0, len(out), None

@@ -60,7 +60,8 @@ const char *ahip_last_error(void);
 /* ABI version of this header (major << 16 | minor). */
 uint32_t ahip_abi_version(void);  /* 2.1: + ahip_gzip_decode_shards, ahip_gzip_encode_device, ahip_zlib_encode_device;
                                     * 2.2: + ahip_deflate_shards, ahip_bzip2_decode_shards, ahip_debug_last_chunks;
-                                    * 2.3: + ahip_debug_bz_reruns, ahip_last_consumed */
+                                    * 2.3: + ahip_debug_bz_reruns, ahip_last_consumed;
+                                    * 2.4: + ahip_stream_split_* */
 
 /* ---- Inflate: host-pointer entry points (what dart:ffi binds) ---- */
 
@@ -173,6 +174,51 @@ void ahip_gzip_plan_destroy(ahip_gzip_plan *plan);
  * {end_pos lo,hi, out_len lo,hi, status, blocks, windows, rounds, fallbacks, partial, cyc[8], tok_words lo,hi}
  * (cyc: per-phase shader-clock cycles / 16, filled by -DAHIP_PROFILE builds only). */
 int32_t ahip_debug_plan_results(ahip_gzip_plan *plan, uint32_t *host_words, size_t max_members, size_t *n_members);
+
+/* ---- ONE long DEFLATE stream decoded by several ranks (one process per GPU) ----
+ * ref: zlib/inflate.dart:104-156 is one loop over the blocks of one stream and _gzip_decoder_web.dart:29-55 one loop over
+ * members: a stream of ONE member offers the member loop nothing to shard ("replicas only until the
+ * speculative path exists").  Here every rank holds the whole COMPRESSED stream in its device memory and decodes an equal
+ * range of it: it finds the DEFLATE block starts behind its own cuts, sizes them, resolves the chunks that turn out to lie
+ * on the true chain of blocks to 16-bit symbols (a byte, or "byte j of the 32 KiB in front of my range"), learns those
+ * 32 KiB from the ranks in front of it and writes ITS slice of the output.  Three all-gathers carry everything that
+ * crosses between ranks; the CALLER performs them (torch.distributed over RCCL, MPI, ...: archive_amd/sharding.py
+ * ::ShardedStreamDecoder is the Python host), the library never talks to another rank:
+ *
+ *   ahip_stream_split_create      (host only) rank r of `world` takes the cuts [n r / world, n (r + 1) / world)
+ *   ahip_stream_split_candidates  -> this rank's block starts (bit positions, ascending; rank 0's begin with data_off * 8)
+ *        all-gather #1: the lists, concatenated in rank order (= stream order)
+ *   ahip_stream_split_size        -> 4 words per OWN candidate {status, bytes produced, end position, blocks}
+ *        all-gather #2: the results, concatenated in rank order (entry i belongs to candidate i of the gathered list)
+ *   ahip_stream_split_chain       (host only) follows the chain of "ends where the next one starts" from the stream's first
+ *                                 bit: where this rank's slice lies in the stream's output, how long it is, the total
+ *   ahip_stream_split_resolve     -> this rank's window map in d_map (ahip_stream_split_map_bytes() bytes of device memory)
+ *        all-gather #3: the maps, concatenated in rank order (64 KiB + a status word per rank)
+ *   ahip_stream_split_finish      -> the rank's slice in d_out
+ *
+ * *handled = 0 (size, chain, finish): not a case for this path -- too short, too few block starts, a damaged stream, a chunk
+ * that decodes differently with its true history.  Every rank reaches the same verdict at the same step (it follows from
+ * gathered data); the caller then decodes the stream with ahip_inflate_raw / ahip_gzip_decode_device on one rank, which
+ * has the reference's exact semantics for every malformed input.  A handle belongs to the thread that created it. */
+typedef struct ahip_stream_split ahip_stream_split;
+int32_t ahip_stream_split_create(const void *d_in, size_t in_len, size_t data_off, uint32_t rank, uint32_t world, void *stream,
+                                 ahip_stream_split **split);
+/* AHIP_E_CAP with *n = the count when cap is too small (call again). */
+int32_t ahip_stream_split_candidates(ahip_stream_split *split, uint64_t *cand, size_t cap, size_t *n);
+int32_t ahip_stream_split_size(ahip_stream_split *split, const uint64_t *all_cand, size_t n_all, uint64_t *results, size_t cap_words,
+                               int32_t *handled);
+/* rank_off / rank_len: this rank's slice of the stream's output; total_out: the whole output; end_pos: the reference's
+ * InputStream position behind the stream (inflate.dart:104-156). */
+int32_t ahip_stream_split_chain(ahip_stream_split *split, const uint64_t *all_results, size_t n_all, int32_t *handled, uint64_t *rank_off,
+                                uint64_t *rank_len, uint64_t *total_out, uint64_t *end_pos);
+size_t ahip_stream_split_map_bytes(void);
+int32_t ahip_stream_split_resolve(ahip_stream_split *split, void *d_map);
+/* d_maps: world x ahip_stream_split_map_bytes() bytes of device memory, rank order.  d_out: rank_len bytes. */
+int32_t ahip_stream_split_finish(ahip_stream_split *split, const void *d_maps, void *d_out, size_t out_cap, size_t *out_len, int32_t *handled);
+void ahip_stream_split_destroy(ahip_stream_split *split);
+/* Diagnostics / tests (no device, no handle): the chain walk of ahip_stream_split_chain for a rank that owns candidates
+ * [c0, c1) of n; out[0..5] = handled, slice offset, slice length, total, end position, the rank's chunks on the chain. */
+int32_t ahip_debug_stream_split_chain(const uint64_t *cand, const uint64_t *results, size_t n, uint32_t c0, uint32_t c1, uint64_t *out);
 
 /* ---- Deflate ----
  * ref: codecs/zlib/deflate.dart:39-48 `Deflate(bytes, level: L, windowBits: W).getBytes()`; level 0..9 as in

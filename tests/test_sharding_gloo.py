@@ -206,3 +206,69 @@ def test_two_rank_bzip2_block_ranges_and_crc_fold():
     assert res[0][1] == res[1][1]
     flat = res[0][1]
     assert merge_block_folds([(flat[0], flat[1]), (flat[2], flat[3])]) == cands[-1][2]
+
+
+# ---- one long member across ranks: the host side of ahip_stream_split_* ----
+def test_stream_split_chain_walk_on_plain_arrays(native_built):
+    """ahip_stream_split_chain's walk (no device): six block starts of which two are false finds (they decode garbage and
+    nothing ends on them), three ranks owning two candidates each.  The chain 0 -> 2 -> 3 -> 5 gives every rank its slice of
+    the output: offsets are the sums in front, a rank whose candidates are all off the chain gets an empty slice where the
+    chain passes its range, the total and the end position are everybody's."""
+    import ctypes
+    from archive_amd import _native as N
+    L = N.lib()
+    OK, CHUNK_END = 0, 19
+    cand = np.array([80, 1000, 2000, 3000, 3500, 4000], dtype=np.uint64)
+    res = np.array([[CHUNK_END, 70000, 2000, 3], [7, 123, 1111, 1], [CHUNK_END, 50000, 3000, 2], [CHUNK_END, 10, 4000, 1],
+                    [1, 5, 3600, 1], [OK, 900, 520, 2]], dtype=np.uint64)
+
+    def walk(c0, c1, r=res, c=cand):
+        out = np.zeros(6, dtype=np.uint64)
+        rc = L.ahip_debug_stream_split_chain(c.ctypes.data, np.ascontiguousarray(r).ctypes.data, len(c), c0, c1, out.ctypes.data)
+        return rc, [int(v) for v in out]
+    assert walk(0, 2) == (0, [1, 0, 70000, 120910, 520, 1])
+    assert walk(2, 4) == (0, [1, 70000, 50010, 120910, 520, 2])
+    assert walk(4, 6) == (0, [1, 120010, 900, 120910, 520, 1])
+    assert walk(4, 5) == (0, [1, 120010, 0, 120910, 520, 0])      # only the false find: an empty slice where the chain passes
+    assert walk(6, 6) == (0, [1, 120910, 0, 120910, 520, 0])      # no candidates at all (a range inside one long block)
+    assert walk(0, 6) == (0, [1, 0, 120910, 120910, 520, 4])      # one rank: everything
+    bad = res.copy(); bad[3, 0] = 4                                # a chunk of the chain ends with an error status: not for this path
+    assert walk(2, 4, bad)[1][0] == 0 and walk(0, 2, bad)[1][0] == 0
+    broken = res.copy(); broken[2, 2] = 3001                       # ends where nothing starts: cannot happen (ends ARE candidates)
+    assert walk(0, 2, broken)[0] == N.AHIP_E_DEVICE
+    back = res.copy(); back[2, 2] = 1000                           # ... or on an earlier candidate
+    assert walk(0, 2, back)[0] == N.AHIP_E_DEVICE
+    assert walk(0, 2, res[:3], cand[:3])[1][0] == 0                # fewer than four block starts: the one-wave path's
+
+
+def _gather_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from archive_amd.sharding import _all_gather_u64
+        mine = [np.array([80, 2 ** 63 + 5, 7], dtype=np.uint64), np.zeros(0, dtype=np.uint64)][rank]
+        a = _all_gather_u64(mine, "cpu", None)
+        b = _all_gather_u64(np.array([rank * 10 + 1, rank * 10 + 2], dtype=np.uint64), "cpu", None)
+        c = _all_gather_u64(np.zeros(0, dtype=np.uint64), "cpu", None)
+        q.put((rank, a.tolist(), b.tolist(), c.tolist()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gather_of_ragged_lists():
+    """The two list exchanges of the split decode (block starts, sizing results): lists of different lengths -- one rank's may
+    be empty -- concatenated in rank order, values above 2^63 intact."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, a, b, c in got:
+        assert a == [80, 2 ** 63 + 5, 7] and b == [1, 2, 11, 12] and c == []
