@@ -450,7 +450,7 @@ struct DevBuf {
   }
   void release() {
     if (!p) return;
-    if (g_pool.size() < 64) g_pool.push_back({p, cap}); else (void)hipFree(p);
+    if (g_pool.size() < 256) g_pool.push_back({p, cap}); else (void)hipFree(p);
     p = nullptr; cap = 0;
   }
   template <class T> T *as() const { return (T *)p; }
@@ -2520,9 +2520,12 @@ int32_t ahip_stream_split_create(const void *d_in, size_t in_len, size_t data_of
   ahip_stream_split *sp = new ahip_stream_split();
   SplitState &h = sp->s;
   h.d_in = (const u8 *)d_in; h.n = in_len; h.off = data_off; h.rank = rank; h.world = world; h.st = (hipStream_t)stream;
-  h.cb = sm_chunk_bytes();
+  // Several ranks: fewer chunks per GPU, and a chunk is one wave's serial work -- 16 KiB cuts make about every block of a
+  // zlib stream a chunk of its own (1 GiB of text on 8 ranks: 3.9 ms against 6.0 with 32 KiB cuts, profiles/r06_stream_split.md);
+  // one rank keeps the single-device path's 48 KiB.  AHIP_SM_CHUNK overrides both.
+  h.cb = (world > 1 && !getenv("AHIP_SM_CHUNK")) ? (16ull << 10) : sm_chunk_bytes();
   const u64 len = in_len - data_off;
-  while ((len + h.cb - 1) / h.cb > 32768) h.cb *= 2;
+  while (((len + h.cb - 1) / h.cb + world - 1) / world > 32768) h.cb *= 2;  // (a RANK's chunks are the grid.y of its per-chunk kernels)
   h.n_cuts = (u32)((len + h.cb - 1) / h.cb);
   h.k0 = (u32)((u64)h.n_cuts * rank / world);
   h.k1 = (u32)((u64)h.n_cuts * (rank + 1) / world);
