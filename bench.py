@@ -18,6 +18,9 @@ The JSON line also carries
             the shard CRCs are combined the same way and must equal the whole stream's;
   weak      (N > 1, unless --no-extras) every rank decoding its OWN 65 536 members (rank r holds members
             [r*M, (r+1)*M) of a stream of N*M members): per-GPU work fixed, reported next to the headline;
+  one_member (N > 1, unless --no-extras) ONE gzip member of --one-member-mib MiB decoded by all ranks together
+            (ahip_stream_split_*: a rank's range of the stream's blocks, three all-gathers a step), with the same member's
+            single-device time beside it;
   extras    (N = 1) the other BASELINE configs, device-resident unless said otherwise: 2a one 256 MiB member, 2b
             4 096 members of wiki-like text, 3 Deflate level 6 on 1 GiB, 4 without the BGZF BC subfield, 5 bzip2,
             and the host-pointer entry point end to end (PCIe included).
@@ -118,6 +121,7 @@ def main():
     ap.add_argument("--no-bc", action="store_true", help="omit the BGZF BC subfield (forces sizing runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration (0 = skip)")
     ap.add_argument("--check", action="store_true", help="also compare the decoded bytes with the generator's plain text")
+    ap.add_argument("--one-member-mib", type=int, default=512, help="N > 1: size of the single member the ranks decode together (the `one_member` leg)")
     ap.add_argument("--no-extras", action="store_true", help="skip the other configs (N = 1) / the strong-scaling leg (N > 1)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collectives of the N > 1 run: nccl (= RCCL over xGMI, GPU tensors) or gloo (CPU tensors; for boxes with fewer GPUs than ranks)")
@@ -255,9 +259,10 @@ def main():
         sharding = ("ONE stream cut into %d contiguous member ranges balanced on compressed bytes, one process per GPU" % world
                     if not args.one_device else "ONE stream cut into %d member ranges, %d processes on ONE GPU (functional run)" % (world, world))
 
-    weak = None
+    weak = one = None
     if world > 1 and not args.no_extras:
         weak = weak_scaling(args, L, N, corpus, dist, torch, np, dev, cdev, sh, rank, world, kind, seed, threads, decode_loop)
+        one = one_member_split(args, L, N, corpus, dist, torch, np, dev, dev_index, cdev, sh, rank, world)
 
     if rank == 0:
         # C + U of what rank 0's kernels handled: compressed read once + output written once (N = 1: the whole stream)
@@ -310,6 +315,8 @@ def main():
             pass
         if weak is not None:
             line["weak"] = weak
+        if one is not None:
+            line["one_member"] = one
         if world == 1 and not args.no_extras:
             del d_out
             line["extras"] = extras(args, L, N, corpus, torch, np, dev, sh, comp, d_in, out_bytes, decode_loop)
@@ -362,6 +369,69 @@ def weak_scaling(args, L, N, corpus, dist, torch, np, dev, cdev, sh, rank, world
             "ms_per_step": round(elapsed / steps * 1e3, 4), "n_gpus": world, "kernel_ms": round(kern_ms, 4),
             "workload": "%d members x %d B PER GPU (rank r: members r*M .. (r+1)*M of one stream of N*M)" % (args.members, args.member_bytes),
             "check": {"ok": True, "what": "per-rank device CRC-32 vs the member trailers, every rank"}}
+
+
+def one_member_split(args, L, N, corpus, dist, torch, np, dev, dev_index, cdev, sh, rank, world):
+    """ONE gzip member (BASELINE config 2a's kind of stream, --one-member-mib of wiki text, compressed pigz-style on rank 0
+    and broadcast untimed) decoded by ALL ranks: archive_amd.sharding.ShardedStreamDecoder -- every rank finds, sizes and
+    resolves its range of the stream's blocks and writes its slice; three all-gathers per step.  Rides along like `weak`."""
+    import zlib
+    from archive_amd.sharding import ShardedStreamDecoder
+    nbytes = args.one_member_mib << 20
+    if rank == 0:
+        gz, want_crc = corpus.make_one_member(kind=corpus.WIKI, seed=8, nbytes=nbytes, level=6, threads=os.cpu_count() or 1)
+    n_in = torch.tensor([len(gz) if rank == 0 else 0, want_crc if rank == 0 else 0], dtype=torch.int64, device=cdev)
+    dist.broadcast(n_in, 0)
+    whole = torch.from_numpy(gz.copy()).to(cdev) if rank == 0 else torch.empty(int(n_in[0].item()), dtype=torch.uint8, device=cdev)
+    dist.broadcast(whole, 0)
+    d_in = whole.to(dev)
+    want_crc = int(n_in[1].item())
+    dec = ShardedStreamDecoder(device_index=dev_index, collective_device=None if cdev.type == "cuda" else "cpu")
+    steps = max(3, args.steps // 2)
+
+    def step():
+        return dec.decode(d_in, 10)
+    step()
+    torch.cuda.synchronize(); dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        d_out, n, offset, total, end_pos = step()
+    torch.cuda.synchronize(); dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=cdev)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    got = ctypes.c_uint32()
+    if L.ahip_crc32_device(d_out.data_ptr(), n, 0, ctypes.byref(got), sh) != 0:
+        raise SystemExit("crc32_device: " + N.last_error())
+    mine = torch.tensor([got.value, n, offset, 1 if dec.last_handled else 0], dtype=torch.int64, device=cdev)
+    allv = torch.zeros(4 * world, dtype=torch.int64, device=cdev)
+    dist.all_gather_into_tensor(allv, mine)
+    single_ms = None
+    if rank == 0:  # the same member on one device, for the ratio
+        o1 = torch.empty(nbytes + 64, dtype=torch.uint8, device=dev)
+        olen = ctypes.c_size_t()
+        for i in range(4):
+            if i == 1:
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+            if L.ahip_gzip_decode_device(d_in.data_ptr(), d_in.numel(), o1.data_ptr(), o1.numel(), ctypes.byref(olen), sh) != 0:
+                raise SystemExit("gzip_decode_device: " + N.last_error())
+        torch.cuda.synchronize()
+        single_ms = (time.perf_counter() - t1) / 3 * 1e3
+        del o1
+    dist.barrier()
+    if rank != 0:
+        return None
+    rows = [[int(v) for v in allv[4 * r:4 * r + 4].tolist()] for r in range(world)]
+    combined = crc32_of_concat([r[0] for r in rows], [r[1] for r in rows])
+    ok = combined == want_crc and sum(r[1] for r in rows) == nbytes == total and end_pos == d_in.numel() - 8
+    if not ok:
+        raise SystemExit("one member on %d ranks: slices combine to %08x (%d bytes), expected %08x (%d)" % (world, combined, sum(r[1] for r in rows), want_crc, nbytes))
+    sec = float(el.item()) / steps
+    return {"value": round(nbytes / sec / 1e9, 3), "unit": "GB/s", "ms_per_step": round(sec * 1e3, 4), "steps": steps, "n_gpus": world,
+            "single_device_ms": round(single_ms, 4), "speedup_vs_single_device": round(single_ms / (sec * 1e3), 3),
+            "split_path_on_every_rank": all(r[3] == 1 for r in rows), "slice_MiB": [round(r[1] / 2 ** 20, 1) for r in rows],
+            "workload": "ONE gzip member of %d MiB wiki text (pigz-style level 6, %.1f MiB compressed) decoded by %d ranks: ahip_stream_split_*, three all-gathers per step" % (
+                args.one_member_mib, d_in.numel() / 2 ** 20, world),
+            "check": {"ok": True, "what": "per-slice device CRC-32 combined over GF(2) in rank order vs the member's trailer; slices back to back; end position in front of the trailer"}}
 
 
 def strong_scaling(args, L, N, corpus, dist, torch, np, dev, cdev, sh, rank, world, comp0, decode_loop):

@@ -87,11 +87,13 @@ def test_two_ranks_on_one_device_gloo(native_built):
     # on 127.0.0.1 and a free port) -- the form `python bench.py --gpus N` takes when a driver runs it like the N = 1 line.
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--one-device",
-                        "--steps", "2", "--warmup", "1", "--members", "2048", "--cpu-seconds", "0"],
+                        "--steps", "2", "--warmup", "1", "--members", "2048", "--cpu-seconds", "0", "--one-member-mib", "24"],
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["check"]["ok"]
+    om = line["one_member"]  # ONE gzip member decoded by both ranks together (ahip_stream_split_*): two slices, CRCs combine to the trailer's
+    assert om["check"]["ok"] and om["split_path_on_every_rank"] and len(om["slice_MiB"]) == 2 and min(om["slice_MiB"]) > 0, om
     assert line["check"]["crc32_combined"] == line["check"]["crc32_expected"]
     assert line["config"]["collectives"].startswith("gloo")
     mpr = line["config"]["members_per_rank"]

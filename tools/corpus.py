@@ -72,3 +72,31 @@ def make_gzip(kind=LOG, seed=1234, n_members=16, member_bytes=65536, level=6, bc
         done += k
     comp = parts[0] if len(parts) == 1 else np.concatenate(parts)
     return comp, plain
+
+
+def make_one_member(kind=WIKI, seed=8, nbytes=256 << 20, level=6, threads=None, piece=8 << 20):
+    """ONE gzip member of nbytes of synthetic text, compressed the way pigz does it: pieces of `piece` bytes on `threads`
+    threads, every piece primed with the 32 KiB in front of it (its matches reach back across the cut like zlib's own would)
+    and closed on a byte boundary by a sync flush (an empty stored block), the last one by the final block -- laid end to end
+    the pieces ARE one raw DEFLATE stream.  Returns (gzip member as uint8 array, crc32 of the text)."""
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+    data = text(kind, seed, 0, nbytes)
+    view = memoryview(data)
+    cuts = list(range(0, nbytes, piece)) or [0]
+
+    def one(i):
+        lo, hi = cuts[i], min(nbytes, cuts[i] + piece)
+        kw = {"zdict": bytes(view[max(0, lo - 32768):lo])} if lo else {}
+        co = zlib.compressobj(level, zlib.DEFLATED, -15, 9, zlib.Z_DEFAULT_STRATEGY, **kw)
+        return co.compress(view[lo:hi]) + co.flush(zlib.Z_FINISH if hi == nbytes else zlib.Z_SYNC_FLUSH)
+
+    def crc(i):
+        return zlib.crc32(view[cuts[i]:min(nbytes, cuts[i] + piece)])
+    with ThreadPoolExecutor(threads or min(32, os.cpu_count() or 1)) as ex:
+        parts = list(ex.map(one, range(len(cuts))))
+    c = 0
+    for i in range(len(cuts)):  # (sequential: crc32 of 1 GiB is a second)
+        c = zlib.crc32(view[cuts[i]:min(nbytes, cuts[i] + piece)], c)
+    gz = bytes([0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 255]) + b"".join(parts) + c.to_bytes(4, "little") + (nbytes & 0xffffffff).to_bytes(4, "little")
+    return np.frombuffer(gz, dtype=np.uint8), c
