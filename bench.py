@@ -262,7 +262,10 @@ def main():
     weak = one = None
     if world > 1 and not args.no_extras:
         weak = weak_scaling(args, L, N, corpus, dist, torch, np, dev, cdev, sh, rank, world, kind, seed, threads, decode_loop)
-        one = one_member_split(args, L, N, corpus, dist, torch, np, dev, dev_index, cdev, sh, rank, world)
+        try:  # (rides along: whatever goes wrong in it must not cost the headline its line)
+            one = one_member_split(args, L, N, corpus, dist, torch, np, dev, dev_index, cdev, sh, rank, world)
+        except Exception as e:  # noqa: BLE001
+            one = {"error": "%s: %s" % (type(e).__name__, e)} if rank == 0 else None
 
     if rank == 0:
         # C + U of what rank 0's kernels handled: compressed read once + output written once (N = 1: the whole stream)
@@ -424,7 +427,7 @@ def one_member_split(args, L, N, corpus, dist, torch, np, dev, dev_index, cdev, 
     combined = crc32_of_concat([r[0] for r in rows], [r[1] for r in rows])
     ok = combined == want_crc and sum(r[1] for r in rows) == nbytes == total and end_pos == d_in.numel() - 8
     if not ok:
-        raise SystemExit("one member on %d ranks: slices combine to %08x (%d bytes), expected %08x (%d)" % (world, combined, sum(r[1] for r in rows), want_crc, nbytes))
+        return {"error": "one member on %d ranks: slices combine to %08x (%d bytes), expected %08x (%d)" % (world, combined, sum(r[1] for r in rows), want_crc, nbytes)}
     sec = float(el.item()) / steps
     return {"value": round(nbytes / sec / 1e9, 3), "unit": "GB/s", "ms_per_step": round(sec * 1e3, 4), "steps": steps, "n_gpus": world,
             "single_device_ms": round(single_ms, 4), "speedup_vs_single_device": round(single_ms / (sec * 1e3), 3),

@@ -215,3 +215,51 @@ def test_two_ranks_one_member_gloo(native_built, tmp_path):
                         "--master-port", str(29500 + os.getpid() % 2000), str(script)], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "case long ok" in r.stdout and "case short ok" in r.stdout, r.stdout[-2000:]
+
+
+_RCCL_SCRIPT = r"""
+import os, sys, zlib
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+from tools import corpus
+from archive_amd.sharding import ShardedStreamDecoder
+world_gpus = int(os.environ["WORLD_SIZE"])
+dev = torch.device("cuda", int(os.environ["LOCAL_RANK"]))
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", device_id=dev)
+gz, crc = corpus.make_one_member(nbytes=48 << 20)      # pigz-style: pieces closed by sync-flush markers, one DEFLATE stream
+d_in = torch.from_numpy(gz.copy()).to(dev)
+dec = ShardedStreamDecoder(device_index=dev.index)     # collectives on the stream's device: RCCL
+d_out, n, off, total, end = dec.decode(d_in, 10)
+mine = torch.tensor([zlib.crc32(bytes(d_out[:n].cpu().numpy())), n, off], dtype=torch.int64, device=dev)
+rows = torch.zeros(3 * world_gpus, dtype=torch.int64, device=dev)
+dist.all_gather_into_tensor(rows, mine)
+if dist.get_rank() == 0:
+    from archive_amd.sharding import crc32_combine
+    rows = rows.view(world_gpus, 3).tolist()
+    c, at = 0, 0
+    for rc, rn, ro in rows:
+        assert ro == at
+        c = crc32_combine(c, rc, rn) if rn else c
+        at += rn
+    assert c == crc and at == total == (48 << 20) and end == len(gz) - 8 and dec.last_handled, (rows, total, end)
+    print("rccl ranks %%d ok" %% world_gpus)
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("ranks", [1, 2])
+def test_gathers_over_rccl(native_built, tmp_path, ranks):
+    """The three exchanges on GPU tensors through RCCL (`collective_device=None`), the way a multi-GPU launch has them: with one
+    rank on the one GPU of this box (the all-gathers of int64 / uint8 device tensors run, a world of one), with two where
+    there are two GPUs.  The member is pigz-style: several pieces, each closed by an empty stored block."""
+    import torch
+    if torch.cuda.device_count() < ranks:
+        pytest.skip("needs %d GPUs" % ranks)
+    script = tmp_path / "rccl.py"
+    script.write_text(_RCCL_SCRIPT % {"root": ROOT})
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % ranks, "--master-addr", "127.0.0.1",
+                        "--master-port", str(31500 + os.getpid() % 2000), str(script)], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "rccl ranks %d ok" % ranks in r.stdout, r.stdout[-2000:]
