@@ -239,9 +239,10 @@ class ShardedStreamDecoder:
             _check(rc)
         self.last_handled = None
 
-    def decode(self, d_in, data_off=0, group=None):
+    def decode(self, d_in, data_off=0, group=None, fallback=True):
         """Returns (d_out, n, offset, total, end_pos): this rank's n bytes at `offset` of the stream's `total`; end_pos = the
-        reference's stream position behind the DEFLATE data (inflate.dart:104-156), None on the fallback."""
+        reference's stream position behind the DEFLATE data (inflate.dart:104-156), None on the fallback (fallback=False:
+        returns None instead of decoding on one rank)."""
         on = dist.is_available() and dist.is_initialized()
         rank = dist.get_rank(group) if on else 0
         world = dist.get_world_size(group) if on else 1
@@ -268,12 +269,58 @@ class ShardedStreamDecoder:
                 return d_out, n, offset, total, end_pos
         finally:
             sp.close()
-        # the exact path, on one rank
+        if not fallback:
+            return None
+        return self._one_rank(d_in, cdev, group, rank, raw_from=data_off)
+
+    def _one_rank(self, d_in, cdev, group, rank, raw_from=None):
+        """The exact single-device path on rank 0 (every malformed input keeps the reference's verdict there); the other ranks'
+        slices are empty.  raw_from: a raw DEFLATE stream from that byte on; None: the buffer is a gzip stream."""
         if rank != 0:
             total = exchange_output_offsets(0, device=cdev, group=group)[1]
             return torch.empty(0, dtype=torch.uint8, device=d_in.device), 0, total, total, None
-        from .codecs import Inflate
-        out = Inflate(bytes(d_in[data_off:].cpu().numpy())).get_bytes()
+        from .codecs import GZipDecoder, Inflate
+        host = bytes(d_in.cpu().numpy())
+        out = Inflate(host[raw_from:]).get_bytes() if raw_from is not None else GZipDecoder().decode_bytes(host)
         exchange_output_offsets(len(out), device=cdev, group=group)
         d_out = torch.frombuffer(bytearray(out), dtype=torch.uint8).to(d_in.device) if out else torch.empty(0, dtype=torch.uint8, device=d_in.device)
         return d_out, len(out), 0, len(out), None
+
+    @staticmethod
+    def gzip_data_offset(head):
+        """Where the DEFLATE data of a gzip member starts -- the reference's `_readHeader`, _gzip_decoder_web.dart:59-139:
+        signature, method 8, flags, then the optional extra field, name, comment and header CRC are skipped.  None: no gzip
+        header here (the reference falls back to zlib) or it does not end inside `head`."""
+        if len(head) < 10 or head[0] != 0x1f or head[1] != 0x8b or head[2] != 8:
+            return None
+        flags, pos = head[3], 10
+        if flags & 4:
+            if pos + 2 > len(head):
+                return None
+            pos += 2 + (head[pos] | (head[pos + 1] << 8))
+        for bit in (8, 16):  # name, comment: zero-terminated
+            if flags & bit:
+                end = head.find(b"\0", pos)
+                if end < 0:
+                    return None
+                pos = end + 1
+        if flags & 2:
+            pos += 2
+        return pos if pos <= len(head) else None
+
+    def decode_gzip(self, d_in, group=None):
+        """`GZipDecoder().decodeBytes` (_gzip_decoder_web.dart:19-55) of a stream that is ONE member, by all ranks together:
+        the header is skipped like `_readHeader` does, the DEFLATE data split over the ranks, and the member must end eight
+        bytes (CRC-32, ISIZE: read, never checked by the reference) in front of the end of the buffer.  Anything else -- no gzip
+        header, more members or other bytes behind the first, a stream the split does not take -- is decoded by rank 0 alone
+        with the reference's exact member loop.  Returns what `decode` returns."""
+        on = dist.is_available() and dist.is_initialized()
+        rank = dist.get_rank(group) if on else 0
+        cdev = self.collective_device or d_in.device
+        data_off = self.gzip_data_offset(bytes(d_in[:1 << 17].cpu().numpy()))
+        if data_off is not None and data_off < d_in.numel():
+            res = self.decode(d_in, data_off, group, fallback=False)
+            if res is not None and res[4] == d_in.numel() - 8:
+                return res
+        self.last_handled = False
+        return self._one_rank(d_in, cdev, group, rank)

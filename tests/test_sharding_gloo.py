@@ -272,3 +272,32 @@ def test_two_rank_gather_of_ragged_lists():
         assert p.exitcode == 0
     for rank, a, b, c in got:
         assert a == [80, 2 ** 63 + 5, 7] and b == [1, 2, 11, 12] and c == []
+
+
+def test_gzip_data_offset_follows_the_reference_header_walk():
+    """ShardedStreamDecoder.gzip_data_offset = `_readHeader` (_gzip_decoder_web.dart:59-139): every combination of the optional
+    fields (extra, name, comment, header CRC), checked by inflating from the offset it returns."""
+    import zlib
+    from archive_amd.sharding import ShardedStreamDecoder as D
+    payload = b"the quick brown fox " * 50
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    raw = co.compress(payload) + co.flush()
+    for flags in range(32):
+        if flags & 1 and flags & ~1 == 0:
+            pass  # (FTEXT alone: a hint, nothing to skip)
+        h = bytes([0x1f, 0x8b, 8, flags, 1, 2, 3, 4, 0, 255])
+        if flags & 4:
+            h += (8).to_bytes(2, "little") + b"\0extra\0\1"       # (zero bytes inside the extra field do not end anything)
+        if flags & 8:
+            h += b"name.txt\0"
+        if flags & 16:
+            h += b"a comment\0"
+        if flags & 2:
+            h += b"\xaa\xbb"
+        off = D.gzip_data_offset(h + raw + bytes(8))
+        assert off == len(h), (flags, off, len(h))
+        assert zlib.decompress((h + raw)[off:], -15) == payload
+    assert D.gzip_data_offset(b"\x1f\x8b\x07" + bytes(20)) is None        # not deflate
+    assert D.gzip_data_offset(b"\x78\x9c" + bytes(20)) is None            # a zlib stream: the reference falls back to ZLibDecoder
+    assert D.gzip_data_offset(bytes([0x1f, 0x8b, 8, 8, 0, 0, 0, 0, 0, 3]) + b"never ends") is None
+    assert D.gzip_data_offset(bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 3, 200, 0]) + bytes(50)) is None  # extra field runs past the buffer

@@ -143,6 +143,35 @@ def test_what_the_path_does_not_take(native_built, corpora):
     assert got is None or got != data  # (a flipped bit that still decodes is the reference's verdict too; usually it does not)
 
 
+def test_gzip_streams_through_the_host_class(native_built, corpora):
+    """ShardedStreamDecoder.decode_gzip without a process group (a world of one): a member with every optional header field goes
+    through the split; two members, bytes behind the trailer and a zlib stream go to the exact member loop (GZipDecoder) and
+    come back with the reference's result for them."""
+    import torch
+    import archive_amd
+    from archive_amd.sharding import ShardedStreamDecoder
+    data = corpora["log"]
+    raw = _raw(data)
+    tail = zlib.crc32(data).to_bytes(4, "little") + (len(data) & 0xffffffff).to_bytes(4, "little")
+    head = bytes([0x1f, 0x8b, 8, 4 | 8 | 16 | 2, 0, 0, 0, 0, 0, 3]) + (5).to_bytes(2, "little") + b"ab\0cd" + b"log.txt\0" + b"synthetic\0" + b"\x12\x34"
+    dec = ShardedStreamDecoder(device_index=0)
+
+    def run(stream):
+        d_in = torch.frombuffer(bytearray(stream), dtype=torch.uint8).cuda()
+        d_out, n, off, total, end = dec.decode_gzip(d_in)
+        return bytes(d_out[:n].cpu().numpy()), off, total, end, dec.last_handled
+    one = head + raw + tail
+    assert run(one) == (data, 0, len(data), len(one) - 8, True)
+    two = one + gzip.compress(b"second member", mtime=0)
+    want = archive_amd.GZipDecoder().decode_bytes(two)
+    assert want == data + b"second member"
+    assert run(two) == (want, 0, len(want), None, False)
+    for stream in (one + b"junk behind the trailer", zlib.compress(data[:3 << 20])):
+        want = archive_amd.GZipDecoder().decode_bytes(stream)
+        got = run(stream)
+        assert got[0] == want and got[4] is False
+
+
 def test_api_misuse_is_an_error_not_a_crash(native_built, corpora):
     import ctypes
     import torch
