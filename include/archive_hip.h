@@ -199,7 +199,9 @@ int32_t ahip_debug_plan_results(ahip_gzip_plan *plan, uint32_t *host_words, size
  * *handled = 0 (size, chain, finish): not a case for this path -- too short, too few block starts, a damaged stream, a chunk
  * that decodes differently with its true history.  Every rank reaches the same verdict at the same step (it follows from
  * gathered data); the caller then decodes the stream with ahip_inflate_raw / ahip_gzip_decode_device on one rank, which
- * has the reference's exact semantics for every malformed input.  A handle belongs to the thread that created it. */
+ * has the reference's exact semantics for every malformed input.  The stream has an output of its own (nothing in front of
+ * its first byte can be referenced: a gzip member that follows others in one output -- the reference's shared OutputStream --
+ * is the single-device path's).  A handle belongs to the thread that created it. */
 typedef struct ahip_stream_split ahip_stream_split;
 int32_t ahip_stream_split_create(const void *d_in, size_t in_len, size_t data_off, uint32_t rank, uint32_t world, void *stream,
                                  ahip_stream_split **split);
