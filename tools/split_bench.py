@@ -3,7 +3,7 @@
 process, one after another on the one GPU there is, so a rank's phases are timed as they would run on a GPU of its own;
 the gathers are numpy concatenations here (a real launch: two all-gathers of a few KB and one of 64 KiB a rank).
 
-    python tools/split_bench.py [MiB] > profiles/r06_stream_split.md
+    python tools/split_bench.py [MiB [ranks,ranks,...]] > profiles/r06_stream_split.md
 
 Per world size: for every phase the slowest rank's time (a step of a real job is the sum of those, plus the three
 exchanges), next to the single-device decode of the same stream (ahip_gzip_decode_device)."""
@@ -51,7 +51,7 @@ def main():
     print("(`ahip_gzip_decode_device`, the chunked path of section 10): **%.2f ms = %.1f GB/s**.\n" % (one * 1e3, len(data) / one / 1e9))
     print("| ranks | find | size | chain (host) | resolve + maps | finish (link, windows, translate) | step | GB/s out | x single device | slices (MiB, min .. max) |")
     print("|---|---|---|---|---|---|---|---|---|---|")
-    for world in (1, 2, 4, 8):
+    for world in ([int(w) for w in sys.argv[2].split(",")] if len(sys.argv) > 2 else (1, 2, 4, 8)):
         best = None
         for rep in range(3):
             sps = [StreamSplit(d_in, 10, r, world) for r in range(world)]
