@@ -1620,6 +1620,7 @@ int32_t split_size(SplitState *h, const u64 *all, size_t n_all, bool *handled) {
   if (!getenv("AHIP_SM_TWO_PASS") && span <= (4ull << 30) &&
       h->dtok.reserve(((size_t)span * IN_R + (size_t)nown * IN_PAD + 64) * 4) == hipSuccess &&
       h->ddir.reserve(((size_t)(span / 32) + (size_t)nown * 64 + 64) * DIR_BYTES) == hipSuccess) h->have_tokens = true;
+  else (void)hipGetLastError();  // (no room to keep the tokens: sized without, tokenized again later)
   const u32 grid = nown < (u32)sm_resident_waves() ? nown : (u32)sm_resident_waves();
   u32 *ctr = nullptr;
   HIP_TRY(split_counter(h, 0, &ctr));
