@@ -5,6 +5,8 @@ sizes the CPU oracle finishes in seconds; here the checks are checksums and roun
              device == CRC-32 of the generator's plain text taken by zlib on the host.
   config 2a  ONE gzip member holding 256 MiB of wiki-like text (the chunked single-stream path), and the same stream
              without BGZF hints: size, device CRC-32 == host CRC-32, head and tail byte for byte.
+             The same kind of member (512 MiB, pigz-style) decoded by EIGHT ranks through ahip_stream_split_*: the slices'
+             device CRC-32s chained in rank order == the member's trailer.
   config 2b  4 096 members x 64 KiB of wiki-like text, with and without the BC subfield: the same checks.
   config 3   1 GiB of log text, Deflate level 6: the stream inflates to the input through zlib (CRC-32 and length),
              its size is within the stated tolerance of what the reference's level 6 produces on a sample, and the
@@ -131,3 +133,42 @@ def test_config2b_4096_wiki_members(native_built, bc):
     comp, plain = corpus.make_gzip(kind=corpus.WIKI, seed=8, n_members=4096, member_bytes=65536, level=6, bc=bc, want_plain=True)
     plain = bytes(plain)
     _device_checks(L, N, torch.from_numpy(comp).cuda(), len(plain), zlib.crc32(plain), plain[:65536], plain[-65536:])
+
+
+def test_config2a_one_member_on_eight_ranks(native_built):
+    """ONE gzip member holding 512 MiB of wiki-like text (pigz-style: pieces primed with the 32 KiB in front of them and
+    closed by sync-flush markers) decoded by eight ranks -- handles of this process, one after another on the one GPU --
+    through ahip_stream_split_*: eight slices back to back, every one a sixteenth to a fifth of the output, their device
+    CRC-32s chained in rank order == the member's trailer, head and tail of every slice byte for byte."""
+    import torch
+    from archive_amd import _native as N
+    from archive_amd.sharding import StreamSplit
+    from tools import corpus
+    L = N.lib()
+    assert L.ahip_init(0) == 0
+    nbytes, world = 512 << 20, 8
+    gz, want_crc = corpus.make_one_member(kind=corpus.WIKI, seed=8, nbytes=nbytes)
+    plain = corpus.text(corpus.WIKI, 8, 0, nbytes)
+    d_in = torch.from_numpy(gz.copy()).cuda()
+    sps = [StreamSplit(d_in, 10, r, world) for r in range(world)]
+    all_cand = np.concatenate([sp.candidates() for sp in sps])
+    sized = [sp.size(all_cand) for sp in sps]
+    assert all(h for h, _ in sized)
+    all_res = np.concatenate([r for _, r in sized])
+    chains = [sp.chain(all_res) for sp in sps]
+    assert all(c[0] and c[3] == nbytes and c[4] == len(gz) - 8 for c in chains)
+    maps = torch.cat([sp.resolve() for sp in sps])
+    crc, at = 0, 0
+    for sp, (_, off, n, _, _) in zip(sps, chains):
+        assert off == at and nbytes // 16 <= n <= nbytes // 5, (off, at, n)
+        d_out = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+        handled, got = sp.finish(maps, d_out)
+        assert handled and got == n
+        c = ctypes.c_uint32()
+        assert L.ahip_crc32_device(d_out.data_ptr(), n, crc, ctypes.byref(c), None) == 0
+        crc = c.value
+        assert bytes(d_out[:4096].cpu().numpy()) == bytes(plain[off:off + 4096])
+        assert bytes(d_out[n - 4096:n].cpu().numpy()) == bytes(plain[off + n - 4096:off + n])
+        at += n
+        sp.close()
+    assert at == nbytes and crc == want_crc
