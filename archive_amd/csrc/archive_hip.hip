@@ -1551,8 +1551,8 @@ struct SplitState {
   u64 base_out = 0, out_len = 0, total_out = 0, end_pos = 0;
   bool kept = false, have_tokens = false;
   u32 gs = 1, ng = 0;
-  DevBuf dfind, dcand, dchunks, dres, dsym, dwin, dwsym, dgsym, dgwin, dlink, dtok, ddir, derr, dctr;
-  void release() { for (DevBuf *b : {&dfind, &dcand, &dchunks, &dres, &dsym, &dwin, &dwsym, &dgsym, &dgwin, &dlink, &dtok, &ddir, &derr, &dctr}) b->release(); }
+  DevBuf dfind, dcand, dchunks, dres, dsym, dwin, dwsym, dgsym, dgwin, dlink, dtok, ddir, derr, dctr, dmap, dmaps;  // (dmap / dmaps: the one-process form's exchange buffers)
+  void release() { for (DevBuf *b : {&dfind, &dcand, &dchunks, &dres, &dsym, &dwin, &dwsym, &dgsym, &dgwin, &dlink, &dtok, &ddir, &derr, &dctr, &dmap, &dmaps}) b->release(); }
 };
 
 hipError_t split_counter(SplitState *h, u32 slot, u32 **out) {
@@ -2511,16 +2511,9 @@ void ahip_gzip_plan_destroy(ahip_gzip_plan *plan) {
 }
 
 // ---- one long stream, several ranks (SplitState above; include/archive_hip.h has the protocol) ----
-int32_t ahip_stream_split_create(const void *d_in, size_t in_len, size_t data_off, uint32_t rank, uint32_t world, void *stream,
-                                 ahip_stream_split **split) {
-  if (!split) return fail(AHIP_E_ARG, "split == NULL");
-  *split = nullptr;
-  if (!world || rank >= world || world > 4096) return fail(AHIP_E_ARG, "stream split: rank / world");
-  if (data_off > in_len) return fail(AHIP_E_ARG, "stream split: data_off behind the input");
-  std::lock_guard<std::recursive_mutex> lk(g_mu);
-  ahip_stream_split *sp = new ahip_stream_split();
-  SplitState &h = sp->s;
-  h.d_in = (const u8 *)d_in; h.n = in_len; h.off = data_off; h.rank = rank; h.world = world; h.st = (hipStream_t)stream;
+// what ahip_stream_split_create decides (host only): the cuts of the stream and this rank's range of them
+static void split_setup(SplitState &h, const void *d_in, size_t in_len, size_t data_off, uint32_t rank, uint32_t world, hipStream_t st) {
+  h.d_in = (const u8 *)d_in; h.n = in_len; h.off = data_off; h.rank = rank; h.world = world; h.st = st;
   // Several ranks: fewer chunks per GPU, and a chunk is one wave's serial work -- 16 KiB cuts make about every block of a
   // zlib stream a chunk of its own (1 GiB of text on 8 ranks: 3.9 ms against 6.0 with 32 KiB cuts, profiles/r06_stream_split.md);
   // one rank keeps the single-device path's 48 KiB.  AHIP_SM_CHUNK overrides both.
@@ -2531,6 +2524,17 @@ int32_t ahip_stream_split_create(const void *d_in, size_t in_len, size_t data_of
   h.k0 = (u32)((u64)h.n_cuts * rank / world);
   h.k1 = (u32)((u64)h.n_cuts * (rank + 1) / world);
   h.eligible = !getenv("AHIP_NO_SM") && len >= sm_min_bytes() && h.n_cuts >= 4;
+}
+
+int32_t ahip_stream_split_create(const void *d_in, size_t in_len, size_t data_off, uint32_t rank, uint32_t world, void *stream,
+                                 ahip_stream_split **split) {
+  if (!split) return fail(AHIP_E_ARG, "split == NULL");
+  *split = nullptr;
+  if (!world || rank >= world || world > 4096) return fail(AHIP_E_ARG, "stream split: rank / world");
+  if (data_off > in_len) return fail(AHIP_E_ARG, "stream split: data_off behind the input");
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  ahip_stream_split *sp = new ahip_stream_split();
+  split_setup(sp->s, d_in, in_len, data_off, rank, world, (hipStream_t)stream);
   *split = sp;
   return AHIP_OK;
 }
@@ -3289,6 +3293,105 @@ int32_t ahip_gzip_decode_shards(uint32_t n_shards, const int32_t *devices, const
   }
   exchange_sizes(n_shards, devices, got.data(), offsets, cur);
   return worst;
+}
+
+// ONE long DEFLATE stream decoded by the device contexts of THIS process (the one-process form of ahip_stream_split_*: the same
+// phases, shard s in the context of its device; what the ranks of a job all-gather is host memory here -- the block starts and the
+// sizing results are concatenated on the calling thread, the 64 KiB window maps go through the host, 64 KiB x n each way).
+// ref: zlib/inflate.dart:104-156, the block loop of one stream.  d_in[s]: the WHOLE compressed stream on shard s's device; the
+// DEFLATE data starts at data_off.  d_out[s] / out_cap[s]: room for shard s's slice (slices are balanced on compressed bytes:
+// allow for more than total / n); out_len[s], offsets[s] (offsets[n] = the total): what it wrote and where that lies in the
+// stream's output; *end_pos: the reference's stream position behind the stream.  *handled = 0: not a case for the chunked
+// decode (see ahip_stream_split_*): nothing was written, use ahip_inflate_raw / ahip_gzip_decode_device.
+int32_t ahip_inflate_stream_shards(uint32_t n_shards, const int32_t *devices, const void *const *d_in, size_t in_len, size_t data_off,
+                                   void *const *d_out, const size_t *out_cap, size_t *out_len, uint64_t *offsets, uint64_t *end_pos,
+                                   int32_t *handled) {
+  std::unique_lock<std::recursive_mutex> lk(g_mu);
+  int32_t rc = ensure_init();
+  if (rc != AHIP_OK) return rc;
+  if (n_shards == 0 || n_shards > 4096 || !devices || !d_in || !d_out || !out_cap || !out_len || !offsets || !handled) return fail(AHIP_E_ARG, "NULL shard table");
+  if (data_off > in_len) return fail(AHIP_E_ARG, "data_off behind the input");
+  *handled = 0;
+  if (end_pos) *end_pos = 0;
+  for (u32 s = 0; s <= n_shards; ++s) { offsets[s] = 0; if (s < n_shards) out_len[s] = 0; }
+  int cur = 0;
+  HIP_TRY(hipGetDevice(&cur));
+  std::vector<int> wk;
+  if (!shard_workers(n_shards, devices, cur, wk)) return fail(AHIP_E_ARG, "shard on a device that ahip_init_devices() did not select");
+  std::vector<std::unique_ptr<SplitState>> hs(n_shards);
+  std::vector<int32_t> rcs(n_shards, AHIP_OK);
+  std::vector<std::string> errs(n_shards);
+  std::vector<u8> oks(n_shards, 0);
+  // a phase on every shard, each in its own context (a state's buffers belong to the thread that runs its phases); true = all well
+  auto phase = [&](const std::function<int32_t(u32, SplitState &)> &f) -> bool {
+    std::function<void(u32)> run_shard = [&](u32 s) {
+      if (rcs[s] < 0) return;
+      if (!hs[s]) { hs[s].reset(new SplitState()); split_setup(*hs[s], d_in[s], in_len, data_off, s, n_shards, g_ctx_stream); }
+      rcs[s] = f(s, *hs[s]);
+      if (rcs[s] < 0) errs[s] = g_err;
+    };
+    run_shards(n_shards, wk, run_shard, lk);
+    for (u32 s = 0; s < n_shards; ++s) if (rcs[s] < 0) return false;
+    return true;
+  };
+  auto done = [&](int32_t ret) -> int32_t {  // the states' buffers go back to their own threads' pools
+    std::function<void(u32)> drop = [&](u32 s) { if (hs[s]) hs[s]->release(); };
+    run_shards(n_shards, wk, drop, lk);
+    for (u32 s = 0; s < n_shards; ++s) if (rcs[s] < 0) { g_err = "shard " + std::to_string(s) + ": " + errs[s]; return rcs[s]; }
+    return ret;
+  };
+  // 1. block starts
+  if (!phase([&](u32, SplitState &h) -> int32_t {
+        if (h.eligible) return split_candidates(&h);
+        h.own.clear();
+        if (h.rank == 0) h.own.push_back(h.off * 8);
+        h.phase = 1;
+        return AHIP_OK;
+      })) return done(AHIP_OK);
+  if (!hs[0]->eligible) return done(AHIP_OK);
+  std::vector<u64> all;
+  for (u32 s = 0; s < n_shards; ++s) all.insert(all.end(), hs[s]->own.begin(), hs[s]->own.end());
+  // 2. sizes
+  if (!phase([&](u32 s, SplitState &h) -> int32_t { bool ok = false; const int32_t r = split_size(&h, all.data(), all.size(), &ok); oks[s] = ok; return r; })) return done(AHIP_OK);
+  for (u32 s = 0; s < n_shards; ++s) if (!oks[s]) return done(AHIP_OK);
+  std::vector<u64> res;
+  for (u32 s = 0; s < n_shards; ++s)
+    for (const MemberResult &r : hs[s]->own_res) { res.push_back(r.status); res.push_back(r.out_len); res.push_back(r.end_pos); res.push_back(r.blocks); }
+  // 3. the chain, symbols, window maps (through the host)
+  std::vector<u16> maps((size_t)n_shards * SPLIT_MAP_ELEMS);
+  if (!phase([&](u32 s, SplitState &h) -> int32_t {
+        bool ok = false;
+        int32_t r = split_chain(&h, res.data(), all.size(), &ok);
+        oks[s] = ok;
+        if (r != AHIP_OK || !ok) return r;
+        if (h.dmap.reserve((size_t)SPLIT_MAP_ELEMS * 2) != hipSuccess) return fail(AHIP_E_DEVICE, "out of device memory");
+        r = split_resolve(&h, h.dmap.as<u16>());
+        if (r != AHIP_OK) return r;
+        if (hipMemcpyAsync(maps.data() + (size_t)s * SPLIT_MAP_ELEMS, h.dmap.p, (size_t)SPLIT_MAP_ELEMS * 2, hipMemcpyDeviceToHost, h.st) != hipSuccess ||
+            hipStreamSynchronize(h.st) != hipSuccess) return fail(AHIP_E_DEVICE, "window map read-back failed");
+        return AHIP_OK;
+      })) return done(AHIP_OK);
+  for (u32 s = 0; s < n_shards; ++s) if (!oks[s]) return done(AHIP_OK);
+  // 4. the bytes in front of every range, the slices
+  std::vector<size_t> got(n_shards, 0);
+  if (!phase([&](u32 s, SplitState &h) -> int32_t {
+        if (h.dmaps.reserve(maps.size() * 2) != hipSuccess) return fail(AHIP_E_DEVICE, "out of device memory");
+        if (hipMemcpyAsync(h.dmaps.p, maps.data(), maps.size() * 2, hipMemcpyHostToDevice, h.st) != hipSuccess) return fail(AHIP_E_DEVICE, "window map upload failed");
+        bool ok = false;
+        const int32_t r = split_finish(&h, h.dmaps.as<u16>(), (u8 *)d_out[s], out_cap[s], &got[s], &ok);
+        oks[s] = ok;
+        return r;
+      })) {
+    for (u32 s = 0; s < n_shards; ++s) out_len[s] = got[s];  // (AHIP_E_CAP: the sizes that are needed)
+    return done(AHIP_OK);
+  }
+  for (u32 s = 0; s < n_shards; ++s) if (!oks[s]) return done(AHIP_OK);  // (some chunk differs from its sizing run: what was written is void)
+  for (u32 s = 0; s < n_shards; ++s) { out_len[s] = got[s]; offsets[s] = hs[s]->base_out; }
+  offsets[n_shards] = hs[0]->total_out;
+  if (end_pos) *end_pos = hs[0]->end_pos;
+  *handled = 1;
+  g_last_shards = (int32_t)n_shards;
+  return done(AHIP_OK);
 }
 
 int32_t ahip_device_count(void) {

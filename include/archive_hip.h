@@ -61,7 +61,7 @@ const char *ahip_last_error(void);
 uint32_t ahip_abi_version(void);  /* 2.1: + ahip_gzip_decode_shards, ahip_gzip_encode_device, ahip_zlib_encode_device;
                                     * 2.2: + ahip_deflate_shards, ahip_bzip2_decode_shards, ahip_debug_last_chunks;
                                     * 2.3: + ahip_debug_bz_reruns, ahip_last_consumed;
-                                    * 2.4: + ahip_stream_split_* */
+                                    * 2.4: + ahip_stream_split_*, ahip_inflate_stream_shards */
 
 /* ---- Inflate: host-pointer entry points (what dart:ffi binds) ---- */
 
@@ -218,6 +218,15 @@ int32_t ahip_stream_split_resolve(ahip_stream_split *split, void *d_map);
 /* d_maps: world x ahip_stream_split_map_bytes() bytes of device memory, rank order.  d_out: rank_len bytes. */
 int32_t ahip_stream_split_finish(ahip_stream_split *split, const void *d_maps, void *d_out, size_t out_cap, size_t *out_len, int32_t *handled);
 void ahip_stream_split_destroy(ahip_stream_split *split);
+/* The same decode with ONE process driving the devices (ahip_init_devices): shard s = rank s of n_shards, run by the context of
+ * devices[s]; d_in[s] = the WHOLE compressed stream on that device (DEFLATE data from byte data_off on).  What the ranks of a job
+ * all-gather is host memory here (the window maps go through the host: 64 KiB a shard each way).  d_out[s] / out_cap[s]: room for
+ * shard s's slice -- slices are balanced on COMPRESSED bytes, allow for more than total / n; AHIP_E_CAP leaves the sizes needed in
+ * out_len[].  offsets[s] (offsets[n] = the total): where slice s lies in the stream's output; *end_pos: the reference's stream
+ * position behind the DEFLATE data.  *handled = 0: not a case for the chunked decode, nothing usable was written. */
+int32_t ahip_inflate_stream_shards(uint32_t n_shards, const int32_t *devices, const void *const *d_in, size_t in_len, size_t data_off,
+                                   void *const *d_out, const size_t *out_cap, size_t *out_len, uint64_t *offsets, uint64_t *end_pos,
+                                   int32_t *handled);
 /* Diagnostics / tests (no device, no handle): the chain walk of ahip_stream_split_chain for a rank that owns candidates
  * [c0, c1) of n; out[0..5] = handled, slice offset, slice length, total, end position, the rank's chunks on the chain. */
 int32_t ahip_debug_stream_split_chain(const uint64_t *cand, const uint64_t *results, size_t n, uint32_t c0, uint32_t c1, uint64_t *out);

@@ -456,3 +456,63 @@ def test_shards_call_and_host_decode_from_two_threads(native_built, monkeypatch)
     finally:
         monkeypatch.delenv("AHIP_FAKE_DEVICES")
         assert L.ahip_init_devices(1) == 0 and L.ahip_device_count() == 1
+
+
+def _stream_shards(L, N, n, d_in, in_len, data_off, caps):
+    import ctypes
+    import torch
+    d_outs = [torch.full((c + 64,), 0xA5, dtype=torch.uint8, device="cuda") for c in caps]
+    arr_dev = (ctypes.c_int32 * n)(*([0] * n))
+    arr_in = (ctypes.c_void_p * n)(*([d_in.data_ptr()] * n))   # (one device here: every "device" sees the same copy)
+    arr_out = (ctypes.c_void_p * n)(*[t.data_ptr() for t in d_outs])
+    arr_cap = (ctypes.c_size_t * n)(*caps)
+    out_len = (ctypes.c_size_t * n)()
+    offsets = (ctypes.c_uint64 * (n + 1))()
+    end_pos, handled = ctypes.c_uint64(), ctypes.c_int32()
+    rc = L.ahip_inflate_stream_shards(n, arr_dev, arr_in, in_len, data_off, arr_out, arr_cap, out_len, offsets, ctypes.byref(end_pos), ctypes.byref(handled))
+    return rc, d_outs, list(out_len), list(offsets), end_pos.value, handled.value
+
+
+def test_one_member_over_the_contexts_of_one_process(native_built, monkeypatch):
+    """ahip_inflate_stream_shards: ONE long DEFLATE stream decoded by the device contexts of one process -- three contexts of the
+    one device there is (AHIP_FAKE_DEVICES, worker threads) and, without ahip_init_devices, several shards on the calling
+    thread.  The slices at their offsets are the input; a slice that does not fit reports the sizes that are needed; a short
+    stream is not taken."""
+    import gzip
+    import torch
+    from archive_amd import _native as N
+    from tools import corpus
+    L = N.lib()
+    assert L.ahip_init(0) == 0
+    data = bytes(corpus.text(corpus.LOG, 55, 0, 11 << 20))
+    g = gzip.compress(data, 6, mtime=0)
+    d_in = torch.frombuffer(bytearray(g), dtype=torch.uint8).cuda()
+
+    def check(n):
+        rc, d_outs, out_len, offsets, end_pos, handled = _stream_shards(L, N, n, d_in, len(g), 10, [len(data)] * n)
+        assert rc == 0 and handled == 1, (rc, handled, N.last_error())
+        assert offsets[n] == len(data) and end_pos == len(g) - 8
+        whole = bytearray(len(data))
+        for s in range(n):
+            assert offsets[s] + out_len[s] == offsets[s + 1]
+            assert bool((d_outs[s][out_len[s]:] == 0xA5).all())
+            whole[offsets[s]:offsets[s] + out_len[s]] = bytes(d_outs[s][:out_len[s]].cpu().numpy())
+        assert bytes(whole) == data
+        assert sum(1 for v in out_len if v) == n
+        return out_len
+    check(2)                      # no worker contexts: the shards run one after another on the calling thread
+    monkeypatch.setenv("AHIP_FAKE_DEVICES", "3")
+    assert L.ahip_init_devices(1) == 0, N.last_error()
+    try:
+        sizes = check(3)
+        assert L.ahip_debug_last_shards() == 3
+        check(5)                  # more shards than contexts: dealt out round robin
+        rc, _, need, _, _, handled = _stream_shards(L, N, 3, d_in, len(g), 10, [sizes[0], sizes[1] - 1, sizes[2]])
+        assert rc == N.AHIP_E_CAP and handled == 0 and list(need) == list(sizes), (rc, need, sizes)
+        short = gzip.compress(data[:200000], 6, mtime=0)
+        d_short = torch.frombuffer(bytearray(short), dtype=torch.uint8).cuda()
+        rc, _, out_len, offsets, _, handled = _stream_shards(L, N, 3, d_short, len(short), 10, [200000] * 3)
+        assert rc == 0 and handled == 0 and sum(out_len) == 0
+    finally:
+        monkeypatch.delenv("AHIP_FAKE_DEVICES")
+        assert L.ahip_init_devices(1) == 0 and L.ahip_device_count() == 1
