@@ -21,7 +21,7 @@ The JSON line also carries
   one_member (N > 1, unless --no-extras) ONE gzip member of --one-member-mib MiB decoded by all ranks together
             (ahip_stream_split_*: a rank's range of the stream's blocks, three all-gathers a step), with the same member's
             single-device time beside it;
-  extras    (N = 1) the other BASELINE configs, device-resident unless said otherwise: 2a one 256 MiB member, 2b
+  extras    (N = 1) the other BASELINE configs, device-resident unless said otherwise: 2a one 256 MiB member (and one of 1 GiB), 2b
             4 096 members of wiki-like text, 3 Deflate level 6 on 1 GiB, 4 without the BGZF BC subfield, 5 bzip2,
             and the host-pointer entry point end to end (PCIe included).
 """
@@ -636,6 +636,26 @@ def extras(args, L, N, corpus, torch, np, dev, sh, comp, d_in, out_bytes, decode
         del d4, o4, data, gz
     except AssertionError as e:
         res["config2a_one_256MiB_member"] = {"error": str(e)}
+
+    try:  # config 2a at four times the size, compressed the way pigz does it (pieces primed with the 32 KiB in front, sync-flush markers between)
+        gz1, crc1 = corpus.make_one_member(kind=corpus.WIKI, seed=8, nbytes=1 << 30, level=6, threads=os.cpu_count() or 1)
+        d8 = torch.from_numpy(gz1.copy()).to(dev)
+        o8 = torch.empty((1 << 30) + 64, dtype=torch.uint8, device=dev)
+        olen = ctypes.c_size_t()
+
+        def call8():
+            rc = L.ahip_gzip_decode_device(d8.data_ptr(), d8.numel(), o8.data_ptr(), o8.numel(), ctypes.byref(olen), None)
+            assert rc == 0 and olen.value == 1 << 30, (rc, olen.value, N.last_error())
+        sec = timed(call8)
+        got = ctypes.c_uint32()
+        L.ahip_crc32_device(o8.data_ptr(), 1 << 30, 0, ctypes.byref(got), None)
+        res["config2a_one_1GiB_member_pigz"] = {"value": round((1 << 30) / sec / 1e9, 2), "unit": "GB/s out", "ms": round(sec * 1e3, 2),
+                                                "hbm_frac": frac(len(gz1), 1 << 30, sec), "crc_ok": bool(got.value == crc1),
+                                                "chunks": int(L.ahip_debug_last_chunks()),
+                                                "what": "ONE gzip member of 1 GiB wiki text (not a BASELINE config: the 256 MiB member above is): a member of this size fills the chip's waves several times over"}
+        del d8, o8, gz1
+    except AssertionError as e:
+        res["config2a_one_1GiB_member_pigz"] = {"error": str(e)}
 
     try:  # config 3: Deflate level 6 on 1 GiB of log text
         n = 1 << 30
