@@ -23,7 +23,7 @@ EXPORTS = [
     "ahip_gzip_decode_shards", "ahip_debug_last_exchange", "ahip_gzip_encode_device", "ahip_zlib_encode_device",
     "ahip_debug_last_chunks", "ahip_deflate_shards", "ahip_bzip2_decode_shards", "ahip_debug_bz_reruns", "ahip_last_consumed",
     "ahip_stream_split_create", "ahip_stream_split_candidates", "ahip_stream_split_size", "ahip_stream_split_chain", "ahip_stream_split_map_bytes",
-    "ahip_stream_split_resolve", "ahip_stream_split_finish", "ahip_stream_split_destroy", "ahip_debug_stream_split_chain", "ahip_inflate_stream_shards",
+    "ahip_stream_split_resolve", "ahip_stream_split_finish", "ahip_stream_split_destroy", "ahip_debug_stream_split_chain", "ahip_inflate_stream_shards", "ahip_deflate_piece_device", "ahip_bzip2_decode_range_device",
 ]
 
 _lib = None
@@ -100,6 +100,8 @@ def lib():
     L.ahip_stream_split_finish.argtypes = [vp, vp, vp, sz, szp, i32p]; L.ahip_stream_split_finish.restype = i32
     L.ahip_stream_split_destroy.argtypes = [vp]; L.ahip_stream_split_destroy.restype = None
     L.ahip_inflate_stream_shards.argtypes = [u32, vp, vp, sz, sz, vp, vp, vp, vp, u64p, i32p]; L.ahip_inflate_stream_shards.restype = i32
+    L.ahip_deflate_piece_device.argtypes = [vp, sz, i32, i32, i32, vp, sz, szp, ctypes.POINTER(u32), vp]; L.ahip_deflate_piece_device.restype = i32
+    L.ahip_bzip2_decode_range_device.argtypes = [vp, sz, i32, u32, u32, u64, vp, sz, szp, vp, vp]; L.ahip_bzip2_decode_range_device.restype = i32
     L.ahip_debug_stream_split_chain.argtypes = [vp, vp, sz, u32, u32, vp]; L.ahip_debug_stream_split_chain.restype = i32
     L.ahip_crc32.argtypes = [vp, sz, u32]; L.ahip_crc32.restype = u32
     L.ahip_adler32.argtypes = [vp, sz, u32]; L.ahip_adler32.restype = u32

@@ -2145,6 +2145,33 @@ int32_t ahip_bzip2_decode_device(const void *d_in, size_t in_len, int32_t verify
   return bzip2_device_impl(hdr, (const u8 *)d_in, in_len, verify, (u8 *)d_out, out_cap, out_len, nullptr, st);
 }
 
+// One RANK's part of a bzip2 stream (one process per GPU; the one-process form is ahip_bzip2_decode_shards, which does the
+// same per shard and merges): the blocks among the block-magic candidates [K rank / world, K (rank + 1) / world) -- or, from
+// != ~0, from candidate `from` on (the merge's second try: the ranks in front ended somewhere else, on a false magic inside a
+// block's data).  info[8] = {blocks folded, CRC fold of those blocks, met the end-of-stream block, its stored CRC, the stream
+// ended inside this range, first candidate the chain started at, candidate it expects next, 0}: what the caller gathers and
+// merges in rank order exactly like decodeStream (archive_amd/sharding.py::merge_bzip2_ranks; ref bzip2_decoder.dart:20-88).
+int32_t ahip_bzip2_decode_range_device(const void *d_in, size_t in_len, int32_t verify, uint32_t rank, uint32_t world, uint64_t from,
+                                       void *d_out, size_t out_cap, size_t *out_len, uint64_t *info, void *stream) {
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  if (!info || !world || rank >= world) return fail(AHIP_E_ARG, "bzip2 range: rank / world / info");
+  hipStream_t st = (hipStream_t)stream;
+  if (out_len) *out_len = 0;
+  for (int i = 0; i < 8; ++i) info[i] = 0;
+  u8 hdr[4] = {0, 0, 0, 0};
+  if (in_len > 0) {
+    int32_t rc = ensure_init();
+    if (rc != AHIP_OK) return rc;
+    HIP_TRY(copy_on(hdr, d_in, in_len < 4 ? in_len : 4, hipMemcpyDeviceToHost, st));
+  }
+  BzShard sh;
+  sh.index = rank; sh.count = world; sh.from = from;
+  const int32_t rc = bzip2_device_impl(hdr, (const u8 *)d_in, in_len, verify, (u8 *)d_out, out_cap, out_len, &sh, st);
+  info[0] = sh.nblocks; info[1] = sh.fold; info[2] = sh.saw_eos ? 1 : 0; info[3] = sh.eos_stored; info[4] = sh.stopped ? 1 : 0;
+  info[5] = sh.first; info[6] = sh.next;
+  return rc;
+}
+
 int32_t ahip_bzip2_decode(const uint8_t *in, size_t in_len, int32_t verify, uint8_t *out, size_t out_cap,
                           size_t *out_len) {
   std::lock_guard<std::recursive_mutex> lk(g_mu);
@@ -2306,6 +2333,20 @@ int32_t ahip_deflate_raw_device(const void *d_in, size_t in_len, int32_t level, 
   int32_t rc = ensure_init();
   if (rc != AHIP_OK) return rc;
   return deflate_device_impl((const u8 *)d_in, in_len, level, window_bits, (u8 *)d_out, out_cap, out_len, (hipStream_t)stream);
+}
+
+// One RANK's piece of a sharded Deflate (one process per GPU; the one-process form is ahip_deflate_shards): the piece is
+// compressed on its own; every piece but the last (`last` = 0) ends with the byte-aligning empty stored block the reference
+// itself writes as a flush marker (deflate.dart:219) instead of a final block, so the pieces laid end to end in rank order
+// are ONE raw DEFLATE stream of the whole input.  crc32 (may be NULL): CRC-32 of the piece's INPUT, for a gzip trailer.
+int32_t ahip_deflate_piece_device(const void *d_in, size_t in_len, int32_t level, int32_t window_bits, int32_t last, void *d_out,
+                                  size_t out_cap, size_t *out_len, uint32_t *crc32, void *stream) {
+  std::lock_guard<std::recursive_mutex> lk(g_mu);
+  int32_t rc = ensure_init();
+  if (rc != AHIP_OK) return rc;
+  rc = deflate_device_impl((const u8 *)d_in, in_len, level, window_bits, (u8 *)d_out, out_cap, out_len, (hipStream_t)stream, !last);
+  if (rc == AHIP_OK && crc32) rc = crc32_device_impl((const u8 *)d_in, in_len, 0, crc32, (hipStream_t)stream);
+  return rc;
 }
 
 // host-pointer Deflate; the checksums of the input are taken from its device copy

@@ -324,3 +324,121 @@ class ShardedStreamDecoder:
                 return res
         self.last_handled = False
         return self._one_rank(d_in, cdev, group, rank)
+
+
+# ---- Deflate and BZip2, one process per GPU (the one-process forms are ahip_deflate_shards / ahip_bzip2_decode_shards) ----
+class ShardedDeflate:
+    """`Deflate(bytes, level: L, windowBits: W).getBytes()` (deflate.dart:39-48) of an input cut over the ranks
+    (`partition_bytes`): every rank compresses its piece on its own GPU; the pieces, laid end to end at the offsets of one
+    all-gather of sizes, are ONE raw DEFLATE stream of the whole input (every piece but the last ends with the reference's own
+    flush marker, deflate.dart:219)."""
+
+    def __init__(self, device_index=None, collective_device=None):
+        self.device_index = torch.cuda.current_device() if device_index is None else device_index
+        self.collective_device = collective_device
+        rc = N.lib().ahip_init(self.device_index)
+        if rc != 0:
+            _check(rc)
+
+    def encode_piece(self, d_piece, level=6, window_bits=15, group=None):
+        """d_piece: this rank's bytes (uint8 CUDA tensor, may be empty).  Returns (d_out, n, offset, total, crc32 of the WHOLE
+        input): n compressed bytes that belong at `offset` of the stream's `total`."""
+        L = N.lib()
+        on = dist.is_available() and dist.is_initialized()
+        rank = dist.get_rank(group) if on else 0
+        world = dist.get_world_size(group) if on else 1
+        cdev = self.collective_device or d_piece.device
+        n_in = d_piece.numel()
+        d_out = torch.empty(L.ahip_deflate_bound(n_in) + 64, dtype=torch.uint8, device=d_piece.device)
+        olen, crc = ctypes.c_size_t(), ctypes.c_uint32()
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _check(L.ahip_deflate_piece_device(d_piece.data_ptr() if n_in else None, n_in, level, window_bits, 1 if rank == world - 1 else 0,
+                                           d_out.data_ptr(), d_out.numel(), ctypes.byref(olen), ctypes.byref(crc), stream))
+        offset, total, _ = exchange_output_offsets(olen.value, device=cdev, group=group)
+        whole_crc = crc.value
+        if on:  # the gzip trailer's CRC: the pieces' CRCs combined over GF(2) in rank order
+            mine = torch.tensor([crc.value, n_in], dtype=torch.int64, device=cdev)
+            rows = torch.zeros(2 * world, dtype=torch.int64, device=cdev)
+            dist.all_gather_into_tensor(rows, mine, group=group)
+            rows = rows.view(world, 2).tolist()
+            whole_crc = 0
+            for c, ln in rows:
+                whole_crc = crc32_combine(whole_crc, int(c), int(ln))
+        return d_out, olen.value, offset, total, whole_crc
+
+
+def merge_bzip2_ranks(rows, verify):
+    """The merge of ahip_bzip2_decode_shards on gathered rows, rank order = stream order (bzip2_decoder.dart:20-88).
+    rows[r] = (status, bytes, blocks folded, fold, saw_eos, eos_stored, stopped, first, next).
+    Returns (rank that must run again or None, candidate it must start at, verdict, bytes counted per rank)."""
+    worst, ended, saw_eos, eos_stored, combined = 0, False, False, 0, 0
+    stands = None
+    counted = []
+    for r, (st, nbytes, nblocks, fold, eos, stored, stopped, first, nxt) in enumerate(rows):
+        if ended:
+            counted.append(0)
+            continue
+        if r > 0 and stands is not None and st != N.AHIP_E_DEVICE and first != stands:
+            return r, stands, None, None  # what rank r decoded began at a non-block: again from where the chain stands
+        stands = nxt
+        counted.append(nbytes)
+        rot = nblocks & 31
+        combined = ((((combined << rot) | (combined >> (32 - rot))) & 0xffffffff) if rot else combined) ^ fold
+        if st != 0:
+            worst, ended = st, True
+        elif stopped:
+            ended, saw_eos, eos_stored = True, bool(eos), stored
+    if saw_eos and verify and eos_stored != combined and worst == 0:
+        worst = N.AHIP_FALSE
+    return None, None, worst, counted
+
+
+class ShardedBZip2Decoder:
+    """`BZip2Decoder().decodeBytes(data, verify)` (bzip2_decoder.dart:13-88) with the blocks of the stream spread over the ranks:
+    every rank holds the whole compressed stream and decodes the blocks among its range of the block-magic candidates; one
+    all-gather of nine words per rank carries what the merge needs (the chain of blocks, the CRC folds, the verdicts); a rank
+    whose range began on a false magic (inside another block's data) runs once more from where the chain really stands."""
+
+    def __init__(self, device_index=None, collective_device=None):
+        self.device_index = torch.cuda.current_device() if device_index is None else device_index
+        self.collective_device = collective_device
+        rc = N.lib().ahip_init(self.device_index)
+        if rc != 0:
+            _check(rc)
+        self.reruns = 0
+
+    def decode(self, d_in, out_cap, verify=False, group=None):
+        """Returns (d_out, n, offset, total, status): this rank's n bytes at `offset` of the `total` the stream decodes to;
+        status = what ahip_bzip2_decode_device returns for the stream (0 true, 1 false, 2 RangeError)."""
+        L = N.lib()
+        on = dist.is_available() and dist.is_initialized()
+        rank = dist.get_rank(group) if on else 0
+        world = dist.get_world_size(group) if on else 1
+        cdev = self.collective_device or d_in.device
+        d_out = torch.empty(out_cap + 64, dtype=torch.uint8, device=d_in.device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        start, row = 0xffffffffffffffff, None
+        for _ in range(world + 1):
+            if row is None:  # (the first time, and again only on the rank the merge sends back)
+                olen = ctypes.c_size_t()
+                info = (ctypes.c_uint64 * 8)()
+                st = L.ahip_bzip2_decode_range_device(d_in.data_ptr(), d_in.numel(), 1 if verify else 0, rank, world, start, d_out.data_ptr(), out_cap,
+                                                      ctypes.byref(olen), info, stream)
+                self.last_error = N.last_error() if st < 0 else ""
+                row = [st, olen.value, info[0], info[1], info[2], info[3], info[4], info[5] & 0x7fffffffffffffff, info[6] & 0x7fffffffffffffff]
+            if on:
+                mine = torch.tensor(row, dtype=torch.int64, device=cdev)
+                rows = torch.zeros(9 * world, dtype=torch.int64, device=cdev)
+                dist.all_gather_into_tensor(rows, mine, group=group)
+                rows = [tuple(int(v) for v in r) for r in rows.view(world, 9).tolist()]
+            else:
+                rows = [tuple(row)]
+            again, at, verdict, counted = merge_bzip2_ranks(rows, verify)
+            if again is None:
+                if verdict < 0:  # (every rank sees the same verdict: all raise)
+                    _check(verdict)
+                return d_out, counted[rank], sum(counted[:rank]), sum(counted), verdict
+            self.reruns += 1
+            if again == rank:
+                start, row = at, None
+        raise RuntimeError("bzip2 merge did not settle")

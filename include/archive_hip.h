@@ -61,7 +61,8 @@ const char *ahip_last_error(void);
 uint32_t ahip_abi_version(void);  /* 2.1: + ahip_gzip_decode_shards, ahip_gzip_encode_device, ahip_zlib_encode_device;
                                     * 2.2: + ahip_deflate_shards, ahip_bzip2_decode_shards, ahip_debug_last_chunks;
                                     * 2.3: + ahip_debug_bz_reruns, ahip_last_consumed;
-                                    * 2.4: + ahip_stream_split_*, ahip_inflate_stream_shards */
+                                    * 2.4: + ahip_stream_split_*, ahip_inflate_stream_shards, ahip_deflate_piece_device,
+                                    *      ahip_bzip2_decode_range_device */
 
 /* ---- Inflate: host-pointer entry points (what dart:ffi binds) ---- */
 
@@ -151,6 +152,21 @@ int32_t ahip_deflate_shards(uint32_t n_shards, const int32_t *devices, const voi
 int32_t ahip_bzip2_decode_shards(uint32_t n_shards, const int32_t *devices, const void *const *d_in, size_t in_len,
                                  int32_t verify, void *const *d_out, const size_t *out_cap, size_t *out_len,
                                  uint64_t *offsets, int32_t *status);
+/* The same two, one RANK at a time (one process per GPU; the caller exchanges and merges: archive_amd/sharding.py).
+ * ahip_deflate_piece_device: this rank's piece of the input compressed on its own; every piece but the last (last = 0) ends
+ * with the reference's flush marker (ref: deflate.dart:219) instead of a final block, so the pieces laid end to end in rank
+ * order are ONE raw DEFLATE stream; *crc32 (may be NULL) = CRC-32 of the piece's input.
+ * ahip_bzip2_decode_range_device: the blocks among the block-magic candidates [K rank / world, K (rank + 1) / world) of the
+ * stream (d_in = the WHOLE compressed stream), or from candidate `from` on when from != ~0 (the merge's second try).
+ * info[8] = {blocks folded, CRC fold of those blocks, met the end-of-stream block, its stored CRC, the stream ended inside
+ * this range, the candidate the chain started at, the candidate it expects next, 0}; merged in rank order like decodeStream
+ * (ref: bzip2_decoder.dart:20-88): a rank whose chain did not start where the ranks in front expect the next block runs again
+ * with `from`; the first verdict that is not AHIP_OK or the end-of-stream block ends the stream; the stream CRC is
+ * rotl-xor over the ranks' folds. */
+int32_t ahip_deflate_piece_device(const void *d_in, size_t in_len, int32_t level, int32_t window_bits, int32_t last, void *d_out,
+                                  size_t out_cap, size_t *out_len, uint32_t *crc32, void *stream);
+int32_t ahip_bzip2_decode_range_device(const void *d_in, size_t in_len, int32_t verify, uint32_t rank, uint32_t world, uint64_t from,
+                                       void *d_out, size_t out_cap, size_t *out_len, uint64_t *info, void *stream);
 /* Diagnostics: shards ahip_bzip2_decode_shards has decoded a second time, process-wide -- the chain of the shards in front
  * ended somewhere else than at the shard's first candidate (a false block magic inside a block's data on the boundary). */
 int32_t ahip_debug_bz_reruns(void);

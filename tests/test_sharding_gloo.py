@@ -301,3 +301,33 @@ def test_gzip_data_offset_follows_the_reference_header_walk():
     assert D.gzip_data_offset(b"\x78\x9c" + bytes(20)) is None            # a zlib stream: the reference falls back to ZLibDecoder
     assert D.gzip_data_offset(bytes([0x1f, 0x8b, 8, 8, 0, 0, 0, 0, 0, 3]) + b"never ends") is None
     assert D.gzip_data_offset(bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 3, 200, 0]) + bytes(50)) is None  # extra field runs past the buffer
+
+
+def test_bzip2_rank_merge_follows_the_block_loop():
+    """merge_bzip2_ranks = the merge of ahip_bzip2_decode_shards on gathered rows (decodeStream's loop, bzip2_decoder.dart:20-88):
+    ranks in stream order, a rank whose chain began somewhere else than the ranks in front expect goes again, the first
+    verdict that is not OK or the end-of-stream block ends the stream (what lies behind counts for nothing), the stream CRC is
+    the rotl-xor fold of the ranks' folds."""
+    from archive_amd import _native as N
+    from archive_amd.sharding import fold_block_crcs, merge_bzip2_ranks
+    crcs = [0x11111111, 0x22222222, 0x80000001, 0x44444444, 0x55555555]
+    whole = fold_block_crcs(crcs)
+
+    def row(st, nbytes, blk, eos, stored, stopped, first, nxt):
+        return (st, nbytes, len(blk), fold_block_crcs(blk), eos, stored, stopped, first, nxt)
+    # three ranks: 2 + 2 + 1 blocks, the last meets the end-of-stream block
+    rows = [row(0, 200, crcs[0:2], 0, 0, 0, 0, 2), row(0, 150, crcs[2:4], 0, 0, 0, 2, 4), row(0, 70, crcs[4:5], 1, whole, 1, 4, 6)]
+    assert merge_bzip2_ranks(rows, True) == (None, None, 0, [200, 150, 70])
+    bad = list(rows); bad[2] = row(0, 70, crcs[4:5], 1, whole ^ 1, 1, 4, 6)
+    assert merge_bzip2_ranks(bad, True)[2] == N.AHIP_FALSE and merge_bzip2_ranks(bad, False)[2] == 0   # the stored CRC only matters with verify
+    # rank 1 began on a false magic (candidate 2, the chain expects 3): it must go again from 3
+    off = list(rows); off[0] = row(0, 260, crcs[0:2], 0, 0, 0, 0, 3)
+    assert merge_bzip2_ranks(off, True)[:2] == (1, 3)
+    # the stream ends inside rank 1 (`false` in its second block): rank 2 counts for nothing
+    stop = [rows[0], row(1, 90, crcs[2:3], 0, 0, 1, 2, 4), rows[2]]
+    assert merge_bzip2_ranks(stop, True) == (None, None, 1, [200, 90, 0])
+    # the end-of-stream block inside rank 0: everything behind is another stream (the reference decodes ONE)
+    early = [row(0, 200, crcs[0:2], 1, fold_block_crcs(crcs[0:2]), 1, 0, 3), rows[1], rows[2]]
+    assert merge_bzip2_ranks(early, True) == (None, None, 0, [200, 0, 0])
+    # an error on a rank is the stream's verdict
+    assert merge_bzip2_ranks([rows[0], row(N.AHIP_E_CAP, 0, [], 0, 0, 0, 2, 2), rows[2]], False)[2] == N.AHIP_E_CAP
