@@ -49,6 +49,34 @@ def exchange_output_offsets(local_out_bytes, device=None, group=None):
     return int(excl[rank].item()), int(sum(sizes_l)), sizes_l
 
 
+class _OffsetsExchange:
+    """The size all-gather in flight (exchange_output_offsets_begin): `result()` waits for it."""
+
+    def __init__(self, local, sizes, work, rank):
+        self.local, self.sizes, self.work, self.rank = int(local), sizes, work, rank
+
+    def result(self):
+        if self.sizes is None:
+            return 0, self.local, [self.local]
+        if self.work is not None:
+            self.work.wait()
+        sizes_l = [int(v) for v in self.sizes.tolist()]
+        return sum(sizes_l[:self.rank]), sum(sizes_l), sizes_l
+
+
+def exchange_output_offsets_begin(local_out_bytes, device=None, group=None):
+    """Starts the size all-gather and returns at once: a shard's output size is known from the member index (the ISIZE
+    trailers: trusted, then verified by the decode) BEFORE its members are decoded, so the exchange can run under the inflate
+    kernels instead of behind them.  `.result()` = what exchange_output_offsets returns."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return _OffsetsExchange(local_out_bytes, None, None, 0)
+    world = dist.get_world_size(group)
+    mine = torch.tensor([int(local_out_bytes)], dtype=torch.int64, device=device)
+    sizes = torch.zeros(world, dtype=torch.int64, device=device)
+    work = dist.all_gather_into_tensor(sizes, mine, group=group, async_op=True)
+    return _OffsetsExchange(local_out_bytes, sizes, work, dist.get_rank(group))
+
+
 def partition_bytes(n, world_size, align=32768):
     """Contiguous byte ranges [(lo, hi), ...] of an n-byte Deflate input, one per rank, cut on multiples of `align`
     (the encoder's chunk size: a cut there loses nothing; only the 32 KiB of history behind a cut are not used)."""
@@ -137,12 +165,16 @@ class ShardedGZipDecoder:
             L.ahip_gzip_plan_info(plan, ctypes.byref(members), ctypes.byref(out_bytes), ctypes.byref(payload))
             if d_out is None or d_out.numel() < out_bytes.value:
                 d_out = torch.empty(out_bytes.value + 64, dtype=torch.uint8, device=d_in.device)
+            # the index already knows the shard's size (ISIZE trailers): the exchange runs under the inflate kernels
+            ex = exchange_output_offsets_begin(out_bytes.value, device=d_in.device, group=group)
             _check(L.ahip_gzip_plan_run(plan, d_out.data_ptr(), d_out.numel(), stream))
             n = ctypes.c_size_t()
             _check(L.ahip_gzip_plan_status(plan, ctypes.byref(n)))
         finally:
             L.ahip_gzip_plan_destroy(plan)
-        offset, total, _ = exchange_output_offsets(n.value, device=d_in.device, group=group)
+        offset, total, _ = ex.result()
+        if n.value != out_bytes.value:  # (cannot happen with status 0: plan_status reports an index that disagrees with the data)
+            offset, total, _ = exchange_output_offsets(n.value, device=d_in.device, group=group)
         return d_out, n.value, offset, total
 
 

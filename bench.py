@@ -183,6 +183,14 @@ def main():
             rc = L.ahip_gzip_plan_create(d_src.data_ptr(), d_src.numel(), sh, ctypes.byref(plan))
             if rc != 0:
                 raise SystemExit("plan_create: %d %s" % (rc, N.last_error()))
+            ex = None
+            if exchange and world > 1:
+                # the path's one exchange: output-size all-gather -> shard offsets (RCCL).  The index knows the shard's size (the
+                # ISIZE trailers, verified by the decode below), so the all-gather is started here and runs UNDER the inflate kernels
+                from archive_amd.sharding import exchange_output_offsets_begin
+                ob = ctypes.c_uint64()
+                L.ahip_gzip_plan_info(plan, None, ctypes.byref(ob), None)
+                ex = exchange_output_offsets_begin(ob.value, device=cdev)
             if i is not None and not with_index:
                 ev0[i].record(stream)
             rc = L.ahip_gzip_plan_run(plan, d_dst.data_ptr(), d_dst.numel(), sh)
@@ -195,9 +203,10 @@ def main():
             L.ahip_gzip_plan_destroy(plan)
             if rc != 0 or (expect_bytes is not None and olen.value != expect_bytes):
                 raise SystemExit("decode verdict %d, %d bytes (expected %s): %s" % (rc, olen.value, expect_bytes, N.last_error()))
-            if exchange and world > 1:  # the path's one exchange: output-size all-gather -> shard offsets (RCCL)
-                from archive_amd.sharding import exchange_output_offsets
-                exchange_output_offsets(olen.value, device=cdev)
+            if ex is not None:
+                _, _, sizes = ex.result()
+                if sizes[rank] != olen.value:
+                    raise SystemExit("rank %d: the index said %d bytes, the decode made %d" % (rank, sizes[rank], olen.value))
             return olen.value
 
         for _ in range(warmup):

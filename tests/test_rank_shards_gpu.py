@@ -1,5 +1,6 @@
-"""Deflate and BZip2 sharded one process per GPU (archive_amd/sharding.py: ShardedDeflate over ahip_deflate_piece_device,
-ShardedBZip2Decoder over ahip_bzip2_decode_range_device; the one-process forms are ahip_deflate_shards /
+"""gzip members, Deflate and BZip2 sharded one process per GPU (archive_amd/sharding.py: ShardedGZipDecoder -- member ranges, the
+size exchange started under the decode --, ShardedDeflate over ahip_deflate_piece_device, ShardedBZip2Decoder over
+ahip_bzip2_decode_range_device; the one-process forms are ahip_deflate_shards /
 ahip_bzip2_decode_shards, tests/test_multidevice_gpu.py).  Two real processes on the one GPU of this box, collectives on gloo --
 the code a launch on two GPUs runs with RCCL in their place -- and the same calls without a process group (a world of one)."""
 import os
@@ -37,6 +38,23 @@ def gather(obj):
     dist.all_gather_object(out, obj)
     return out
 
+
+# ---- gzip members: contiguous member ranges, the size exchange started under the decode ----
+from archive_amd.sharding import ShardedGZipDecoder, partition_members
+plains = [streams.text(20000 + 977 * i, 100 + i) for i in range(48)]
+members = [streams.gz_member(p, level=6) for p in plains]
+lo, hi = partition_members([len(m) for m in members], world)[rank]
+shard = b"".join(members[lo:hi])
+gdec = ShardedGZipDecoder(device_index=0)
+if world > 1:
+    import archive_amd.sharding as _sh
+    _begin = _sh.exchange_output_offsets_begin
+    _sh.exchange_output_offsets_begin = lambda n, device=None, group=None: _begin(n, device="cpu", group=group)  # (gloo: CPU tensors)
+d_sh = torch.frombuffer(bytearray(shard), dtype=torch.uint8).cuda()
+d_o, n, off, total = gdec.decode_shard(d_sh)
+want = b"".join(plains[lo:hi])
+assert bytes(d_o[:n].cpu().numpy()) == want and total == sum(len(p) for p in plains) and off == sum(len(p) for p in plains[:lo]), (rank, n, off, total)
+print("gzip ok") if rank == 0 else None
 
 # ---- Deflate: the pieces at their offsets are ONE stream of the whole input ----
 data = streams.text(1500000, 11) + bytes(200000) + streams.text(700001, 12)
@@ -112,4 +130,4 @@ def test_deflate_and_bzip2_one_process_per_rank(native_built, tmp_path, ranks):
                "--master-port", str(33500 + os.getpid() % 2000), str(script)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert "deflate ok" in r.stdout and "bzip2 ok" in r.stdout, r.stdout[-2000:]
+    assert "gzip ok" in r.stdout and "deflate ok" in r.stdout and "bzip2 ok" in r.stdout, r.stdout[-2000:]

@@ -251,6 +251,10 @@ def _gather_worker(rank, world, port, q):
         a = _all_gather_u64(mine, "cpu", None)
         b = _all_gather_u64(np.array([rank * 10 + 1, rank * 10 + 2], dtype=np.uint64), "cpu", None)
         c = _all_gather_u64(np.zeros(0, dtype=np.uint64), "cpu", None)
+        # the size exchange started ahead of the decode (exchange_output_offsets_begin) gives what the blocking one gives
+        from archive_amd.sharding import exchange_output_offsets, exchange_output_offsets_begin
+        ex = exchange_output_offsets_begin(1000 + rank, device="cpu")
+        assert ex.result() == exchange_output_offsets(1000 + rank, device="cpu") == ([0, 1000][rank], 2001, [1000, 1001])
         q.put((rank, a.tolist(), b.tolist(), c.tolist()))
         dist.barrier()
     finally:
