@@ -1663,9 +1663,11 @@ int32_t split_chain(SplitState *h, const u64 *res, size_t n_all, bool *handled) 
     total += out_len;
     if (status == MS_OK) { h->end_pos = end_pos; break; }
     if (status != MS_CHUNK_END) { if (dbg) fprintf(stderr, "[ahip] stream split: chunk %zu ended with status %llu: not for this path\n", i, (unsigned long long)status); return AHIP_OK; }
-    auto it = std::lower_bound(h->cand.begin(), h->cand.end(), end_pos);
-    if (it == h->cand.end() || *it != end_pos || (size_t)(it - h->cand.begin()) <= i) return fail(AHIP_E_DEVICE, "internal: chunk chain broken");
-    i = (size_t)(it - h->cand.begin());
+    // (a chunk nearly always ends on the very next block start: look there first, search only when it does not)
+    size_t j = i + 1;
+    if (j >= n_all || h->cand[j] != end_pos) j = (size_t)(std::lower_bound(h->cand.begin(), h->cand.end(), end_pos) - h->cand.begin());
+    if (j >= n_all || h->cand[j] != end_pos || j <= i) return fail(AHIP_E_DEVICE, "internal: chunk chain broken");
+    i = j;
   }
   if (!based) h->base_out = total;
   h->total_out = total;
@@ -1740,7 +1742,8 @@ int32_t split_finish(SplitState *h, const u16 *d_maps, u8 *d_out, size_t out_cap
   if (out_len) *out_len = 0;
   if (h->phase != 4 && h->phase != 6) return fail(AHIP_E_ARG, "stream split: finish before resolve");
   std::vector<u32> ok(h->world, 0);
-  for (u32 r = 0; r < h->world; ++r) HIP_TRY(hipMemcpyAsync(&ok[r], d_maps + (size_t)r * SPLIT_MAP_ELEMS + SM_WINDOW, 4, hipMemcpyDeviceToHost, h->st));
+  // (the status words of all ranks in ONE strided copy: a copy per rank was 24 us each)
+  HIP_TRY(hipMemcpy2DAsync(ok.data(), 4, d_maps + SM_WINDOW, (size_t)SPLIT_MAP_ELEMS * 2, 4, h->world, hipMemcpyDeviceToHost, h->st));
   HIP_TRY(hipStreamSynchronize(h->st));
   for (u32 r = 0; r < h->world; ++r) if (ok[r] != 1) { h->phase = 5; return AHIP_OK; }  // some rank's chunk differs from its sizing run: the caller's exact path
   if (out_len) *out_len = h->out_len;
