@@ -1314,9 +1314,11 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
       g_sm.blocks += (r.blocks & 0x00ffffffu) | (i == 0 ? (r.blocks & MR_REACH) : 0u);
       if (r.status == MS_OK) { g_sm.end_pos = r.end_pos; break; }
       if (r.status != MS_CHUNK_END) { if (dbg) fprintf(stderr, "[ahip] sm: chunk %u ended with status %u: one-wave path\n", i, r.status); return AHIP_OK; }
-      auto it = std::lower_bound(cand.begin(), cand.end(), r.end_pos);
-      if (it == cand.end() || *it != r.end_pos || (u32)(it - cand.begin()) <= i) return fail(AHIP_E_DEVICE, "internal: chunk chain broken");
-      i = (u32)(it - cand.begin());
+      // (a chunk nearly always ends on the very next block start: look there first, search only when it does not)
+      size_t j = (size_t)i + 1;
+      if (j >= cand.size() || cand[j] != r.end_pos) j = (size_t)(std::lower_bound(cand.begin(), cand.end(), r.end_pos) - cand.begin());
+      if (j >= cand.size() || cand[j] != r.end_pos || j <= i) return fail(AHIP_E_DEVICE, "internal: chunk chain broken");
+      i = (u32)j;
     }
     // Only chunk 0 is WATCHED for references into what earlier gzip members wrote (q8).  A later chunk can reach there too
     // when chunk 0 made less than a window of output (a small AHIP_SM_CHUNK; 15-bit literal codes): taken as reaching --
