@@ -1294,7 +1294,7 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
     u32 *ctr0 = nullptr;
     HIP_TRY(sm_counter(st, 0, &ctr0));
     hipLaunchKernelGGL(sm_tokenize_kernel, dim3(grid), dim3(64), 0, st, d_in, n, dchunks.as<ChunkDesc>(), nc, dcand.as<u64>(), nc,
-                       (u32 *)ktp, (DirEnt *)ksp, dres.as<MemberResult>(), kept_gen ? 1u : 0u, ctr0, SmBase{0, 0, 0});
+                       (u32 *)ktp, (DirEnt *)ksp, dres.as<MemberResult>(), kept_gen ? 1u : 0u, ctr0, SmBase{0, 0, 0, 0, 0, 0});
     std::vector<MemberResult> rs(nc);
     HIP_TRY(hipMemcpyAsync(rs.data(), dres.p, (size_t)nc * sizeof(MemberResult), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -1371,7 +1371,7 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
     u32 *ctr1 = nullptr;
     HIP_TRY(sm_counter(st, 1, &ctr1));
     hipLaunchKernelGGL(sm_tokenize_kernel, dim3(grid), dim3(64), 0, st, d_in, n, dchunks.as<ChunkDesc>(), nch, dcand.as<u64>(), nc,
-                       (u32 *)tp, (DirEnt *)sp, dres.as<MemberResult>(), 0u, ctr1, SmBase{0, 0, 0});
+                       (u32 *)tp, (DirEnt *)sp, dres.as<MemberResult>(), 0u, ctr1, SmBase{0, 0, 0, 0, 0, 0});
     std::vector<MemberResult> rs(nch);
     HIP_TRY(hipMemcpyAsync(rs.data(), dres.p, (size_t)nch * sizeof(MemberResult), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -1390,7 +1390,7 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
   u32 *ctr2 = nullptr;
   HIP_TRY(sm_counter(st, 2, &ctr2));
   hipLaunchKernelGGL(sm_resolve_kernel, dim3(grid), dim3(64), 0, st, d_in, n, dchunks.as<ChunkDesc>(), nch, dsym.as<u16>(), (const u32 *)tp,
-                     (const DirEnt *)sp, dres.as<MemberResult>(), dcand.as<u64>(), nc, kept ? 1u : 0u, derr.as<u32>(), ctr2, SmBase{0, 0, 0});
+                     (const DirEnt *)sp, dres.as<MemberResult>(), dcand.as<u64>(), nc, kept ? 1u : 0u, derr.as<u32>(), ctr2, SmBase{0, 0, 0, 0, 0, 0});
   {
     static thread_local DevBuf dwsym, dgwin;
     u32 gs = 1;
@@ -1548,13 +1548,15 @@ struct SplitState {
   std::vector<u64> own, cand;  // this rank's block starts; everybody's (rank order = stream order)
   u32 c0 = 0, c1 = 0;          // own == cand[c0 .. c1)
   u64 byte0 = 0;               // first input byte of the range (token areas are laid out from there)
+  SmBase base_in{0, 0, 0, 0, 0, 0};  // ... and how (sm_layout_in)
   std::vector<MemberResult> own_res, sized;
   std::vector<ChunkDesc> chain;  // the chunks of the chain this rank owns; out_off counted from base_out
+  std::vector<u8> retok;         // ... and which of them cannot use the tokens their sizing run kept
   u64 base_out = 0, out_len = 0, total_out = 0, end_pos = 0;
   bool kept = false, have_tokens = false;
   u32 gs = 1, ng = 0;
-  DevBuf dfind, dcand, dchunks, dres, dsym, dwin, dwsym, dgsym, dgwin, dlink, dtok, ddir, derr, dctr, dmap, dmaps;  // (dmap / dmaps: the one-process form's exchange buffers)
-  void release() { for (DevBuf *b : {&dfind, &dcand, &dchunks, &dres, &dsym, &dwin, &dwsym, &dgsym, &dgwin, &dlink, &dtok, &ddir, &derr, &dctr, &dmap, &dmaps}) b->release(); }
+  DevBuf dfind, dcand, dchunks, dres, dsym, dwin, dwsym, dgsym, dgwin, dlink, dtok, ddir, derr, dctr, dmap, dmaps, dtok2, ddir2, dsubc, dsubr;  // (dmap / dmaps: the one-process form's exchange buffers; dtok2 ..: chunks tokenized again next to kept ones)
+  void release() { for (DevBuf *b : {&dfind, &dcand, &dchunks, &dres, &dsym, &dwin, &dwsym, &dgsym, &dgwin, &dlink, &dtok, &ddir, &derr, &dctr, &dmap, &dmaps, &dtok2, &ddir2, &dsubc, &dsubr}) b->release(); }
 };
 
 hipError_t split_counter(SplitState *h, u32 slot, u32 **out) {
@@ -1616,19 +1618,23 @@ int32_t split_size(SplitState *h, const u64 *all, size_t n_all, bool *handled) {
   HIP_TRY(hipMemcpyAsync(h->dchunks.p, cd.data(), (size_t)nown * sizeof(ChunkDesc), hipMemcpyHostToDevice, h->st));
   // the tokens are kept, laid out along the range's input bytes (tok_layout_in, like the sizing pass of sm_inflate)
   h->byte0 = h->own[0] >> 3;
-  const u64 byte1 = h->c1 < nc ? (h->cand[h->c1] >> 3) + 1 : h->n;
+  // several ranks: four buffers of areas (sm_layout_in), an area reaches to the fourth candidate behind its own
+  const u32 ways = h->world > 1 ? 4u : 1u;
+  const u64 byte1 = h->c1 - 1 + ways < nc ? (h->cand[h->c1 - 1 + ways] >> 3) + 1 : h->n;
   const u64 span = byte1 > h->byte0 ? byte1 - h->byte0 : 0;
+  const u64 way_words = (span * IN_R + (u64)nown * IN_PAD + 64 + 15) & ~15ull, way_dirs = span / 32 + (u64)nown * 64 + 64;
+  h->base_in = SmBase{h->byte0, h->c0, h->c0, ways, way_words, way_dirs};
   h->have_tokens = false;
   if (!getenv("AHIP_SM_TWO_PASS") && span <= (4ull << 30) &&
-      h->dtok.reserve(((size_t)span * IN_R + (size_t)nown * IN_PAD + 64) * 4) == hipSuccess &&
-      h->ddir.reserve(((size_t)(span / 32) + (size_t)nown * 64 + 64) * DIR_BYTES) == hipSuccess) h->have_tokens = true;
+      h->dtok.reserve((size_t)way_words * ways * 4) == hipSuccess &&
+      h->ddir.reserve((size_t)way_dirs * ways * DIR_BYTES) == hipSuccess) h->have_tokens = true;
   else (void)hipGetLastError();  // (no room to keep the tokens: sized without, tokenized again later)
   const u32 grid = nown < (u32)sm_resident_waves() ? nown : (u32)sm_resident_waves();
   u32 *ctr = nullptr;
   HIP_TRY(split_counter(h, 0, &ctr));
   hipLaunchKernelGGL(sm_tokenize_kernel, dim3(grid), dim3(64), 0, h->st, h->d_in, h->n, h->dchunks.as<ChunkDesc>(), nown, h->dcand.as<u64>(), nc,
                      h->have_tokens ? h->dtok.as<u32>() : (u32 *)nullptr, h->have_tokens ? h->ddir.as<DirEnt>() : (DirEnt *)nullptr,
-                     h->dres.as<MemberResult>(), h->have_tokens ? 1u : 0u, ctr, SmBase{h->byte0, h->c0, h->c0});
+                     h->dres.as<MemberResult>(), h->have_tokens ? 1u : 0u, ctr, h->base_in);
   HIP_TRY(hipMemcpyAsync(h->own_res.data(), h->dres.p, (size_t)nown * sizeof(MemberResult), hipMemcpyDeviceToHost, h->st));
   HIP_TRY(hipStreamSynchronize(h->st));
   HIP_TRY(hipGetLastError());
@@ -1641,7 +1647,7 @@ int32_t split_chain(SplitState *h, const u64 *res, size_t n_all, bool *handled) 
   *handled = false;
   if (h->phase != 2 || n_all != h->cand.size()) return fail(AHIP_E_ARG, "stream split: results for another candidate list");
   h->phase = 3;
-  h->chain.clear(); h->sized.clear();
+  h->chain.clear(); h->sized.clear(); h->retok.clear();
   h->base_out = 0; h->out_len = 0; h->total_out = 0; h->end_pos = 0;
   if (n_all < 4) return AHIP_OK;
   h->kept = h->have_tokens;
@@ -1658,8 +1664,9 @@ int32_t split_chain(SplitState *h, const u64 *res, size_t n_all, bool *handled) 
       if (r.status != status || r.out_len != out_len || r.end_pos != end_pos) return fail(AHIP_E_ARG, "stream split: the gathered results differ from this rank's own");
       h->chain.push_back(ChunkDesc{h->cand[i], total - h->base_out, out_len, (u32)(total < SM_WINDOW ? total : SM_WINDOW), (u32)i});
       h->sized.push_back(r);
-      if (i && total < SM_WINDOW) h->kept = false;  // sized with a full window in front, has less: tokenize again (see sm_inflate)
-      if (blocks & MR_FAR) h->kept = false;         // its token area did not hold
+      // sized with a full window in front but has less (see sm_inflate), or its token area did not hold: THIS chunk is tokenized again
+      h->retok.push_back((i && total < SM_WINDOW) || (blocks & MR_FAR) ? 1 : 0);
+      if (dbg && h->retok.back()) fprintf(stderr, "[ahip] stream split: rank %u chunk %zu (candidate %zu, %llu bytes out) is tokenized again\n", h->rank, h->chain.size() - 1, i, (unsigned long long)out_len);
       h->out_len += out_len;
     }
     total += out_len;
@@ -1689,33 +1696,74 @@ int32_t split_resolve(SplitState *h, u16 *d_map) {
     HIP_TRY(h->dchunks.reserve((size_t)nch * sizeof(ChunkDesc)));
     HIP_TRY(h->dres.reserve((size_t)nch * sizeof(MemberResult)));
     HIP_TRY(hipMemcpyAsync(h->dchunks.p, h->chain.data(), (size_t)nch * sizeof(ChunkDesc), hipMemcpyHostToDevice, h->st));
-    const u32 grid = nch < (u32)sm_resident_waves() ? nch : (u32)sm_resident_waves();
-    const u32 *tp = h->dtok.as<u32>();
-    const DirEnt *sp = h->ddir.as<DirEnt>();
-    if (h->kept) HIP_TRY(hipMemcpyAsync(h->dres.p, h->sized.data(), (size_t)nch * sizeof(MemberResult), hipMemcpyHostToDevice, h->st));
-    else {
-      // exact offsets, exact windows: tokenize the own chunks again (tok_layout on offsets counted from the range's first byte)
-      HIP_TRY(h->dtok.reserve(((size_t)(h->out_len * 3 / 2) + (size_t)nch * 1024 + 64) * 4));
-      HIP_TRY(h->ddir.reserve(((size_t)(h->out_len / 16) + (size_t)nch * 64 + 64) * DIR_BYTES));
-      tp = h->dtok.as<u32>(); sp = h->ddir.as<DirEnt>();
-      u32 *ctr1 = nullptr;
-      HIP_TRY(split_counter(h, 1, &ctr1));
-      hipLaunchKernelGGL(sm_tokenize_kernel, dim3(grid), dim3(64), 0, h->st, h->d_in, h->n, h->dchunks.as<ChunkDesc>(), nch, h->dcand.as<u64>(), nc,
-                         h->dtok.as<u32>(), h->ddir.as<DirEnt>(), h->dres.as<MemberResult>(), 0u, ctr1, SmBase{0, 0, h->chain[0].pad});
-      std::vector<MemberResult> rs(nch);
-      HIP_TRY(hipMemcpyAsync(rs.data(), h->dres.p, (size_t)nch * sizeof(MemberResult), hipMemcpyDeviceToHost, h->st));
-      HIP_TRY(hipStreamSynchronize(h->st));
-      HIP_TRY(hipGetLastError());
-      for (u32 i = 0; i < nch; ++i)
-        if (rs[i].status != h->sized[i].status || rs[i].out_len != h->sized[i].out_len || rs[i].end_pos != h->sized[i].end_pos) ok = 0;
-    }
+    const u32 resident = (u32)sm_resident_waves();
+    // the chunks that use the tokens their sizing run kept (K) and those that are tokenized again with exact offsets and
+    // windows (R: one whose token area did not hold, one near the stream's start that was sized with a full window)
+    std::vector<u32> K, R;
+    // AHIP_SPLIT_TEST_RETOK=n (tests): every n-th chunk is tokenized again whatever its sizing run said, and the two kinds are kept apart
+    static const u32 test_every = [] { const char *e = getenv("AHIP_SPLIT_TEST_RETOK"); return e && atoi(e) > 0 ? (u32)atoi(e) : 0u; }();
+    for (u32 k = 0; k < nch; ++k) (h->have_tokens && !h->retok[k] && !(test_every && k % test_every == test_every - 1) ? K : R).push_back(k);
+    // (The two kernels of the R chunks cost a chunk's serial time each, behind one another: worth it only where tokenizing
+    //  everything again is several rounds of the resident waves.  Otherwise: all of them again, side by side.)
+    if (!R.empty() && !K.empty() && nch <= 2 * resident && !test_every) { K.clear(); R.clear(); for (u32 k = 0; k < nch; ++k) R.push_back(k); }
+    h->kept = R.empty();
+    std::vector<MemberResult> full = h->sized;
     HIP_TRY(h->derr.reserve(16));
     HIP_TRY(hipMemsetAsync(h->derr.p, 0, 4, h->st));
+    const u32 nK = (u32)K.size(), nR = (u32)R.size();
+    // sub-lists (device): [0, nK) the kept chunks, [nK, nch) the others -- the whole list itself when there is only one kind
+    const ChunkDesc *dK = h->dchunks.as<ChunkDesc>(), *dR = h->dchunks.as<ChunkDesc>();
+    MemberResult *rK = h->dres.as<MemberResult>(), *rR = h->dres.as<MemberResult>();
+    if (nK && nR) {
+      std::vector<ChunkDesc> sc(nch);
+      std::vector<MemberResult> sr(nch);
+      for (u32 a = 0; a < nK; ++a) { sc[a] = h->chain[K[a]]; sr[a] = h->sized[K[a]]; }
+      for (u32 a = 0; a < nR; ++a) { sc[nK + a] = h->chain[R[a]]; sr[nK + a] = h->sized[R[a]]; }
+      HIP_TRY(h->dsubc.reserve((size_t)nch * sizeof(ChunkDesc)));
+      HIP_TRY(h->dsubr.reserve((size_t)nch * sizeof(MemberResult)));
+      HIP_TRY(hipMemcpyAsync(h->dsubc.p, sc.data(), (size_t)nch * sizeof(ChunkDesc), hipMemcpyHostToDevice, h->st));
+      HIP_TRY(hipMemcpyAsync(h->dsubr.p, sr.data(), (size_t)nch * sizeof(MemberResult), hipMemcpyHostToDevice, h->st));
+      HIP_TRY(hipStreamSynchronize(h->st));  // (sc / sr are locals)
+      dK = h->dsubc.as<ChunkDesc>(); dR = dK + nK;
+      rK = h->dsubr.as<MemberResult>(); rR = rK + nK;
+    }
+    const u32 *tpR = nullptr;
+    const DirEnt *spR = nullptr;
+    if (nR) {
+      // exact offsets, exact windows: tokenize these again (tok_layout on offsets counted from the range's first byte; token areas of
+      // their own, the kept tokens stay where they are)
+      HIP_TRY(h->dtok2.reserve(((size_t)(h->out_len * 3 / 2) + (size_t)nch * 1024 + 64) * 4));
+      HIP_TRY(h->ddir2.reserve(((size_t)(h->out_len / 16) + (size_t)nch * 64 + 64) * DIR_BYTES));
+      tpR = h->dtok2.as<u32>(); spR = h->ddir2.as<DirEnt>();
+      u32 *ctr1 = nullptr;
+      HIP_TRY(split_counter(h, 1, &ctr1));
+      hipLaunchKernelGGL(sm_tokenize_kernel, dim3(nR < resident ? nR : resident), dim3(64), 0, h->st, h->d_in, h->n, dR, nR, h->dcand.as<u64>(), nc,
+                         h->dtok2.as<u32>(), h->ddir2.as<DirEnt>(), rR, 0u, ctr1, SmBase{0, 0, h->chain[R[0]].pad, 0, 0, 0});
+      std::vector<MemberResult> rs(nR);
+      HIP_TRY(hipMemcpyAsync(rs.data(), rR, (size_t)nR * sizeof(MemberResult), hipMemcpyDeviceToHost, h->st));
+      HIP_TRY(hipStreamSynchronize(h->st));
+      HIP_TRY(hipGetLastError());
+      for (u32 a = 0; a < nR; ++a) {
+        const MemberResult &z = h->sized[R[a]];
+        if (rs[a].status != z.status || rs[a].out_len != z.out_len || rs[a].end_pos != z.end_pos) ok = 0;
+        full[R[a]] = rs[a];
+      }
+    }
+    // (the windows and the last pass read sizes from the list in chain order)
+    if (!(nR && !nK)) HIP_TRY(hipMemcpyAsync(h->dres.p, full.data(), (size_t)nch * sizeof(MemberResult), hipMemcpyHostToDevice, h->st));
     if (ok) {
-      u32 *ctr2 = nullptr;
-      HIP_TRY(split_counter(h, 2, &ctr2));
-      hipLaunchKernelGGL(sm_resolve_kernel, dim3(grid), dim3(64), 0, h->st, h->d_in, h->n, h->dchunks.as<ChunkDesc>(), nch, h->dsym.as<u16>(), tp, sp,
-                         h->dres.as<MemberResult>(), h->dcand.as<u64>(), nc, h->kept ? 1u : 0u, h->derr.as<u32>(), ctr2, SmBase{h->byte0, h->c0, h->c0});
+      if (nK) {
+        u32 *ctr2 = nullptr;
+        HIP_TRY(split_counter(h, 2, &ctr2));
+        hipLaunchKernelGGL(sm_resolve_kernel, dim3(nK < resident ? nK : resident), dim3(64), 0, h->st, h->d_in, h->n, dK, nK, h->dsym.as<u16>(), h->dtok.as<u32>(),
+                           h->ddir.as<DirEnt>(), rK, h->dcand.as<u64>(), nc, 1u, h->derr.as<u32>(), ctr2, h->base_in);
+      }
+      if (nR) {
+        u32 *ctr3 = nullptr;
+        HIP_TRY(split_counter(h, 3, &ctr3));
+        hipLaunchKernelGGL(sm_resolve_kernel, dim3(nR < resident ? nR : resident), dim3(64), 0, h->st, h->d_in, h->n, dR, nR, h->dsym.as<u16>(), tpR, spR,
+                           rR, h->dcand.as<u64>(), nc, 0u, h->derr.as<u32>(), ctr3, SmBase{0, 0, 0, 0, 0, 0});
+      }
       while ((u64)h->gs * h->gs < nch) ++h->gs;
       h->ng = (nch + h->gs - 1) / h->gs;
       HIP_TRY(h->dwsym.reserve((size_t)nch * SM_WINDOW * 2));

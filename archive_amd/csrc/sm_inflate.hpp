@@ -340,11 +340,20 @@ __global__ __launch_bounds__(64) void sm_find_kernel(const u8 *__restrict__ in, 
 // there, and the write pass resolves the chunks of the chain straight from them (one tokenizer pass instead of two).
 // base: a rank that decodes only a range of the candidates (ahip_stream_split_*) counts input bytes and candidates from the
 // first of its own, so that its areas fill a buffer sized for the range (all zero: the whole stream).
-struct SmBase { u64 byte0; u32 cand0; u32 k0; };  // first byte / first candidate of the range; k0: list entry 0 is entry k0 of the stream's
+struct SmBase {
+  u64 byte0; u32 cand0; u32 k0;  // first byte / first candidate of the range; k0: list entry 0 is entry k0 of the stream's
+  u32 ways;                      // 0 / 1: an area reaches to the next candidate.  W > 1: candidate c keeps its tokens in buffer c % W
+  u64 way_words, way_dirs;       //   (way_words token words, way_dirs directory entries each) and its area reaches to candidate c + W
+};
+// W ways: with cuts as close as the stream split makes them (16 KiB) the finder also returns starts that are not on the chain of
+// blocks; the chunk in front of one decodes across it, and an area that ended there would be full (MR_FAR: tokenized again,
+// + 0.9 ms for the whole rank).  The candidates that share a buffer are W apart: a chunk may run over W - 1 false starts.
 AHIP_DEVINL void sm_layout_in(const u64 *cand_bits, u32 n_cand, u64 in_len, u32 c, const SmBase &base, u64 &toff, u32 &col_cap, u64 &doff, u32 &dir_cap) {
+  const u32 W = base.ways > 1 ? base.ways : 1u;
   const u64 p0 = uniform64(cand_bits[c]) >> 3;
-  const u64 p1 = c + 1 < n_cand ? (uniform64(cand_bits[c + 1]) >> 3) + 1 : in_len;
+  const u64 p1 = c + W < n_cand ? (uniform64(cand_bits[c + W]) >> 3) + 1 : in_len;
   tok_layout_in(p0 - base.byte0, p1 > p0 ? p1 - p0 : 0, c - base.cand0, toff, col_cap, doff, dir_cap);
+  if (W > 1) { const u32 way = (c - base.cand0) % W; toff += (u64)way * base.way_words; doff += (u64)way * base.way_dirs; }
 }
 // The next chunk of a workgroup: the next value of a device counter (lane 0's atomicAdd, like next_member of the member
 // kernels), or -- next == nullptr -- what the grid's stride says (`strided`).

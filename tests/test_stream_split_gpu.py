@@ -128,6 +128,27 @@ def test_tokenizing_again_gives_the_same_bytes(native_built, corpora, monkeypatc
         assert got == corpora[name] and end_pos == len(raw), name
 
 
+def test_some_chunks_tokenized_again_next_to_kept_ones(native_built, corpora):
+    """A chunk whose token area did not hold in the sizing run (it decoded across block starts that are not on the chain) is
+    tokenized again with exact offsets while the others use what they kept -- two tokenizer outputs, two resolver launches, one
+    symbol array.  AHIP_SPLIT_TEST_RETOK=3 makes every third chunk such a chunk (in a subprocess: the knob is read once)."""
+    code = (
+        "import sys, zlib; sys.path.insert(0, %r)\n"
+        "from tests.test_stream_split_gpu import split_decode, _raw\n"
+        "from tools import corpus\n"
+        "from archive_amd import _native as N\n"
+        "assert N.lib().ahip_init(0) == 0\n"
+        "data = bytes(corpus.text(corpus.LOG, 4321, 0, 10 << 20))\n"
+        "raw = _raw(data)\n"
+        "for world in (1, 3):\n"
+        "    got, end_pos, _ = split_decode(raw, world)\n"
+        "    assert got == data and end_pos == len(raw), world\n"
+        "print('mixed ok')\n" % ROOT)
+    env = dict(os.environ, AHIP_SPLIT_TEST_RETOK="3", AHIP_DEBUG="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0 and "mixed ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 def test_what_the_path_does_not_take(native_built, corpora):
     """Too short, no block start to find (a Z_FIXED stream), a truncated or damaged stream: every rank says `not handled` at
     the same step and nothing is written; ShardedStreamDecoder then decodes on one rank with the exact path (verdicts of the
