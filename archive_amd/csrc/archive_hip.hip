@@ -1194,6 +1194,7 @@ struct SmPlan {  // what the sizing pass learned, kept for the write pass of the
   bool valid = false;
   u64 tok_gen = 0;             // the sizing pass kept its tokens (along the input) as scratch contents number tok_gen (0: it did not)
   std::vector<u32> chain_cand; // candidate index of every chunk of the chain
+  SmBase lay{0, 0, 0, 0, 0, 0}; // how the kept tokens are laid out (sm_layout_in)
 };
 static thread_local SmPlan g_sm;
 static thread_local int32_t g_last_chunks = 0;  // chunks of this thread's last long stream (ahip_debug_last_chunks)
@@ -1286,15 +1287,27 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
     // then only resolves them (AHIP_SM_TWO_PASS=1: tokenize again with exact offsets, as the first version did)
     void *ktp = nullptr, *ksp = nullptr;
     u64 kept_gen = 0;
+    // Several buffers of areas where the memory is there (SmBase::ways, sm_layout_in: an area then reaches to the W-th candidate
+    // behind its own): a chunk whose columns fill unevenly, or that decodes across a false block start, no longer runs out of room
+    // -- one such chunk sends the WHOLE stream to "tokenize again" (a 1 GiB pigz-style member: 15.4 ms of which 2.6 are that).
+    const u64 way_words = ((u64)n * IN_R + (u64)nc * IN_PAD + 64 + 15) & ~15ull, way_dirs = (u64)(n / 32) + (u64)nc * 64 + 64;
+    u32 ways = 1;
+    {
+      static const int forced = [] { const char *e = getenv("AHIP_SM_WAYS"); return e ? atoi(e) : 0; }();  // (dev: 1, 2, 4)
+      const u64 budget = 24ull << 30;
+      for (u32 w : {4u, 2u}) if (ways == 1 && way_words * 4 * w <= budget) ways = w;
+      if (forced == 1 || forced == 2 || forced == 4) ways = (u32)forced;
+    }
+    g_sm.lay = SmBase{0, 0, 0, ways, way_words, way_dirs};
     if (!getenv("AHIP_SM_TWO_PASS") && n <= (4ull << 30)) {
-      if (tokens_reserve(((size_t)n * IN_R + (size_t)nc * IN_PAD + 64) * 4, &ktp) == hipSuccess &&
-          scratch_reserve(((size_t)(n / 32) + (size_t)nc * 64 + 64) * DIR_BYTES, &ksp) == hipSuccess) kept_gen = g_tok_gen;
-      else { ktp = nullptr; ksp = nullptr; }
+      if (tokens_reserve((size_t)way_words * ways * 4, &ktp) == hipSuccess &&
+          scratch_reserve((size_t)way_dirs * ways * DIR_BYTES, &ksp) == hipSuccess) kept_gen = g_tok_gen;
+      else { (void)hipGetLastError(); ktp = nullptr; ksp = nullptr; }
     }
     u32 *ctr0 = nullptr;
     HIP_TRY(sm_counter(st, 0, &ctr0));
     hipLaunchKernelGGL(sm_tokenize_kernel, dim3(grid), dim3(64), 0, st, d_in, n, dchunks.as<ChunkDesc>(), nc, dcand.as<u64>(), nc,
-                       (u32 *)ktp, (DirEnt *)ksp, dres.as<MemberResult>(), kept_gen ? 1u : 0u, ctr0, SmBase{0, 0, 0, 0, 0, 0});
+                       (u32 *)ktp, (DirEnt *)ksp, dres.as<MemberResult>(), kept_gen ? 1u : 0u, ctr0, g_sm.lay);
     std::vector<MemberResult> rs(nc);
     HIP_TRY(hipMemcpyAsync(rs.data(), dres.p, (size_t)nc * sizeof(MemberResult), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -1390,7 +1403,7 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
   u32 *ctr2 = nullptr;
   HIP_TRY(sm_counter(st, 2, &ctr2));
   hipLaunchKernelGGL(sm_resolve_kernel, dim3(grid), dim3(64), 0, st, d_in, n, dchunks.as<ChunkDesc>(), nch, dsym.as<u16>(), (const u32 *)tp,
-                     (const DirEnt *)sp, dres.as<MemberResult>(), dcand.as<u64>(), nc, kept ? 1u : 0u, derr.as<u32>(), ctr2, SmBase{0, 0, 0, 0, 0, 0});
+                     (const DirEnt *)sp, dres.as<MemberResult>(), dcand.as<u64>(), nc, kept ? 1u : 0u, derr.as<u32>(), ctr2, g_sm.lay);
   {
     static thread_local DevBuf dwsym, dgwin;
     u32 gs = 1;
