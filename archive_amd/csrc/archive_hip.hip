@@ -1631,8 +1631,9 @@ int32_t split_size(SplitState *h, const u64 *all, size_t n_all, bool *handled) {
   HIP_TRY(hipMemcpyAsync(h->dchunks.p, cd.data(), (size_t)nown * sizeof(ChunkDesc), hipMemcpyHostToDevice, h->st));
   // the tokens are kept, laid out along the range's input bytes (tok_layout_in, like the sizing pass of sm_inflate)
   h->byte0 = h->own[0] >> 3;
-  // several ranks: four buffers of areas (sm_layout_in), an area reaches to the fourth candidate behind its own
-  const u32 ways = h->world > 1 ? 4u : 1u;
+  // four buffers of areas (sm_layout_in), an area reaches to the fourth candidate behind its own
+  u32 ways = 4;
+  while (ways > 1 && (u64)(h->n - h->byte0) * IN_R * 4 * ways > (24ull << 30)) ways >>= 1;  // (a crude bound: the exact size follows)
   const u64 byte1 = h->c1 - 1 + ways < nc ? (h->cand[h->c1 - 1 + ways] >> 3) + 1 : h->n;
   const u64 span = byte1 > h->byte0 ? byte1 - h->byte0 : 0;
   const u64 way_words = (span * IN_R + (u64)nown * IN_PAD + 64 + 15) & ~15ull, way_dirs = span / 32 + (u64)nown * 64 + 64;
