@@ -2628,10 +2628,15 @@ static void split_setup(SplitState &h, const void *d_in, size_t in_len, size_t d
   h.d_in = (const u8 *)d_in; h.n = in_len; h.off = data_off; h.rank = rank; h.world = world; h.st = st;
   // Several ranks: fewer chunks per GPU, and a chunk is one wave's serial work -- 16 KiB cuts make about every block of a
   // zlib stream a chunk of its own (1 GiB of text on 8 ranks: 3.9 ms against 6.0 with 32 KiB cuts, profiles/r06_stream_split.md);
-  // one rank keeps the single-device path's 48 KiB.  AHIP_SM_CHUNK overrides both.
-  h.cb = (world > 1 && !getenv("AHIP_SM_CHUNK")) ? (16ull << 10) : sm_chunk_bytes();
+  // one rank keeps the single-device path's rule.  AHIP_SM_CHUNK overrides.
+  h.cb = sm_chunk_bytes();
   const u64 len = in_len - data_off;
-  if (world == 1 && !getenv("AHIP_SM_CHUNK")) { const u64 want = (len / 8192 + 4095) & ~4095ull; h.cb = want < h.cb ? h.cb : (want > (128ull << 10) ? (128ull << 10) : want); }  // (like sm_inflate)
+  if (!getenv("AHIP_SM_CHUNK")) {
+    // about 8 000 chunks a rank (sm_inflate's rule) between 48 and 128 KiB; a rank with less than that to do: 16 KiB with several
+    // ranks (measured: 24 and 32 KiB are worse than both 16 and 48 -- the same block starts, longer finder parts)
+    const u64 want = (len / world / 8192 + 4095) & ~4095ull;
+    h.cb = want >= (40ull << 10) ? (want > (128ull << 10) ? (128ull << 10) : (want < h.cb ? h.cb : want)) : (world > 1 ? (16ull << 10) : h.cb);
+  }
   while (((len + h.cb - 1) / h.cb + world - 1) / world > 32768) h.cb *= 2;  // (a RANK's chunks are the grid.y of its per-chunk kernels)
   h.n_cuts = (u32)((len + h.cb - 1) / h.cb);
   h.k0 = (u32)((u64)h.n_cuts * rank / world);
