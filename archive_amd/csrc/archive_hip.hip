@@ -1302,12 +1302,16 @@ int32_t sm_inflate(const u8 *d_in, u64 n, u64 off, u8 *d_out, u64 out_cap, bool 
       for (u32 w : {4u, 2u}) if (ways == 1 && way_words * 4 * w <= budget) ways = w;
       if (forced == 1 || forced == 2 || forced == 4) ways = (u32)forced;
     }
-    g_sm.lay = SmBase{0, 0, 0, ways, way_words, way_dirs};
     if (!getenv("AHIP_SM_TWO_PASS") && n <= (4ull << 30)) {
-      if (tokens_reserve((size_t)way_words * ways * 4, &ktp) == hipSuccess &&
-          scratch_reserve((size_t)way_dirs * ways * DIR_BYTES, &ksp) == hipSuccess) kept_gen = g_tok_gen;
-      else { (void)hipGetLastError(); ktp = nullptr; ksp = nullptr; }
+      for (;; ways >>= 1) {  // (a device short of memory: fewer buffers before none at all)
+        if (tokens_reserve((size_t)way_words * ways * 4, &ktp) == hipSuccess &&
+            scratch_reserve((size_t)way_dirs * ways * DIR_BYTES, &ksp) == hipSuccess) { kept_gen = g_tok_gen; break; }
+        (void)hipGetLastError();
+        ktp = nullptr; ksp = nullptr;
+        if (ways == 1) break;
+      }
     }
+    g_sm.lay = SmBase{0, 0, 0, ways, way_words, way_dirs};
     u32 *ctr0 = nullptr;
     HIP_TRY(sm_counter(st, 0, &ctr0));
     hipLaunchKernelGGL(sm_tokenize_kernel, dim3(grid), dim3(64), 0, st, d_in, n, dchunks.as<ChunkDesc>(), nc, dcand.as<u64>(), nc,
