@@ -80,11 +80,17 @@ AHIP_DEVINL TokSink member_sink(u32 *tokens, DirEnt *dir, u64 out_rel, u64 out_l
 struct MemberSel { const u32 *ids; const u64 *rel; };
 AHIP_DEVINL u32 member_index(const MemberSel &sel, u32 first, u32 k) { return sel.ids ? uniform(sel.ids[k]) : first + k; }
 // Token areas laid out along the input (tok_layout_in): `pos` = the K candidate positions of the stream.
-struct InLayout { const u64 *pos; u32 K; u64 in_len; };
+// ways W > 1: candidate c keeps its tokens in buffer c % W (way_words token words, way_dirs directory entries each) and its area
+// reaches to candidate c + W -- a `1f 8b 08` inside a member's compressed data is a candidate too (one per 16 MiB or so), and an
+// area that ended there was full: 36 of the benchmark's 65 536 members without size hints were tokenized again in a launch pair
+// of their own (0.73 ms of 18.5).  Same idea as SmBase::ways (sm_inflate.hpp).
+struct InLayout { const u64 *pos; u32 K; u64 in_len; u32 ways; u64 way_words, way_dirs; };
 AHIP_DEVINL void in_layout(const InLayout &lay, u32 c, u64 &toff, u32 &col_cap, u64 &doff, u32 &dir_cap) {
+  const u32 W = lay.ways > 1 ? lay.ways : 1u;
   const u64 p0 = uniform64(lay.pos[c]);
-  const u64 p1 = c + 1 < lay.K ? uniform64(lay.pos[c + 1]) : lay.in_len;
+  const u64 p1 = c + W < lay.K ? uniform64(lay.pos[c + W]) : lay.in_len;
   tok_layout_in(p0, p1 > p0 ? p1 - p0 : 0, c, toff, col_cap, doff, dir_cap);
+  if (W > 1) { toff += (u64)(c % W) * lay.way_words; doff += (u64)(c % W) * lay.way_dirs; }
 }
 AHIP_DEVINL TokSink candidate_sink(u32 *tokens, DirEnt *dir, const InLayout &lay, u32 c) {
   TokSink sk{nullptr, 0, nullptr, 0, 0, ~0u, 0, 0, false, true};
@@ -510,6 +516,7 @@ static u64 group_out_max() {
 #define GROUP_OUT_MAX group_out_max()
 
 // members[first .. first+count) with output offsets [out0, out1): tokenize (+ resolve when WRITE)
+static thread_local InLayout g_kept_lay{nullptr, 0, 0, 0, 0, 0};  // how the sizing run that kept its tokens laid them out
 static thread_local int tok_resident = 0, res_resident = 0;  // workgroups of the tokenizer / resolver resident at once (per device context)
 static thread_local DevBuf g_late, g_exact, g_tokens2, g_scratch2;
 // The token / directory scratch is shared by every launch of the thread: a launch on another stream than the
@@ -556,10 +563,19 @@ hipError_t launch_inflate_group(const u8 *in, u64 n, const MemberDesc *members, 
   if (!WRITE && lay_pos && first == 0 && !getenv("AHIP_NO_TOKEN_REUSE") && n <= (4ull << 30)) {
     // (12 B per input byte: when the device cannot spare that, the sizing run simply does not keep its tokens -- it needs
     //  none itself -- and the decode proper tokenizes again)
-    e = tokens_reserve(((size_t)n * IN_R + (size_t)count * IN_PAD + 64) * 4, &tp);
-    if (e == hipSuccess) e = scratch_reserve(((size_t)(n / 32) + (size_t)count * 64 + 64) * DIR_BYTES, &dp);
+    const u64 way_words = ((u64)n * IN_R + (u64)count * IN_PAD + 64 + 15) & ~15ull, way_dirs = (u64)(n / 32) + (u64)count * 64 + 64;
+    u32 ways = 1;
+    for (u32 w : {4u, 2u}) if (ways == 1 && way_words * 4 * w <= (48ull << 30)) ways = w;  // (in_layout: buffers of areas)
+    if (const char *ew = getenv("AHIP_IN_WAYS")) { const int v = atoi(ew); if (v == 1 || v == 2 || v == 4) ways = (u32)v; }  // (dev)
+    for (;; ways >>= 1) {
+      e = tokens_reserve((size_t)way_words * ways * 4, &tp);
+      if (e == hipSuccess) e = scratch_reserve((size_t)way_dirs * ways * DIR_BYTES, &dp);
+      if (e == hipSuccess || ways == 1) break;
+      (void)hipGetLastError();
+    }
     if (e == hipSuccess) {
-      lay = InLayout{lay_pos, count, n};
+      lay = InLayout{lay_pos, count, n, ways, way_words, way_dirs};
+      g_kept_lay = lay;  // (what launch_resolve_kept lays the same tokens out by)
       if (gen_out) *gen_out = g_tok_gen;
     } else {
       (void)hipGetLastError();
@@ -644,11 +660,11 @@ hipError_t launch_resolve_kept(const u8 *in, u64 n, const MemberDesc *members, u
   if (e != hipSuccess) return e;
   if (use_res_wg())
     hipLaunchKernelGGL(inflate_resolve_wg_kernel<true>, dim3(grid), dim3(WG_THREADS), 0, st, in, members, 0u, M, out, (const u32 *)g_tokens.p,
-                       (const DirEnt *)g_scratch.p, (u64)0, res, InLayout{cand_pos, K, n}, sized, MemberSel{nullptr, nullptr},
+                       (const DirEnt *)g_scratch.p, (u64)0, res, InLayout{cand_pos, K, n, g_kept_lay.ways, g_kept_lay.way_words, g_kept_lay.way_dirs}, sized, MemberSel{nullptr, nullptr},
                        g_late.as<u32>() + 2);
   else
     hipLaunchKernelGGL(inflate_resolve_kernel<true>, dim3(grid), dim3(64), 0, st, in, members, 0u, M, out, (const u32 *)g_tokens.p,
-                       (const DirEnt *)g_scratch.p, (u64)0, res, InLayout{cand_pos, K, n}, sized, MemberSel{nullptr, nullptr},
+                       (const DirEnt *)g_scratch.p, (u64)0, res, InLayout{cand_pos, K, n, g_kept_lay.ways, g_kept_lay.way_words, g_kept_lay.way_dirs}, sized, MemberSel{nullptr, nullptr},
                        g_late.as<u32>() + 2);
   e = hipEventRecord(scratch_free, st);
   if (e != hipSuccess) return e;
